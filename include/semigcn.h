@@ -1,0 +1,155 @@
+/*
+ * semigcn.h -- C ABI of libsemigcn_hip.so: the MI355X (gfx950) implementation of
+ * SeMIGCN's graph-convolution message-passing hot path.
+ *
+ * Boundary.  The reference (100 % Python) reaches this arithmetic through
+ * torch-geometric 2.2.0 / torch-scatter 2.1.0; every entry point below names the
+ * reference interface (file:line under the reference tree, or the [3P]
+ * third-party operator it calls there) that it replaces.  All data pointers are
+ * DEVICE pointers owned by the caller (PyTorch-ROCm tensors in the shipped host
+ * code); the library only borrows them for the duration of a stream-ordered
+ * launch.  Handles own their index buffers.  `stream` is a hipStream_t passed
+ * as void* (NULL = the null stream).  No C++ exception crosses this ABI: every
+ * call returns SG_OK or a negative code, and sg_last_error() (thread-local)
+ * holds the message.  Handles are immutable after creation and may be shared
+ * between threads; launches are asynchronous.
+ *
+ * There is NO CPU implementation behind this ABI.
+ */
+#ifndef SEMIGCN_H
+#define SEMIGCN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define SG_API __attribute__((visibility("default")))
+#else
+#define SG_API
+#endif
+
+#define SG_ABI_VERSION 1
+
+enum sg_status {
+  SG_OK = 0,
+  SG_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, misaligned, index out of range) */
+  SG_ERR_HIP = -2,         /* a HIP runtime call failed; message has hipGetErrorString */
+  SG_ERR_UNSUPPORTED = -3, /* dtype / shape not implemented */
+  SG_ERR_NO_DEVICE = -4    /* no gfx950 device visible */
+};
+
+enum sg_dtype {
+  SG_F32 = 0,  /* float32 storage, float32 accumulate (the reference's precision) */
+  SG_BF16 = 1  /* bfloat16 storage, float32 accumulate */
+};
+
+typedef struct sg_graph sg_graph; /* scaled Laplacian L^ = -D^-1/2 A D^-1/2 of one edge_index, CSR */
+typedef struct sg_pool sg_pool;   /* one pool_hash (fine->coarse cluster map), CSR both ways */
+
+SG_API const char* sg_last_error(void);
+SG_API int sg_abi_version(void);
+/* Number of visible HIP devices, or a negative sg_status. Does not create a context on failure. */
+SG_API int sg_device_count(void);
+
+/* ------------------------------------------------------------------------- *
+ * Graph preprocessing -- replaces ChebConv.__norm__ [3P torch_geometric 2.2.0]
+ * (remove_self_loops, get_laplacian('sym'), 2/lambda_max scaling with
+ * lambda_max = 2.0, add_self_loops(+1) / add_self_loops(-1)), which the
+ * reference re-runs inside EVERY conv call: util/networks.py:42,49 and
+ * util/meshnet.py:40,44,50,54,58,106,112,116,120,124,224,232,240.
+ *
+ * edge_index: int64 [2, E] row-major COO in the reference layout
+ * (util/mesh.py:229-230, util/datamaker.py:76-77); row 0 = source, row 1 =
+ * target.  Any order; self-loops are dropped; duplicate edges are kept and
+ * counted (as the reference's scatter does).  Done once per edge_index:
+ *   rowptr[V+1], colidx[nnz] int32 sorted by (target, source);
+ *   dis[v] = deg(v)^-1/2 with deg taken over SOURCE occurrences, 0 where deg = 0.
+ * If the edge multiset is not symmetric a transposed CSR is kept for backward.
+ * ------------------------------------------------------------------------- */
+SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void* stream, sg_graph** out);
+
+/* Rectangular operator for one vertex partition (no reference
+ * counterpart -- the reference is single-device).  Rows = the V_dst owned
+ * vertices, columns = V_src >= V_dst "owned | halo" vertices; `dis_src`
+ * float32 [V_src] holds the GLOBAL deg^-1/2 of every column vertex (the first
+ * V_dst entries are the owned rows').  (dst[i], src[i]) int64 pairs, i < n. */
+SG_API int sg_graph_create_rect(const int64_t* dst, const int64_t* src, int64_t n, int64_t V_dst,
+                         int64_t V_src, const float* dis_src, void* stream, sg_graph** out);
+
+SG_API int sg_graph_destroy(sg_graph* g);
+
+typedef struct sg_graph_info {
+  int64_t V_dst, V_src; /* rows, columns */
+  int64_t nnz;          /* stored entries (self-loops removed) */
+  int32_t symmetric;    /* 1: L^ == L^T (backward reuses the forward CSR) */
+  int32_t max_degree;   /* longest CSR row */
+} sg_graph_info;
+SG_API int sg_graph_query(const sg_graph* g, sg_graph_info* info);
+/* Copies the forward CSR and dis into caller-owned DEVICE buffers on `stream`:
+ * rowptr int32 [V_dst+1], colidx int32 [nnz], dis float32 [V_src]; any may be NULL. */
+SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, float* dis, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Edge aggregation -- replaces MessagePassing.propagate -> message ->
+ * SumAggregation -> torch_scatter.scatter(reduce='sum') -> ATen scatter_add_
+ * [3P], i.e. the two `propagate` calls of every ChebConv.forward and the two
+ * index_add_ calls of its autograd backward:
+ *
+ *     Y = alpha * op(L^) * X  +  beta * X0  +  gamma * X1
+ *
+ * op = L^ (transpose = 0) or L^T (transpose = 1).  Covers Tx1 = L^ x
+ * (alpha 1), Tx2 = 2 L^ Tx1 - x (alpha 2, beta -1, X0 = x) and both backward
+ * aggregations.  X [V_src, C], X0/X1/Y [V_dst, C] (transpose swaps the roles),
+ * row-major with row strides ldx/ldx0/ldx1/ldy in ELEMENTS (so column blocks of
+ * a wider [V, 3C] buffer can be read and written in place); X0/X1 may be NULL
+ * (then beta/gamma are ignored).  Y must not alias X.  Edge weights
+ * -dis[i]*dis[j] are recomputed, never stored.  Deterministic: one owner per
+ * output row, fixed summation order, no atomics.
+ * ------------------------------------------------------------------------- */
+SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx, const void* X0,
+            int64_t ldx0, const void* X1, int64_t ldx1, void* Y, int64_t ldy, int64_t C, int dtype,
+            float alpha, float beta, float gamma, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Mesh pooling -- replaces MeshPool.forward (util/meshnet.py:14-17: sparse
+ * P.x divided by the DENSE row-sum of P, rebuilt every call) and
+ * MeshUnpool.forward (util/meshnet.py:25-27: sparse U.x), whose 0/1 matrices
+ * come from pool_hash_to_mask / unpool_hash_to_mask (util/meshnet.py:331-341),
+ * and their autograd transposes.
+ *
+ * (fine[i], coarse[i]) int64 pairs, i < n: the rows of Mesh.pool_hash
+ * (util/mesh.py:653-676).  Duplicate pairs count twice, like the reference's
+ * coalesced sparse matrices.
+ *   pool_mean       Y[s] = (sum_{(o,s)} X[o]) / count[s]          X [n_fine,C]  -> Y [n_coarse,C]
+ *   pool_mean_bwd   dX[o] = sum_{(o,s)} dY[s] / count[s]          dY [n_coarse,C] -> dX [n_fine,C]
+ *   unpool          Y[o] = sum_{(o,s)} X[s]                       X [n_coarse,C] -> Y [n_fine,C]
+ *   unpool_bwd      dX[s] = sum_{(o,s)} dY[o]                     dY [n_fine,C] -> dX [n_coarse,C]
+ * A coarse row with no member yields 0 (the reference yields 0/0 = NaN there).
+ * ------------------------------------------------------------------------- */
+SG_API int sg_pool_create(const int64_t* fine, const int64_t* coarse, int64_t n, int64_t n_fine,
+                   int64_t n_coarse, void* stream, sg_pool** out);
+SG_API int sg_pool_destroy(sg_pool* p);
+SG_API int sg_pool_mean(const sg_pool* p, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t C,
+                 int dtype, void* stream);
+SG_API int sg_pool_mean_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* dX, int64_t lddx,
+                     int64_t C, int dtype, void* stream);
+SG_API int sg_unpool(const sg_pool* p, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t C,
+              int dtype, void* stream);
+SG_API int sg_unpool_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* dX, int64_t lddx,
+                  int64_t C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Row gather / scatter for halo exchange (new, no reference
+ * counterpart): Y[i] = X[rows[i]] packs boundary rows into a contiguous send
+ * buffer; rows int32 [n] device.
+ * ------------------------------------------------------------------------- */
+SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y,
+                   int64_t ldy, int64_t C, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMIGCN_H */

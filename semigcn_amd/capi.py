@@ -1,0 +1,271 @@
+"""ctypes binding of libsemigcn_hip.so (include/semigcn.h) for PyTorch-ROCm tensors.
+
+This is the only seam between the Python host code and the HIP kernels.  There
+is no CPU implementation behind it: if the library is missing, cannot be loaded,
+or a tensor is not on a HIP device, the call raises -- it never falls back.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from typing import Optional
+
+import torch  # imported first so that libamdhip64.so.7 resolves to the copy torch already loaded
+
+_LIB_NAME = "libsemigcn_hip.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+SG_F32, SG_BF16 = 0, 1
+_DTYPES = {torch.float32: SG_F32, torch.bfloat16: SG_BF16}
+
+
+class SemigcnLibraryError(RuntimeError):
+    """libsemigcn_hip.so is absent / unloadable, or a call into it failed."""
+
+
+class sg_graph_info(ctypes.Structure):
+    _fields_ = [("V_dst", c_int64), ("V_src", c_int64), ("nnz", c_int64),
+                ("symmetric", c_int32), ("max_degree", c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/semigcn.h one to one
+_SIGNATURES = {
+    "sg_last_error": (c_char_p, []),
+    "sg_abi_version": (c_int, []),
+    "sg_device_count": (c_int, []),
+    "sg_graph_create": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(c_void_p)]),
+    "sg_graph_create_rect": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                     POINTER(c_void_p)]),
+    "sg_graph_destroy": (c_int, [c_void_p]),
+    "sg_graph_query": (c_int, [c_void_p, POINTER(sg_graph_info)]),
+    "sg_graph_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sg_spmm": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                        c_void_p, c_int64, c_int64, c_int, c_float, c_float, c_float, c_void_p]),
+    "sg_pool_create": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, POINTER(c_void_p)]),
+    "sg_pool_destroy": (c_int, [c_void_p]),
+    "sg_pool_mean": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "sg_pool_mean_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "sg_unpool": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "sg_unpool_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "sg_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
+                               c_void_p]),
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (idempotent). Raises SemigcnLibraryError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(_LIB_PATH):
+        raise SemigcnLibraryError(
+            f"{_LIB_PATH} not found: build it with `make -C semigcn_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "semigcn_amd has no CPU or PyTorch fallback for its HIP kernels.")
+    try:
+        lib = ctypes.CDLL(_LIB_PATH, mode=ctypes.RTLD_LOCAL)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise SemigcnLibraryError(f"cannot load {_LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SemigcnLibraryError(f"{_LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.sg_abi_version() != 1:
+        raise SemigcnLibraryError(f"ABI version mismatch: library reports {lib.sg_abi_version()}")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sg_last_error()
+        raise SemigcnLibraryError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def _require_device(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise SemigcnLibraryError(
+            f"{name} is on {t.device}: the semigcn_amd kernels run on a HIP device only "
+            "(there is no CPU path; move the model and its inputs to cuda)")
+
+
+def _stream(t: torch.Tensor) -> c_void_p:
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> c_void_p:
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def _rows2d(t: torch.Tensor, name: str) -> int:
+    """Row stride (elements) of a 2-D tensor whose rows are contiguous."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise SemigcnLibraryError(f"{name}: need a 2-D tensor with unit column stride, got "
+                                  f"shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise SemigcnLibraryError(f"unsupported dtype {t.dtype} (float32 and bfloat16 only)") from None
+
+
+class GraphHandle:
+    """Owns one sg_graph (CSR of the scaled Laplacian of one edge_index)."""
+
+    def __init__(self, handle: int, device: torch.device):
+        self._h = c_void_p(handle)
+        self.device = device
+        info = sg_graph_info()
+        _check(load().sg_graph_query(self._h, byref(info)), "sg_graph_query")
+        self.num_rows, self.num_cols, self.nnz = info.V_dst, info.V_src, info.nnz
+        self.symmetric, self.max_degree = bool(info.symmetric), info.max_degree
+
+    @classmethod
+    def from_edge_index(cls, edge_index: torch.Tensor, num_vertices: int) -> "GraphHandle":
+        _require_device(edge_index, "edge_index")
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise SemigcnLibraryError("edge_index must be int64 [2, E]")
+        ei = edge_index.contiguous()
+        out = c_void_p()
+        with torch.cuda.device(ei.device):
+            _check(load().sg_graph_create(_ptr(ei), ei.shape[1], int(num_vertices), _stream(ei), byref(out)),
+                   "sg_graph_create")
+        return cls(out.value, ei.device)
+
+    @classmethod
+    def from_partition(cls, dst: torch.Tensor, src: torch.Tensor, n_owned: int, n_ext: int,
+                       dis_ext: torch.Tensor) -> "GraphHandle":
+        for t, n in ((dst, "dst"), (src, "src"), (dis_ext, "dis_ext")):
+            _require_device(t, n)
+        dst, src = dst.contiguous(), src.contiguous()
+        dis_ext = dis_ext.contiguous().float()
+        assert dst.dtype == torch.int64 and src.dtype == torch.int64 and dis_ext.numel() == n_ext
+        out = c_void_p()
+        with torch.cuda.device(dst.device):
+            _check(load().sg_graph_create_rect(_ptr(dst), _ptr(src), dst.numel(), int(n_owned), int(n_ext),
+                                               _ptr(dis_ext), _stream(dst), byref(out)),
+                   "sg_graph_create_rect")
+        return cls(out.value, dst.device)
+
+    def arrays(self):
+        """(rowptr int32 [rows+1], colidx int32 [nnz], dis float32 [cols]) as torch tensors."""
+        rp = torch.empty(self.num_rows + 1, dtype=torch.int32, device=self.device)
+        ci = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+        ds = torch.empty(self.num_cols, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(load().sg_graph_export(self._h, _ptr(rp), _ptr(ci), _ptr(ds), _stream(rp)), "sg_graph_export")
+        return rp, ci, ds
+
+    def spmm(self, X: torch.Tensor, Y: torch.Tensor, *, alpha: float = 1.0, X0: Optional[torch.Tensor] = None,
+             beta: float = 0.0, X1: Optional[torch.Tensor] = None, gamma: float = 0.0,
+             transpose: bool = False) -> torch.Tensor:
+        """Y = alpha * op(L^) X + beta * X0 + gamma * X1 (in place into Y)."""
+        for t, n in ((X, "X"), (Y, "Y"), (X0, "X0"), (X1, "X1")):
+            if t is not None:
+                _require_device(t, n)
+                if t.dtype != X.dtype:
+                    raise SemigcnLibraryError(f"{n} dtype {t.dtype} != X dtype {X.dtype}")
+        C = X.shape[1]
+        n_in, n_out = (self.num_rows, self.num_cols) if transpose else (self.num_cols, self.num_rows)
+        if X.shape[0] != n_in or Y.shape != (n_out, C):
+            raise SemigcnLibraryError(f"spmm shape mismatch: X {tuple(X.shape)} Y {tuple(Y.shape)} "
+                                      f"operator {n_out}x{n_in}")
+        for t, n in ((X0, "X0"), (X1, "X1")):
+            if t is not None and t.shape != (n_out, C):
+                raise SemigcnLibraryError(f"{n} shape {tuple(t.shape)} != {(n_out, C)}")
+        with torch.cuda.device(X.device):
+            _check(load().sg_spmm(self._h, int(transpose), _ptr(X), _rows2d(X, "X"),
+                                  _ptr(X0), 0 if X0 is None else _rows2d(X0, "X0"),
+                                  _ptr(X1), 0 if X1 is None else _rows2d(X1, "X1"),
+                                  _ptr(Y), _rows2d(Y, "Y"), C, dtype_code(X),
+                                  float(alpha), float(beta), float(gamma), _stream(X)), "sg_spmm")
+        return Y
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().sg_graph_destroy(self._h)
+            self._h = c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PoolHandle:
+    """Owns one sg_pool (cluster map of one pool_hash)."""
+
+    def __init__(self, fine: torch.Tensor, coarse: torch.Tensor, n_fine: int, n_coarse: int):
+        _require_device(fine, "fine")
+        _require_device(coarse, "coarse")
+        fine, coarse = fine.contiguous().long(), coarse.contiguous().long()
+        self.device, self.n_fine, self.n_coarse = fine.device, int(n_fine), int(n_coarse)
+        out = c_void_p()
+        with torch.cuda.device(fine.device):
+            _check(load().sg_pool_create(_ptr(fine), _ptr(coarse), fine.numel(), self.n_fine, self.n_coarse,
+                                         _stream(fine), byref(out)), "sg_pool_create")
+        self._h = out
+
+    def _run(self, fn_name: str, X: torch.Tensor, n_in: int, n_out: int) -> torch.Tensor:
+        _require_device(X, "X")
+        if X.dim() != 2 or X.shape[0] != n_in:
+            raise SemigcnLibraryError(f"{fn_name}: expected [{n_in}, C], got {tuple(X.shape)}")
+        if X.stride(1) != 1 and X.shape[1] > 1:
+            X = X.contiguous()
+        Y = torch.empty((n_out, X.shape[1]), dtype=X.dtype, device=X.device)
+        with torch.cuda.device(X.device):
+            _check(getattr(load(), fn_name)(self._h, _ptr(X), _rows2d(X, "X"), _ptr(Y), _rows2d(Y, "Y"),
+                                            X.shape[1], dtype_code(X), _stream(X)), fn_name)
+        return Y
+
+    def pool_mean(self, X):
+        return self._run("sg_pool_mean", X, self.n_fine, self.n_coarse)
+
+    def pool_mean_bwd(self, dY):
+        return self._run("sg_pool_mean_bwd", dY, self.n_coarse, self.n_fine)
+
+    def unpool(self, X):
+        return self._run("sg_unpool", X, self.n_coarse, self.n_fine)
+
+    def unpool_bwd(self, dY):
+        return self._run("sg_unpool_bwd", dY, self.n_fine, self.n_coarse)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().sg_pool_destroy(self._h)
+            self._h = c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gather_rows(rows: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = X[rows[i]]; rows int32 on the device (halo packing)."""
+    _require_device(X, "X")
+    _require_device(rows, "rows")
+    if rows.dtype != torch.int32:
+        raise SemigcnLibraryError("rows must be int32")
+    rows = rows.contiguous()
+    if out is None:
+        out = torch.empty((rows.numel(), X.shape[1]), dtype=X.dtype, device=X.device)
+    with torch.cuda.device(X.device):
+        _check(load().sg_gather_rows(_ptr(rows), rows.numel(), _ptr(X), _rows2d(X, "X"), _ptr(out),
+                                     _rows2d(out, "out"), X.shape[1], dtype_code(X), _stream(X)),
+               "sg_gather_rows")
+    return out

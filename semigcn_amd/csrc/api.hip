@@ -1,0 +1,295 @@
+// extern "C" entry points of libsemigcn_hip.so (declared in include/semigcn.h).
+#include <stdarg.h>
+
+#include <new>
+
+#include "sg_common.h"
+
+namespace sg {
+
+static thread_local std::string t_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  t_error = buf;
+}
+
+namespace {
+
+struct ScopedFree {
+  void* p = nullptr;
+  ~ScopedFree() { if (p) (void)hipFree(p); }
+};
+
+void destroy_graph(sg_graph* g) {
+  if (!g) return;
+  g->fwd.release();
+  g->bwd.release();
+  if (g->dis_src && g->dis_src != g->dis_dst) (void)hipFree(g->dis_src);
+  if (g->dis_dst) (void)hipFree(g->dis_dst);
+  delete g;
+}
+
+void destroy_pool(sg_pool* p) {
+  if (!p) return;
+  p->by_coarse.release();
+  p->by_fine.release();
+  if (p->inv_count) (void)hipFree(p->inv_count);
+  delete p;
+}
+
+int check_dense(const char* what, const void* X, int64_t ld, int64_t C) {
+  SG_REQUIRE(X != nullptr, "%s: null pointer", what);
+  SG_REQUIRE(ld >= C, "%s: row stride %lld < C %lld", what, (long long)ld, (long long)C);
+  return SG_OK;
+}
+
+int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64_t ldx,
+            const void* X0, int64_t ldx0, const void* X1, int64_t ldx1, void* Y, int64_t ldy,
+            int64_t C, int dtype, float alpha, float beta, float gamma, hipStream_t stream) {
+  SG_REQUIRE(C >= 0 && C <= INT32_MAX, "C out of range");
+  if (c.n_rows == 0 || C == 0) return SG_OK;
+  int rc;
+  if ((rc = check_dense("X", X, ldx, C)) != SG_OK) return rc;
+  if ((rc = check_dense("Y", Y, ldy, C)) != SG_OK) return rc;
+  if (X0 && (rc = check_dense("X0", X0, ldx0, C)) != SG_OK) return rc;
+  if (X1 && (rc = check_dense("X1", X1, ldx1, C)) != SG_OK) return rc;
+  SG_REQUIRE(X != Y, "Y must not alias X");
+  SpmmArgs a;
+  a.rowptr = c.rowptr;
+  a.idx = c.idx;
+  a.scale_dst = sd;
+  a.scale_src = ss;
+  a.X = X; a.X0 = X0; a.X1 = X1; a.Y = Y;
+  a.ldx = ldx; a.ldx0 = X0 ? ldx0 : 0; a.ldx1 = X1 ? ldx1 : 0; a.ldy = ldy;
+  a.n_rows = (int32_t)c.n_rows;
+  a.C = (int32_t)C;
+  a.alpha = alpha; a.beta = beta; a.gamma = gamma;
+  return launch_spmm(a, dtype, stream);
+}
+
+}  // namespace
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+SG_API const char* sg_last_error(void) { return t_error.c_str(); }
+
+SG_API int sg_abi_version(void) { return SG_ABI_VERSION; }
+
+SG_API int sg_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return SG_ERR_NO_DEVICE;
+  }
+  return n;
+}
+
+SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void* stream_, sg_graph** out) {
+  SG_REQUIRE(out != nullptr, "sg_graph_create: out is null");
+  *out = nullptr;
+  SG_REQUIRE(E >= 0 && V >= 0, "sg_graph_create: negative size");
+  SG_REQUIRE(E == 0 || edge_index != nullptr, "sg_graph_create: edge_index is null");
+  hipStream_t stream = (hipStream_t)stream_;
+  sg_graph* g = new (std::nothrow) sg_graph();
+  SG_REQUIRE(g != nullptr, "out of host memory");
+  const int64_t* src = edge_index;      // row 0: source j
+  const int64_t* dst = edge_index + E;  // row 1: target i
+  ScopedFree kf, kb;
+  int rc = SG_OK;
+  do {
+    if (E > 0) {
+      if (hipMalloc(&kf.p, E * sizeof(uint64_t)) != hipSuccess ||
+          hipMalloc(&kb.p, E * sizeof(uint64_t)) != hipSuccess) {
+        set_error("hipMalloc of sort keys failed");
+        rc = SG_ERR_HIP;
+        break;
+      }
+    }
+    if ((rc = build_csr(dst, src, E, V, V, true, stream, &g->fwd, (uint64_t*)kf.p)) != SG_OK) break;
+    // transposed: rows = sources.  Its row lengths are the PyG degrees (taken over edge_index[0]).
+    if ((rc = build_csr(src, dst, E, V, V, true, stream, &g->bwd, (uint64_t*)kb.p)) != SG_OK) break;
+    if (hipMalloc((void**)&g->dis_dst, (V > 0 ? V : 1) * sizeof(float)) != hipSuccess) {
+      set_error("hipMalloc of dis failed");
+      rc = SG_ERR_HIP;
+      break;
+    }
+    g->dis_src = g->dis_dst;
+    if ((rc = degree_scale(g->bwd, true, g->dis_dst, stream)) != SG_OK) break;
+    int equal = 1;
+    if ((rc = keys_equal((const uint64_t*)kf.p, (const uint64_t*)kb.p, g->fwd.nnz, stream, &equal)) != SG_OK) break;
+    g->symmetric = equal != 0;
+    g->square = true;
+    if (g->symmetric) g->bwd.release();
+    if (hipStreamSynchronize(stream) != hipSuccess) {
+      set_error("stream sync failed in sg_graph_create");
+      rc = SG_ERR_HIP;
+      break;
+    }
+  } while (0);
+  if (rc != SG_OK) {
+    destroy_graph(g);
+    return rc;
+  }
+  *out = g;
+  return SG_OK;
+}
+
+SG_API int sg_graph_create_rect(const int64_t* dst, const int64_t* src, int64_t n, int64_t V_dst,
+                         int64_t V_src, const float* dis_src, void* stream_, sg_graph** out) {
+  SG_REQUIRE(out != nullptr, "sg_graph_create_rect: out is null");
+  *out = nullptr;
+  SG_REQUIRE(n >= 0 && V_dst >= 0 && V_src >= V_dst, "sg_graph_create_rect: need V_src >= V_dst >= 0");
+  SG_REQUIRE(V_src == 0 || dis_src != nullptr, "sg_graph_create_rect: dis_src is null");
+  hipStream_t stream = (hipStream_t)stream_;
+  sg_graph* g = new (std::nothrow) sg_graph();
+  SG_REQUIRE(g != nullptr, "out of host memory");
+  int rc = build_csr(dst, src, n, V_dst, V_src, false, stream, &g->fwd, nullptr);
+  if (rc == SG_OK) {
+    if (hipMalloc((void**)&g->dis_src, (V_src > 0 ? V_src : 1) * sizeof(float)) != hipSuccess) {
+      set_error("hipMalloc of dis failed");
+      rc = SG_ERR_HIP;
+    } else {
+      g->dis_dst = g->dis_src;  // owned rows are the first V_dst columns
+      if (V_src > 0 &&
+          (hipMemcpyAsync(g->dis_src, dis_src, V_src * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+           hipStreamSynchronize(stream) != hipSuccess)) {
+        set_error("copy of dis failed");
+        rc = SG_ERR_HIP;
+      }
+    }
+  }
+  if (rc != SG_OK) {
+    if (g->dis_src) { (void)hipFree(g->dis_src); g->dis_src = g->dis_dst = nullptr; }
+    destroy_graph(g);
+    return rc;
+  }
+  g->symmetric = true;  // the partitioned operator is applied owner-computes in both directions
+  g->square = false;
+  *out = g;
+  return SG_OK;
+}
+
+SG_API int sg_graph_destroy(sg_graph* g) {
+  destroy_graph(g);
+  return SG_OK;
+}
+
+SG_API int sg_graph_query(const sg_graph* g, sg_graph_info* info) {
+  SG_REQUIRE(g && info, "sg_graph_query: null argument");
+  info->V_dst = g->fwd.n_rows;
+  info->V_src = g->fwd.n_cols;
+  info->nnz = g->fwd.nnz;
+  info->symmetric = g->symmetric ? 1 : 0;
+  info->max_degree = g->fwd.max_degree;
+  return SG_OK;
+}
+
+SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, float* dis, void* stream_) {
+  SG_REQUIRE(g != nullptr, "sg_graph_export: null graph");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (rowptr)
+    SG_HIP_TRY(hipMemcpyAsync(rowptr, g->fwd.rowptr, (g->fwd.n_rows + 1) * sizeof(int32_t),
+                              hipMemcpyDeviceToDevice, stream));
+  if (colidx && g->fwd.nnz > 0)
+    SG_HIP_TRY(hipMemcpyAsync(colidx, g->fwd.idx, g->fwd.nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  if (dis && g->fwd.n_cols > 0)
+    SG_HIP_TRY(hipMemcpyAsync(dis, g->dis_src, g->fwd.n_cols * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  return SG_OK;
+}
+
+SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx, const void* X0, int64_t ldx0,
+            const void* X1, int64_t ldx1, void* Y, int64_t ldy, int64_t C, int dtype, float alpha,
+            float beta, float gamma, void* stream) {
+  SG_REQUIRE(g != nullptr, "sg_spmm: null graph");
+  const bool t = transpose != 0;
+  if (t && !g->square) {
+    set_error("sg_spmm: transpose of a rectangular (partition) operator is not available; "
+              "apply it owner-computes on exchanged gradient rows");
+    return SG_ERR_UNSUPPORTED;
+  }
+  const Csr& c = (t && !g->symmetric) ? g->bwd : g->fwd;
+  // L^[i,j] = -dis[i] dis[j] (#edges j->i); the transposed CSR carries the same scales
+  return run_csr(c, g->dis_dst, g->dis_src, X, ldx, X0, ldx0, X1, ldx1, Y, ldy, C, dtype, -alpha,
+                 beta, gamma, (hipStream_t)stream);
+}
+
+SG_API int sg_pool_create(const int64_t* fine, const int64_t* coarse, int64_t n, int64_t n_fine,
+                   int64_t n_coarse, void* stream_, sg_pool** out) {
+  SG_REQUIRE(out != nullptr, "sg_pool_create: out is null");
+  *out = nullptr;
+  SG_REQUIRE(n >= 0 && n_fine >= 0 && n_coarse >= 0, "sg_pool_create: negative size");
+  hipStream_t stream = (hipStream_t)stream_;
+  sg_pool* p = new (std::nothrow) sg_pool();
+  SG_REQUIRE(p != nullptr, "out of host memory");
+  int rc = build_csr(coarse, fine, n, n_coarse, n_fine, false, stream, &p->by_coarse, nullptr);
+  if (rc == SG_OK) rc = build_csr(fine, coarse, n, n_fine, n_coarse, false, stream, &p->by_fine, nullptr);
+  if (rc == SG_OK && hipMalloc((void**)&p->inv_count, (n_coarse > 0 ? n_coarse : 1) * sizeof(float)) != hipSuccess) {
+    set_error("hipMalloc of inv_count failed");
+    rc = SG_ERR_HIP;
+  }
+  if (rc == SG_OK) rc = degree_scale(p->by_coarse, false, p->inv_count, stream);
+  if (rc == SG_OK && hipStreamSynchronize(stream) != hipSuccess) {
+    set_error("stream sync failed in sg_pool_create");
+    rc = SG_ERR_HIP;
+  }
+  if (rc != SG_OK) {
+    destroy_pool(p);
+    return rc;
+  }
+  *out = p;
+  return SG_OK;
+}
+
+SG_API int sg_pool_destroy(sg_pool* p) {
+  destroy_pool(p);
+  return SG_OK;
+}
+
+SG_API int sg_pool_mean(const sg_pool* p, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t C, int dtype,
+                 void* stream) {
+  SG_REQUIRE(p != nullptr, "sg_pool_mean: null pool");
+  return run_csr(p->by_coarse, p->inv_count, nullptr, X, ldx, nullptr, 0, nullptr, 0, Y, ldy, C, dtype,
+                 1.f, 0.f, 0.f, (hipStream_t)stream);
+}
+
+SG_API int sg_pool_mean_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* dX, int64_t lddx, int64_t C,
+                     int dtype, void* stream) {
+  SG_REQUIRE(p != nullptr, "sg_pool_mean_bwd: null pool");
+  return run_csr(p->by_fine, nullptr, p->inv_count, dY, lddy, nullptr, 0, nullptr, 0, dX, lddx, C, dtype,
+                 1.f, 0.f, 0.f, (hipStream_t)stream);
+}
+
+SG_API int sg_unpool(const sg_pool* p, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t C, int dtype,
+              void* stream) {
+  SG_REQUIRE(p != nullptr, "sg_unpool: null pool");
+  return run_csr(p->by_fine, nullptr, nullptr, X, ldx, nullptr, 0, nullptr, 0, Y, ldy, C, dtype, 1.f, 0.f,
+                 0.f, (hipStream_t)stream);
+}
+
+SG_API int sg_unpool_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* dX, int64_t lddx, int64_t C,
+                  int dtype, void* stream) {
+  SG_REQUIRE(p != nullptr, "sg_unpool_bwd: null pool");
+  return run_csr(p->by_coarse, nullptr, nullptr, dY, lddy, nullptr, 0, nullptr, 0, dX, lddx, C, dtype,
+                 1.f, 0.f, 0.f, (hipStream_t)stream);
+}
+
+SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y, int64_t ldy,
+                   int64_t C, int dtype, void* stream) {
+  SG_REQUIRE(n >= 0 && C >= 0, "sg_gather_rows: negative size");
+  if (n == 0 || C == 0) return SG_OK;
+  SG_REQUIRE(rows && X && Y, "sg_gather_rows: null pointer");
+  SG_REQUIRE(ldx >= C && ldy >= C, "sg_gather_rows: stride < C");
+  return launch_gather_rows(rows, n, X, ldx, Y, ldy, C, dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Internal declarations shared by the HIP translation units of libsemigcn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "semigcn.h"
+
+namespace sg {
+
+void set_error(const char* fmt, ...);
+
+#define SG_HIP_TRY(expr)                                                              \
+  do {                                                                                \
+    hipError_t e__ = (expr);                                                          \
+    if (e__ != hipSuccess) {                                                          \
+      sg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                    __LINE__);                                                        \
+      return SG_ERR_HIP;                                                              \
+    }                                                                                 \
+  } while (0)
+
+#define SG_REQUIRE(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      sg::set_error(__VA_ARGS__);  \
+      return SG_ERR_INVALID;       \
+    }                              \
+  } while (0)
+
+// Bipartite CSR: for each of n_rows destination rows, the list of source columns.
+struct Csr {
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  int32_t* rowptr = nullptr;  // [n_rows + 1] device
+  int32_t* idx = nullptr;     // [nnz] device, ascending inside a row
+  int32_t max_degree = 0;
+  void release();
+};
+
+// Builds a Csr from (dst, src) int64 device pairs. Pairs with dst == src are dropped when
+// drop_self. If keys_out != nullptr the sorted (dst << 32 | src) keys (n entries, dropped
+// pairs sort last) are left there for the caller (device buffer of n uint64).
+int build_csr(const int64_t* dst, const int64_t* src, int64_t n, int64_t n_rows, int64_t n_cols,
+              bool drop_self, hipStream_t stream, Csr* out, uint64_t* keys_out);
+
+// out[i] = (rowptr[i+1]-rowptr[i])^-1/2 (0 where the row is empty); or 1/count when inv_only.
+int degree_scale(const Csr& c, bool inv_sqrt, float* out, hipStream_t stream);
+// *equal = 1 iff the first n keys of a and b are identical.
+int keys_equal(const uint64_t* a, const uint64_t* b, int64_t n, hipStream_t stream, int* equal);
+
+struct SpmmArgs {
+  const int32_t* rowptr;
+  const int32_t* idx;
+  const float* scale_dst;  // nullable, [n_rows]
+  const float* scale_src;  // nullable, [n_cols]
+  const void* X;
+  const void* X0;  // nullable
+  const void* X1;  // nullable
+  void* Y;
+  int64_t ldx, ldx0, ldx1, ldy;
+  int32_t n_rows;
+  int32_t C;
+  float alpha, beta, gamma;
+};
+
+// Y[r] = alpha * sd[r] * sum_k ss[idx[k]] * X[idx[k]] + beta * X0[r] + gamma * X1[r]
+int launch_spmm(const SpmmArgs& a, int dtype, hipStream_t stream);
+int launch_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y,
+                       int64_t ldy, int64_t C, int dtype, hipStream_t stream);
+
+}  // namespace sg
+
+struct sg_graph {
+  sg::Csr fwd;            // rows = targets, cols = sources
+  sg::Csr bwd;            // transposed; empty when symmetric
+  float* dis_dst = nullptr;  // [V_dst]
+  float* dis_src = nullptr;  // [V_src]; == dis_dst for square graphs
+  bool symmetric = true;
+  bool square = true;
+};
+
+struct sg_pool {
+  sg::Csr by_coarse;  // rows = coarse, cols = fine
+  sg::Csr by_fine;    // rows = fine, cols = coarse
+  float* inv_count = nullptr;  // [n_coarse]
+};

@@ -1,0 +1,382 @@
+// Edge aggregation for gfx950: Y[r] = alpha*sd[r] * sum_{k in row r} ss[idx[k]] * X[idx[k]]
+//                                       + beta*X0[r] + gamma*X1[r]
+//
+// Replaces MessagePassing.propagate -> torch_scatter.scatter(sum) -> ATen scatter_add_ [3P]
+// (the two `propagate` calls per ChebConv.forward reached from util/networks.py:42,49 and
+// util/meshnet.py:40-58,106-124,224-240), its autograd transposes, and the sparse mm of
+// MeshPool / MeshUnpool (util/meshnet.py:14-17,25-27).
+//
+// Design (HBM-bound; no MFMA on purpose):
+//  * CSR rows, one owner per output row -> no atomics, deterministic, Y written once.  The
+//    reference materialises an [E+2V, C] message tensor per call; here X is gathered straight
+//    into registers and reduced there.
+//  * A row of C features is spread over G = C/VEC lanes (16-byte vectors: 4 f32 / 8 bf16 per
+//    lane), so a 64-lane wavefront owns 64/G rows at a time and every gather instruction
+//    moves whole 16-B..1-KiB row segments.  C > 64*VEC uses R vectors per lane.
+//  * Each wavefront owns a chunk of `ch` consecutive rows.  Its row pointers and its whole
+//    neighbour list (index + deg^-1/2 of the neighbour) are staged ONCE into LDS with
+//    coalesced loads, so the inner loop's only global traffic is the feature gather; the
+//    dependent rowptr -> idx -> scale chain is paid once per chunk, not once per row.
+//  * Up to U gathers are issued back to back per row before the first FMA (U*16 B per lane in
+//    flight), which is what hides HBM/L2 latency at 8 waves per SIMD.
+//  * Chunks are dealt to workgroups so that the workgroups sharing an XCD (blockIdx % 8)
+//    sweep one contiguous range of rows: neighbouring rows' gathers then hit that XCD's L2.
+#include "sg_common.h"
+
+namespace sg {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kChMax = 64;   // rows per wavefront chunk (upper bound)
+constexpr int kCap = 512;    // staged neighbour slots per wavefront
+
+struct bf16_tag {};
+
+template <typename T> struct Vt;
+template <> struct Vt<float> {
+  static constexpr int VEC = 4;
+  using raw = float4;
+  using elem = float;
+  static __device__ __forceinline__ void unpack(const raw& v, float* f) {
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  static __device__ __forceinline__ raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+  static __device__ __forceinline__ float load1(const void* p, int64_t i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void store1(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct Vt<bf16_tag> {
+  static constexpr int VEC = 8;
+  using raw = uint4;
+  using elem = uint16_t;
+  static __device__ __forceinline__ void unpack(const raw& v, float* f) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ uint32_t cvt2(float lo, float hi) {
+    // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+    uint16_t a = __builtin_bit_cast(uint16_t, (__bf16)lo);
+    uint16_t b = __builtin_bit_cast(uint16_t, (__bf16)hi);
+    return (uint32_t)a | ((uint32_t)b << 16);
+  }
+  static __device__ __forceinline__ raw pack(const float* f) {
+    return make_uint4(cvt2(f[0], f[1]), cvt2(f[2], f[3]), cvt2(f[4], f[5]), cvt2(f[6], f[7]));
+  }
+  static __device__ __forceinline__ float load1(const void* p, int64_t i) {
+    return __uint_as_float((uint32_t)((const uint16_t*)p)[i] << 16);
+  }
+  static __device__ __forceinline__ void store1(void* p, int64_t i, float v) {
+    ((uint16_t*)p)[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+  }
+};
+
+// Workgroups b and b+8 share an XCD (round-robin dispatch; speed only, never correctness).
+// Give each XCD label one contiguous run of tiles; bijective for every nblocks.
+__device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = b & 7, slot = b >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+template <typename T, int G, int R, int U>
+__global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int ch, const int nblocks) {
+  using V = Vt<T>;
+  constexpr int VEC = V::VEC;
+  constexpr int RPW = 64 / G;  // rows a wavefront works on simultaneously
+  using raw_t = typename V::raw;
+  using elem_t = typename V::elem;
+
+  __shared__ int32_t s_rp[kWaves][kChMax + 1];
+  __shared__ int2 s_e[kWaves][kCap];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tile = xcd_contiguous(blockIdx.x, nblocks);
+  const int r0 = (tile * kWaves + wave) * ch;
+  int nrows = a.n_rows - r0;
+  nrows = nrows < 0 ? 0 : (nrows > ch ? ch : nrows);
+
+  // ---- stage this chunk's row pointers and neighbour list in LDS (coalesced) ----
+  if (nrows > 0)
+    for (int l = lane; l <= nrows; l += 64) s_rp[wave][l] = a.rowptr[r0 + l];
+  __syncthreads();
+  int e0 = 0, ne = 0;
+  if (nrows > 0) {
+    e0 = s_rp[wave][0];
+    ne = s_rp[wave][nrows] - e0;
+  }
+  const bool staged = ne <= kCap;  // wave-uniform; a chunk with a huge row reads idx from global
+  if (staged) {
+    for (int k = lane; k < ne; k += 64) {
+      const int j = a.idx[e0 + k];
+      const float w = a.scale_src ? a.scale_src[j] : 1.0f;
+      s_e[wave][k] = make_int2(j, __float_as_int(w));
+    }
+  }
+  __syncthreads();
+
+  const int g = lane / G;   // which of the RPW simultaneous rows
+  const int gl = lane % G;  // lane inside the row group
+  const int nvec = a.C / VEC;
+  const elem_t* __restrict__ X = (const elem_t*)a.X;
+  const elem_t* __restrict__ X0 = (const elem_t*)a.X0;
+  const elem_t* __restrict__ X1 = (const elem_t*)a.X1;
+  elem_t* __restrict__ Y = (elem_t*)a.Y;
+
+  for (int it = 0; it * RPW < nrows; ++it) {
+    const int lr = it * RPW + g;
+    const bool rvalid = lr < nrows;
+    const int row = r0 + lr;
+    int ks = 0, ke = 0;
+    if (rvalid) {
+      ks = s_rp[wave][lr] - e0;
+      ke = s_rp[wave][lr + 1] - e0;
+    }
+    // issue the epilogue operands early so they fly with the gather
+    raw_t x0v[R], x1v[R];
+    float sdst = a.alpha;
+    if (rvalid) {
+      if (a.scale_dst) sdst *= a.scale_dst[row];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int vi = gl + r * G;
+        if (vi < nvec) {
+          if (X0) x0v[r] = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + vi * VEC);
+          if (X1) x1v[r] = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + vi * VEC);
+        }
+      }
+    }
+    float acc[R][VEC];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[r][c] = 0.f;
+
+    for (int k = ks; k < ke; k += U) {
+      int j[U];
+      float w[U];
+      bool v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int kk = k + u;
+        v[u] = kk < ke;
+        j[u] = 0;
+        w[u] = 0.f;
+        if (v[u]) {
+          if (staged) {
+            const int2 e = s_e[wave][kk];
+            j[u] = e.x;
+            w[u] = __int_as_float(e.y);
+          } else {
+            j[u] = a.idx[e0 + kk];
+            w[u] = a.scale_src ? a.scale_src[j[u]] : 1.0f;
+          }
+        }
+      }
+      raw_t xv[U][R];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (v[u]) {
+          const elem_t* src = X + (int64_t)j[u] * a.ldx;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int vi = gl + r * G;
+            if (vi < nvec) xv[u][r] = *(const raw_t*)(src + vi * VEC);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (v[u]) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (gl + r * G < nvec) {
+              float f[VEC];
+              V::unpack(xv[u][r], f);
+#pragma unroll
+              for (int c = 0; c < VEC; ++c) acc[r][c] = fmaf(w[u], f[c], acc[r][c]);
+            }
+          }
+        }
+      }
+    }
+
+    if (rvalid) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int vi = gl + r * G;
+        if (vi < nvec) {
+          float y[VEC];
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) y[c] = sdst * acc[r][c];
+          if (X0) {
+            float f[VEC];
+            V::unpack(x0v[r], f);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
+          }
+          if (X1) {
+            float f[VEC];
+            V::unpack(x1v[r], f);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
+          }
+          *(raw_t*)(Y + (int64_t)row * a.ldy + vi * VEC) = V::pack(y);
+        }
+      }
+    }
+  }
+}
+
+// Any C, any stride, any alignment: one thread per output element, lanes along the channel.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spmm_scalar(const SpmmArgs a) {
+  using V = Vt<T>;
+  const int64_t total = (int64_t)a.n_rows * a.C;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    const int row = (int)(t / a.C);
+    const int c = (int)(t - (int64_t)row * a.C);
+    float acc = 0.f;
+    for (int k = a.rowptr[row]; k < a.rowptr[row + 1]; ++k) {
+      const int j = a.idx[k];
+      const float w = a.scale_src ? a.scale_src[j] : 1.0f;
+      acc = fmaf(w, V::load1(a.X, (int64_t)j * a.ldx + c), acc);
+    }
+    float y = a.alpha * (a.scale_dst ? a.scale_dst[row] : 1.0f) * acc;
+    if (a.X0) y = fmaf(a.beta, V::load1(a.X0, (int64_t)row * a.ldx0 + c), y);
+    if (a.X1) y = fmaf(a.gamma, V::load1(a.X1, (int64_t)row * a.ldx1 + c), y);
+    V::store1(a.Y, (int64_t)row * a.ldy + c, y);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_rows_vec(const int32_t* __restrict__ rows, int64_t n,
+                                                          const void* X, int64_t ldx, void* Y,
+                                                          int64_t ldy, int nvec) {
+  using V = Vt<T>;
+  using raw_t = typename V::raw;
+  using elem_t = typename V::elem;
+  const int64_t total = n * nvec;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = t / nvec;
+    const int vi = (int)(t - i * nvec);
+    const raw_t v = *(const raw_t*)((const elem_t*)X + (int64_t)rows[i] * ldx + vi * V::VEC);
+    *(raw_t*)((elem_t*)Y + i * ldy + vi * V::VEC) = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_rows_scalar(const int32_t* __restrict__ rows, int64_t n,
+                                                             const void* X, int64_t ldx, void* Y,
+                                                             int64_t ldy, int C) {
+  using V = Vt<T>;
+  const int64_t total = n * C;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = t / C;
+    const int c = (int)(t - i * C);
+    V::store1(Y, i * ldy + c, V::load1(X, (int64_t)rows[i] * ldx + c));
+  }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int chunk_rows_override() {
+  static int v = [] {
+    const char* s = getenv("SG_SPMM_CH");
+    return s ? atoi(s) : 0;
+  }();
+  return v;
+}
+
+template <typename T, int G, int R, int U>
+int launch_rows(const SpmmArgs& a, hipStream_t stream) {
+  constexpr int RPW = 64 / G;
+  // rows per wavefront chunk: large enough to amortise staging, small enough to keep
+  // >> 256 workgroups in flight on small meshes
+  int ch = chunk_rows_override();
+  if (ch <= 0) {
+    ch = 32;
+    while (ch > RPW && (int64_t)a.n_rows / ch < 8192) ch >>= 1;
+  }
+  if (ch < RPW) ch = RPW;
+  if (ch > kChMax) ch = kChMax;
+  ch = (ch / RPW) * RPW;
+  const int64_t chunks = ((int64_t)a.n_rows + ch - 1) / ch;
+  const int nblocks = (int)((chunks + kWaves - 1) / kWaves);
+  spmm_rows<T, G, R, U><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+template <typename T>
+int launch_typed(const SpmmArgs& a, hipStream_t stream) {
+  constexpr int VEC = Vt<T>::VEC;
+  constexpr int esz = sizeof(typename Vt<T>::elem);
+  const bool vec_ok = a.C % VEC == 0 && a.ldx % VEC == 0 && a.ldy % VEC == 0 && aligned16(a.X) &&
+                      aligned16(a.Y) && (!a.X0 || (a.ldx0 % VEC == 0 && aligned16(a.X0))) &&
+                      (!a.X1 || (a.ldx1 % VEC == 0 && aligned16(a.X1))) && a.C / VEC <= 256;
+  (void)esz;
+  if (!vec_ok) {
+    const int64_t total = (int64_t)a.n_rows * a.C;
+    int64_t nb = (total + kBlock - 1) / kBlock;
+    if (nb > 256 * 32) nb = 256 * 32;
+    spmm_scalar<T><<<(int)nb, kBlock, 0, stream>>>(a);
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
+  }
+  const int nvec = a.C / VEC;
+  if (nvec <= 1) return launch_rows<T, 1, 1, 8>(a, stream);
+  if (nvec <= 2) return launch_rows<T, 2, 1, 8>(a, stream);
+  if (nvec <= 4) return launch_rows<T, 4, 1, 8>(a, stream);
+  if (nvec <= 8) return launch_rows<T, 8, 1, 8>(a, stream);
+  if (nvec <= 16) return launch_rows<T, 16, 1, 8>(a, stream);
+  if (nvec <= 32) return launch_rows<T, 32, 1, 8>(a, stream);
+  if (nvec <= 64) return launch_rows<T, 64, 1, 8>(a, stream);
+  if (nvec <= 128) return launch_rows<T, 64, 2, 4>(a, stream);
+  return launch_rows<T, 64, 4, 2>(a, stream);
+}
+
+}  // namespace
+
+int launch_spmm(const SpmmArgs& a, int dtype, hipStream_t stream) {
+  if (a.n_rows == 0 || a.C == 0) return SG_OK;
+  switch (dtype) {
+    case SG_F32: return launch_typed<float>(a, stream);
+    case SG_BF16: return launch_typed<bf16_tag>(a, stream);
+    default: set_error("unsupported dtype %d", dtype); return SG_ERR_UNSUPPORTED;
+  }
+}
+
+int launch_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y,
+                       int64_t ldy, int64_t C, int dtype, hipStream_t stream) {
+  if (n == 0 || C == 0) return SG_OK;
+  auto run = [&](auto tag) -> int {
+    using T = decltype(tag);
+    constexpr int VEC = Vt<T>::VEC;
+    const bool vec_ok = C % VEC == 0 && ldx % VEC == 0 && ldy % VEC == 0 && aligned16(X) && aligned16(Y);
+    const int64_t total = vec_ok ? n * (C / VEC) : n * C;
+    int64_t nb = (total + kBlock - 1) / kBlock;
+    if (nb > 256 * 16) nb = 256 * 16;
+    if (vec_ok)
+      gather_rows_vec<T><<<(int)nb, kBlock, 0, stream>>>(rows, n, X, ldx, Y, ldy, (int)(C / VEC));
+    else
+      gather_rows_scalar<T><<<(int)nb, kBlock, 0, stream>>>(rows, n, X, ldx, Y, ldy, (int)C);
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
+  };
+  switch (dtype) {
+    case SG_F32: return run(float{});
+    case SG_BF16: return run(bf16_tag{});
+    default: set_error("unsupported dtype %d", dtype); return SG_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace sg

@@ -1,0 +1,139 @@
+"""Autograd wrappers around the HIP kernels (forward AND backward call sg_spmm / sg_pool_*).
+
+``cheb_conv`` is the whole of ChebConv.forward [3P torch_geometric 2.2.0] (call
+sites util/networks.py:42,49; util/meshnet.py:40-240):
+
+    Tx0 = x, Tx1 = L^ x, Txk = 2 L^ Tx(k-1) - Tx(k-2),  out = sum_k Txk Wk^T + b
+
+The K terms are written side by side into one [V, K*Cin] buffer by the
+aggregation kernel (strided output, fused ``2 L^ X - X0`` epilogue), so the K
+bias-free ``linear`` calls of the reference collapse into ONE [V,K*Cin] x
+[K*Cin,Cout] GEMM (hipBLASLt through torch.addmm; MFMA work stays in the GEMM).
+Backward: dT = dOut Wcat (one GEMM), dWcat = dOut^T T (one GEMM), then the
+recurrence is unwound with K-1 fused aggregations (L^ is symmetric for a mesh;
+otherwise the transposed CSR kept by sg_graph_create is used).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import capi
+from .graph import MeshGraph
+
+
+class _ChebConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph: MeshGraph, x: torch.Tensor, bias: Optional[torch.Tensor], *weights: torch.Tensor):
+        K = len(weights)
+        V, C = x.shape
+        wcat = weights[0] if K == 1 else torch.cat(list(weights), dim=1)  # [Cout, K*C]
+        wcat = wcat.to(x.dtype)
+        if K == 1:
+            T = x.contiguous()
+        else:
+            T = torch.empty((V, K * C), dtype=x.dtype, device=x.device)
+            blk = [T[:, k * C:(k + 1) * C] for k in range(K)]
+            blk[0].copy_(x)
+            graph.aggregate(blk[0], blk[1], alpha=1.0)
+            for k in range(2, K):
+                graph.aggregate(blk[k - 1], blk[k], alpha=2.0, X0=blk[k - 2], beta=-1.0)
+        if bias is not None:
+            out = torch.addmm(bias.to(x.dtype), T, wcat.t())
+        else:
+            out = T @ wcat.t()
+        ctx.graph, ctx.K, ctx.C = graph, K, C
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(T, wcat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        T, wcat = ctx.saved_tensors
+        graph, K, C = ctx.graph, ctx.K, ctx.C
+        dout = dout.contiguous()
+        need_x, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_w = any(ctx.needs_input_grad[3:])
+        dws = [None] * K
+        if need_w:
+            dwcat = dout.t() @ T  # [Cout, K*C]
+            dws = [dwcat[:, k * C:(k + 1) * C] for k in range(K)]
+        db = dout.sum(0) if (ctx.has_bias and need_b) else None
+        dx = None
+        if need_x:
+            dT = dout @ wcat  # [V, K*C]; block k = dL/dTx_k before the recurrence is unwound
+            if K == 1:
+                dx = dT
+            else:
+                g = [dT[:, k * C:(k + 1) * C] for k in range(K)]
+                tr = not graph.symmetric
+                # g_k += 2 L^T g_(k+1) - g_(k+2), highest k first, in place (Y may alias X0)
+                for k in range(K - 2, 0, -1):
+                    x1 = g[k + 2] if k + 2 <= K - 1 else None
+                    graph.aggregate(g[k + 1], g[k], alpha=2.0, X0=g[k], beta=1.0, X1=x1, gamma=-1.0,
+                                    transpose=tr)
+                dx = torch.empty((T.shape[0], C), dtype=dout.dtype, device=dout.device)
+                x1 = g[2] if K >= 3 else None
+                graph.aggregate(g[1], dx, alpha=1.0, X0=g[0], beta=1.0, X1=x1, gamma=-1.0, transpose=tr)
+        return (None, dx, db, *dws)
+
+
+def cheb_conv(graph: MeshGraph, x: torch.Tensor, weights: Sequence[torch.Tensor],
+              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ChebConv forward on a prepared graph; ``weights[k]`` is ``lins[k].weight`` [Cout, Cin]."""
+    if x.dim() != 2:
+        raise ValueError(f"x must be [V, C], got {tuple(x.shape)}")
+    if x.shape[0] != graph.num_vertices:
+        raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.num_vertices} vertices")
+    return _ChebConvFn.apply(graph, x, bias, *weights)
+
+
+class _LaplacianFn(torch.autograd.Function):
+    """y = alpha * L^ x (+ beta * x0): the bare `propagate` step, differentiable."""
+
+    @staticmethod
+    def forward(ctx, graph: MeshGraph, x, alpha: float, x0, beta: float):
+        x = x.contiguous() if x.stride(-1) != 1 else x
+        y = torch.empty((graph.handle.num_rows, x.shape[1]), dtype=x.dtype, device=x.device)
+        graph.aggregate(x, y, alpha=alpha, X0=x0, beta=beta)
+        ctx.graph, ctx.alpha, ctx.beta = graph, alpha, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.graph
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty((g.handle.num_cols, dy.shape[1]), dtype=dy.dtype, device=dy.device)
+            g.aggregate(dy, dx, alpha=ctx.alpha, transpose=not g.symmetric)
+        dx0 = ctx.beta * dy if ctx.needs_input_grad[3] else None
+        return None, dx, None, dx0, None
+
+
+def laplacian_apply(graph: MeshGraph, x, alpha: float = 1.0, x0=None, beta: float = 0.0):
+    return _LaplacianFn.apply(graph, x, alpha, x0, beta)
+
+
+class _PoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pool: capi.PoolHandle, x, mode: str):
+        ctx.pool, ctx.mode = pool, mode
+        return pool.pool_mean(x) if mode == "pool" else pool.unpool(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = ctx.pool.pool_mean_bwd(dy) if ctx.mode == "pool" else ctx.pool.unpool_bwd(dy)
+        return None, dx, None
+
+
+def mesh_pool(pool: capi.PoolHandle, x: torch.Tensor) -> torch.Tensor:
+    """MeshPool.forward (util/meshnet.py:14-17): cluster mean."""
+    return _PoolFn.apply(pool, x, "pool")
+
+
+def mesh_unpool(pool: capi.PoolHandle, x: torch.Tensor) -> torch.Tensor:
+    """MeshUnpool.forward (util/meshnet.py:25-27): gather by pool_hash."""
+    return _PoolFn.apply(pool, x, "unpool")

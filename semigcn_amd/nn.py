@@ -1,0 +1,148 @@
+"""Operator tier of the drop-in boundary: what the reference imports from
+``torch_geometric.nn`` (util/networks.py:4, util/meshnet.py:6) -- ``ChebConv``,
+``GCNConv`` (name only) and ``Sequential`` -- with the same constructor
+arguments, parameter names/shapes (``lins.{k}.weight`` [Cout, Cin], ``bias``
+[Cout]), child naming (``module_{i}``) and call signatures, running on the HIP
+kernels.  ``semigcn_amd.compat.install()`` makes ``import torch_geometric``
+resolve here so the reference's scripts run unmodified.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import functional as F_sg
+from .graph import MeshGraph, graph_for
+
+
+class _GlorotLinear(nn.Module):
+    """Bias-free weight holder equal to torch_geometric's ``Linear(in, out, bias=False,
+    weight_initializer='glorot')``: ``weight`` [out, in] ~ U(-a, a), a = sqrt(6/(in+out))."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = math.sqrt(6.0 / (self.in_channels + self.out_channels))
+        nn.init.uniform_(self.weight, -bound, bound)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return x @ self.weight.t()
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, bias=False"
+
+
+class ChebConv(nn.Module):
+    """Chebyshev spectral graph convolution, ``ChebConv(in, out, K, normalization='sym',
+    bias=True)``; ``forward(x[V,Cin], edge_index[2,E]) -> [V,Cout]``.
+
+    The scaled Laplacian of ``edge_index`` is prepared once (graph cache) instead
+    of once per call; ``forward`` also accepts an already prepared ``MeshGraph``
+    in place of ``edge_index``."""
+
+    def __init__(self, in_channels: int, out_channels: int, K: int, normalization: Optional[str] = "sym",
+                 bias: bool = True, **kwargs):
+        super().__init__()
+        if K <= 0:
+            raise ValueError("K must be positive")
+        if normalization != "sym":
+            raise NotImplementedError("only normalization='sym' (the reference's setting) is implemented")
+        self.in_channels, self.out_channels, self.K = in_channels, out_channels, K
+        self.normalization = normalization
+        self.lins = nn.ModuleList([_GlorotLinear(in_channels, out_channels) for _ in range(K)])
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for lin in self.lins:
+            lin.reset_parameters()
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def forward(self, x: Tensor, edge_index: Union[Tensor, MeshGraph], edge_weight=None, batch=None,
+                lambda_max=None) -> Tensor:
+        if edge_weight is not None or batch is not None or lambda_max is not None:
+            raise NotImplementedError("edge_weight / batch / lambda_max are not used by the reference "
+                                      "and are not implemented")
+        graph = edge_index if isinstance(edge_index, MeshGraph) else graph_for(edge_index, x.shape[0])
+        return F_sg.cheb_conv(graph, x, [lin.weight for lin in self.lins], self.bias)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, K={self.K}, "
+                f"normalization={self.normalization})")
+
+
+class GCNConv(nn.Module):
+    """Importable by name only: every ``conv == "gcnconv"`` branch of the reference is
+    dead code (util/networks.py:13,21-37; util/meshnet.py:36,64-90,131-158)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("GCNConv is never instantiated by SeMIGCN (conv is hard-wired to "
+                                  "'chebconv'); only ChebConv is implemented")
+
+
+def _signature(desc: str) -> Tuple[List[str], List[str]]:
+    if "->" not in desc:
+        raise ValueError(f"bad Sequential signature {desc!r}")
+    lhs, rhs = desc.split("->")
+    return [a.strip() for a in lhs.split(",") if a.strip()], [a.strip() for a in rhs.split(",") if a.strip()]
+
+
+class Sequential(nn.Module):
+    """``Sequential(input_args, [(module, "x, edge_index -> x"), module, ...])``.
+
+    Children are registered as ``module_0 .. module_{n-1}`` (so reference
+    checkpoints' keys such as ``blocks.3.module_0.lins.1.weight`` load); an entry
+    without a signature string maps the previous entry's outputs to themselves."""
+
+    def __init__(self, input_args: str, modules: Sequence[Union[nn.Module, Tuple[nn.Module, str]]]):
+        super().__init__()
+        self._args = [a.strip() for a in input_args.split(",") if a.strip()]
+        self._plan: List[Tuple[str, List[str], List[str]]] = []
+        last_out: Optional[List[str]] = None
+        for i, entry in enumerate(modules):
+            if isinstance(entry, (tuple, list)):
+                module, desc = entry
+                ins, outs = _signature(desc)
+            else:
+                module = entry
+                if last_out is None:
+                    raise ValueError("the first entry of Sequential needs an explicit signature")
+                ins, outs = list(last_out), list(last_out)
+            name = f"module_{i}"
+            if isinstance(module, nn.Module):
+                self.add_module(name, module)
+            else:
+                object.__setattr__(self, name, module)
+            self._plan.append((name, ins, outs))
+            last_out = outs
+
+    def forward(self, *args, **kwargs):
+        scope = dict(zip(self._args, args))
+        scope.update(kwargs)
+        result = None
+        for name, ins, outs in self._plan:
+            result = getattr(self, name)(*[scope[a] for a in ins])
+            if len(outs) == 1:
+                scope[outs[0]] = result
+            else:
+                scope.update(zip(outs, result))
+        return result
+
+    def __len__(self):
+        return len(self._plan)
+
+    def __getitem__(self, i: int):
+        return getattr(self, self._plan[i][0])

@@ -1,0 +1,91 @@
+"""Shared by oracle/make_golden.py (writer) and the tests (readers): deterministic
+parameter fill that does not depend on torch's RNG stream (numpy RandomState is
+frozen by policy), so golden files hold inputs/outputs but not megabytes of weights.
+"""
+from __future__ import annotations
+
+import math
+import os
+import zlib
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _seed_for(name: str, seed: int) -> int:
+    return (zlib.crc32(name.encode()) + 1000003 * seed) % (2 ** 31 - 1)
+
+
+def fill_state(module: torch.nn.Module, seed: int) -> None:
+    """Overwrite every floating parameter/buffer of ``module`` in place, keyed by its
+    state-dict name: 2-D weights glorot-uniform, BatchNorm scale/var in [0.5, 1.5], every
+    other vector in [-0.1, 0.1].  Sparse and integer buffers are left alone."""
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if t.is_sparse or not t.is_floating_point():
+                continue
+            rs = np.random.RandomState(_seed_for(name, seed))
+            if t.dim() == 2:
+                b = math.sqrt(6.0 / (t.shape[0] + t.shape[1]))
+                v = rs.uniform(-b, b, size=tuple(t.shape))
+            elif name.endswith("running_var") or (name.endswith("weight") and t.dim() == 1):
+                v = rs.uniform(0.5, 1.5, size=tuple(t.shape))
+            else:
+                v = rs.uniform(-0.1, 0.1, size=tuple(t.shape))
+            t.copy_(torch.from_numpy(v.astype(np.float32)).to(t.device))
+
+
+def probe(name: str, shape, seed: int = 7) -> np.ndarray:
+    """Fixed random direction used to compress a big gradient into one number."""
+    rs = np.random.RandomState(_seed_for("probe/" + name, seed))
+    return rs.standard_normal(size=tuple(shape)).astype(np.float32)
+
+
+def grad_summary(named_grads, full_below: int = 3000):
+    """{name: full grad} for small tensors, {name+'#dot', name+'#norm'} for big ones."""
+    out = {}
+    for name, g in named_grads:
+        g = g.detach().cpu().float().numpy()
+        if g.size <= full_below:
+            out[name] = g
+        else:
+            out[name + "#dot"] = np.float64((g.astype(np.float64) * probe(name, g.shape)).sum())
+            out[name + "#norm"] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+    return out
+
+
+def check_grad_summary(named_grads, golden, rtol: float, where: str = "", floor_frac: float = 1e-2):
+    """Assert gradients match a summary written by ``grad_summary``.  Relative to the
+    tensor's own scale in L2: |a-b|_2 <= rtol * max(|b|_2, floor * sqrt(n)) with floor =
+    floor_frac * the largest gradient entry of the whole model.  (L2, not max: a single
+    LeakyReLU sign flip caused by 1-ulp noise moves ONE channel's gradient by ~1/V.)  The floor matters for the
+    ChebConv biases in front of a BatchNorm, whose true gradient is exactly zero (BN removes
+    constant shifts) so that what autograd returns there is rounding noise."""
+    named_grads = list(named_grads)
+    abs_floor = floor_frac * max(float(np.abs(v).max()) for k, v in golden.items() if not k.endswith("#dot"))
+    for name, g in named_grads:
+        g = g.detach().cpu().float().numpy()
+        if name in golden:
+            ref = golden[name].astype(np.float64)
+            scale = max(float(np.sqrt((ref ** 2).sum())), abs_floor * np.sqrt(ref.size))
+            err = float(np.sqrt(((g - ref) ** 2).sum())) / scale
+            assert err <= rtol, f"{where}{name}: rel L2 err {err:.3e} > {rtol:.1e}"
+        else:
+            dot = float((g.astype(np.float64) * probe(name, g.shape)).sum())
+            norm = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            rn = float(golden[name + "#norm"])
+            # |<g - ref, p>| ~ |g - ref| for a unit-variance probe
+            assert abs(dot - float(golden[name + "#dot"])) <= rtol * max(rn, abs_floor) * 8, \
+                f"{where}{name}: probe mismatch {dot} vs {float(golden[name + '#dot'])}"
+            assert abs(norm - rn) <= rtol * max(rn, abs_floor) * 8, f"{where}{name}: norm mismatch"
+
+
+def rel_l2(a, b) -> float:
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
+def load(name: str):
+    return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
