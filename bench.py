@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: SGCN training iterations (forward + loss + backward, Adam every
+5th iteration -- the loop of /root/reference/sgcn.py:118-147) on a synthetic closed manifold
+mesh of V = 1 M vertices / E = 6 M directed edges (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `value` = training iterations per second of the whole job,
+inputs resident in HBM; `roofline` = the dominant edge-aggregation kernel's ALGORITHMIC
+bytes per launch / its mean launch duration measured with HIP events over the timed region;
+`cpu_baseline` = the oracle's PyG-equivalent ATen path on this box's host cores on a bounded
+sample (a reported baseline, not the target).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+AGG_PER_ITER = 52              # SGCN: 26 aggregations forward + 26 backward
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg: str):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mesh", default="1000x1000", help="torus nu x nv (per job at N=1; see --weak)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--permute", action="store_true", help="random vertex order (raw-scan like)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="250x200", help="torus for the CPU baseline sample")
+    ap.add_argument("--no-launch-timer", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(V: int, E: int, C: int, elem: int, n_epilogue: int) -> float:
+    """read X once + write Y (+ one read per epilogue operand), int32 column
+    index per edge, row pointers, deg^-1/2."""
+    return (2 + n_epilogue) * V * C * elem + 4.0 * E + 4.0 * (V + 1) + 4.0 * V
+
+
+def build_mesh_batch(mesh, device, n_masks: int):
+    from semigcn_amd import synth, train
+    V = mesh.num_vertices
+    faces = torch.from_numpy(mesh.faces).to(device)
+    target = torch.from_numpy(mesh.vs.astype(np.float32)).to(device)
+    v_keep = torch.from_numpy(mesh.v_mask.astype(np.float32)).view(-1, 1).to(device)
+    f_keep = (v_keep[faces[:, 0]] * v_keep[faces[:, 1]] * v_keep[faces[:, 2]])
+    dm = torch.from_numpy(synth.make_dummy_masks(mesh.edge_index, V, dm_size=n_masks, k=4, p=0.014, seed=317)).to(device)
+
+    class Data:
+        z1 = torch.from_numpy(mesh.z1).to(device).requires_grad_(True)   # util/datamaker.py:71
+        x_pos = torch.from_numpy(mesh.x_pos).to(device)
+        edge_index = torch.from_numpy(mesh.edge_index).to(device)
+
+    return train.MeshBatch(Data, faces, target, train.face_normals(target, faces), v_keep, f_keep, dm)
+
+
+def cpu_baseline(sample: str, full_V: int, budget_s: float = 20.0):
+    """Oracle (PyG-equivalent ATen ops on CPU) SGCN iteration on a smaller torus, scaled
+    linearly in V (the path is O(V) at fixed valence).  Bounded: a 5 K-vertex probe picks the
+    largest sample (<= `sample`) whose iterations fit `budget_s` seconds."""
+    from oracle import models as OM            # cpu_baseline leg: the only oracle use in bench.py
+    from semigcn_amd import synth
+    cores = min(os.cpu_count() or 1, 32)       # ATen's scatter/index kernels stop scaling long before that
+    torch.set_num_threads(cores)
+    torch.manual_seed(314)
+    net = OM.SGCNOracle().train()
+
+    def make(nu, nv):
+        m = synth.torus_mesh(nu, nv)
+        z1 = torch.from_numpy(m.z1).requires_grad_(True)
+        x_pos, ei = torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index)
+        faces = torch.from_numpy(m.faces)
+        tgt = torch.from_numpy(m.vs.astype(np.float32))
+        tfn = OM.compute_fn(tgt, faces)
+        f_mask = m.v_mask[m.faces].all(1)
+        dm = torch.from_numpy(synth.make_dummy_masks(m.edge_index, m.num_vertices, 1)).float()
+
+        def it():
+            net.zero_grad(set_to_none=True)
+            pos = net(z1, x_pos, ei, dm)
+            loss = OM.mask_pos_rec_loss(pos, tgt, m.v_mask) + 4.0 * OM.mask_norm_rec_loss(OM.compute_fn(pos, faces), tfn, f_mask)
+            loss.backward()
+        return m, it
+
+    t_start = time.perf_counter()
+    m, it = make(100, 50)
+    it()
+    t0 = time.perf_counter(); it(); probe = time.perf_counter() - t0
+    nu, nv = map(int, sample.split("x"))
+    per_vertex = probe / m.num_vertices
+    while nu * nv * per_vertex * 3 > budget_s and nu * nv > 2 * m.num_vertices:
+        nu, nv = max(nu * 3 // 4, 16), max(nv * 3 // 4, 16)
+    if nu * nv > m.num_vertices:
+        m, it = make(nu, nv)
+        it()                                    # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t_start < budget_s and n < 8):
+        it()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    scaled = (1.0 / dt) * (m.num_vertices / full_V)
+    return {"value": scaled, "unit": "iter/s", "cores": cores, "kind": "port",
+            "sample": f"{n} timed SGCN iterations (fwd+loss+bwd, fp32) of the oracle on a {m.nu}x{m.nv} torus "
+                      f"(V={m.num_vertices}, E={m.num_edges}), {dt:.2f} s each on {cores} threads "
+                      f"(host has {os.cpu_count()} logical CPUs), scaled linearly in V to V={full_V}",
+            "edges_aggregated_per_s": AGG_PER_ITER * m.num_edges / dt}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from semigcn_amd import capi, synth, train
+    from semigcn_amd.networks import SingleScaleGCN
+    capi.load()
+
+    log("library loaded")
+    nu, nv = map(int, args.mesh.split("x"))
+    dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
+    if world > 1:
+        from semigcn_amd import dist as sgdist
+        job = sgdist.build_weak_scaling_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype)
+        trainer, V_total, E_total, workload = job.trainer, job.V_total, job.E_total, job.workload
+    else:
+        mesh = synth.torus_mesh(nu, nv, permute=args.permute)
+        V_total, E_total = mesh.num_vertices, mesh.num_edges
+        log(f"mesh generated V={V_total} E={E_total}")
+        batch = build_mesh_batch(mesh, device, n_masks=5)
+        log("mesh resident on device")
+        torch.manual_seed(314)                               # sgcn.py:19-25,76
+        model = SingleScaleGCN(device).to(device)
+        if dtype != torch.float32:
+            model.set_feature_dtype(dtype)
+        trainer = train.SGCNTrainer(model, batch)
+        workload = (f"SGCN train iteration (13 ChebConv K=3 + BN + LeakyReLU, fwd+loss+bwd, Adam every 5th) on a "
+                    f"closed torus mesh {nu}x{nv}: V={V_total} E={E_total} directed, "
+                    f"{'random' if args.permute else 'grid'} vertex order")
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    log("model built; warm-up")
+    for i in range(args.warmup):
+        trainer.iteration_step()
+        torch.cuda.synchronize(device)
+        log(f"warm-up iteration {i} done")
+    timer = None if args.no_launch_timer else capi.LaunchTimer()
+    sync()
+    capi.set_launch_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.iteration_step()
+    sync()
+    dt = time.perf_counter() - t0
+    capi.set_launch_timer(None)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_mean = float(trainer.loss_sum.item()) / max(trainer.iteration, 1)
+    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/iteration")
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = args.steps / dt
+        elem = 4 if dtype == torch.float32 else 2
+        V_local = V_total // world
+        E_local = E_total // world
+        kernels, roof = [], None
+        if timer is not None:
+            res = timer.results()
+            for (C, dt_name, n_epi), times in sorted(res.items(), key=lambda kv: -sum(kv[1])):
+                mean_ms = float(np.mean(times))
+                B = algorithmic_bytes(V_local, E_local, C, elem, n_epi)
+                kernels.append({"C": C, "dtype": dt_name, "epilogue_operands": n_epi, "launches": len(times),
+                                "mean_ms": round(mean_ms, 4), "total_ms": round(float(np.sum(times)), 3),
+                                "algorithmic_MB": round(B / 1e6, 2), "achieved_GBs": round(B / mean_ms / 1e6, 1)})
+            total_B = sum(k["algorithmic_MB"] * k["launches"] for k in kernels)
+            total_t = sum(k["total_ms"] for k in kernels)
+            dom = kernels[0]
+            roof = {"bound": "hbm", "kernel": f"sg::spmm_rows C={dom['C']} {dom['dtype']} (+{dom['epilogue_operands']} epilogue operands)",
+                    "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "all_aggregations_GBs": round(total_B / total_t, 1),
+                    "all_aggregations_frac": round(total_B / total_t / HBM_PEAK_GBS, 4),
+                    "aggregation_share_of_step": round(total_t / (dt * 1e3), 4)}
+        line = {
+            "metric": "GCN train iters/sec + edges-aggregated/sec, 1M-vert mesh",
+            "value": value, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if dtype == torch.float32 else "bf16 storage / f32 accumulate", "data": "synthetic",
+            "config": {"workload": workload, "V": V_total, "E": E_total,
+                       "aggregations_per_iteration": AGG_PER_ITER},
+            "edges_aggregated_per_s": AGG_PER_ITER * E_total * value,
+            "optimizer_steps_per_s": value / 5.0,
+            "mean_loss": loss_mean,
+            "roofline": roof, "aggregation_kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, V_total)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,29 @@ _SIGNATURES = {
 _lib = None
 
 
+class LaunchTimer:
+    """Optional per-launch timing of the aggregation kernel with HIP events recorded on the
+    stream the kernel is launched on (torch's current stream).  bench.py installs one over
+    its timed region; ``results()`` must be called after a device synchronize."""
+
+    def __init__(self):
+        self.records = []  # (key, start_event, end_event)
+
+    def results(self):
+        out = {}
+        for key, a, b in self.records:
+            out.setdefault(key, []).append(a.elapsed_time(b))  # milliseconds
+        return out
+
+
+_timer: Optional[LaunchTimer] = None
+
+
+def set_launch_timer(timer: Optional[LaunchTimer]) -> None:
+    global _timer
+    _timer = timer
+
+
 def library_path() -> str:
     return _LIB_PATH
 
@@ -185,12 +208,20 @@ class GraphHandle:
         for t, n in ((X0, "X0"), (X1, "X1")):
             if t is not None and t.shape != (n_out, C):
                 raise SemigcnLibraryError(f"{n} shape {tuple(t.shape)} != {(n_out, C)}")
+        timer = _timer
         with torch.cuda.device(X.device):
+            if timer is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             _check(load().sg_spmm(self._h, int(transpose), _ptr(X), _rows2d(X, "X"),
                                   _ptr(X0), 0 if X0 is None else _rows2d(X0, "X0"),
                                   _ptr(X1), 0 if X1 is None else _rows2d(X1, "X1"),
                                   _ptr(Y), _rows2d(Y, "Y"), C, dtype_code(X),
                                   float(alpha), float(beta), float(gamma), _stream(X)), "sg_spmm")
+            if timer is not None:
+                ev1.record()
+                n_epi = int(X0 is not None) + int(X1 is not None)
+                timer.records.append(((C, str(X.dtype).replace("torch.", ""), n_epi), ev0, ev1))
         return Y
 
     def close(self):

@@ -1,0 +1,81 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/semigcn.h
+declares; the product has no CPU path and no route into oracle/."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from semigcn_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "semigcn.h")).read()
+    return re.findall(r"^SG_API\s+[\w\s\*]+?\b(sg_\w+)\s*\(", text, flags=re.M)
+
+
+def test_header_declares_expected_entry_points():
+    syms = header_symbols()
+    assert len(syms) == len(set(syms)) and len(syms) >= 16
+    for must in ("sg_graph_create", "sg_spmm", "sg_pool_mean", "sg_unpool", "sg_gather_rows", "sg_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_header_symbol():
+    assert os.path.isfile(capi.library_path()), "build with: make -C semigcn_amd/csrc"
+    lib = ctypes.CDLL(capi.library_path())
+    for name in header_symbols():
+        assert hasattr(lib, name), f"{name} declared in semigcn.h but not exported"
+
+
+def test_ctypes_signatures_cover_header():
+    assert sorted(capi._SIGNATURES) == sorted(header_symbols())
+    lib = capi.load()
+    assert lib.sg_abi_version() == 1
+    assert isinstance(lib.sg_last_error(), bytes)
+
+
+def test_argument_validation_without_gpu():
+    lib = capi.load()
+    out = ctypes.c_void_p()
+    assert lib.sg_graph_create(None, -1, 4, None, ctypes.byref(out)) == -1
+    assert b"negative" in lib.sg_last_error()
+    assert lib.sg_graph_create(None, 5, 4, None, ctypes.byref(out)) == -1
+    assert lib.sg_spmm(None, 0, None, 0, None, 0, None, 0, None, 0, 4, 0, 1.0, 0.0, 0.0, None) == -1
+    assert b"null graph" in lib.sg_last_error()
+    assert lib.sg_graph_destroy(None) == 0 and lib.sg_pool_destroy(None) == 0
+
+
+def test_no_cpu_fallback():
+    ei = torch.tensor([[0, 1], [1, 0]])
+    with pytest.raises(capi.SemigcnLibraryError, match="HIP device only"):
+        capi.GraphHandle.from_edge_index(ei, 2)
+    from semigcn_amd.nn import ChebConv
+    with pytest.raises(capi.SemigcnLibraryError):
+        ChebConv(4, 8, K=3)(torch.randn(2, 4), ei)
+    from semigcn_amd.networks import SingleScaleGCN
+
+    class D:
+        z1, x_pos, edge_index = torch.randn(2, 3), torch.randn(2, 3), ei
+    with pytest.raises(capi.SemigcnLibraryError):
+        SingleScaleGCN("cpu")(D)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "_LIB_PATH", "/nonexistent/libsemigcn_hip.so")
+    with pytest.raises(capi.SemigcnLibraryError, match="no CPU or PyTorch fallback"):
+        capi.load()
+
+
+def test_product_never_touches_oracle():
+    pkg = os.path.join(ROOT, "semigcn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "/root/reference" not in src or f in ("synth.py",) or "reference/" in src

@@ -1,0 +1,408 @@
+"""Parity tests proper: the HIP kernels, called through the C ABI, against the oracle on the
+same seeded inputs, against the committed golden vectors (reference's own code), and -- at
+benchmark size -- through size-independent properties.
+
+Tolerances (north_star: "within 1e-5 relative fp32"):
+  KERNEL_TOL  1e-5   max|a-b| / max|b| for one aggregation / one ChebConv layer, fp32
+  MODEL_TOL   1e-5   relative L2 for a 13-layer SGCN forward (oracle's own run-to-run noise ~2e-6)
+  bf16 storage: 2^-8 relative per stored value -> 1.5e-2 on layer outputs
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as GU
+from oracle import dense, models as OM, pyg_restatement as P
+from semigcn_amd import capi, nn as sgnn, synth
+from semigcn_amd.graph import MeshGraph, graph_for
+from semigcn_amd.networks import SingleScaleGCN
+
+pytestmark = pytest.mark.gpu
+KERNEL_TOL = 1e-5
+MODEL_TOL = 1e-5
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def oracle_lhat(edge_index, x, alpha=1.0, x0=None, beta=0.0, x1=None, gamma=0.0, transpose=False):
+    """alpha * L^ x + beta x0 + gamma x1 with the oracle's gather/scatter (CPU fp32)."""
+    ei, _ = P.remove_self_loops(edge_index)
+    row, col = ei[0], ei[1]
+    deg = P.scatter_sum(torch.ones(row.numel()), row, x.shape[0])
+    dis = deg.pow(-0.5)
+    dis[dis == float("inf")] = 0
+    w = -(dis[row] * dis[col])
+    src, dst = (col, row) if transpose else (row, col)
+    y = alpha * P.scatter_sum(w.view(-1, 1) * x.index_select(0, src), dst, x.shape[0])
+    if x0 is not None:
+        y = y + beta * x0
+    if x1 is not None:
+        y = y + gamma * x1
+    return y
+
+
+def nasty_graph(V=500, E=6000, seed=0):
+    rs = np.random.RandomState(seed)
+    ei = rs.randint(0, V - 1, size=(2, E))
+    ei[:, :50] = ei[:, 50:100]
+    ei[1, 100:150] = ei[0, 100:150]
+    ei[1, 200:1400] = 7          # one hub row with ~1200 neighbours: overflows the LDS stage
+    return torch.from_numpy(ei).long()
+
+
+# --------------------------------------------------------------------------------------
+# graph preprocessing (bit-exact integer work)
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("which", ["torus", "sphere", "nasty"])
+def test_graph_build_bit_exact(which, fixture_meshes):
+    if which == "nasty":
+        ei, V = nasty_graph(), 500
+    else:
+        m = fixture_meshes[which]
+        ei, V = torch.from_numpy(m.edge_index), m.num_vertices
+    h = capi.GraphHandle.from_edge_index(ei.to(DEV), V)
+    rp, ci, dis = [t.cpu().numpy() for t in h.arrays()]
+    e = ei.numpy()
+    e = e[:, e[0] != e[1]]
+    order = np.lexsort((e[0], e[1]))          # by (target, source)
+    assert h.nnz == e.shape[1]
+    assert np.array_equal(ci, e[0][order].astype(np.int32))
+    assert np.array_equal(rp, np.concatenate([[0], np.cumsum(np.bincount(e[1], minlength=V))]).astype(np.int32))
+    deg = np.bincount(e[0], minlength=V).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        want = np.where(deg > 0, 1.0 / np.sqrt(deg), 0).astype(np.float32)
+    assert np.abs(dis - want).max() <= 1.2e-7
+    key = lambda a, b: np.sort(a.astype(np.int64) * V + b)
+    assert h.symmetric == bool(np.array_equal(key(e[0], e[1]), key(e[1], e[0])))
+    assert h.max_degree == int(np.bincount(e[1], minlength=V).max())
+
+
+def test_graph_build_edge_cases():
+    empty = capi.GraphHandle.from_edge_index(torch.zeros((2, 0), dtype=torch.long, device=DEV), 5)
+    assert empty.nnz == 0 and empty.num_rows == 5
+    x = torch.randn(5, 8, device=DEV)
+    y = torch.full((5, 8), 3.0, device=DEV)
+    empty.spmm(x, y)
+    assert float(y.abs().max()) == 0.0
+    only_loops = capi.GraphHandle.from_edge_index(torch.tensor([[0, 1, 2], [0, 1, 2]], device=DEV), 3)
+    assert only_loops.nnz == 0
+    with pytest.raises(capi.SemigcnLibraryError, match="out of range"):
+        capi.GraphHandle.from_edge_index(torch.tensor([[0, 9], [1, 0]], device=DEV), 3)
+    with pytest.raises(capi.SemigcnLibraryError, match="int64"):
+        capi.GraphHandle.from_edge_index(torch.zeros((2, 4), dtype=torch.int32, device=DEV), 3)
+    zero_v = capi.GraphHandle.from_edge_index(torch.zeros((2, 0), dtype=torch.long, device=DEV), 0)
+    assert zero_v.num_rows == 0
+
+
+# --------------------------------------------------------------------------------------
+# aggregation kernel
+# --------------------------------------------------------------------------------------
+CHANNELS = [1, 3, 4, 5, 8, 12, 16, 32, 48, 64, 128, 256, 260, 512, 1024, 1028]
+
+
+@pytest.mark.parametrize("C", CHANNELS)
+@pytest.mark.parametrize("which", ["torus", "nasty"])
+def test_spmm_fp32_vs_oracle(C, which, fixture_meshes):
+    if which == "nasty":
+        ei, V = nasty_graph(), 500
+    else:
+        ei, V = torch.from_numpy(fixture_meshes["torus"].edge_index), 240
+    h = capi.GraphHandle.from_edge_index(ei.to(DEV), V)
+    rs = np.random.RandomState(C)
+    x, x0, x1 = (torch.from_numpy(rs.standard_normal((V, C)).astype(np.float32)) for _ in range(3))
+    for tr in ([False, True] if which == "nasty" else [False]):
+        want = oracle_lhat(ei, x, transpose=tr)
+        got = h.spmm(x.to(DEV), torch.empty(V, C, device=DEV), transpose=tr)
+        assert rel(got, want) < KERNEL_TOL
+        want = oracle_lhat(ei, x, 2.0, x0, -1.0, x1, 0.5, transpose=tr)
+        got = h.spmm(x.to(DEV), torch.empty(V, C, device=DEV), alpha=2.0, X0=x0.to(DEV), beta=-1.0,
+                     X1=x1.to(DEV), gamma=0.5, transpose=tr)
+        assert rel(got, want) < KERNEL_TOL
+
+
+def test_spmm_vs_dense_fp64_reference_matrix():
+    """Against the reference's own D^-1/2 A D^-1/2 (util/mesh.py:276-285) frozen in g0."""
+    g0 = GU.load("g0_mesh_layout.npz")
+    for name in ("sphere", "torus"):
+        ei = torch.from_numpy(g0[f"{name}/edge_index"])
+        L = g0[f"{name}/lhat_dense_ref"].astype(np.float64)
+        V = L.shape[0]
+        x = torch.from_numpy(np.random.RandomState(2).standard_normal((V, 64)).astype(np.float32))
+        got = capi.GraphHandle.from_edge_index(ei.to(DEV), V).spmm(x.to(DEV), torch.empty(V, 64, device=DEV))
+        assert rel(got, L @ x.double().numpy()) < 2e-6
+
+
+def test_spmm_strided_blocks_and_in_place_epilogue(fixture_meshes):
+    """Column blocks of one [V, 3C] buffer as X / X0 / Y (what cheb_conv does), Y aliasing X0."""
+    m = fixture_meshes["sphere"]
+    ei, V, C = torch.from_numpy(m.edge_index), m.num_vertices, 32
+    h = capi.GraphHandle.from_edge_index(ei.to(DEV), V)
+    T = torch.from_numpy(np.random.RandomState(3).standard_normal((V, 3 * C)).astype(np.float32))
+    Td = T.to(DEV)
+    h.spmm(Td[:, :C], Td[:, C:2 * C])
+    h.spmm(Td[:, C:2 * C], Td[:, 2 * C:], alpha=2.0, X0=Td[:, :C], beta=-1.0)
+    t1 = oracle_lhat(ei, T[:, :C])
+    t2 = oracle_lhat(ei, t1, 2.0, T[:, :C], -1.0)
+    assert torch.equal(Td[:, :C].cpu(), T[:, :C])
+    assert rel(Td[:, C:2 * C], t1) < KERNEL_TOL and rel(Td[:, 2 * C:], t2) < KERNEL_TOL
+    g = T.clone().to(DEV)                     # in place: Y is X0
+    h.spmm(g[:, 2 * C:], g[:, C:2 * C], alpha=2.0, X0=g[:, C:2 * C], beta=1.0)
+    assert rel(g[:, C:2 * C], oracle_lhat(ei, T[:, 2 * C:], 2.0, T[:, C:2 * C], 1.0)) < KERNEL_TOL
+    odd = torch.randn(V, 3 * C + 1, device=DEV)  # stride not a multiple of 4 -> scalar kernel
+    got = h.spmm(odd[:, 1:C + 1], torch.empty(V, C, device=DEV))
+    assert rel(got, oracle_lhat(ei, odd[:, 1:C + 1].cpu())) < KERNEL_TOL
+
+
+@pytest.mark.parametrize("C", [8, 16, 64, 256, 512, 24, 7])
+def test_spmm_bf16_storage(C, fixture_meshes):
+    m = fixture_meshes["torus"]
+    ei, V = torch.from_numpy(m.edge_index), m.num_vertices
+    h = capi.GraphHandle.from_edge_index(ei.to(DEV), V)
+    rs = np.random.RandomState(C)
+    x = torch.from_numpy(rs.standard_normal((V, C)).astype(np.float32)).bfloat16()
+    x0 = torch.from_numpy(rs.standard_normal((V, C)).astype(np.float32)).bfloat16()
+    want = oracle_lhat(ei, x.float(), 2.0, x0.float(), -1.0)      # fp32 math on the bf16 values
+    got = h.spmm(x.to(DEV), torch.empty(V, C, device=DEV, dtype=torch.bfloat16), alpha=2.0, X0=x0.to(DEV), beta=-1.0)
+    assert got.dtype == torch.bfloat16
+    assert rel(got.float(), want) < 2.0 ** -8     # one bf16 rounding of the fp32 result
+    assert torch.equal(got.cpu(), want.bfloat16()) or rel(got.float(), want.bfloat16().float()) < 2.0 ** -7
+
+
+def test_spmm_deterministic_and_rejects_bad_arguments(fixture_meshes):
+    m = fixture_meshes["torus"]
+    h = capi.GraphHandle.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), 240)
+    x = torch.randn(240, 64, device=DEV)
+    a = h.spmm(x, torch.empty_like(x)).clone()
+    for _ in range(3):
+        assert torch.equal(h.spmm(x, torch.empty_like(x)), a)
+    with pytest.raises(capi.SemigcnLibraryError, match="alias"):
+        h.spmm(x, x)
+    with pytest.raises(capi.SemigcnLibraryError, match="shape"):
+        h.spmm(x[:100], torch.empty(240, 64, device=DEV))
+    with pytest.raises(capi.SemigcnLibraryError, match="dtype"):
+        h.spmm(x.double(), torch.empty(240, 64, device=DEV, dtype=torch.float64))
+    with pytest.raises(capi.SemigcnLibraryError, match="HIP device only"):
+        h.spmm(x.cpu(), torch.empty(240, 64))
+
+
+# --------------------------------------------------------------------------------------
+# ChebConv layer: golden vectors (G1) + oracle autograd
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,cin,cout", [("sphere", 4, 16), ("sphere", 32, 64), ("sphere", 256, 512),
+                                           ("torus", 4, 16), ("torus", 32, 64), ("torus", 3, 5)])
+def test_chebconv_layer_vs_golden(name, cin, cout, fixture_meshes):
+    g1 = GU.load("g1_chebconv.npz")
+    tag = f"{name}/{cin}x{cout}"
+    m = fixture_meshes[name]
+    conv = sgnn.ChebConv(cin, cout, K=3)
+    GU.fill_state(conv, seed=11)
+    conv.to(DEV)
+    x = torch.from_numpy(g1[tag + "/x"]).to(DEV).requires_grad_(True)
+    y = conv(x, torch.from_numpy(m.edge_index).to(DEV))
+    assert rel(y, g1[tag + "/out"]) < KERNEL_TOL
+    (y * torch.from_numpy(g1[tag + "/r"]).to(DEV)).sum().backward()
+    assert rel(x.grad, g1[tag + "/dx"]) < KERNEL_TOL
+    golden = {k[len(tag + "/grad/"):]: g1[k] for k in g1.files if k.startswith(tag + "/grad/")}
+    GU.check_grad_summary([(n, p.grad) for n, p in conv.named_parameters()], golden, 2e-5, tag)
+    # accuracy arbiter: fp64 dense
+    y64 = dense.cheb_conv_dense(g1[tag + "/x"], m.edge_index,
+                                [l.weight.detach().cpu().numpy() for l in conv.lins], conv.bias.detach().cpu().numpy())
+    assert rel(y, y64) < KERNEL_TOL
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 5])
+def test_chebconv_asymmetric_graph_autograd(K):
+    ei, V = nasty_graph(), 500
+    mine, ora = sgnn.ChebConv(12, 20, K=K), P.ChebConv(12, 20, K=K)
+    GU.fill_state(ora, seed=5)
+    mine.load_state_dict(ora.state_dict())
+    mine.to(DEV)
+    rs = np.random.RandomState(K)
+    x = torch.from_numpy(rs.standard_normal((V, 12)).astype(np.float32))
+    r = torch.from_numpy(rs.standard_normal((V, 20)).astype(np.float32))
+    xa, xb = x.to(DEV).requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = mine(xa, ei.to(DEV)), ora(xb, ei)
+    assert rel(ya, yb) < KERNEL_TOL
+    (ya * r.to(DEV)).sum().backward()
+    (yb * r).sum().backward()
+    assert rel(xa.grad, xb.grad) < KERNEL_TOL
+    for (n, p), (_, q) in zip(mine.named_parameters(), ora.named_parameters()):
+        assert rel(p.grad, q.grad) < 2e-5, n
+
+
+# --------------------------------------------------------------------------------------
+# SGCN model vs the reference's own code (G2) and vs the fp64 oracle
+# --------------------------------------------------------------------------------------
+class _Data:
+    def __init__(self, m, device="cpu"):
+        self.z1 = torch.from_numpy(m.z1).to(device).requires_grad_(True)
+        self.x_pos = torch.from_numpy(m.x_pos).to(device)
+        self.edge_index = torch.from_numpy(m.edge_index).to(device)
+
+
+@pytest.mark.parametrize("name", ["sphere", "torus"])
+@pytest.mark.parametrize("skip", [False, True])
+def test_sgcn_vs_reference_golden(name, skip, fixture_meshes):
+    g2 = GU.load("g2_sgcn.npz")
+    m = fixture_meshes[name]
+    tag = f"{name}/skip{int(skip)}"
+    net = SingleScaleGCN(DEV, skip=skip)
+    assert list(net.state_dict().keys()) == list(g2[f"{name}/state_dict_keys"])
+    GU.fill_state(net, seed=314)
+    net.to(DEV)
+    data, dm = _Data(m), g2[f"{name}/dm"]        # host tensors, like the reference's dataset
+    net.eval()
+    with torch.no_grad():
+        assert GU.rel_l2(net(data, torch.from_numpy(dm)).cpu(), g2[tag + "/eval_dm_tensor"]) < MODEL_TOL
+        assert GU.rel_l2(net(data, dm).cpu(), g2[tag + "/eval_dm_ndarray"]) < MODEL_TOL
+        assert GU.rel_l2(net(data, None).cpu(), g2[tag + "/eval_dm_none"]) < MODEL_TOL
+    net.train()
+    pos = net(data, torch.from_numpy(dm))
+    assert pos.device.type == "cuda"
+    assert GU.rel_l2(pos.detach().cpu(), g2[tag + "/train_out"]) < MODEL_TOL
+    r = torch.from_numpy(GU.probe(tag + "/r", (m.num_vertices, 3))).to(DEV)
+    (pos * r).sum().backward()
+    assert GU.rel_l2(data.z1.grad, g2[tag + "/dz1"]) < 2e-3      # reference's own fp32 noise floor
+    golden = {k[len(tag + "/grad/"):]: g2[k] for k in g2.files if k.startswith(tag + "/grad/")}
+    GU.check_grad_summary([(n, p.grad) for n, p in net.named_parameters() if p.grad is not None], golden, 2e-3, tag)
+    for k in g2.files:
+        if k.startswith(tag + "/bn/"):
+            assert rel(net.state_dict()[k[len(tag + "/bn/"):]], g2[k]) < 1e-5
+
+
+def test_sgcn_error_no_worse_than_fp32_oracle_against_fp64(fixture_meshes):
+    """Arbiter: evaluate the oracle in float64; the HIP path's error must be of the size of the
+    fp32 oracle's own error (forward and input gradient)."""
+    m = fixture_meshes["torus"]
+    ora32 = OM.SGCNOracle()
+    GU.fill_state(ora32, seed=8)
+    ora64 = OM.SGCNOracle().double()
+    ora64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in ora32.state_dict().items()})
+    net = SingleScaleGCN(DEV)
+    net.load_state_dict(ora32.state_dict())
+    net.to(DEV)
+    z1, xp, ei = torch.from_numpy(m.z1), torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index)
+    r = torch.from_numpy(GU.probe("arbiter", (m.num_vertices, 3)))
+    outs, grads = {}, {}
+    for key, mod, cast in (("f32", ora32, torch.float32), ("f64", ora64, torch.float64)):
+        mod.train()
+        z = z1.detach().clone().to(cast).requires_grad_(True)
+        p = mod(z, xp.to(cast), ei, None)
+        (p * r.to(cast)).sum().backward()
+        outs[key], grads[key] = p.detach().double(), z.grad.double()
+    data = _Data(m, DEV)
+    net.train()
+    p = net(data, None)
+    (p * r.to(DEV)).sum().backward()
+    e_hip, e_ref = GU.rel_l2(p.detach().cpu().double(), outs["f64"]), GU.rel_l2(outs["f32"], outs["f64"])
+    assert e_hip < max(3 * e_ref, 2e-6), (e_hip, e_ref)
+    g_hip, g_ref = GU.rel_l2(data.z1.grad.cpu().double(), grads["f64"]), GU.rel_l2(grads["f32"], grads["f64"])
+    assert g_hip < max(3 * g_ref, 1e-5), (g_hip, g_ref)
+
+
+# --------------------------------------------------------------------------------------
+# pooling (G3: the reference's MeshPool / MeshUnpool classes)
+# --------------------------------------------------------------------------------------
+def test_pool_unpool_vs_reference_classes_and_autograd():
+    from semigcn_amd import functional as F_sg
+    g3 = GU.load("g3_mgcn.npz")
+    ph = g3["pool_hash/0"]
+    nf, nc = int(ph[:, 0].max()) + 1, int(ph[:, 1].max()) + 1
+    pool = capi.PoolHandle(torch.from_numpy(ph[:, 0]).to(DEV), torch.from_numpy(ph[:, 1]).to(DEV), nf, nc)
+    x = torch.from_numpy(g3["pool/x"]).to(DEV).requires_grad_(True)
+    px = F_sg.mesh_pool(pool, x)
+    assert rel(px, g3["pool/out"]) < 1e-6
+    up = F_sg.mesh_unpool(pool, px)
+    assert rel(up, g3["unpool/out"]) < 1e-6
+    r = torch.randn_like(up)
+    (up * r).sum().backward()
+    xo = torch.from_numpy(g3["pool/x"]).requires_grad_(True)
+    upo = OM.unpool_gather(ph, OM.pool_mean(ph, xo))
+    (upo * r.cpu()).sum().backward()
+    assert rel(x.grad, xo.grad) < 1e-6
+    for C in (3, 32, 130):
+        xx = torch.randn(nf, C, device=DEV)
+        assert rel(pool.pool_mean(xx), OM.pool_mean(ph, xx.cpu())) < 1e-6
+        yy = torch.randn(nc, C, device=DEV)
+        assert rel(pool.unpool(yy), OM.unpool_gather(ph, yy.cpu())) < 1e-6
+
+
+def test_gather_rows():
+    x = torch.randn(1000, 48, device=DEV)
+    rows = torch.randint(0, 1000, (333,), device=DEV, dtype=torch.int32)
+    assert torch.equal(capi.gather_rows(rows, x), x[rows.long()])
+    xb = x.bfloat16()
+    assert torch.equal(capi.gather_rows(rows, xb), xb[rows.long()])
+    x5 = torch.randn(1000, 5, device=DEV)
+    assert torch.equal(capi.gather_rows(rows, x5), x5[rows.long()])
+
+
+# --------------------------------------------------------------------------------------
+# benchmark size: properties that need no oracle run (1 M vertices / 6 M edges)
+# --------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_graph():
+    m = synth.torus_mesh(1000, 1000, masks=False)
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    return m, ei, MeshGraph.from_edge_index(ei, m.num_vertices)
+
+
+@pytest.mark.parametrize("C,dtype", [(4, torch.float32), (64, torch.float32), (256, torch.float32),
+                                     (512, torch.float32), (256, torch.bfloat16)])
+def test_full_size_properties(big_graph, C, dtype):
+    m, ei, g = big_graph
+    V = m.num_vertices
+    assert V == 1_000_000 and ei.shape[1] == 6_000_000 and g.symmetric
+    tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+    gen = torch.Generator(device=DEV).manual_seed(C)
+    x = torch.randn(V, C, device=DEV, generator=gen).to(dtype)
+    y = torch.randn(V, C, device=DEV, generator=gen).to(dtype)
+    Lx = g.aggregate(x, torch.empty_like(x))
+    Ly = g.aggregate(y, torch.empty_like(y))
+    # (1) eigenvector: L^ (D^1/2 1) = -(D^1/2 1)
+    deg = torch.bincount(ei[0], minlength=V).float()
+    s = deg.sqrt().view(-1, 1).expand(V, C).contiguous().to(dtype)
+    Ls = g.aggregate(s, torch.empty_like(s))
+    assert float((Ls.float() + s.float()).abs().max() / s.float().abs().max()) < (2e-6 if dtype == torch.float32 else 2e-2)
+    # (2) linearity: L(2x - y) = 2 Lx - Ly     (fused epilogue path as well)
+    z = (2 * x.float() - y.float()).to(dtype)
+    Lz = g.aggregate(z, torch.empty_like(z))
+    ref = 2 * Lx.float() - Ly.float()
+    assert float((Lz.float() - ref).abs().max() / ref.abs().max()) < (tol if dtype == torch.float32 else 3e-2)
+    # (3) symmetry: <y, L x> = <L y, x>
+    a = float((y.double() * Lx.double()).sum())
+    b = float((Ly.double() * x.double()).sum())
+    assert abs(a - b) <= 1e-6 * max(abs(a), float(x.double().norm() * y.double().norm()) * 1e-2)
+    # (4) fused epilogue == separate ops
+    fused = g.aggregate(x, torch.empty_like(x), alpha=2.0, X0=y, beta=-1.0)
+    sep = 2 * Lx.float() - y.float()
+    assert float((fused.float() - sep).abs().max() / sep.abs().max()) < (tol if dtype == torch.float32 else 3e-2)
+    # (5) spot rows against a direct gather on the host
+    rows = torch.randint(0, V, (64,), generator=torch.Generator().manual_seed(1))
+    rp, ci, dis = g.handle.arrays()
+    rp, dis_c = rp.cpu(), dis.cpu()
+    for rr in rows.tolist():
+        nb = ci[rp[rr]:rp[rr + 1]].long()
+        want = -(dis_c[rr] * (dis[nb].view(-1, 1) * x[nb].float()).sum(0)).cpu()
+        assert float((Lx[rr].float().cpu() - want).abs().max()) <= tol * max(float(want.abs().max()), 1e-3) * 4 + (0 if dtype == torch.float32 else 2e-2)
+
+
+def test_full_size_sgcn_step_runs_and_is_finite(big_graph):
+    m, ei, g = big_graph
+    net = SingleScaleGCN(DEV).to(DEV)
+
+    class D:
+        z1 = torch.from_numpy(m.z1).to(DEV).requires_grad_(True)
+        x_pos = torch.from_numpy(m.x_pos).to(DEV)
+        edge_index = ei
+    net.train()
+    out = net(D, None)
+    out.square().mean().backward()
+    assert out.shape == (m.num_vertices, 3) and bool(torch.isfinite(out).all())
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+    assert graph_for(ei, m.num_vertices) is not None
