@@ -149,6 +149,18 @@ SG_API int sg_unpool_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* d
 SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y,
                    int64_t ldy, int64_t C, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Launch tuning of the aggregation kernel (process-wide, not thread-safe; for
+ * benchmarking -- results never depend on it).
+ * ------------------------------------------------------------------------- */
+enum sg_tune_knob {
+  SG_TUNE_CHUNK_ROWS = 0, /* rows per wavefront chunk; 0 = automatic */
+  SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map */
+  SG_TUNE_UNROLL = 2,     /* reserved */
+  SG_TUNE_SLAB = 3        /* channels per column slab (one sweep of all rows per slab); 0 = off */
+};
+SG_API int sg_tuning_set(int knob, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,7 @@ _SIGNATURES = {
     "sg_pool_mean_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sg_unpool": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sg_unpool_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "sg_tuning_set": (c_int, [c_int, c_int]),
     "sg_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
                                c_void_p]),
 }
@@ -284,6 +285,14 @@ class PoolHandle:
             self.close()
         except Exception:
             pass
+
+
+TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB = 0, 1, 2, 3
+
+
+def tuning_set(knob: int, value: int) -> None:
+    """Launch tuning of the aggregation kernel (benchmarking aid; results do not depend on it)."""
+    _check(load().sg_tuning_set(int(knob), int(value)), "sg_tuning_set")
 
 
 def gather_rows(rows: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

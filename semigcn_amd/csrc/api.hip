@@ -283,6 +283,8 @@ SG_API int sg_unpool_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* d
                  1.f, 0.f, 0.f, (hipStream_t)stream);
 }
 
+SG_API int sg_tuning_set(int knob, int value) { return set_tuning(knob, value); }
+
 SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y, int64_t ldy,
                    int64_t C, int dtype, void* stream) {
   SG_REQUIRE(n >= 0 && C >= 0, "sg_gather_rows: negative size");

@@ -66,6 +66,7 @@ struct SpmmArgs {
 
 // Y[r] = alpha * sd[r] * sum_k ss[idx[k]] * X[idx[k]] + beta * X0[r] + gamma * X1[r]
 int launch_spmm(const SpmmArgs& a, int dtype, hipStream_t stream);
+int set_tuning(int knob, int value);
 int launch_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y,
                        int64_t ldy, int64_t C, int dtype, hipStream_t stream);
 

@@ -17,8 +17,8 @@
 //    neighbour list (index + deg^-1/2 of the neighbour) are staged ONCE into LDS with
 //    coalesced loads, so the inner loop's only global traffic is the feature gather; the
 //    dependent rowptr -> idx -> scale chain is paid once per chunk, not once per row.
-//  * Up to U gathers are issued back to back per row before the first FMA (U*16 B per lane in
-//    flight), which is what hides HBM/L2 latency at 8 waves per SIMD.
+//  * Up to 8 gathers per row are issued back to back, branch-free, before the first FMA (up to
+//    256 B per lane in flight); the batch size (2/4/6/8) follows the longest row in flight.
 //  * Chunks are dealt to workgroups so that the workgroups sharing an XCD (blockIdx % 8)
 //    sweep one contiguous range of rows: neighbouring rows' gathers then hit that XCD's L2.
 #include "sg_common.h"
@@ -32,22 +32,26 @@ constexpr int kChMax = 64;   // rows per wavefront chunk (upper bound)
 constexpr int kCap = 512;    // staged neighbour slots per wavefront
 
 struct bf16_tag {};
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+enum : int { kFlagXcdMap = 1 };
 
 template <typename T> struct Vt;
 template <> struct Vt<float> {
   static constexpr int VEC = 4;
-  using raw = float4;
+  using raw = f32x4;
   using elem = float;
   static __device__ __forceinline__ void unpack(const raw& v, float* f) {
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   }
-  static __device__ __forceinline__ raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+  static __device__ __forceinline__ raw pack(const float* f) { return raw{f[0], f[1], f[2], f[3]}; }
   static __device__ __forceinline__ float load1(const void* p, int64_t i) { return ((const float*)p)[i]; }
   static __device__ __forceinline__ void store1(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
 };
 template <> struct Vt<bf16_tag> {
   static constexpr int VEC = 8;
-  using raw = uint4;
+  using raw = u32x4;
   using elem = uint16_t;
   static __device__ __forceinline__ void unpack(const raw& v, float* f) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -64,7 +68,7 @@ template <> struct Vt<bf16_tag> {
     return (uint32_t)a | ((uint32_t)b << 16);
   }
   static __device__ __forceinline__ raw pack(const float* f) {
-    return make_uint4(cvt2(f[0], f[1]), cvt2(f[2], f[3]), cvt2(f[4], f[5]), cvt2(f[6], f[7]));
+    return raw{cvt2(f[0], f[1]), cvt2(f[2], f[3]), cvt2(f[4], f[5]), cvt2(f[6], f[7])};
   }
   static __device__ __forceinline__ float load1(const void* p, int64_t i) {
     return __uint_as_float((uint32_t)((const uint16_t*)p)[i] << 16);
@@ -83,8 +87,49 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
   return base + slot;
 }
 
-template <typename T, int G, int R, int U>
-__global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int ch, const int nblocks) {
+// One batch of N neighbour gathers for the row(s) this wavefront is working on.  Every load is
+// UNCONDITIONAL (slots past the end of a row re-read the row's last neighbour, an L1 hit, and are
+// dropped by a select): hipcc puts `s_waitcnt vmcnt(0)` in front of every load that sits behind
+// a branch, which serialises the gathers -- the batch must be branch-free to keep N*R*16 B per
+// lane in flight.
+template <typename T, int R, int N>
+__device__ __forceinline__ void gather_batch(const int2* __restrict__ edges, int k, int ke,
+                                             const typename Vt<T>::elem* __restrict__ X, int64_t ldx,
+                                             const int (&voff)[R], float (&acc)[R][Vt<T>::VEC]) {
+  using V = Vt<T>;
+  using raw_t = typename V::raw;
+  constexpr int VEC = V::VEC;
+  int2 e[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    int kc = k + u < ke ? k + u : ke - 1;
+    kc = kc < 0 ? 0 : kc;
+    e[u] = edges[kc];
+  }
+  raw_t xv[N][R];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const typename V::elem* src = X + (int64_t)e[u].x * ldx;
+#pragma unroll
+    for (int r = 0; r < R; ++r) xv[u][r] = *(const raw_t*)(src + voff[r]);
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const bool valid = k + u < ke;
+    const float w = __int_as_float(e[u].y);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float f[VEC];
+      V::unpack(xv[u][r], f);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[r][c] = valid ? fmaf(w, f[c], acc[r][c]) : acc[r][c];
+    }
+  }
+}
+
+template <typename T, int G, int R, int NEPI>
+__global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int ch, const int nblocks,
+                                                     const int flags) {
   using V = Vt<T>;
   constexpr int VEC = V::VEC;
   constexpr int RPW = 64 / G;  // rows a wavefront works on simultaneously
@@ -92,25 +137,28 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
   using elem_t = typename V::elem;
 
   __shared__ int32_t s_rp[kWaves][kChMax + 1];
+  __shared__ float s_sd[kWaves][kChMax];
   __shared__ int2 s_e[kWaves][kCap];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int tile = xcd_contiguous(blockIdx.x, nblocks);
+  const int tile = (flags & kFlagXcdMap) ? xcd_contiguous(blockIdx.x, nblocks) : (int)blockIdx.x;
   const int r0 = (tile * kWaves + wave) * ch;
   int nrows = a.n_rows - r0;
   nrows = nrows < 0 ? 0 : (nrows > ch ? ch : nrows);
 
-  // ---- stage this chunk's row pointers and neighbour list in LDS (coalesced) ----
-  if (nrows > 0)
+  // ---- stage this chunk's row pointers, row scales and neighbour list in LDS (coalesced) ----
+  if (nrows > 0) {
     for (int l = lane; l <= nrows; l += 64) s_rp[wave][l] = a.rowptr[r0 + l];
+    for (int l = lane; l < nrows; l += 64) s_sd[wave][l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
+  }
   __syncthreads();
   int e0 = 0, ne = 0;
   if (nrows > 0) {
     e0 = s_rp[wave][0];
     ne = s_rp[wave][nrows] - e0;
   }
-  const bool staged = ne <= kCap;  // wave-uniform; a chunk with a huge row reads idx from global
+  const bool staged = ne <= kCap;  // wave-uniform; a chunk holding a huge row takes the slow path
   if (staged) {
     for (int k = lane; k < ne; k += 64) {
       const int j = a.idx[e0 + k];
@@ -127,29 +175,31 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
   const elem_t* __restrict__ X0 = (const elem_t*)a.X0;
   const elem_t* __restrict__ X1 = (const elem_t*)a.X1;
   elem_t* __restrict__ Y = (elem_t*)a.Y;
+  const int2* __restrict__ edges = s_e[wave];
+
+  int voff[R];     // element offset of this lane's r-th vector inside a row (clamped: loads stay in bounds)
+  bool vok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int vi = gl + r * G;
+    vok[r] = vi < nvec;
+    voff[r] = (vok[r] ? vi : nvec - 1) * VEC;
+  }
 
   for (int it = 0; it * RPW < nrows; ++it) {
     const int lr = it * RPW + g;
     const bool rvalid = lr < nrows;
-    const int row = r0 + lr;
-    int ks = 0, ke = 0;
-    if (rvalid) {
-      ks = s_rp[wave][lr] - e0;
-      ke = s_rp[wave][lr + 1] - e0;
-    }
-    // issue the epilogue operands early so they fly with the gather
+    const int lrc = rvalid ? lr : 0;
+    const int row = r0 + lrc;
+    const int ks = s_rp[wave][lrc] - e0;
+    const int ke = rvalid ? s_rp[wave][lrc + 1] - e0 : ks;
+    const float sdst = a.alpha * s_sd[wave][lrc];
+    // epilogue operands are issued first so they fly together with the gathers
     raw_t x0v[R], x1v[R];
-    float sdst = a.alpha;
-    if (rvalid) {
-      if (a.scale_dst) sdst *= a.scale_dst[row];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int vi = gl + r * G;
-        if (vi < nvec) {
-          if (X0) x0v[r] = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + vi * VEC);
-          if (X1) x1v[r] = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + vi * VEC);
-        }
-      }
+    for (int r = 0; r < R; ++r) {
+      if (NEPI >= 1) x0v[r] = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff[r]);
+      if (NEPI >= 2) x1v[r] = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + voff[r]);
     }
     float acc[R][VEC];
 #pragma unroll
@@ -157,78 +207,47 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 #pragma unroll
       for (int c = 0; c < VEC; ++c) acc[r][c] = 0.f;
 
-    for (int k = ks; k < ke; k += U) {
-      int j[U];
-      float w[U];
-      bool v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int kk = k + u;
-        v[u] = kk < ke;
-        j[u] = 0;
-        w[u] = 0.f;
-        if (v[u]) {
-          if (staged) {
-            const int2 e = s_e[wave][kk];
-            j[u] = e.x;
-            w[u] = __int_as_float(e.y);
-          } else {
-            j[u] = a.idx[e0 + kk];
-            w[u] = a.scale_src ? a.scale_src[j[u]] : 1.0f;
-          }
-        }
+    if (staged) {
+      int k = ks;
+      while (__any(k < ke)) {                 // wave-uniform trip count: the longest row decides
+        const int rem = ke - k;
+        if (R * 8 <= 16 && __any(rem > 6)) { gather_batch<T, R, 8>(edges, k, ke, X, a.ldx, voff, acc); k += 8; }
+        else if (R * 6 <= 16 && __any(rem > 4)) { gather_batch<T, R, 6>(edges, k, ke, X, a.ldx, voff, acc); k += 6; }
+        else if (R * 4 <= 16 && __any(rem > 2)) { gather_batch<T, R, 4>(edges, k, ke, X, a.ldx, voff, acc); k += 4; }
+        else { gather_batch<T, R, 2>(edges, k, ke, X, a.ldx, voff, acc); k += 2; }
       }
-      raw_t xv[U][R];
+    } else {
+      for (int k = ks; k < ke; ++k) {         // rare: more than kCap neighbours in one chunk
+        const int j = a.idx[e0 + k];
+        const float w = a.scale_src ? a.scale_src[j] : 1.0f;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (v[u]) {
-          const elem_t* src = X + (int64_t)j[u] * a.ldx;
+        for (int r = 0; r < R; ++r) {
+          float f[VEC];
+          V::unpack(*(const raw_t*)(X + (int64_t)j * a.ldx + voff[r]), f);
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int vi = gl + r * G;
-            if (vi < nvec) xv[u][r] = *(const raw_t*)(src + vi * VEC);
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (v[u]) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            if (gl + r * G < nvec) {
-              float f[VEC];
-              V::unpack(xv[u][r], f);
-#pragma unroll
-              for (int c = 0; c < VEC; ++c) acc[r][c] = fmaf(w[u], f[c], acc[r][c]);
-            }
-          }
+          for (int c = 0; c < VEC; ++c) acc[r][c] = fmaf(w, f[c], acc[r][c]);
         }
       }
     }
 
-    if (rvalid) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int vi = gl + r * G;
-        if (vi < nvec) {
-          float y[VEC];
+    for (int r = 0; r < R; ++r) {
+      float y[VEC];
 #pragma unroll
-          for (int c = 0; c < VEC; ++c) y[c] = sdst * acc[r][c];
-          if (X0) {
-            float f[VEC];
-            V::unpack(x0v[r], f);
+      for (int c = 0; c < VEC; ++c) y[c] = sdst * acc[r][c];
+      if (NEPI >= 1) {
+        float f[VEC];
+        V::unpack(x0v[r], f);
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
-          }
-          if (X1) {
-            float f[VEC];
-            V::unpack(x1v[r], f);
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
-          }
-          *(raw_t*)(Y + (int64_t)row * a.ldy + vi * VEC) = V::pack(y);
-        }
+        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
       }
+      if (NEPI >= 2) {
+        float f[VEC];
+        V::unpack(x1v[r], f);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
+      }
+      if (rvalid && vok[r]) *(raw_t*)(Y + (int64_t)row * a.ldy + voff[r]) = V::pack(y);
     }
   }
 }
@@ -288,36 +307,50 @@ __global__ __launch_bounds__(kBlock) void gather_rows_scalar(const int32_t* __re
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-int chunk_rows_override() {
-  static int v = [] {
-    const char* s = getenv("SG_SPMM_CH");
-    return s ? atoi(s) : 0;
-  }();
-  return v;
-}
+struct Tuning {
+  int chunk_rows = 0;             // 0 = automatic
+  int flags = kFlagXcdMap;        // kFlag* bits
+  int unroll = 0;                 // 0 = default per shape
+  int slab = 0;                   // channels per column slab; 0 = whole rows
+};
+Tuning g_tuning;
 
-template <typename T, int G, int R, int U>
-int launch_rows(const SpmmArgs& a, hipStream_t stream) {
+template <typename T, int G, int R, int NEPI>
+int launch_rows_epi(const SpmmArgs& a, hipStream_t stream) {
   constexpr int RPW = 64 / G;
-  // rows per wavefront chunk: large enough to amortise staging, small enough to keep
-  // >> 256 workgroups in flight on small meshes
-  int ch = chunk_rows_override();
+  // rows per wavefront chunk: large enough to amortise staging, small enough to keep the band
+  // of rows that are in flight at once (the sweep front) thin, and >> 256 workgroups in flight
+  int ch = g_tuning.chunk_rows;
   if (ch <= 0) {
-    ch = 32;
-    while (ch > RPW && (int64_t)a.n_rows / ch < 8192) ch >>= 1;
+    // measured on the 1 M-vertex mesh (tools/agg_bench.py): wide rows want a thin sweep front
+    const int row_bytes = a.C * (int)sizeof(typename Vt<T>::elem);
+    ch = row_bytes >= 2048 ? 4 : row_bytes >= 1024 ? (sizeof(typename Vt<T>::elem) == 4 ? 4 : 8) : 16;
+    while (ch > RPW && (int64_t)a.n_rows / ch < 4096) ch >>= 1;
   }
   if (ch < RPW) ch = RPW;
   if (ch > kChMax) ch = kChMax;
   ch = (ch / RPW) * RPW;
   const int64_t chunks = ((int64_t)a.n_rows + ch - 1) / ch;
   const int nblocks = (int)((chunks + kWaves - 1) / kWaves);
-  spmm_rows<T, G, R, U><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks);
+  spmm_rows<T, G, R, NEPI><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks, g_tuning.flags);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
 
+template <typename T, int G, int R>
+int launch_rows(const SpmmArgs& a, hipStream_t stream) {
+  if (a.X0 && a.X1) return launch_rows_epi<T, G, R, 2>(a, stream);
+  if (a.X0) return launch_rows_epi<T, G, R, 1>(a, stream);
+  if (a.X1) {  // only X1 given: treat it as the first operand
+    SpmmArgs b = a;
+    b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f;
+    return launch_rows_epi<T, G, R, 1>(b, stream);
+  }
+  return launch_rows_epi<T, G, R, 0>(a, stream);
+}
+
 template <typename T>
-int launch_typed(const SpmmArgs& a, hipStream_t stream) {
+int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
   constexpr int VEC = Vt<T>::VEC;
   constexpr int esz = sizeof(typename Vt<T>::elem);
   const bool vec_ok = a.C % VEC == 0 && a.ldx % VEC == 0 && a.ldy % VEC == 0 && aligned16(a.X) &&
@@ -333,18 +366,50 @@ int launch_typed(const SpmmArgs& a, hipStream_t stream) {
     return SG_OK;
   }
   const int nvec = a.C / VEC;
-  if (nvec <= 1) return launch_rows<T, 1, 1, 8>(a, stream);
-  if (nvec <= 2) return launch_rows<T, 2, 1, 8>(a, stream);
-  if (nvec <= 4) return launch_rows<T, 4, 1, 8>(a, stream);
-  if (nvec <= 8) return launch_rows<T, 8, 1, 8>(a, stream);
-  if (nvec <= 16) return launch_rows<T, 16, 1, 8>(a, stream);
-  if (nvec <= 32) return launch_rows<T, 32, 1, 8>(a, stream);
-  if (nvec <= 64) return launch_rows<T, 64, 1, 8>(a, stream);
-  if (nvec <= 128) return launch_rows<T, 64, 2, 4>(a, stream);
-  return launch_rows<T, 64, 4, 2>(a, stream);
+  if (nvec <= 1) return launch_rows<T, 1, 1>(a, stream);
+  if (nvec <= 2) return launch_rows<T, 2, 1>(a, stream);
+  if (nvec <= 4) return launch_rows<T, 4, 1>(a, stream);
+  if (nvec <= 8) return launch_rows<T, 8, 1>(a, stream);
+  if (nvec <= 16) return launch_rows<T, 16, 1>(a, stream);
+  if (nvec <= 32) return launch_rows<T, 32, 1>(a, stream);
+  if (nvec <= 64) return launch_rows<T, 64, 1>(a, stream);
+  if (nvec <= 128) return launch_rows<T, 64, 2>(a, stream);
+  return launch_rows<T, 64, 4>(a, stream);
+}
+
+// Column slabs: sweep all rows once per slab of `slab` channels, so that the rows a sweep
+// keeps re-gathering (the neighbouring "lines" of the mesh) shrink to slab-wide segments
+// that stay L2-resident.
+template <typename T>
+int launch_typed(const SpmmArgs& a, hipStream_t stream) {
+  constexpr int VEC = Vt<T>::VEC;
+  const int slab = g_tuning.slab;
+  if (slab <= 0 || a.C <= slab || slab % VEC != 0) return launch_typed_one<T>(a, stream);
+  using elem_t = typename Vt<T>::elem;
+  for (int c0 = 0; c0 < a.C; c0 += slab) {
+    SpmmArgs s = a;
+    s.C = a.C - c0 < slab ? a.C - c0 : slab;
+    s.X = (const elem_t*)a.X + c0;
+    s.Y = (elem_t*)a.Y + c0;
+    if (a.X0) s.X0 = (const elem_t*)a.X0 + c0;
+    if (a.X1) s.X1 = (const elem_t*)a.X1 + c0;
+    int rc = launch_typed_one<T>(s, stream);
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
 }
 
 }  // namespace
+
+int set_tuning(int knob, int value) {
+  switch (knob) {
+    case SG_TUNE_CHUNK_ROWS: g_tuning.chunk_rows = value; return SG_OK;
+    case SG_TUNE_FLAGS: g_tuning.flags = value; return SG_OK;
+    case SG_TUNE_UNROLL: g_tuning.unroll = value; return SG_OK;
+    case SG_TUNE_SLAB: g_tuning.slab = value; return SG_OK;
+    default: set_error("unknown tuning knob %d", knob); return SG_ERR_INVALID;
+  }
+}
 
 int launch_spmm(const SpmmArgs& a, int dtype, hipStream_t stream) {
   if (a.n_rows == 0 || a.C == 0) return SG_OK;

@@ -23,6 +23,16 @@ from . import capi
 from .graph import MeshGraph
 
 
+def _mm_f32_out(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a @ b with an fp32 result also for bf16 operands (the weight gradient sums over all V)."""
+    if a.dtype == torch.float32:
+        return a @ b
+    try:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    except (TypeError, RuntimeError):
+        return (a @ b).float()
+
+
 class _ChebConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph: MeshGraph, x: torch.Tensor, bias: Optional[torch.Tensor], *weights: torch.Tensor):
@@ -45,6 +55,7 @@ class _ChebConvFn(torch.autograd.Function):
             out = T @ wcat.t()
         ctx.graph, ctx.K, ctx.C = graph, K, C
         ctx.has_bias = bias is not None
+        ctx.param_dtype = weights[0].dtype
         ctx.save_for_backward(T, wcat)
         return out
 
@@ -57,9 +68,9 @@ class _ChebConvFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[3:])
         dws = [None] * K
         if need_w:
-            dwcat = dout.t() @ T  # [Cout, K*C]
+            dwcat = _mm_f32_out(dout.t(), T).to(ctx.param_dtype)  # [Cout, K*C], reduced over V in fp32
             dws = [dwcat[:, k * C:(k + 1) * C] for k in range(K)]
-        db = dout.sum(0) if (ctx.has_bias and need_b) else None
+        db = dout.sum(0, dtype=torch.float32).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
         dx = None
         if need_x:
             dT = dout @ wcat  # [V, K*C]; block k = dL/dTx_k before the recurrence is unwound

@@ -3,9 +3,14 @@ constructor, ``forward(data, dm=None)`` contract, parameter creation order and
 state-dict keys (/root/reference/util/networks.py:8-103), running on the HIP
 aggregation kernels through :mod:`semigcn_amd.nn`.
 
-Differences that are deliberate (none changes results):
+Differences that are deliberate (none changes results beyond fp32 summation order):
   * ``data.x_pos`` / ``data.edge_index`` are uploaded once per source tensor instead of
     on every forward (util/networks.py:65), and the edge_index is turned into a CSR once;
+  * ``reorder=True`` (default): vertices are processed in Morton order of ``data.x_pos`` so
+    that the aggregation's gathers hit L2 whatever order the scan arrived in; inputs are
+    permuted at entry and the [V,3] result is returned in the caller's vertex order;
+  * ``set_feature_dtype(torch.bfloat16)`` stores the per-vertex features between layers in
+    bf16 (fp32 accumulation, fp32 parameters, fp32 output) -- BASELINE config c4;
   * on a CPU device the first aggregation raises (capi) -- there is no CPU path.
 """
 from __future__ import annotations
@@ -16,6 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import reorder as _reorder
 from .graph import MeshGraph, graph_for
 from .nn import ChebConv, Sequential
 
@@ -56,23 +62,39 @@ def prepare_input(z1: torch.Tensor, dm: torch.Tensor) -> torch.Tensor:
     return torch.cat([dm * centred, dm], dim=1)
 
 
+class _Fp32Linear(nn.Linear):
+    """nn.Linear whose parameters stay fp32: a reduced-precision input is widened first."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return super().forward(x.to(self.weight.dtype))
+
+
 class SingleScaleGCN(nn.Module):
-    def __init__(self, device, activation: str = "lrelu", skip: bool = False):
+    def __init__(self, device, activation: str = "lrelu", skip: bool = False, reorder: bool = True):
         super().__init__()
         self.device = torch.device(device)
         self.skip = skip
+        self.reorder = reorder
+        self.feature_dtype = torch.float32
         act = {"relu": nn.ReLU(), "lrelu": nn.LeakyReLU()}[activation]  # one shared instance (:17-18)
         h = CHANNELS
         blocks: List[nn.Module] = []
         for i in range(N_BLOCKS):
             layers = [(ChebConv(h[i], h[i + 1], K=3), "x, edge_index -> x"), nn.BatchNorm1d(h[i + 1]), act]
             if i == N_BLOCKS - 1:
-                layers.append((nn.Linear(h[i + 1], h[i + 2]), "x -> x"))
+                layers.append((_Fp32Linear(h[i + 1], h[i + 2]), "x -> x"))
             blocks.append(Sequential("x, edge_index", layers))
         self.blocks = nn.ModuleList(blocks)
         # created unconditionally, after the blocks (RNG order), used only when skip=True (:58-61)
-        self.skip_blocks = nn.ModuleList([nn.Linear(2 * h[j + 1], h[j + 1]) for j in range(N_ENCODER)])
+        self.skip_blocks = nn.ModuleList([_Fp32Linear(2 * h[j + 1], h[j + 1]) for j in range(N_ENCODER)])
         self._consts = _DeviceCache()
+        self._orders: Dict[int, tuple] = {}
+
+    def set_feature_dtype(self, dtype: torch.dtype) -> "SingleScaleGCN":
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("feature dtype must be float32 or bfloat16")
+        self.feature_dtype = dtype
+        return self
 
     # -- helpers ---------------------------------------------------------------------------
     def _mask(self, dm, n: int, dtype) -> torch.Tensor:
@@ -82,23 +104,47 @@ class SingleScaleGCN(nn.Module):
             return torch.ones((n, 1), dtype=dtype, device=self.device)
         return dm.to(self.device)
 
-    def graph(self, data) -> MeshGraph:
+    def _layout(self, data):
+        """(graph, order, rank) for this mesh: the CSR of the (re-numbered) edge_index and the
+        Morton permutation, computed once per (edge_index, x_pos) pair."""
         ei = self._consts.get(data.edge_index, self.device)
-        return graph_for(ei, data.z1.shape[0])
+        if not self.reorder:
+            return graph_for(ei, data.z1.shape[0]), None, None
+        key = (id(data.edge_index), id(data.x_pos))
+        ent = self._orders.get(key)
+        if (ent is not None and ent[0] is data.edge_index and ent[1] is data.x_pos
+                and ent[2] == (data.edge_index._version, data.x_pos._version)):
+            return ent[3], ent[4], ent[5]
+        x_pos = self._consts.get(data.x_pos, self.device)
+        order, rank = _reorder.morton_order(x_pos)
+        graph = MeshGraph.from_edge_index(_reorder.permute_edge_index(ei, rank), data.z1.shape[0])
+        if len(self._orders) > 8:
+            self._orders.clear()
+        self._orders[key] = (data.edge_index, data.x_pos, (data.edge_index._version, data.x_pos._version),
+                             graph, order, rank)
+        return graph, order, rank
+
+    def graph(self, data) -> MeshGraph:
+        return self._layout(data)[0]
 
     # -- forward ---------------------------------------------------------------------------
     def forward(self, data, dm=None):
         z1 = data.z1.to(self.device)
         x_pos = self._consts.get(data.x_pos, self.device)
-        graph = self.graph(data)
+        graph, order, rank = self._layout(data)
         x = prepare_input(z1, self._mask(dm, z1.shape[0], z1.dtype))
+        if order is not None:
+            x = x.index_select(0, order)
+        x = x.to(self.feature_dtype)
 
         enc: List[torch.Tensor] = []
         for i, block in enumerate(self.blocks):
             if self.skip and i >= FIRST_DECODER:
                 j = N_BLOCKS - i  # 5, 4, 3, 2, 1 -- skip_blocks[0] is never used (:96-99)
-                x = self.skip_blocks[j](torch.cat([enc[j], x], dim=1))
+                x = self.skip_blocks[j](torch.cat([enc[j], x], dim=1)).to(self.feature_dtype)
             x = block(x, graph)
             if i < N_ENCODER:
                 enc.append(x)
+        if rank is not None:
+            x = x.index_select(0, rank)
         return x_pos + x
