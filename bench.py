@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mesh", default="1000x1000", help="torus nu x nv (per job at N=1; see --weak)")
+    ap.add_argument("--mesh", default="1000x1000", help="torus nu x nv of the whole job (the same mesh at every N: strong scaling)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--permute", action="store_true", help="random vertex order (raw-scan like)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,7 +152,7 @@ def main():
     dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
     if world > 1:
         from semigcn_amd import dist as sgdist
-        job = sgdist.build_weak_scaling_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype)
+        job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype)
         trainer, V_total, E_total, workload = job.trainer, job.V_total, job.E_total, job.workload
     else:
         mesh = synth.torus_mesh(nu, nv, permute=args.permute)
@@ -225,7 +225,7 @@ def main():
         line = {
             "metric": "GCN train iters/sec + edges-aggregated/sec, 1M-vert mesh",
             "value": value, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "bf16 storage / f32 accumulate", "data": "synthetic",
             "config": {"workload": workload, "V": V_total, "E": E_total,
                        "aggregations_per_iteration": AGG_PER_ITER},

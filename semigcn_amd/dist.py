@@ -1,0 +1,486 @@
+"""Vertex-partitioned SGCN over the GPUs of one node.
+
+New design -- the reference is single-process, single-device and has no counterpart
+(no torch.distributed / NCCL call anywhere in /root/reference).  The contract is
+"N-GPU result == 1-GPU result" to fp32 summation order.
+
+  * The mesh is renumbered along a Morton curve (semigcn_amd.reorder) and cut into
+    ``world`` contiguous blocks of vertices: each rank OWNS the rows of every [V, C]
+    tensor for its block, and the CSR rows of L^ for them with the column indices
+    remapped to ``[owned | halo]`` (sg_graph_create_rect).
+  * Before every aggregation the 1-ring halo rows are exchanged: boundary rows are packed by
+    a HIP gather kernel (sg_gather_rows), sent with ONE all_to_all_single (RCCL over xGMI:
+    grouped point-to-point sends to the few neighbouring ranks), and land at the tail of the
+    ``[owned | halo]`` feature buffer the kernel reads.  Backward is owner-computes on
+    exchanged GRADIENT rows (the global L^ is symmetric), so no reverse scatter is needed.
+  * BatchNorm statistics couple all vertices (util/networks.py:43): per-rank (count, mean,
+    M2) are all-gathered and merged with Chan's formula (forward), per-channel
+    (sum dy, sum dy*xhat) are all-reduced (backward).
+  * The bounding-box normalisation (util/networks.py:67-70) all-reduces min / max; the
+    losses all-reduce their masked sums; face normals read halo positions through a
+    differentiable exchange (every vertex of a face that touches an owned vertex is in that
+    vertex's 1-ring, i.e. already in the halo plan).
+  * Parameter gradients are partial sums over the owned vertices: one flat all-reduce per
+    optimiser step (7 MB for SGCN), after the ``accumulate`` backward passes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import capi
+from . import reorder as _reorder
+
+
+# --------------------------------------------------------------------------------------
+# collectives.  RCCL ("nccl") takes device tensors directly.  Under gloo -- the CPU tests, and the
+# single-GPU self-test where several ranks share one device -- device tensors are staged through
+# host memory, because gloo moves host buffers only.
+# --------------------------------------------------------------------------------------
+def _staged(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t: torch.Tensor, op, group) -> None:
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _all_gather_rows(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    if _staged(inp, group):
+        ho, hi = out.cpu(), inp.cpu()
+        dist.all_gather_into_tensor(ho, hi, group=group)
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _all_to_all_rows(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits, group) -> None:
+    if _staged(send, group):
+        hr, hs = recv.cpu(), send.cpu()
+        dist.all_to_all_single(hr, hs, list(recv_splits), list(send_splits), group=group)
+        recv.copy_(hr)
+    else:
+        dist.all_to_all_single(recv, send, list(recv_splits), list(send_splits), group=group)
+
+
+# --------------------------------------------------------------------------------------
+# partition plan
+# --------------------------------------------------------------------------------------
+def block_bounds(num_vertices: int, world: int) -> List[int]:
+    """Balanced contiguous blocks: bounds[r] .. bounds[r+1] is rank r's range."""
+    base, rem = divmod(num_vertices, world)
+    b = [0]
+    for r in range(world):
+        b.append(b[-1] + base + (1 if r < rem else 0))
+    return b
+
+
+class DistMeshGraph:
+    """One rank's share of the scaled Laplacian plus its halo-exchange plan."""
+    is_distributed = True
+
+    def __init__(self, edge_index: torch.Tensor, num_vertices: int, rank: int, world: int,
+                 group=None, bounds: Optional[Sequence[int]] = None):
+        """``edge_index`` [2,E] int64 on the compute device, ALREADY in processing order
+        (callers renumber with reorder.morton_order first); every rank passes the full graph."""
+        dev = edge_index.device
+        self.group, self.rank, self.world = group, rank, world
+        self.num_vertices_global = int(num_vertices)
+        bounds = list(bounds) if bounds is not None else block_bounds(num_vertices, world)
+        self.bounds = bounds
+        start, end = bounds[rank], bounds[rank + 1]
+        self.start, self.end, self.n_own = start, end, end - start
+        b = torch.tensor(bounds, device=dev, dtype=torch.long)
+
+        ei = edge_index[:, edge_index[0] != edge_index[1]]
+        src, dst = ei[0], ei[1]
+        fwd = torch.sort(dst * num_vertices + src)[0]
+        bwd = torch.sort(src * num_vertices + dst)[0]
+        if not torch.equal(fwd, bwd):
+            raise ValueError("vertex partitioning needs a symmetric edge_index (an undirected mesh graph)")
+        deg = torch.bincount(src, minlength=num_vertices).float()
+        dis = torch.where(deg > 0, deg.rsqrt(), torch.zeros_like(deg))
+
+        owner_dst = torch.bucketize(dst, b[1:], right=True)
+        owner_src = torch.bucketize(src, b[1:], right=True)
+        mine = owner_dst == rank
+        d_loc = dst[mine] - start
+        s_glob = src[mine]
+        s_own = owner_src[mine] == rank
+        halo = torch.unique(s_glob[~s_own])                      # sorted global ids = grouped by owner
+        self.halo_ids = halo
+        self.n_halo = int(halo.numel())
+        self.n_ext = self.n_own + self.n_halo
+        s_ext = torch.where(s_own, s_glob - start, self.n_own + torch.searchsorted(halo, s_glob))
+        dis_ext = torch.cat([dis[start:end], dis[halo]])
+        self.handle = capi.GraphHandle.from_partition(d_loc, s_ext, self.n_own, self.n_ext, dis_ext)
+
+        # what I receive from each peer: my halo ids that it owns (contiguous runs of `halo`)
+        halo_owner = torch.bucketize(halo, b[1:], right=True)
+        self.recv_splits = torch.bincount(halo_owner, minlength=world).tolist()
+        # what I send to peer q: my rows that are sources of edges into q's rows, ascending
+        out_edges = (owner_src == rank) & (owner_dst != rank)
+        pair = torch.unique(owner_dst[out_edges] * num_vertices + src[out_edges])   # sorted by (q, row)
+        self.send_splits = torch.bincount(pair // num_vertices, minlength=world).tolist()
+        self.send_rows = (pair % num_vertices - start).to(torch.int32)
+        self.n_send = int(self.send_rows.numel())
+        self.device = dev
+        self.symmetric = True
+
+    # MeshGraph-compatible surface -----------------------------------------------------
+    @property
+    def num_vertices(self) -> int:
+        return self.n_own
+
+    def aggregate(self, X_ext: torch.Tensor, Y_own: torch.Tensor, **kw):
+        return self.handle.spmm(X_ext, Y_own, **kw)
+
+    # halo exchange --------------------------------------------------------------------
+    def _a2a(self, recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits):
+        if self.world == 1:
+            return
+        _all_to_all_rows(recv, send, recv_splits, send_splits, self.group)
+
+    def exchange(self, blk_ext: torch.Tensor) -> None:
+        """Fill rows [n_own:] of ``blk_ext`` ([n_ext, C], unit column stride, any row stride) with
+        the neighbours' copies of those vertices; rows [:n_own] must be final."""
+        if self.n_halo == 0 and self.n_send == 0:
+            return
+        own = blk_ext[:self.n_own]
+        send = capi.gather_rows(self.send_rows, own)
+        recv = torch.empty((self.n_halo, blk_ext.shape[1]), dtype=blk_ext.dtype, device=blk_ext.device)
+        self._a2a(recv, send, self.recv_splits, self.send_splits)
+        blk_ext[self.n_own:].copy_(recv)
+
+    def exchange_reverse_add(self, grad_halo: torch.Tensor, grad_own: torch.Tensor) -> None:
+        """Adjoint of ``exchange``: halo-row gradients travel back to their owners and are added."""
+        if self.n_halo == 0 and self.n_send == 0:
+            return
+        recv = torch.empty((self.n_send, grad_halo.shape[1]), dtype=grad_halo.dtype, device=grad_halo.device)
+        self._a2a(recv, grad_halo.contiguous(), self.send_splits, self.recv_splits)
+        grad_own.index_add_(0, self.send_rows.long(), recv)
+
+
+class _HaloExtend(torch.autograd.Function):
+    """x_own [n,C] -> [x_own ; halo rows] [n_ext, C], differentiable."""
+
+    @staticmethod
+    def forward(ctx, g: DistMeshGraph, x: torch.Tensor):
+        ext = torch.empty((g.n_ext, x.shape[1]), dtype=x.dtype, device=x.device)
+        ext[:g.n_own].copy_(x)
+        g.exchange(ext)
+        ctx.g = g
+        return ext
+
+    @staticmethod
+    def backward(ctx, grad_ext):
+        g = ctx.g
+        grad_own = grad_ext[:g.n_own].clone()
+        g.exchange_reverse_add(grad_ext[g.n_own:], grad_own)
+        return None, grad_own
+
+
+def halo_extend(g: DistMeshGraph, x: torch.Tensor) -> torch.Tensor:
+    return _HaloExtend.apply(g, x)
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x; every rank continues with the same replicated computation, so
+    the gradient of the replicated result w.r.t. the local term is the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        y = x.clone()
+        _all_reduce(y, dist.ReduceOp.SUM, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None
+
+
+def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return x
+    return _AllReduceSum.apply(x, group)
+
+
+# --------------------------------------------------------------------------------------
+# ChebConv on a partition
+# --------------------------------------------------------------------------------------
+class _DistChebConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g: DistMeshGraph, x, bias, *weights):
+        from .functional import _mm_f32_out  # noqa: F401  (shared helper)
+        K, n = len(weights), g.n_own
+        C = x.shape[1]
+        wcat = (weights[0] if K == 1 else torch.cat(list(weights), dim=1)).to(x.dtype)
+        T = torch.empty((g.n_ext if K > 1 else n, K * C), dtype=x.dtype, device=x.device)
+        blk = [T[:, k * C:(k + 1) * C] for k in range(K)]
+        blk[0][:n].copy_(x)
+        if K > 1:
+            g.exchange(blk[0])
+            g.aggregate(blk[0], blk[1][:n], alpha=1.0)
+        for k in range(2, K):
+            g.exchange(blk[k - 1])
+            g.aggregate(blk[k - 1], blk[k][:n], alpha=2.0, X0=blk[k - 2][:n], beta=-1.0)
+        own = T[:n]
+        out = torch.addmm(bias.to(x.dtype), own, wcat.t()) if bias is not None else own @ wcat.t()
+        ctx.g, ctx.K, ctx.C = g, K, C
+        ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
+        ctx.save_for_backward(T, wcat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .functional import _mm_f32_out
+        T, wcat = ctx.saved_tensors
+        g, K, C, n = ctx.g, ctx.K, ctx.C, ctx.g.n_own
+        dout = dout.contiguous()
+        need_x, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dws = [None] * K
+        if any(ctx.needs_input_grad[3:]):
+            dwcat = _mm_f32_out(dout.t(), T[:n]).to(ctx.param_dtype)   # partial: summed over ranks later
+            dws = [dwcat[:, k * C:(k + 1) * C] for k in range(K)]
+        db = dout.sum(0, dtype=torch.float32).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
+        dx = None
+        if need_x:
+            dT = torch.empty((g.n_ext if K > 1 else n, K * C), dtype=dout.dtype, device=dout.device)
+            torch.mm(dout, wcat, out=dT[:n])
+            if K == 1:
+                dx = dT
+            else:
+                gk = [dT[:, k * C:(k + 1) * C] for k in range(K)]
+                for k in range(K - 2, 0, -1):
+                    g.exchange(gk[k + 1])
+                    x1 = gk[k + 2][:n] if k + 2 <= K - 1 else None
+                    g.aggregate(gk[k + 1], gk[k][:n], alpha=2.0, X0=gk[k][:n], beta=1.0, X1=x1, gamma=-1.0)
+                g.exchange(gk[1])
+                dx = torch.empty((n, C), dtype=dout.dtype, device=dout.device)
+                x1 = gk[2][:n] if K >= 3 else None
+                g.aggregate(gk[1], dx, alpha=1.0, X0=gk[0][:n], beta=1.0, X1=x1, gamma=-1.0)
+        return (None, dx, db, *dws)
+
+
+def dist_cheb_conv(g: DistMeshGraph, x, weights, bias=None):
+    if x.shape[0] != g.n_own:
+        raise ValueError(f"x has {x.shape[0]} rows but this rank owns {g.n_own} vertices")
+    return _DistChebConvFn.apply(g, x, bias, *weights)
+
+
+# --------------------------------------------------------------------------------------
+# BatchNorm over ALL vertices of the mesh
+# --------------------------------------------------------------------------------------
+class _SyncBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
+        xf = x.float()
+        n = x.shape[0]
+        C = x.shape[1]
+        var_r, mean_r = torch.var_mean(xf, dim=0, unbiased=False)
+        world = dist.get_world_size(group)
+        local = torch.cat([mean_r, var_r * n, xf.new_tensor([float(n)])])
+        allst = torch.empty((world, 2 * C + 1), dtype=torch.float32, device=x.device)
+        _all_gather_rows(allst, local.unsqueeze(0).contiguous(), group)
+        cnt = allst[:, 2 * C:]                                   # [world, 1]
+        N = cnt.sum()
+        mean = (allst[:, :C] * cnt).sum(0) / N
+        m2 = (allst[:, C:2 * C] + cnt * (allst[:, :C] - mean) ** 2).sum(0)   # Chan et al. merge
+        var = m2 / N
+        invstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1 - momentum).add_((m2 / (N - 1)).to(running_var.dtype), alpha=momentum)
+        xhat = (xf - mean) * invstd
+        y = xhat * weight.float() + bias.float()
+        ctx.save_for_backward(xhat, invstd, weight)
+        ctx.group, ctx.N = group, N
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, invstd, weight = ctx.saved_tensors
+        dyf = dy.float()
+        s1 = dyf.sum(0)
+        s2 = (dyf * xhat).sum(0)
+        dw, db = s2.clone(), s1.clone()                          # partial sums (reduced with the other grads)
+        red = torch.stack([s1, s2])
+        _all_reduce(red, dist.ReduceOp.SUM, ctx.group)
+        N = ctx.N
+        dx = (weight.float() * invstd) * (dyf - red[0] / N - xhat * (red[1] / N))
+        return dx.to(dy.dtype), dw.to(weight.dtype), db.to(weight.dtype), None, None, None, None, None
+
+
+class DistBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d whose training statistics span all ranks' vertices (same parameters,
+    buffers and state-dict keys)."""
+    group = None
+
+    def forward(self, x):
+        if not self.training or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return super().forward(x)
+        if self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        momentum = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+        return _SyncBNFn.apply(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                               self.running_var if self.track_running_stats else None, self.eps, momentum, self.group)
+
+
+def convert_batchnorm(model: nn.Module, group=None) -> nn.Module:
+    """Switch every BatchNorm1d of ``model`` to mesh-wide statistics, in place."""
+    for mod in model.modules():
+        if type(mod) is nn.BatchNorm1d:
+            mod.__class__ = DistBatchNorm1d
+            mod.group = group
+    return model
+
+
+def all_reduce_gradients(params, group=None) -> None:
+    """Sum the per-rank partial parameter gradients: one flat bucket, one all-reduce."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    _all_reduce(flat, dist.ReduceOp.SUM, group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def dist_min_max(z1: torch.Tensor, group=None):
+    lo, hi = z1.min(dim=0, keepdim=True)[0], z1.max(dim=0, keepdim=True)[0]
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        lo, hi = lo.detach().clone(), hi.detach().clone()
+        _all_reduce(lo, dist.ReduceOp.MIN, group)
+        _all_reduce(hi, dist.ReduceOp.MAX, group)
+    return lo, hi
+
+
+# --------------------------------------------------------------------------------------
+# per-rank training state
+# --------------------------------------------------------------------------------------
+@dataclass
+class PartitionedMesh:
+    """One rank's slice of the training constants (all in processing order, owned rows only
+    unless noted)."""
+    graph: DistMeshGraph
+    z1: torch.Tensor            # [n,3] requires_grad
+    x_pos: torch.Tensor         # [n,3]
+    faces_ext: torch.Tensor     # [F_own,3] indices into [owned | halo]
+    target_pos: torch.Tensor    # [n,3]
+    target_fn: torch.Tensor     # [F_own,3]
+    v_keep: torch.Tensor        # [n,1]
+    f_keep: torch.Tensor        # [F_own,1]
+    dummy_masks: torch.Tensor   # [n,M]
+    n_v_keep: float             # GLOBAL counts
+    n_f_keep: float
+    edge_index = None           # SingleScaleGCN reads .graph instead
+
+
+def partition_mesh(mesh, rank: int, world: int, device, group=None, n_masks: int = 5, seed: int = 317) -> PartitionedMesh:
+    """Cut a synth.SynthMesh (every rank builds the same one) into this rank's share."""
+    from . import synth, train
+    V = mesh.num_vertices
+    pos_all = torch.from_numpy(mesh.x_pos).to(device)
+    order, rank_of = _reorder.morton_order(pos_all)
+    ei = _reorder.permute_edge_index(torch.from_numpy(mesh.edge_index).to(device), rank_of)
+    g = DistMeshGraph(ei, V, rank, world, group)
+    own = order[g.start:g.end]                                   # old ids of my vertices, in my order
+    faces = rank_of[torch.from_numpy(mesh.faces).to(device)]     # new ids
+    f_mine = (faces[:, 0] >= g.start) & (faces[:, 0] < g.end)
+    fo = faces[f_mine]
+    in_own = (fo >= g.start) & (fo < g.end)
+    faces_ext = torch.where(in_own, fo - g.start, g.n_own + torch.searchsorted(g.halo_ids, fo))
+    vs_all = torch.from_numpy(mesh.vs.astype(np.float32)).to(device)
+    tfn_all = train.face_normals(vs_all, torch.from_numpy(mesh.faces).to(device))
+    v_keep_all = torch.from_numpy(mesh.v_mask.astype(np.float32)).to(device)
+    fa = torch.from_numpy(mesh.faces).to(device)
+    f_keep_all = v_keep_all[fa[:, 0]] * v_keep_all[fa[:, 1]] * v_keep_all[fa[:, 2]]
+    dm_all = torch.from_numpy(synth.make_dummy_masks(mesh.edge_index, V, dm_size=n_masks, k=4, p=0.014, seed=seed)).to(device)
+    z1 = torch.from_numpy(mesh.z1).to(device)[own].clone().requires_grad_(True)
+    return PartitionedMesh(g, z1, pos_all[own].clone(), faces_ext, vs_all[own].clone(), tfn_all[f_mine].clone(),
+                           v_keep_all[own].view(-1, 1).clone(), f_keep_all[f_mine].view(-1, 1).clone(),
+                           dm_all[own].clone(), float(v_keep_all.sum()), float(f_keep_all.sum()))
+
+
+class DistSGCNTrainer:
+    """SGCNTrainer (semigcn_amd.train, the loop of sgcn.py:118-147) on a vertex partition."""
+
+    def __init__(self, model: nn.Module, part: PartitionedMesh, group=None, lr: float = 0.01, k1: float = 4.0,
+                 accumulate: int = 5):
+        self.model, self.part, self.group, self.k1, self.accumulate = model, part, group, k1, accumulate
+        convert_batchnorm(model, group)
+        self.params = [p for p in model.parameters()]
+        self.opt = torch.optim.Adam(self.params, lr=lr)
+        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=50, gamma=0.5)
+        self.iteration = 0
+        self.loss_sum = torch.zeros((), device=part.z1.device)
+        self.opt.zero_grad(set_to_none=True)
+
+    def loss(self, pos_own: torch.Tensor) -> torch.Tensor:
+        from . import train
+        p = self.part
+        d = (p.target_pos - pos_own) * p.v_keep
+        lp = torch.sqrt(all_reduce_sum((d * d).sum(), self.group) / p.n_v_keep + 1.0e-6)
+        pos_ext = halo_extend(p.graph, pos_own)
+        fn = train.face_normals(pos_ext, p.faces_ext)
+        ln = all_reduce_sum(((fn - p.target_fn).abs() * p.f_keep).sum(), self.group) / p.n_f_keep
+        return lp + self.k1 * ln
+
+    def iteration_step(self, mask_index: Optional[int] = None) -> torch.Tensor:
+        p = self.part
+        k = self.iteration % p.dummy_masks.shape[1] if mask_index is None else mask_index
+        dm = p.v_keep * p.dummy_masks[:, k:k + 1]
+        self.model.train()
+        pos = self.model(p, dm)
+        loss = self.loss(pos)
+        loss.backward()
+        self.loss_sum += loss.detach()
+        self.iteration += 1
+        if self.iteration % self.accumulate == 0:
+            all_reduce_gradients(self.params, self.group)
+            self.opt.step()
+            self.opt.zero_grad(set_to_none=True)
+        return loss
+
+
+@dataclass
+class _Job:
+    trainer: DistSGCNTrainer
+    V_total: int
+    E_total: int
+    workload: str
+
+
+def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permute: bool = False,
+                          dtype=torch.float32, group=None) -> _Job:
+    """bench.py's N > 1 leg: the SAME nu x nv mesh as the 1-GPU run, cut into ``world`` blocks
+    (strong scaling)."""
+    from . import synth
+    from .networks import SingleScaleGCN
+    mesh = synth.torus_mesh(nu, nv, permute=permute)
+    part = partition_mesh(mesh, rank, world, device, group)
+    torch.manual_seed(314)
+    model = SingleScaleGCN(device).to(device)
+    if dtype != torch.float32:
+        model.set_feature_dtype(dtype)
+    trainer = DistSGCNTrainer(model, part, group)
+    halo = torch.tensor([part.graph.n_halo], device=device)
+    if world > 1:
+        _all_reduce(halo, dist.ReduceOp.MAX, group)
+    workload = (f"SGCN train iteration on a closed torus mesh {nu}x{nv} (V={mesh.num_vertices} E={mesh.num_edges}), "
+                f"Morton-ordered and vertex-partitioned into {world} blocks (<= {int(halo)} halo rows per rank), "
+                f"halo exchange + mesh-wide BatchNorm + gradient all-reduce over RCCL")
+    return _Job(trainer, mesh.num_vertices, mesh.num_edges, workload)

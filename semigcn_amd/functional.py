@@ -95,6 +95,9 @@ def cheb_conv(graph: MeshGraph, x: torch.Tensor, weights: Sequence[torch.Tensor]
     """ChebConv forward on a prepared graph; ``weights[k]`` is ``lins[k].weight`` [Cout, Cin]."""
     if x.dim() != 2:
         raise ValueError(f"x must be [V, C], got {tuple(x.shape)}")
+    if getattr(graph, "is_distributed", False):
+        from .dist import dist_cheb_conv
+        return dist_cheb_conv(graph, x, weights, bias)
     if x.shape[0] != graph.num_vertices:
         raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.num_vertices} vertices")
     return _ChebConvFn.apply(graph, x, bias, *weights)

@@ -52,11 +52,14 @@ class _DeviceCache:
         return dev
 
 
-def prepare_input(z1: torch.Tensor, dm: torch.Tensor) -> torch.Tensor:
+def prepare_input(z1: torch.Tensor, dm: torch.Tensor, lo: Optional[torch.Tensor] = None,
+                  hi: Optional[torch.Tensor] = None) -> torch.Tensor:
     """util/networks.py:67-79 -- bounding-box normalisation with ONE scalar scale and a
-    per-axis centre, masking of all three coordinates, mask appended as 4th channel."""
-    lo = torch.min(z1, dim=0, keepdim=True)[0]
-    hi = torch.max(z1, dim=0, keepdim=True)[0]
+    per-axis centre, masking of all three coordinates, mask appended as 4th channel.
+    ``lo`` / ``hi`` [1,3]: mesh-wide bounds when z1 is only one rank's share."""
+    if lo is None:
+        lo = torch.min(z1, dim=0, keepdim=True)[0]
+        hi = torch.max(z1, dim=0, keepdim=True)[0]
     extent = torch.max(hi - lo)
     centred = (z1 - (lo + hi) * 0.5) / extent
     return torch.cat([dm * centred, dm], dim=1)
@@ -107,6 +110,9 @@ class SingleScaleGCN(nn.Module):
     def _layout(self, data):
         """(graph, order, rank) for this mesh: the CSR of the (re-numbered) edge_index and the
         Morton permutation, computed once per (edge_index, x_pos) pair."""
+        prebuilt = getattr(data, "graph", None)
+        if prebuilt is not None:           # a prepared (possibly partitioned) graph: nothing to derive
+            return prebuilt, None, None
         ei = self._consts.get(data.edge_index, self.device)
         if not self.reorder:
             return graph_for(ei, data.z1.shape[0]), None, None
@@ -132,7 +138,11 @@ class SingleScaleGCN(nn.Module):
         z1 = data.z1.to(self.device)
         x_pos = self._consts.get(data.x_pos, self.device)
         graph, order, rank = self._layout(data)
-        x = prepare_input(z1, self._mask(dm, z1.shape[0], z1.dtype))
+        lo = hi = None
+        if getattr(graph, "is_distributed", False):
+            from .dist import dist_min_max
+            lo, hi = dist_min_max(z1, graph.group)
+        x = prepare_input(z1, self._mask(dm, z1.shape[0], z1.dtype), lo, hi)
         if order is not None:
             x = x.index_select(0, order)
         x = x.to(self.feature_dtype)

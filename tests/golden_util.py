@@ -89,3 +89,44 @@ def rel_l2(a, b) -> float:
 
 def load(name: str):
     return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+
+
+class ActivationMasks:
+    """Records the sign pattern every LeakyReLU/ReLU sees during forward passes.
+
+    A one-ulp difference in a BatchNorm output that happens to sit within ~1e-6 of zero flips
+    that element's LeakyReLU slope (1 -> 0.01) in the backward pass; ONE such flip moves every
+    upstream gradient by ~|g_i|/|g| ~ 0.5 % on the small fixture meshes.  Gradient parity is
+    therefore asserted tightly only between runs with identical activation patterns, and with
+    a per-flip allowance otherwise (see grad_tolerance)."""
+
+    def __init__(self, model: torch.nn.Module):
+        self.masks = []
+        self._hooks = []
+        seen = set()
+        for mod in model.modules():
+            if isinstance(mod, (torch.nn.LeakyReLU, torch.nn.ReLU)) and id(mod) not in seen:
+                seen.add(id(mod))
+                self._hooks.append(mod.register_forward_hook(self._record))
+
+    def _record(self, mod, inputs, output):
+        self.masks.append((inputs[0].detach() > 0).cpu())
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+
+    def flips_against(self, other: "ActivationMasks", row_maps=None) -> int:
+        """Number of elements whose sign differs; ``row_maps[i]`` (optional, LongTensor) re-orders
+        the rows of this recorder's i-th mask into the other's vertex order."""
+        assert len(self.masks) == len(other.masks), (len(self.masks), len(other.masks))
+        n = 0
+        for i, (a, b) in enumerate(zip(self.masks, other.masks)):
+            if row_maps is not None and row_maps[i] is not None:
+                a = a.index_select(0, row_maps[i])
+            n += int((a != b).sum())
+        return n
+
+
+def grad_tolerance(flips: int, tight: float, per_flip: float = 2e-2) -> float:
+    return tight if flips == 0 else tight + per_flip * flips

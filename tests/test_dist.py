@@ -1,0 +1,156 @@
+"""N > 1 path on CPU: world_size 2 and 3 over gloo, HIP handles swapped for the oracle-backed
+doubles (conftest.py).  Contract: N-rank result == 1-rank result (outputs, loss, parameter
+gradients after the gradient all-reduce, BatchNorm running statistics)."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _install_doubles():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    from semigcn_amd import capi
+    capi.GraphHandle = conftest.OracleGraphDouble
+    capi.PoolHandle = conftest.OraclePoolDouble
+    capi.gather_rows = lambda rows, X, out=None: X.index_select(0, rows.long())
+
+
+def _run_rank(rank, world, port, out_dir, skip):
+    _install_doubles()
+    torch.set_num_threads(1)
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import golden_util as GU
+    from semigcn_amd import dist as sgdist, synth
+    from semigcn_amd.networks import SingleScaleGCN
+    mesh = synth.torus_mesh(24, 16, permute=True)
+    part = sgdist.partition_mesh(mesh, rank, world, torch.device("cpu"), n_masks=2)
+    model = SingleScaleGCN("cpu", skip=skip)
+    GU.fill_state(model, seed=77)
+    # (0) the pieces that talk across ranks, without kinks: one ChebConv layer and one BatchNorm
+    from semigcn_amd import nn as sgnn
+    g = part.graph
+    V = mesh.num_vertices
+    order = sgdist._reorder.morton_order(torch.from_numpy(mesh.x_pos))[0]
+    gen = torch.Generator().manual_seed(5)
+    x_all = torch.randn(V, 12, generator=gen)[order]            # processing order
+    r_all = torch.randn(V, 20, generator=gen)[order]
+    conv = sgnn.ChebConv(12, 20, K=3)
+    GU.fill_state(conv, seed=1)
+    x = x_all[g.start:g.end].clone().requires_grad_(True)
+    y = conv(x, g)
+    (y * r_all[g.start:g.end]).sum().backward()
+    sgdist.all_reduce_gradients(list(conv.parameters()))
+    bn = sgdist.DistBatchNorm1d(20)
+    GU.fill_state(bn, seed=2)
+    bn.train()
+    xb = r_all[g.start:g.end].clone().requires_grad_(True)
+    yb = bn(xb)
+    (yb * yb * x_all[g.start:g.end, :1]).sum().backward()
+    sgdist.all_reduce_gradients(list(bn.parameters()))
+    lin = {"conv_y": y.detach().clone(), "conv_dx": x.grad.clone(), "conv_dw": conv.lins[2].weight.grad.clone(),
+           "conv_db": conv.bias.grad.clone(), "bn_y": yb.detach().clone(), "bn_dx": xb.grad.clone(),
+           "bn_dw": bn.weight.grad.clone(), "bn_db": bn.bias.grad.clone(),
+           "bn_rm": bn.running_mean.clone(), "bn_rv": bn.running_var.clone()}
+
+    tr = sgdist.DistSGCNTrainer(model, part, accumulate=2)
+    # (1) one forward/backward on the initial parameters, gradients reduced explicitly
+    model.train()
+    pos = model(part, part.v_keep * part.dummy_masks[:, :1])
+    loss = tr.loss(pos)
+    loss.backward()
+    sgdist.all_reduce_gradients(tr.params)
+    g = part.graph
+    out = {"lin": lin, "loss0": float(loss.detach()), "pos": pos.detach().clone(), "range": (g.start, g.end), "n_halo": g.n_halo,
+           "grads": {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
+           "bn": {k: v.clone() for k, v in model.state_dict().items() if "running" in k}}
+    tr.opt.zero_grad(set_to_none=True)
+    # (2) the training loop proper: two accumulated iterations, then Adam on the reduced gradients
+    out["losses"] = [float(tr.iteration_step().detach()) for _ in range(2)]
+    out["params"] = {n: p.detach().clone() for n, p in model.named_parameters()}
+    torch.save(out, os.path.join(out_dir, f"w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _launch(world, out_dir, skip, port):
+    if world == 1:
+        _run_rank(0, 1, port, out_dir, skip)
+    else:
+        mp.spawn(_run_rank, args=(world, port, out_dir, skip), nprocs=world, join=True)
+    return [torch.load(os.path.join(out_dir, f"w{world}_r{r}.pt")) for r in range(world)]
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+
+
+@pytest.mark.parametrize("world,skip", [(2, False), (3, True)])
+def test_partitioned_training_matches_single_rank(world, skip):
+    with tempfile.TemporaryDirectory() as d:
+        ref = _launch(1, d, skip, 0)[0]
+        parts = _launch(world, d, skip, 29600 + world)
+    assert sum(p["range"][1] - p["range"][0] for p in parts) == 384
+    assert all(p["n_halo"] > 0 for p in parts)
+    # exact pieces: partitioned ChebConv and mesh-wide BatchNorm == their single-rank results
+    for key in ("conv_y", "conv_dx", "bn_y", "bn_dx"):
+        assert rel_l2(torch.cat([p["lin"][key] for p in parts], dim=0), ref["lin"][key]) < 2e-6, key
+    for key in ("conv_dw", "conv_db", "bn_dw", "bn_db", "bn_rm", "bn_rv"):
+        for p in parts:
+            assert rel_l2(p["lin"][key], ref["lin"][key]) < 5e-6, key
+    pos = torch.cat([p["pos"] for p in parts], dim=0)        # blocks are contiguous in processing order
+    assert rel_l2(pos, ref["pos"]) < 2e-5
+    gmax = max(float(v.abs().max()) for v in ref["grads"].values())
+    for p in parts:
+        assert abs(p["loss0"] - ref["loss0"]) < 2e-5 * abs(ref["loss0"])
+        assert np.allclose(p["losses"], ref["losses"], rtol=1e-4)     # 2nd/3rd forward: BN running stats moved
+        for n, g in ref["grads"].items():     # kink-limited (L1 on unit normals, LeakyReLU sign flips): see (0) for exact
+            scale = max(float(g.norm()), 1e-3 * gmax * g.numel() ** 0.5)
+            assert float((p["grads"][n] - g).norm()) <= 3e-2 * scale, n
+        for k, v in ref["bn"].items():
+            assert rel_l2(p["bn"][k], v) < 1e-5, k
+        # Adam moved every parameter by <= lr; where the gradient is not rounding noise the move agrees
+        for n, v in ref["params"].items():
+            assert float((p["params"][n] - v).abs().max()) <= 2.5e-2, n
+    for n in parts[0]["grads"]:                                # every rank holds the same reduced gradient
+        assert torch.equal(parts[0]["grads"][n], parts[1]["grads"][n]), n
+
+
+def test_partition_plan_is_consistent():
+    _install_doubles()
+    from semigcn_amd import dist as sgdist, reorder, synth
+    mesh = synth.torus_mesh(24, 16)
+    V = mesh.num_vertices
+    order, rank_of = reorder.morton_order(torch.from_numpy(mesh.x_pos))
+    ei = reorder.permute_edge_index(torch.from_numpy(mesh.edge_index), rank_of)
+    world = 4
+    gs = [sgdist.DistMeshGraph(ei, V, r, world) for r in range(world)]
+    assert [g.start for g in gs] == [0, 96, 192, 288]
+    for r, g in enumerate(gs):
+        for q, h in enumerate(gs):
+            # what r sends to q is exactly what q expects from r, in the same order
+            sent = g.send_rows[sum(g.send_splits[:q]):sum(g.send_splits[:q + 1])].long() + g.start
+            want = h.halo_ids[sum(h.recv_splits[:r]):sum(h.recv_splits[:r + 1])]
+            assert torch.equal(sent, want), (r, q)
+        assert g.send_splits[r] == 0 and g.recv_splits[r] == 0
+    # the partitioned operator reproduces the global one row for row
+    x = torch.randn(V, 5)
+    full = sgdist.DistMeshGraph(ei, V, 0, 1)
+    y_full = full.handle.spmm(x, torch.empty(V, 5))
+    for g in gs:
+        x_ext = torch.cat([x[g.start:g.end], x[g.halo_ids]])
+        y = g.handle.spmm(x_ext, torch.empty(g.n_own, 5))
+        assert torch.allclose(y, y_full[g.start:g.end], atol=1e-6)
+    with pytest.raises(ValueError, match="symmetric"):
+        sgdist.DistMeshGraph(ei[:, :-1], V, 0, 2)
