@@ -87,7 +87,7 @@ def block_bounds(num_vertices: int, world: int) -> List[int]:
 
 class DistMeshGraph:
     """One rank's share of the scaled Laplacian plus its halo-exchange plan."""
-    is_distributed = True
+    sg_partitioned = True
 
     def __init__(self, edge_index: torch.Tensor, num_vertices: int, rank: int, world: int,
                  group=None, bounds: Optional[Sequence[int]] = None):

@@ -95,7 +95,7 @@ def cheb_conv(graph: MeshGraph, x: torch.Tensor, weights: Sequence[torch.Tensor]
     """ChebConv forward on a prepared graph; ``weights[k]`` is ``lins[k].weight`` [Cout, Cin]."""
     if x.dim() != 2:
         raise ValueError(f"x must be [V, C], got {tuple(x.shape)}")
-    if getattr(graph, "is_distributed", False):
+    if getattr(graph, "sg_partitioned", False):
         from .dist import dist_cheb_conv
         return dist_cheb_conv(graph, x, weights, bias)
     if x.shape[0] != graph.num_vertices:

@@ -139,7 +139,7 @@ class SingleScaleGCN(nn.Module):
         x_pos = self._consts.get(data.x_pos, self.device)
         graph, order, rank = self._layout(data)
         lo = hi = None
-        if getattr(graph, "is_distributed", False):
+        if getattr(graph, "sg_partitioned", False):
             from .dist import dist_min_max
             lo, hi = dist_min_max(z1, graph.group)
         x = prepare_input(z1, self._mask(dm, z1.shape[0], z1.dtype), lo, hi)

@@ -75,7 +75,7 @@ class ChebConv(nn.Module):
         if edge_weight is not None or batch is not None or lambda_max is not None:
             raise NotImplementedError("edge_weight / batch / lambda_max are not used by the reference "
                                       "and are not implemented")
-        prepared = isinstance(edge_index, MeshGraph) or getattr(edge_index, "is_distributed", False)
+        prepared = isinstance(edge_index, MeshGraph) or getattr(edge_index, "sg_partitioned", False)
         graph = edge_index if prepared else graph_for(edge_index, x.shape[0])
         return F_sg.cheb_conv(graph, x, [lin.weight for lin in self.lins], self.bias)
 
