@@ -78,4 +78,5 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
-                assert "/root/reference" not in src or f in ("synth.py",) or "reference/" in src
+                # citations of /root/reference in docstrings are fine; reading it at run time is not
+                assert not re.search(r"(sys\.path[^\n]*reference|open\([^\n]*reference|REFERENCE_ROOT)", src), f
