@@ -59,6 +59,29 @@ def algorithmic_bytes(V: int, E: int, C: int, elem: int, n_epilogue: int) -> flo
     return (2 + n_epilogue) * V * C * elem + 4.0 * E + 4.0 * (V + 1) + 4.0 * V
 
 
+def pmc_traffic(C: int, dtype_name: str, n_epi: int, esize: int):
+    """HBM-side bytes per launch of the aggregation kernel variant that serves (C, dtype, n_epi), from
+    the committed rocprofv3 PMC summary of this same workload (tools/pmc_summary.py; counters cannot be
+    read from inside the process).  None when no summary matches."""
+    vec = 16 // esize
+    nvec = C // vec
+    if C % vec:
+        return None
+    lanes = 1
+    while lanes < min(nvec, 64):
+        lanes *= 2
+    per_lane = 1 if nvec <= 64 else (2 if nvec <= 128 else 4)
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{'fp32' if esize == 4 else 'bf16'}.json")
+    try:
+        for k in json.load(open(path))["kernels"]:
+            if (k["dtype"] == dtype_name and k["lanes_per_row"] == lanes and k["vectors_per_lane"] == per_lane
+                    and k["epilogue_operands"] == n_epi):
+                return k["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def build_mesh_batch(mesh, device, n_masks: int):
     from semigcn_amd import synth, train
     V = mesh.num_vertices
@@ -216,9 +239,14 @@ def main():
             total_B = sum(k["algorithmic_MB"] * k["launches"] for k in kernels)
             total_t = sum(k["total_ms"] for k in kernels)
             dom = kernels[0]
+            traffic = pmc_traffic(dom["C"], dom["dtype"], dom["epilogue_operands"], elem) if (
+                world == 1 and (nu, nv) == (1000, 1000) and not args.permute) else None
             roof = {"bound": "hbm", "kernel": f"sg::spmm_rows C={dom['C']} {dom['dtype']} (+{dom['epilogue_operands']} epilogue operands)",
                     "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE KiB, separate passes) "
+                                    "of this workload, profiles/r01_pmc_traffic_*.json; algorithmic bytes = "
+                                    f"{round(dom['algorithmic_MB'] * 1e6)}",
                     "all_aggregations_GBs": round(total_B / total_t, 1),
                     "all_aggregations_frac": round(total_B / total_t / HBM_PEAK_GBS, 4),
                     "aggregation_share_of_step": round(total_t / (dt * 1e3), 4)}

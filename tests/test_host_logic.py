@@ -245,3 +245,37 @@ def test_mgcn_reference_constructor_path(cpu_kernels):
     assert net.nvs == list(g3["nvs"]) and len(net.meshes) == 4
     assert [tuple(p.shape) for p in net.p_hashes] == [(154, 258), (92, 154), (55, 92)]
     check_mgcn_against_golden(net, g3, "cpu", 5e-5, 2e-3)
+
+
+@pytest.mark.skipif(not __import__("oracle.ref_shim", fromlist=["x"]).available(), reason="/root/reference not present")
+def test_reference_own_model_classes_run_on_this_operator_tier(cpu_kernels, fixture_meshes):
+    """with compat.install() the reference's OWN SingleScaleGCN
+    (util/networks.py, imported in place) runs on semigcn_amd.nn and reproduces its golden output."""
+    import importlib
+    import sys
+    import types
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k.startswith(("torch_geometric", "util"))}
+    had_turtle = "turtle" in sys.modules
+    try:
+        compat.install(force=True)
+        if not had_turtle:
+            sys.modules["turtle"] = types.SimpleNamespace(pd=None)      # util/mesh.py:1
+        sys.path.insert(0, "/root/reference")
+        sys.dont_write_bytecode = True
+        ref_networks = importlib.import_module("util.networks")
+        assert ref_networks.ChebConv is sgnn.ChebConv
+        g2 = GU.load("g2_sgcn.npz")
+        m = fixture_meshes["sphere"]
+        net = ref_networks.SingleScaleGCN("cpu", skip=True)
+        GU.fill_state(net, seed=314)
+        net.eval()
+        with torch.no_grad():
+            out = net(_Data(m), g2["sphere/dm"])
+        assert GU.rel_l2(out, g2["sphere/skip1/eval_dm_ndarray"]) < 1e-5
+    finally:
+        sys.path.remove("/root/reference")
+        for k in [k for k in sys.modules if k.startswith(("torch_geometric", "util"))]:
+            del sys.modules[k]
+        if not had_turtle:
+            sys.modules.pop("turtle", None)
+        sys.modules.update(saved)

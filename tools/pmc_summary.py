@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 --pmc counter CSVs (one pass per counter, as MI355X_MICROARCH.md prescribes:
+FETCH_SIZE and WRITE_SIZE do not fit one pass) into per-launch HBM-side traffic of the
+aggregation kernels.
+
+    python tools/pmc_summary.py <dir with pmc_FETCH_SIZE/ and pmc_WRITE_SIZE/> <out.json> [command string]
+
+Units / corrections (guide, section HBM): both counters are in KiB; on gfx950 FETCH_SIZE reports
+exactly 1/2 of the bytes of wide (16 B/lane) coalesced reads -- this kernel's gathers, epilogue
+loads and staging loads are all such -- so reads = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact for
+16-B/lane streaming stores."""
+import collections
+import csv
+import glob
+import json
+import re
+import statistics
+import sys
+
+
+def load(d):
+    rows = []
+    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    return rows
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    cmd = sys.argv[3] if len(sys.argv) > 3 else ""
+    per = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        agg = collections.defaultdict(list)
+        for r in load(f"{root}/pmc_{cname}"):
+            m = re.search(r"spmm_rows<(.+?), (\d+), (\d+), (\d+)>", r["Kernel_Name"])
+            if not m or r["Counter_Name"] != cname:
+                continue
+            dt = "bfloat16" if "bf16" in m.group(1) else "float32"
+            agg[(dt, int(m.group(2)), int(m.group(3)), int(m.group(4)))].append(float(r["Counter_Value"]))
+        per[cname] = agg
+    res = []
+    for key in sorted(per["FETCH_SIZE"]):
+        f = statistics.mean(per["FETCH_SIZE"][key])
+        w = statistics.mean(per["WRITE_SIZE"].get(key, [0.0]))
+        res.append({"dtype": key[0], "lanes_per_row": key[1], "vectors_per_lane": key[2], "epilogue_operands": key[3],
+                    "launches": len(per["FETCH_SIZE"][key]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
+                    "read_bytes_corrected": round(2 * f * 1024), "write_bytes": round(w * 1024),
+                    "traffic_bytes_per_launch": round(2 * f * 1024 + w * 1024)})
+    json.dump({"command": cmd, "correction": "reads = 2 * FETCH_SIZE * 1024 (gfx950 wide-read under-count), writes = WRITE_SIZE * 1024",
+               "kernels": res}, open(out, "w"), indent=1)
+    print("wrote", out, len(res), "kernel variants")
+
+
+if __name__ == "__main__":
+    main()
