@@ -221,7 +221,6 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
 class _DistChebConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g: DistMeshGraph, x, bias, *weights):
-        from .functional import _mm_f32_out  # noqa: F401  (shared helper)
         K, n = len(weights), g.n_own
         C = x.shape[1]
         wcat = (weights[0] if K == 1 else torch.cat(list(weights), dim=1)).to(x.dtype)
@@ -243,14 +242,14 @@ class _DistChebConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        from .functional import _mm_f32_out
+        from .functional import weight_grad
         T, wcat = ctx.saved_tensors
         g, K, C, n = ctx.g, ctx.K, ctx.C, ctx.g.n_own
         dout = dout.contiguous()
         need_x, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dws = [None] * K
         if any(ctx.needs_input_grad[3:]):
-            dwcat = _mm_f32_out(dout.t(), T[:n]).to(ctx.param_dtype)   # partial: summed over ranks later
+            dwcat = weight_grad(dout, T[:n]).to(ctx.param_dtype)       # partial: summed over ranks later
             dws = [dwcat[:, k * C:(k + 1) * C] for k in range(K)]
         db = dout.sum(0, dtype=torch.float32).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
         dx = None

@@ -279,3 +279,13 @@ def test_reference_own_model_classes_run_on_this_operator_tier(cpu_kernels, fixt
         if not had_turtle:
             sys.modules.pop("turtle", None)
         sys.modules.update(saved)
+
+
+def test_weight_grad_split_reduction_matches_plain_product():
+    from semigcn_amd.functional import weight_grad
+    g = torch.Generator().manual_seed(0)
+    for V in (100, 9001, 20480):
+        dout, T = torch.randn(V, 7, generator=g), torch.randn(V, 12, generator=g)
+        want = dout.double().t() @ T.double()
+        assert rel(weight_grad(dout, T), want) < 1e-5
+        assert rel(weight_grad(dout.bfloat16(), T.bfloat16()), dout.bfloat16().double().t() @ T.bfloat16().double()) < 2e-2
