@@ -370,7 +370,7 @@ def test_chebconv_bf16_layer_error_is_one_rounding(fixture_meshes):
     y16 = conv(x, ei)
     y32 = conv(x.float(), ei)
     assert y16.dtype == torch.bfloat16
-    assert GU.rel_l2(y16.float().cpu(), y32.cpu()) < 2.0 ** -6
+    assert GU.rel_l2(y16.detach().float().cpu(), y32.detach().cpu()) < 2.0 ** -7   # CPU emulation of the roundings: 2.7e-3
 
 
 def test_sgcn_bf16_features_close_to_fp32(fixture_meshes):
