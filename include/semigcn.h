@@ -150,6 +150,48 @@ SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t
                    int64_t ldy, int64_t C, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * BatchNorm over the vertex axis fused with LeakyReLU -- replaces the
+ * nn.BatchNorm1d + nn.LeakyReLU pair after every ChebConv (util/networks.py:
+ * 43-45,50-51; util/meshnet.py:41-62,107-128,226-243), forward and backward.
+ * X / H / dA / Y / dH are [V, C] row-major (row strides in elements), float32
+ * or bfloat16; all per-channel vectors are float32 [C] on the device.
+ * `slope` is the negative slope (0.01 LeakyReLU, 0 ReLU, 1 identity).
+ *
+ *   sg_col_blocks(V)      number of row blocks nb the two reductions use
+ *   sg_col_moments        partial[b][0][c] = mean, partial[b][1][c] = sum (x-mean)^2 of the
+ *                         rows of block b = [b*rpb, min(V,(b+1)*rpb)), rpb = ceil(V/nb);
+ *                         the caller merges the nb (x world-size) partials (Chan et al.)
+ *   sg_scale_shift_act    Y = act(scale*X + shift)           (scale = gamma*invstd, shift = beta - mean*scale)
+ *   sg_bn_act_bwd_reduce  partial[b][0][c] = sum dz, partial[b][1][c] = sum dz*xhat,
+ *                         dz = dA * act'(scale*H + shift), xhat = (H - mean)*invstd
+ *   sg_bn_act_bwd_apply   dH = k * (dz - c1 - xhat*c2)       (training: k = gamma*invstd,
+ *                         c1 = sum dz / N, c2 = sum dz*xhat / N; eval: k = scale, c1 = c2 = 0)
+ *   sg_bn_merge           stats[0][c] = mean, stats[1][c] = sum (x-mean)^2 over all V rows from
+ *                         the nb partials of sg_col_moments (merged in double)
+ *   sg_bn_finalize        from stats [2,C] and the vertex count N (all ranks'): out[0..3][c] =
+ *                         mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; when
+ *                         running_mean / running_var are not NULL they are updated like
+ *                         nn.BatchNorm1d does (momentum, unbiased variance)
+ * partial is float32 [nb, 2, C].
+ * ------------------------------------------------------------------------- */
+SG_API int64_t sg_col_blocks(int64_t V);
+SG_API int sg_col_moments(const void* X, int64_t ldx, int64_t V, int64_t C, int dtype, float* partial,
+                          int64_t nb, void* stream);
+SG_API int sg_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, float* stats, void* stream);
+SG_API int sg_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* out,
+                          void* stream);
+SG_API int sg_scale_shift_act(const void* X, int64_t ldx, const float* scale, const float* shift, float slope,
+                              void* Y, int64_t ldy, int64_t V, int64_t C, int dtype, void* stream);
+SG_API int sg_bn_act_bwd_reduce(const void* dA, int64_t ldda, const void* H, int64_t ldh, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, float slope,
+                                float* partial, int64_t nb, int64_t V, int64_t C, int dtype, void* stream);
+SG_API int sg_bn_act_bwd_apply(const void* dA, int64_t ldda, const void* H, int64_t ldh, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, const float* k,
+                               const float* c1, const float* c2, float slope, void* dH, int64_t lddh, int64_t V,
+                               int64_t C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Launch tuning of the aggregation kernel (process-wide, not thread-safe; for
  * benchmarking -- results never depend on it).
  * ------------------------------------------------------------------------- */

@@ -49,6 +49,18 @@ _SIGNATURES = {
     "sg_unpool": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sg_unpool_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sg_tuning_set": (c_int, [c_int, c_int]),
+    "sg_col_blocks": (c_int64, [c_int64]),
+    "sg_col_moments": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "sg_bn_merge": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "sg_bn_finalize": (c_int, [c_void_p, ctypes.c_double, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                               c_float, c_void_p, c_void_p]),
+    "sg_scale_shift_act": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
+                                   c_int64, c_int, c_void_p]),
+    "sg_bn_act_bwd_reduce": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_float, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "sg_bn_act_bwd_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                    c_void_p]),
     "sg_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
                                c_void_p]),
 }
@@ -309,3 +321,93 @@ def gather_rows(rows: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor]
                                      _rows2d(out, "out"), X.shape[1], dtype_code(X), _stream(X)),
                "sg_gather_rows")
     return out
+
+
+# ---- BatchNorm(+LeakyReLU) over the vertex axis -------------------------------------------------
+def col_blocks(num_rows: int) -> int:
+    return int(load().sg_col_blocks(int(num_rows)))
+
+
+def _f32vec(t: torch.Tensor, n: int, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
+        raise SemigcnLibraryError(f"{name} must be a contiguous float32 vector of {n} elements")
+    _require_device(t, name)
+    return t
+
+
+def col_moments(X: torch.Tensor) -> torch.Tensor:
+    """partial[b] = (mean, sum of squared deviations) per channel over row block b; float32 [nb, 2, C]."""
+    _require_device(X, "X")
+    V, C = X.shape
+    nb = col_blocks(V)
+    part = torch.empty((nb, 2, C), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _check(load().sg_col_moments(_ptr(X), _rows2d(X, "X"), V, C, dtype_code(X), _ptr(part), nb, _stream(X)),
+               "sg_col_moments")
+    return part
+
+
+def bn_merge(partial: torch.Tensor, num_rows: int) -> torch.Tensor:
+    """(mean, M2) [2, C] over all rows from the per-block partials of col_moments."""
+    nb, _, C = partial.shape
+    stats = torch.empty((2, C), dtype=torch.float32, device=partial.device)
+    with torch.cuda.device(partial.device):
+        _check(load().sg_bn_merge(_ptr(partial), nb, int(num_rows), C, _ptr(stats), _stream(partial)), "sg_bn_merge")
+    return stats
+
+
+def bn_finalize(stats: torch.Tensor, count: float, gamma: torch.Tensor, beta: torch.Tensor,
+                running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], momentum: float,
+                eps: float) -> torch.Tensor:
+    """[4, C] = (mean, invstd, scale, shift); updates the running statistics in place when given."""
+    C = stats.shape[1]
+    out = torch.empty((4, C), dtype=torch.float32, device=stats.device)
+    for t, n in ((running_mean, "running_mean"), (running_var, "running_var")):
+        if t is not None:
+            _f32vec(t, C, n)
+    with torch.cuda.device(stats.device):
+        _check(load().sg_bn_finalize(_ptr(stats), float(count), C, _ptr(_f32vec(gamma, C, "weight")),
+                                     _ptr(_f32vec(beta, C, "bias")), _ptr(running_mean), _ptr(running_var),
+                                     float(momentum), float(eps), _ptr(out), _stream(stats)), "sg_bn_finalize")
+    return out
+
+
+def scale_shift_act(X: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, slope: float,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _require_device(X, "X")
+    V, C = X.shape
+    if out is None:
+        out = torch.empty((V, C), dtype=X.dtype, device=X.device)
+    with torch.cuda.device(X.device):
+        _check(load().sg_scale_shift_act(_ptr(X), _rows2d(X, "X"), _ptr(_f32vec(scale, C, "scale")),
+                                         _ptr(_f32vec(shift, C, "shift")), float(slope), _ptr(out), _rows2d(out, "out"),
+                                         V, C, dtype_code(X), _stream(X)), "sg_scale_shift_act")
+    return out
+
+
+def bn_act_bwd_reduce(dA, H, scale, shift, mean, invstd, slope: float) -> torch.Tensor:
+    _require_device(dA, "dA")
+    V, C = H.shape
+    nb = col_blocks(V)
+    part = torch.empty((nb, 2, C), dtype=torch.float32, device=H.device)
+    with torch.cuda.device(H.device):
+        _check(load().sg_bn_act_bwd_reduce(_ptr(dA), _rows2d(dA, "dA"), _ptr(H), _rows2d(H, "H"),
+                                           _ptr(_f32vec(scale, C, "scale")), _ptr(_f32vec(shift, C, "shift")),
+                                           _ptr(_f32vec(mean, C, "mean")), _ptr(_f32vec(invstd, C, "invstd")),
+                                           float(slope), _ptr(part), nb, V, C, dtype_code(H), _stream(H)),
+               "sg_bn_act_bwd_reduce")
+    return part
+
+
+def bn_act_bwd_apply(dA, H, scale, shift, mean, invstd, k, c1, c2, slope: float) -> torch.Tensor:
+    _require_device(dA, "dA")
+    V, C = H.shape
+    dH = torch.empty((V, C), dtype=H.dtype, device=H.device)
+    with torch.cuda.device(H.device):
+        _check(load().sg_bn_act_bwd_apply(_ptr(dA), _rows2d(dA, "dA"), _ptr(H), _rows2d(H, "H"),
+                                          _ptr(_f32vec(scale, C, "scale")), _ptr(_f32vec(shift, C, "shift")),
+                                          _ptr(_f32vec(mean, C, "mean")), _ptr(_f32vec(invstd, C, "invstd")),
+                                          _ptr(_f32vec(k, C, "k")), _ptr(_f32vec(c1, C, "c1")), _ptr(_f32vec(c2, C, "c2")),
+                                          float(slope), _ptr(dH), _rows2d(dH, "dH"), V, C, dtype_code(H), _stream(H)),
+               "sg_bn_act_bwd_apply")
+    return dH

@@ -285,6 +285,63 @@ SG_API int sg_unpool_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* d
 
 SG_API int sg_tuning_set(int knob, int value) { return set_tuning(knob, value); }
 
+SG_API int64_t sg_col_blocks(int64_t V) { return col_blocks(V); }
+
+SG_API int sg_col_moments(const void* X, int64_t ldx, int64_t V, int64_t C, int dtype, float* partial, int64_t nb,
+                          void* stream) {
+  SG_REQUIRE(V >= 0 && C >= 0, "sg_col_moments: negative size");
+  if (V == 0 || C == 0) return SG_OK;
+  SG_REQUIRE(X && partial && ldx >= C, "sg_col_moments: bad argument");
+  return launch_col_reduce(0, X, ldx, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, partial, nb, V, C, dtype,
+                           (hipStream_t)stream);
+}
+
+SG_API int sg_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, float* stats, void* stream) {
+  SG_REQUIRE(V > 0 && C >= 0 && partial && stats, "sg_bn_merge: bad argument");
+  return launch_bn_merge(partial, nb, V, C, stats, (hipStream_t)stream);
+}
+
+SG_API int sg_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* out,
+                          void* stream) {
+  SG_REQUIRE(N > 0 && C >= 0 && stats && gamma && beta && out, "sg_bn_finalize: bad argument");
+  SG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sg_bn_finalize: give both running buffers or none");
+  return launch_bn_finalize(stats, N, C, gamma, beta, running_mean, running_var, momentum, eps, out,
+                            (hipStream_t)stream);
+}
+
+SG_API int sg_scale_shift_act(const void* X, int64_t ldx, const float* scale, const float* shift, float slope, void* Y,
+                              int64_t ldy, int64_t V, int64_t C, int dtype, void* stream) {
+  SG_REQUIRE(V >= 0 && C >= 0, "sg_scale_shift_act: negative size");
+  if (V == 0 || C == 0) return SG_OK;
+  SG_REQUIRE(X && Y && scale && shift && ldx >= C && ldy >= C, "sg_scale_shift_act: bad argument");
+  return launch_col_apply(0, X, ldx, nullptr, 0, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, slope, Y,
+                          ldy, V, C, dtype, (hipStream_t)stream);
+}
+
+SG_API int sg_bn_act_bwd_reduce(const void* dA, int64_t ldda, const void* H, int64_t ldh, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, float slope, float* partial,
+                                int64_t nb, int64_t V, int64_t C, int dtype, void* stream) {
+  SG_REQUIRE(V >= 0 && C >= 0, "sg_bn_act_bwd_reduce: negative size");
+  if (V == 0 || C == 0) return SG_OK;
+  SG_REQUIRE(dA && H && scale && shift && mean && invstd && partial && ldda >= C && ldh >= C,
+             "sg_bn_act_bwd_reduce: bad argument");
+  return launch_col_reduce(1, dA, ldda, H, ldh, scale, shift, mean, invstd, slope, partial, nb, V, C, dtype,
+                           (hipStream_t)stream);
+}
+
+SG_API int sg_bn_act_bwd_apply(const void* dA, int64_t ldda, const void* H, int64_t ldh, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, const float* k,
+                               const float* c1, const float* c2, float slope, void* dH, int64_t lddh, int64_t V,
+                               int64_t C, int dtype, void* stream) {
+  SG_REQUIRE(V >= 0 && C >= 0, "sg_bn_act_bwd_apply: negative size");
+  if (V == 0 || C == 0) return SG_OK;
+  SG_REQUIRE(dA && H && dH && scale && shift && mean && invstd && k && c1 && c2 && ldda >= C && ldh >= C && lddh >= C,
+             "sg_bn_act_bwd_apply: bad argument");
+  return launch_col_apply(1, dA, ldda, H, ldh, scale, shift, mean, invstd, k, c1, c2, slope, dH, lddh, V, C, dtype,
+                          (hipStream_t)stream);
+}
+
 SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y, int64_t ldy,
                    int64_t C, int dtype, void* stream) {
   SG_REQUIRE(n >= 0 && C >= 0, "sg_gather_rows: negative size");

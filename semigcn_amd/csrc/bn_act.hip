@@ -1,0 +1,339 @@
+// BatchNorm over the VERTEX axis fused with LeakyReLU, forward and backward, for gfx950.
+//
+// Replaces the nn.BatchNorm1d + nn.LeakyReLU pair that follows every ChebConv of the reference
+// (util/networks.py:43-45,50-51; util/meshnet.py:41-62,107-128,226-243): batch = all V vertices of
+// the mesh, eps 1e-5, biased variance for normalisation.  All four kernels are pure HBM streams
+// over [V, C] row-major features (16 B per lane, whole rows per wavefront), so the pair costs
+//   forward : 1 read (moments) + 1 read + 1 write (normalise+activate, optionally straight into a
+//             column block of the next layer's [V, 3C] buffer)
+//   backward: 2 reads (reduce) + 2 reads + 1 write (apply)
+// against 5 + 8 passes for the separate ATen kernels plus the copy into the next layer's buffer.
+// The LeakyReLU mask and x-hat are recomputed from the saved conv output; nothing extra is stored.
+#include <type_traits>
+
+#include "sg_common.h"
+
+namespace sg {
+namespace {
+
+constexpr int kBlock = 256;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DT> struct Io;
+template <> struct Io<SG_F32> {
+  static constexpr int VEC = 4;
+  using raw = f32x4;
+  using elem = float;
+  static __device__ __forceinline__ void unpack(const raw& v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+  static __device__ __forceinline__ raw pack(const float* f) { return raw{f[0], f[1], f[2], f[3]}; }
+  static __device__ __forceinline__ float load1(const elem* p) { return *p; }
+  static __device__ __forceinline__ void store1(elem* p, float v) { *p = v; }
+};
+template <> struct Io<SG_BF16> {
+  static constexpr int VEC = 8;
+  using raw = u32x4;
+  using elem = uint16_t;
+  static __device__ __forceinline__ void unpack(const raw& v, float* f) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ uint32_t cvt2(float lo, float hi) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16);
+  }
+  static __device__ __forceinline__ raw pack(const float* f) {
+    return raw{cvt2(f[0], f[1]), cvt2(f[2], f[3]), cvt2(f[4], f[5]), cvt2(f[6], f[7])};
+  }
+  static __device__ __forceinline__ float load1(const elem* p) { return __uint_as_float((uint32_t)*p << 16); }
+  static __device__ __forceinline__ void store1(elem* p, float v) { *p = __builtin_bit_cast(uint16_t, (__bf16)v); }
+};
+
+__device__ __forceinline__ float act_slope(float z, float slope) { return z > 0.f ? 1.0f : slope; }
+
+// ---- column reductions --------------------------------------------------------------------
+// Block b owns rows [b*rpb, (b+1)*rpb).  A row's C channels are spread over `tpr` threads
+// (VEC channels each); the block's 256/tpr row groups are merged through LDS.
+// MODE 0: out[b][0][c] = mean_b, out[b][1][c] = M2_b  of X
+// MODE 1: out[b][0][c] = sum dz, out[b][1][c] = sum dz*xhat; dz = dA*act'(scale*h+shift), xhat=(h-mean)*invstd
+template <int DT, int MODE, int VECW>
+__global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda, const void* H_, int64_t ldh,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     float slope, float* __restrict__ out, int64_t V, int C, int rpb,
+                                                     int tpr) {
+  using IO = Io<DT>;
+  using elem_t = typename IO::elem;
+  using raw_t = typename IO::raw;
+  constexpr int VEC = VECW;  // IO::VEC (vector path) or 1 (scalar path)
+  __shared__ float s_red[2][kBlock][VECW];
+  const elem_t* A = (const elem_t*)A_;
+  const elem_t* H = (const elem_t*)H_;
+  const int groups = kBlock / tpr;
+  const int tg = threadIdx.x / tpr;   // row group of this thread
+  const int tc = threadIdx.x % tpr;   // column slot
+  const int64_t r_begin = (int64_t)blockIdx.x * rpb;
+  int64_t r_end = r_begin + rpb;
+  if (r_end > V) r_end = V;
+  const float n_rows = (float)(r_end - r_begin);
+  const int ncol = (C + VEC - 1) / VEC;   // column slots per row
+
+  for (int c0 = 0; c0 < ncol; c0 += tpr) {      // one pass per 256-thread-wide column chunk (C > tpr*VEC)
+    const int cs = c0 + tc;
+    const bool cok = cs < ncol;
+    float a0[VEC], a1[VEC];
+    float sc[VEC], sh[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      a0[k] = 0.f; a1[k] = 0.f;
+      const int c = cs * VEC + k;
+      const bool ok = cok && c < C;
+      if (MODE == 1) {
+        sc[k] = ok ? scale[c] : 0.f; sh[k] = ok ? shift[c] : 0.f;
+        mu[k] = ok ? mean[c] : 0.f; is[k] = ok ? invstd[c] : 0.f;
+      }
+    }
+    if (cok) {
+      for (int64_t r = r_begin + tg; r < r_end; r += groups) {
+        float x[VEC], h[VEC];
+        if (VEC == 1) {
+          x[0] = IO::load1(A + r * lda + cs);
+          if (MODE == 1) h[0] = IO::load1(H + r * ldh + cs);
+        } else {
+          IO::unpack(*(const raw_t*)(A + r * lda + (int64_t)cs * VEC), x);
+          if (MODE == 1) IO::unpack(*(const raw_t*)(H + r * ldh + (int64_t)cs * VEC), h);
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          if (MODE == 0) {
+            a0[k] += x[k];
+            a1[k] = fmaf(x[k], x[k], a1[k]);
+          } else {
+            const float dz = x[k] * act_slope(fmaf(sc[k], h[k], sh[k]), slope);
+            a0[k] += dz;
+            a1[k] = fmaf(dz, (h[k] - mu[k]) * is[k], a1[k]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { s_red[0][threadIdx.x][k] = a0[k]; s_red[1][threadIdx.x][k] = a1[k]; }
+    __syncthreads();
+    if (tg == 0 && cok) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int g = 0; g < groups; ++g) { s0 += s_red[0][g * tpr + tc][k]; s1 += s_red[1][g * tpr + tc][k]; }
+        const int c = cs * VEC + k;
+        if (c < C) {
+          if (MODE == 0) {
+            const float m = s0 / n_rows;
+            out[((int64_t)blockIdx.x * 2 + 0) * C + c] = m;
+            out[((int64_t)blockIdx.x * 2 + 1) * C + c] = fmaxf(s1 - s0 * m, 0.f);   // sum (x-m)^2 over <= rpb rows
+          } else {
+            out[((int64_t)blockIdx.x * 2 + 0) * C + c] = s0;
+            out[((int64_t)blockIdx.x * 2 + 1) * C + c] = s1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- elementwise --------------------------------------------------------------------------
+// MODE 0: Y = act(scale*X + shift)
+// MODE 1: dH = k*(dz - c1 - xhat*c2), dz = dA*act'(scale*H+shift), xhat = (H-mean)*invstd
+template <int DT, int MODE, int VECW>
+__global__ __launch_bounds__(kBlock) void col_apply(const void* A_, int64_t lda, const void* H_, int64_t ldh,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                    const float* __restrict__ kk, const float* __restrict__ c1,
+                                                    const float* __restrict__ c2, float slope, void* Y_, int64_t ldy,
+                                                    int64_t V, int C) {
+  using IO = Io<DT>;
+  using elem_t = typename IO::elem;
+  using raw_t = typename IO::raw;
+  constexpr int VEC = VECW;
+  const elem_t* A = (const elem_t*)A_;
+  const elem_t* H = (const elem_t*)H_;
+  elem_t* Y = (elem_t*)Y_;
+  const int ncol = (C + VEC - 1) / VEC;
+  const int64_t total = V * ncol;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = t / ncol;
+    const int cs = (int)(t - r * ncol);
+    float x[VEC], h[VEC], y[VEC];
+    if (VEC == 1) {
+      x[0] = IO::load1(A + r * lda + cs);
+      if (MODE == 1) h[0] = IO::load1(H + r * ldh + cs);
+    } else {
+      IO::unpack(*(const raw_t*)(A + r * lda + (int64_t)cs * VEC), x);
+      if (MODE == 1) IO::unpack(*(const raw_t*)(H + r * ldh + (int64_t)cs * VEC), h);
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = cs * VEC + k;
+      if (MODE == 0) {
+        const float z = fmaf(scale[c], x[k], shift[c]);
+        y[k] = z > 0.f ? z : z * slope;
+      } else {
+        const float dz = x[k] * act_slope(fmaf(scale[c], h[k], shift[c]), slope);
+        y[k] = kk[c] * (dz - c1[c] - (h[k] - mean[c]) * invstd[c] * c2[c]);
+      }
+    }
+    if (VEC == 1) IO::store1(Y + r * ldy + cs, y[0]);
+    else *(raw_t*)(Y + r * ldy + (int64_t)cs * VEC) = IO::pack(y);
+  }
+}
+
+// stats[0][c] = mean, stats[1][c] = M2 over all V rows, from the per-block partials (Chan et al.,
+// in double).  32 lanes per channel: each merges every 32nd block, then a shuffle tree merges lanes.
+__global__ __launch_bounds__(256) void bn_merge(const float* __restrict__ partial, int64_t nb, int64_t V, int C,
+                                                int rpb, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 31;
+  const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  if (c < C) {
+    for (int64_t b = lane; b < nb; b += 32) {
+      int64_t rows = V - b * rpb;
+      rows = rows > rpb ? rpb : rows;
+      if (rows <= 0) break;
+      const double nbk = (double)rows, mb = partial[(b * 2 + 0) * C + c], qb = partial[(b * 2 + 1) * C + c];
+      const double tot = n + nbk, delta = mb - mean;
+      mean += delta * (nbk / tot);
+      m2 += qb + delta * delta * (n * nbk / tot);
+      n = tot;
+    }
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {       // lanes l and l+off sit in the same 32-lane half of the wavefront
+    const double n2 = __shfl_down(n, off, 32), mean2 = __shfl_down(mean, off, 32), m22 = __shfl_down(m2, off, 32);
+    const double tot = n + n2;
+    if (tot > 0.0) {
+      const double delta = mean2 - mean;
+      mean += delta * (n2 / tot);
+      m2 += m22 + delta * delta * (n * n2 / tot);
+      n = tot;
+    }
+  }
+  if (c < C && lane == 0) {
+    stats[c] = (float)mean;
+    stats[C + c] = (float)m2;
+  }
+}
+
+// From (mean, M2, N): invstd, scale = gamma*invstd, shift = beta - mean*scale, and the running
+// statistics update of nn.BatchNorm1d (unbiased variance), one thread per channel.
+__global__ void bn_finalize(const float* __restrict__ stats, double N, int C, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, float* running_mean, float* running_var,
+                            float momentum, float eps, float* __restrict__ out /*[4][C]: mean invstd scale shift*/) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = stats[c];
+  const double m2 = stats[C + c];
+  const float var = (float)(m2 / N);
+  const float invstd = rsqrtf(var + eps);
+  const float scale = gamma[c] * invstd;
+  out[c] = mean;
+  out[C + c] = invstd;
+  out[2 * C + c] = scale;
+  out[3 * C + c] = beta[c] - mean * scale;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (N - 1.0));
+  }
+}
+
+inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int threads_per_row(int ncol) {
+  int t = 1;
+  while (t < ncol && t < kBlock) t <<= 1;
+  return t;
+}
+
+}  // namespace
+
+int64_t col_blocks(int64_t V) {
+  int64_t nb = (V + 511) / 512;
+  if (nb < 1) nb = 1;
+  if (nb > 2048) nb = 2048;
+  return nb;
+}
+
+int launch_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, float* stats, hipStream_t stream) {
+  if (C == 0) return SG_OK;
+  SG_REQUIRE(nb == col_blocks(V), "partial buffer must have sg_col_blocks(V) blocks");
+  const int rpb = (int)((V + nb - 1) / nb);
+  bn_merge<<<(int)((C + 7) / 8), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, stats);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int launch_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, float* out,
+                       hipStream_t stream) {
+  if (C == 0) return SG_OK;
+  bn_finalize<<<(int)((C + 127) / 128), 128, 0, stream>>>(stats, N, (int)C, gamma, beta, running_mean, running_var,
+                                                         momentum, eps, out);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int launch_col_reduce(int mode, const void* A, int64_t lda, const void* H, int64_t ldh, const float* scale,
+                      const float* shift, const float* mean, const float* invstd, float slope, float* out,
+                      int64_t nblk, int64_t V, int64_t C, int dtype, hipStream_t stream) {
+  if (V == 0 || C == 0) return SG_OK;
+  SG_REQUIRE(nblk == col_blocks(V), "partial buffer must have sg_col_blocks(V) = %lld blocks", (long long)col_blocks(V));
+  const int rpb = (int)((V + nblk - 1) / nblk);
+  auto run = [&](auto dt_tag) -> int {
+    constexpr int DT = decltype(dt_tag)::value;
+    constexpr int VEC = Io<DT>::VEC;
+    const bool vec = C % VEC == 0 && lda % VEC == 0 && a16(A) && (mode == 0 || (ldh % VEC == 0 && a16(H)));
+    const int ncol = vec ? (int)(C / VEC) : (int)C;
+    const int tpr = threads_per_row(ncol);
+#define SG_LAUNCH(MODE, VW) col_reduce<DT, MODE, VW><<<(int)nblk, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, slope, out, V, (int)C, rpb, tpr)
+    if (mode == 0) { if (vec) SG_LAUNCH(0, VEC); else SG_LAUNCH(0, 1); }
+    else { if (vec) SG_LAUNCH(1, VEC); else SG_LAUNCH(1, 1); }
+#undef SG_LAUNCH
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
+  };
+  if (dtype == SG_F32) return run(std::integral_constant<int, SG_F32>{});
+  if (dtype == SG_BF16) return run(std::integral_constant<int, SG_BF16>{});
+  set_error("unsupported dtype %d", dtype);
+  return SG_ERR_UNSUPPORTED;
+}
+
+int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_t ldh, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, const float* kk, const float* c1,
+                     const float* c2, float slope, void* Y, int64_t ldy, int64_t V, int64_t C, int dtype,
+                     hipStream_t stream) {
+  if (V == 0 || C == 0) return SG_OK;
+  auto run = [&](auto dt_tag) -> int {
+    constexpr int DT = decltype(dt_tag)::value;
+    constexpr int VEC = Io<DT>::VEC;
+    const bool vec = C % VEC == 0 && lda % VEC == 0 && ldy % VEC == 0 && a16(A) && a16(Y) &&
+                     (mode == 0 || (ldh % VEC == 0 && a16(H)));
+    const int64_t total = V * (vec ? C / VEC : C);
+    int64_t nb = (total + kBlock - 1) / kBlock;
+    if (nb > 256 * 16) nb = 256 * 16;
+#define SG_LAUNCH(MODE, VW) col_apply<DT, MODE, VW><<<(int)nb, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C)
+    if (mode == 0) { if (vec) SG_LAUNCH(0, VEC); else SG_LAUNCH(0, 1); }
+    else { if (vec) SG_LAUNCH(1, VEC); else SG_LAUNCH(1, 1); }
+#undef SG_LAUNCH
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
+  };
+  if (dtype == SG_F32) return run(std::integral_constant<int, SG_F32>{});
+  if (dtype == SG_BF16) return run(std::integral_constant<int, SG_BF16>{});
+  set_error("unsupported dtype %d", dtype);
+  return SG_ERR_UNSUPPORTED;
+}
+
+}  // namespace sg

@@ -70,6 +70,20 @@ int set_tuning(int knob, int value);
 int launch_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y,
                        int64_t ldy, int64_t C, int dtype, hipStream_t stream);
 
+// bn_act.hip
+int64_t col_blocks(int64_t V);
+int launch_col_reduce(int mode, const void* A, int64_t lda, const void* H, int64_t ldh, const float* scale,
+                      const float* shift, const float* mean, const float* invstd, float slope, float* out,
+                      int64_t nblk, int64_t V, int64_t C, int dtype, hipStream_t stream);
+int launch_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, float* stats, hipStream_t stream);
+int launch_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, float* out,
+                       hipStream_t stream);
+int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_t ldh, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, const float* kk, const float* c1,
+                     const float* c2, float slope, void* Y, int64_t ldy, int64_t V, int64_t C, int dtype,
+                     hipStream_t stream);
+
 }  // namespace sg
 
 struct sg_graph {

@@ -325,6 +325,7 @@ class DistBatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d whose training statistics span all ranks' vertices (same parameters,
     buffers and state-dict keys)."""
     group = None
+    sg_mesh_wide = True      # functional.bn_act merges the moments across ranks for these modules
 
     def forward(self, x):
         if not self.training or not dist.is_initialized() or dist.get_world_size(self.group) == 1:

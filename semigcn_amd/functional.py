@@ -61,6 +61,16 @@ def weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _adopt_wide(x: torch.Tensor, K: int):
+    """If ``x`` is the first C columns of an otherwise unused [V, K*C] buffer (what ``bn_act(...,
+    widen=K)`` returns), hand back that buffer so Tx1..Tx(K-1) are written next to it without a copy."""
+    V, C = x.shape
+    if (x.stride(1) != 1 or x.stride(0) != K * C or x.storage_offset() != 0
+            or x.untyped_storage().nbytes() != V * K * C * x.element_size()):
+        return None
+    return torch.as_strided(x.detach(), (V, K * C), (K * C, 1), 0)
+
+
 class _ChebConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph: MeshGraph, x: torch.Tensor, bias: Optional[torch.Tensor], *weights: torch.Tensor):
@@ -71,9 +81,13 @@ class _ChebConvFn(torch.autograd.Function):
         if K == 1:
             T = x.contiguous()
         else:
-            T = torch.empty((V, K * C), dtype=x.dtype, device=x.device)
+            T = _adopt_wide(x, K)
+            fresh = T is None
+            if fresh:
+                T = torch.empty((V, K * C), dtype=x.dtype, device=x.device)
             blk = [T[:, k * C:(k + 1) * C] for k in range(K)]
-            blk[0].copy_(x)
+            if fresh:
+                blk[0].copy_(x)
             graph.aggregate(blk[0], blk[1], alpha=1.0)
             for k in range(2, K):
                 graph.aggregate(blk[k - 1], blk[k], alpha=2.0, X0=blk[k - 2], beta=-1.0)
@@ -179,3 +193,111 @@ def mesh_pool(pool: capi.PoolHandle, x: torch.Tensor) -> torch.Tensor:
 def mesh_unpool(pool: capi.PoolHandle, x: torch.Tensor) -> torch.Tensor:
     """MeshUnpool.forward (util/meshnet.py:25-27): gather by pool_hash."""
     return _PoolFn.apply(pool, x, "unpool")
+
+
+# --------------------------------------------------------------------------------------------
+# BatchNorm over the vertex axis + LeakyReLU, fused (csrc/bn_act.hip)
+# --------------------------------------------------------------------------------------------
+def _merge_moments(counts: torch.Tensor, means: torch.Tensor, m2s: torch.Tensor):
+    """Chan et al.: combine per-block (n, mean, M2) along dim 0, in float64."""
+    n = counts.double().view(-1, 1)
+    N = n.sum()
+    mean = (n * means.double()).sum(0) / N
+    m2 = (m2s.double() + n * (means.double() - mean) ** 2).sum(0)
+    return N, mean, m2
+
+
+class _BNActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, group, widen):
+        V, C = x.shape
+        if x.stride(1) != 1 and C > 1:
+            x = x.contiguous()
+        dev = x.device
+        w32 = weight if weight.dtype == torch.float32 else weight.float()
+        b32 = bias if bias.dtype == torch.float32 else bias.float()
+        if training:
+            stats = capi.bn_merge(capi.col_moments(x), V)            # [2, C]: mean, M2 of this rank's rows
+            N = float(V)
+            if ctx_group_active(group):
+                from . import dist as _d
+                import torch.distributed as tdist
+                world = tdist.get_world_size(group)
+                local = torch.cat([stats.view(-1), stats.new_tensor([N])]).unsqueeze(0)
+                allst = torch.empty((world, 2 * C + 1), dtype=torch.float32, device=dev)
+                _d._all_gather_rows(allst, local.contiguous(), group)
+                Nt, mean, m2 = _merge_moments(allst[:, 2 * C], allst[:, :C], allst[:, C:2 * C])
+                stats = torch.stack([mean, m2]).float()
+                N = float(Nt)
+            fin = capi.bn_finalize(stats, N, w32, b32, running_mean, running_var, momentum, eps)
+            mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+            ctx.N = N
+        else:
+            mean = running_mean.float()
+            invstd = torch.rsqrt(running_var.float() + eps)
+            scale = (w32 * invstd).contiguous()
+            shift = (b32 - mean * scale).contiguous()
+            ctx.N = float(V)
+        if widen > 1:
+            y = torch.empty((V, widen * C), dtype=x.dtype, device=dev)[:, :C]
+        else:
+            y = torch.empty((V, C), dtype=x.dtype, device=dev)
+        capi.scale_shift_act(x, scale, shift, slope, out=y)
+        for obs in bn_act_observers:
+            obs(y)
+        ctx.save_for_backward(x, scale, shift, mean, invstd, w32)
+        ctx.training, ctx.slope, ctx.group, ctx.param_dtype = training, slope, group, weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean, invstd, w32 = ctx.saved_tensors
+        if dy.stride(1) != 1 and dy.shape[1] > 1:
+            dy = dy.contiguous()
+        s = capi.bn_act_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.slope).sum(0)   # [2, C]: sum dz, sum dz*xhat
+        dbeta, dgamma = s[0].to(ctx.param_dtype), s[1].to(ctx.param_dtype)            # this rank's partial sums
+        if ctx.training:
+            if ctx_group_active(ctx.group):
+                from . import dist as _d
+                import torch.distributed as tdist
+                s = s.clone()
+                _d._all_reduce(s, tdist.ReduceOp.SUM, ctx.group)
+            c = s / ctx.N
+            c1, c2 = c[0], c[1]
+            k = w32 * invstd
+        else:
+            c1 = torch.zeros_like(scale)
+            c2 = c1
+            k = scale
+        dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+#: callables invoked with every fused BN+activation output (sign(y) == sign of the BatchNorm output);
+#: an observability hook, e.g. for recording activation patterns -- empty in normal operation
+bn_act_observers: list = []
+
+
+def ctx_group_active(group) -> bool:
+    """``group`` is False for a plain (single-device) BatchNorm, else a process group / None = WORLD."""
+    if group is False:
+        return False
+    import torch.distributed as tdist
+    return tdist.is_initialized() and tdist.get_world_size(group) > 1
+
+
+def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int = 1) -> torch.Tensor:
+    """``leaky_relu(bn(x), slope)`` with nn.BatchNorm1d semantics (batch statistics and running-stat
+    updates in training mode, running statistics in eval mode) in two HIP passes.  ``widen = K``
+    returns a view of the first C columns of a fresh [V, K*C] buffer, which the next ChebConv
+    adopts as its [Tx0|Tx1|..] buffer instead of copying."""
+    training = bn.training or not bn.track_running_stats
+    momentum = 0.0
+    if bn.training and bn.track_running_stats:
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    group = getattr(bn, "group", False) if getattr(bn, "sg_mesh_wide", False) else False
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BNActFn.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, float(slope), group, int(widen))

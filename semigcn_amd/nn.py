@@ -130,16 +130,55 @@ class Sequential(nn.Module):
             self._plan.append((name, ins, outs))
             last_out = outs
 
+    #: set by a model when this Sequential's output feeds a ChebConv(K) directly (see functional.bn_act)
+    out_widen = 1
+
+    def _fusable_at(self, i: int):
+        """(slope, widen) when entries i, i+1 are BatchNorm1d -> LeakyReLU/ReLU on one variable."""
+        if i + 1 >= len(self._plan):
+            return None
+        (n0, in0, out0), (n1, in1, out1) = self._plan[i], self._plan[i + 1]
+        bn, act = getattr(self, n0), getattr(self, n1)
+        if not (isinstance(bn, nn.BatchNorm1d) and bn.affine and len(in0) == 1 and in0 == out0 == in1 == out1):
+            return None
+        if isinstance(act, nn.LeakyReLU):
+            slope = act.negative_slope
+        elif isinstance(act, nn.ReLU):
+            slope = 0.0
+        else:
+            return None
+        widen = 1
+        if i + 2 < len(self._plan):
+            nxt = getattr(self, self._plan[i + 2][0])
+            if isinstance(nxt, ChebConv) and nxt.K > 1 and nxt.in_channels == bn.num_features \
+                    and self._plan[i + 2][1][:1] == out1:
+                widen = nxt.K
+        else:
+            widen = self.out_widen
+        return slope, widen
+
     def forward(self, *args, **kwargs):
         scope = dict(zip(self._args, args))
         scope.update(kwargs)
         result = None
-        for name, ins, outs in self._plan:
-            result = getattr(self, name)(*[scope[a] for a in ins])
+        i, n = 0, len(self._plan)
+        while i < n:
+            name, ins, outs = self._plan[i]
+            vals = [scope[a] for a in ins]
+            fused = self._fusable_at(i) if (len(vals) == 1 and torch.is_tensor(vals[0]) and vals[0].is_cuda
+                                             and vals[0].dim() == 2) else None
+            if fused is not None:      # BatchNorm1d + (Leaky)ReLU in two HIP passes instead of five ATen ones
+                widen = fused[1] if not getattr(scope.get(self._args[1]) if len(self._args) > 1 else None,
+                                                "sg_partitioned", False) else 1
+                result = F_sg.bn_act(vals[0], getattr(self, name), fused[0], widen)
+                i += 1
+            else:
+                result = getattr(self, name)(*vals)
             if len(outs) == 1:
                 scope[outs[0]] = result
             else:
                 scope.update(zip(outs, result))
+            i += 1
         return result
 
     def __len__(self):

@@ -100,14 +100,21 @@ class ActivationMasks:
     therefore asserted tightly only between runs with identical activation patterns, and with
     a per-flip allowance otherwise (see grad_tolerance)."""
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, fused: bool = False):
+        """``fused=True`` additionally listens to semigcn_amd's fused BatchNorm+activation op (which
+        bypasses the activation modules); only ONE such recorder may be open at a time."""
         self.masks = []
         self._hooks = []
+        self._observer = None
         seen = set()
         for mod in model.modules():
             if isinstance(mod, (torch.nn.LeakyReLU, torch.nn.ReLU)) and id(mod) not in seen:
                 seen.add(id(mod))
                 self._hooks.append(mod.register_forward_hook(self._record))
+        if fused:
+            from semigcn_amd import functional as F_sg
+            self._observer = lambda y: self.masks.append((y.detach() > 0).cpu())   # sign(act(z)) == sign(z)
+            F_sg.bn_act_observers.append(self._observer)
 
     def _record(self, mod, inputs, output):
         self.masks.append((inputs[0].detach() > 0).cpu())
@@ -115,6 +122,10 @@ class ActivationMasks:
     def close(self):
         for h in self._hooks:
             h.remove()
+        if self._observer is not None:
+            from semigcn_amd import functional as F_sg
+            F_sg.bn_act_observers.remove(self._observer)
+            self._observer = None
 
     def flips_against(self, other: "ActivationMasks", row_maps=None) -> int:
         """Number of elements whose sign differs; ``row_maps[i]`` (optional, LongTensor) re-orders

@@ -120,7 +120,7 @@ def test_sgcn_composition_vs_reference_golden(cpu_kernels, fixture_meshes, skip)
     ora = OM.SGCNOracle(skip=skip)
     ora.load_state_dict(net.state_dict())
     ora.train()
-    rec_o, rec_h = GU.ActivationMasks(ora), GU.ActivationMasks(net)
+    rec_o, rec_h = GU.ActivationMasks(ora), GU.ActivationMasks(net, fused=True)
     ora(torch.from_numpy(m.z1), torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index), torch.from_numpy(dm))
     pos = net(data, torch.from_numpy(dm))
     flips = rec_h.flips_against(rec_o, [net._layout(data)[2]] * len(rec_h.masks))
@@ -181,7 +181,7 @@ def check_mgcn_against_golden(net, g3, device, out_tol, grad_tight):
                         [torch.from_numpy(g3[f"smposs/{l}"]) for l in range(4)], drop=(0.0, 0.0, 0.0))
     ora.load_state_dict({k: v.cpu() for k, v in net.state_dict().items() if not k.endswith("pool_hash")})
     ora.train()
-    rec_o, rec_h = GU.ActivationMasks(ora), GU.ActivationMasks(net)
+    rec_o, rec_h = GU.ActivationMasks(ora), GU.ActivationMasks(net, fused=True)
     ora(torch.from_numpy(g3["z1"]), dm)
     poss = net(D, dm)
     flips = rec_h.flips_against(rec_o)
