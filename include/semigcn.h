@@ -197,9 +197,11 @@ SG_API int sg_bn_act_bwd_apply(const void* dA, int64_t ldda, const void* H, int6
  * ------------------------------------------------------------------------- */
 enum sg_tune_knob {
   SG_TUNE_CHUNK_ROWS = 0, /* rows per wavefront chunk; 0 = automatic */
-  SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map */
+  SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map, bit 1: never use the LDS-tiled kernel */
   SG_TUNE_UNROLL = 2,     /* reserved */
-  SG_TUNE_SLAB = 3        /* channels per column slab (one sweep of all rows per slab); 0 = off */
+  SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */
+  SG_TUNE_TILED_MIN_ROW_BYTES = 4 /* > 0: graphs created from now on carry row tiles and rows at least this
+                                     wide use the experimental LDS-tiled kernel; 0 (default) = off */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

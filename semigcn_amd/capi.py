@@ -299,7 +299,7 @@ class PoolHandle:
             pass
 
 
-TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB = 0, 1, 2, 3
+TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB, TUNE_TILED_MIN_ROW_BYTES = 0, 1, 2, 3, 4
 
 
 def tuning_set(knob: int, value: int) -> None:

@@ -62,6 +62,11 @@ int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64
   SpmmArgs a;
   a.rowptr = c.rowptr;
   a.idx = c.idx;
+  if (c.tile_rows == kTileRows) {
+    a.tile_uptr = c.tile_uptr;
+    a.tile_uniq = c.tile_uniq;
+    a.tile_eloc = c.tile_eloc;
+  }
   a.scale_dst = sd;
   a.scale_src = ss;
   a.X = X; a.X0 = X0; a.X1 = X1; a.Y = Y;
@@ -130,6 +135,10 @@ SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void
     g->symmetric = equal != 0;
     g->square = true;
     if (g->symmetric) g->bwd.release();
+    if (tiles_enabled()) {
+      if ((rc = build_tiles(&g->fwd, stream)) != SG_OK) break;
+      if (!g->symmetric && (rc = build_tiles(&g->bwd, stream)) != SG_OK) break;
+    }
     if (hipStreamSynchronize(stream) != hipSuccess) {
       set_error("stream sync failed in sg_graph_create");
       rc = SG_ERR_HIP;
@@ -154,6 +163,7 @@ SG_API int sg_graph_create_rect(const int64_t* dst, const int64_t* src, int64_t 
   sg_graph* g = new (std::nothrow) sg_graph();
   SG_REQUIRE(g != nullptr, "out of host memory");
   int rc = build_csr(dst, src, n, V_dst, V_src, false, stream, &g->fwd, nullptr);
+  if (rc == SG_OK && tiles_enabled()) rc = build_tiles(&g->fwd, stream);
   if (rc == SG_OK) {
     if (hipMalloc((void**)&g->dis_src, (V_src > 0 ? V_src : 1) * sizeof(float)) != hipSuccess) {
       set_error("hipMalloc of dis failed");

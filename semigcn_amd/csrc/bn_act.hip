@@ -87,6 +87,16 @@ __global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda
     const bool cok = cs < ncol;
     float a0[VEC], a1[VEC];
     float sc[VEC], sh[VEC], mu[VEC], is[VEC];
+    // MODE 0 accumulates deviations from the block's FIRST row: sum (x-K), sum (x-K)^2.  With K within a
+    // few sigma of the mean the subtraction sum2 - sum^2/n no longer cancels (plain sums lose
+    // eps*(mean^2/var) and showed up as 6x the reference's forward error).
+    float kshift[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) kshift[k] = 0.f;
+    if (MODE == 0 && cok && r_begin < r_end) {
+      if (VEC == 1) kshift[0] = IO::load1(A + r_begin * lda + cs);
+      else IO::unpack(*(const raw_t*)(A + r_begin * lda + (int64_t)cs * VEC), kshift);
+    }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       a0[k] = 0.f; a1[k] = 0.f;
@@ -110,8 +120,9 @@ __global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           if (MODE == 0) {
-            a0[k] += x[k];
-            a1[k] = fmaf(x[k], x[k], a1[k]);
+            const float d = x[k] - kshift[k];
+            a0[k] += d;
+            a1[k] = fmaf(d, d, a1[k]);
           } else {
             const float dz = x[k] * act_slope(fmaf(sc[k], h[k], sh[k]), slope);
             a0[k] += dz;
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda
     }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { s_red[0][threadIdx.x][k] = a0[k]; s_red[1][threadIdx.x][k] = a1[k]; }
-    __syncthreads();
+    __syncthreads();   // (every row group of a column slot used the same shift K: the block's first row)
     if (tg == 0 && cok) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
@@ -131,9 +142,9 @@ __global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda
         const int c = cs * VEC + k;
         if (c < C) {
           if (MODE == 0) {
-            const float m = s0 / n_rows;
-            out[((int64_t)blockIdx.x * 2 + 0) * C + c] = m;
-            out[((int64_t)blockIdx.x * 2 + 1) * C + c] = fmaxf(s1 - s0 * m, 0.f);   // sum (x-m)^2 over <= rpb rows
+            const float m = s0 / n_rows;                                          // mean of (x - K)
+            out[((int64_t)blockIdx.x * 2 + 0) * C + c] = kshift[k] + m;
+            out[((int64_t)blockIdx.x * 2 + 1) * C + c] = fmaxf(s1 - s0 * m, 0.f);   // sum (x-mean)^2 over <= rpb rows
           } else {
             out[((int64_t)blockIdx.x * 2 + 0) * C + c] = s0;
             out[((int64_t)blockIdx.x * 2 + 1) * C + c] = s1;

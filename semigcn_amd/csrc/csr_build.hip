@@ -13,8 +13,15 @@ namespace sg {
 void Csr::release() {
   if (rowptr) (void)hipFree(rowptr);
   if (idx) (void)hipFree(idx);
+  if (tile_uptr) (void)hipFree(tile_uptr);
+  if (tile_uniq) (void)hipFree(tile_uniq);
+  if (tile_eloc) (void)hipFree(tile_eloc);
   rowptr = nullptr;
   idx = nullptr;
+  tile_uptr = nullptr;
+  tile_uniq = nullptr;
+  tile_eloc = nullptr;
+  tile_rows = 0;
   nnz = 0;
 }
 
@@ -90,6 +97,75 @@ struct DeviceBuf {
   ~DeviceBuf() { if (p) (void)hipFree(p); }
 };
 
+// One workgroup per row tile: sort the tile's source ids in LDS (bitonic, padded with INT_MAX),
+// keep the distinct ones.  FILL = false: counts[t] = number of distinct ids, or -1 when the tile has
+// more than kTileEdges edges.  FILL = true: write them to uniq[uptr[t]..] and each edge's slot.
+template <bool FILL>
+__global__ __launch_bounds__(256) void tile_pass(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
+                                                 int64_t n_rows, int tile_rows, int32_t* __restrict__ counts,
+                                                 const int32_t* __restrict__ uptr, int32_t* __restrict__ uniq,
+                                                 uint8_t* __restrict__ eloc) {
+  __shared__ int32_t s_key[kTileEdges];
+  __shared__ int32_t s_cnt;
+  const int64_t r0 = (int64_t)blockIdx.x * tile_rows;
+  int64_t r1 = r0 + tile_rows;
+  if (r1 > n_rows) r1 = n_rows;
+  const int e0 = rowptr[r0], ne = rowptr[r1] - e0;
+  if (ne > kTileEdges) {
+    if (!FILL && threadIdx.x == 0) counts[blockIdx.x] = -1;
+    return;
+  }
+  int n2 = 1;
+  while (n2 < ne) n2 <<= 1;
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) s_key[i] = i < ne ? idx[e0 + i] : INT32_MAX;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        const int p = i ^ j;
+        if (p > i) {
+          const int a = s_key[i], b = s_key[p];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { s_key[i] = b; s_key[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // position of each distinct value = number of "first occurrences" before it
+  if (!FILL) {
+    int local = 0;
+    for (int i = threadIdx.x; i < ne; i += blockDim.x) local += (i == 0 || s_key[i] != s_key[i - 1]) ? 1 : 0;
+    atomicAdd(&s_cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt;
+  } else {
+    // serial compaction by one wavefront-sized scan is plenty for <= 512 keys
+    __shared__ int32_t s_rank[kTileEdges];
+    if (threadIdx.x == 0) {
+      int r = -1;
+      for (int i = 0; i < ne; ++i) {
+        if (i == 0 || s_key[i] != s_key[i - 1]) ++r;
+        s_rank[i] = r;
+      }
+    }
+    __syncthreads();
+    const int u0 = uptr[blockIdx.x];
+    for (int i = threadIdx.x; i < ne; i += blockDim.x)
+      if (i == 0 || s_key[i] != s_key[i - 1]) uniq[u0 + s_rank[i]] = s_key[i];
+    for (int i = threadIdx.x; i < ne; i += blockDim.x) {   // slot of edge i = rank of its id
+      const int v = idx[e0 + i];
+      int lo = 0, hi = ne - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s_key[mid] < v) lo = mid + 1; else hi = mid;
+      }
+      eloc[e0 + i] = (uint8_t)s_rank[lo];
+    }
+  }
+}
+
 }  // namespace
 
 int build_csr(const int64_t* dst, const int64_t* src, int64_t n, int64_t n_rows, int64_t n_cols,
@@ -151,6 +227,47 @@ int build_csr(const int64_t* dst, const int64_t* src, int64_t n, int64_t n_rows,
     SG_HIP_TRY(hipGetLastError());
     SG_HIP_TRY(hipStreamSynchronize(stream));  // `sorted` may be freed on return
   }
+  return SG_OK;
+}
+
+int build_tiles(Csr* c, hipStream_t stream) {
+  if (c->n_rows == 0 || c->nnz == 0) return SG_OK;
+  const int64_t nt = (c->n_rows + kTileRows - 1) / kTileRows;
+  DeviceBuf counts, temp;
+  SG_HIP_TRY(hipMalloc(&counts.p, (nt + 1) * sizeof(int32_t)));
+  SG_HIP_TRY(hipMemsetAsync(counts.p, 0, (nt + 1) * sizeof(int32_t), stream));
+  tile_pass<false><<<(int)nt, 256, 0, stream>>>(c->rowptr, c->idx, c->n_rows, kTileRows, (int32_t*)counts.p, nullptr,
+                                               nullptr, nullptr);
+  SG_HIP_TRY(hipGetLastError());
+  // tileable iff every tile has 0 <= distinct <= kTileSlots: min and max over the counts
+  int32_t* d_minmax = nullptr;
+  DeviceBuf mm;
+  SG_HIP_TRY(hipMalloc(&mm.p, 2 * sizeof(int32_t)));
+  d_minmax = (int32_t*)mm.p;
+  size_t tb = 0;
+  SG_HIP_TRY(hipcub::DeviceReduce::Min(nullptr, tb, (int32_t*)counts.p, d_minmax, (int)nt, stream));
+  size_t tb2 = 0;
+  SG_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, (int32_t*)counts.p, (int32_t*)counts.p, (int)nt + 1, stream));
+  if (tb2 > tb) tb = tb2;
+  SG_HIP_TRY(hipMalloc(&temp.p, tb ? tb : 16));
+  SG_HIP_TRY(hipcub::DeviceReduce::Min(temp.p, tb, (int32_t*)counts.p, d_minmax, (int)nt, stream));
+  SG_HIP_TRY(hipcub::DeviceReduce::Max(temp.p, tb, (int32_t*)counts.p, d_minmax + 1, (int)nt, stream));
+  int32_t h_mm[2] = {0, 0};
+  SG_HIP_TRY(hipMemcpyAsync(h_mm, d_minmax, sizeof(h_mm), hipMemcpyDeviceToHost, stream));
+  SG_HIP_TRY(hipStreamSynchronize(stream));
+  if (h_mm[0] < 0 || h_mm[1] > kTileSlots) return SG_OK;   // not tileable: the generic kernel serves this graph
+  SG_HIP_TRY(hipMalloc((void**)&c->tile_uptr, (nt + 1) * sizeof(int32_t)));
+  SG_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, tb, (int32_t*)counts.p, c->tile_uptr, (int)nt + 1, stream));
+  int32_t total = 0;
+  SG_HIP_TRY(hipMemcpyAsync(&total, c->tile_uptr + nt, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  SG_HIP_TRY(hipStreamSynchronize(stream));
+  SG_HIP_TRY(hipMalloc((void**)&c->tile_uniq, (total > 0 ? total : 1) * sizeof(int32_t)));
+  SG_HIP_TRY(hipMalloc((void**)&c->tile_eloc, c->nnz));
+  tile_pass<true><<<(int)nt, 256, 0, stream>>>(c->rowptr, c->idx, c->n_rows, kTileRows, nullptr, c->tile_uptr,
+                                              c->tile_uniq, c->tile_eloc);
+  SG_HIP_TRY(hipGetLastError());
+  SG_HIP_TRY(hipStreamSynchronize(stream));
+  c->tile_rows = kTileRows;
   return SG_OK;
 }
 

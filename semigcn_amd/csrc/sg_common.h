@@ -35,8 +35,20 @@ struct Csr {
   int32_t* rowptr = nullptr;  // [n_rows + 1] device
   int32_t* idx = nullptr;     // [nnz] device, ascending inside a row
   int32_t max_degree = 0;
+  // Row tiles for the LDS-staged aggregation kernel (optional; null when the graph is not tileable):
+  // tile t = rows [t*tile_rows, (t+1)*tile_rows); its DISTINCT source rows are
+  // tile_uniq[tile_uptr[t] .. tile_uptr[t+1]) (ascending) and edge k reads local slot tile_eloc[k].
+  int32_t tile_rows = 0;
+  int32_t* tile_uptr = nullptr;   // [n_tiles + 1]
+  int32_t* tile_uniq = nullptr;   // [tile_uptr[n_tiles]]
+  uint8_t* tile_eloc = nullptr;   // [nnz]
   void release();
 };
+
+constexpr int kTileRows = 32;      // rows per tile
+constexpr int kTileSlots = 128;    // max distinct source rows per tile (LDS slots)
+constexpr int kTileEdges = 512;    // max edges per tile
+int build_tiles(Csr* c, hipStream_t stream);
 
 // Builds a Csr from (dst, src) int64 device pairs. Pairs with dst == src are dropped when
 // drop_self. If keys_out != nullptr the sorted (dst << 32 | src) keys (n entries, dropped
@@ -52,6 +64,9 @@ int keys_equal(const uint64_t* a, const uint64_t* b, int64_t n, hipStream_t stre
 struct SpmmArgs {
   const int32_t* rowptr;
   const int32_t* idx;
+  const int32_t* tile_uptr = nullptr;   // non-null: the CSR carries row tiles (see Csr)
+  const int32_t* tile_uniq = nullptr;
+  const uint8_t* tile_eloc = nullptr;
   const float* scale_dst;  // nullable, [n_rows]
   const float* scale_src;  // nullable, [n_cols]
   const void* X;
@@ -67,6 +82,7 @@ struct SpmmArgs {
 // Y[r] = alpha * sd[r] * sum_k ss[idx[k]] * X[idx[k]] + beta * X0[r] + gamma * X1[r]
 int launch_spmm(const SpmmArgs& a, int dtype, hipStream_t stream);
 int set_tuning(int knob, int value);
+bool tiles_enabled();
 int launch_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y,
                        int64_t ldy, int64_t C, int dtype, hipStream_t stream);
 

@@ -35,7 +35,7 @@ struct bf16_tag {};
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-enum : int { kFlagXcdMap = 1 };
+enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2 };
 
 template <typename T> struct Vt;
 template <> struct Vt<float> {
@@ -252,6 +252,136 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-tiled variant for wide rows -- EXPERIMENTAL, off by default (SG_TUNE_TILED_MIN_ROW_BYTES).
+// Measured on the 1 M-vertex mesh it is bit-identical to spmm_rows but 5-25 % SLOWER except at
+// C = 512 fp32 (-6 %): with 69 KB of LDS only two workgroups fit a CU and every tile pays its
+// metadata chain, the DMA wait and the epilogue-operand latency in sequence.  It needs a persistent,
+// double-buffered pipeline across tiles to pay; kept as the starting point for that.
+// With the vertices in a locality order (Morton), the 32 rows
+// of a tile reference only ~70 DISTINCT source rows for their ~192 edges.  The workgroup pulls each
+// distinct row ONCE, straight into LDS with direct-to-LDS loads (global_load_lds_dwordx4: no VGPRs
+// held while in flight, 2 rows x 512 B per wavefront instruction), then every output row is
+// reduced out of LDS (ds_read_b128 per edge).  L2 -> CU traffic drops from 6 to ~2.2 rows per
+// output row.  Rows wider than 512 B are processed in 512-B column segments over the same tile
+// metadata, so the staging buffer stays at kTileSlots x 512 B = 64 KB (two workgroups per CU: one
+// loads while the other reduces).
+// ---------------------------------------------------------------------------------------------
+constexpr int kSegBytes = 512;
+
+template <typename T, int NEPI>
+__global__ __launch_bounds__(kBlock) void spmm_tiled(const SpmmArgs a, const int ntiles, const int flags) {
+  using V = Vt<T>;
+  constexpr int VEC = V::VEC;
+  using raw_t = typename V::raw;
+  using elem_t = typename V::elem;
+  constexpr int kSegElems = kSegBytes / (int)sizeof(elem_t);
+
+  __shared__ __attribute__((aligned(16))) unsigned char s_rows[kTileSlots * kSegBytes];
+  __shared__ int32_t s_uniq[kTileSlots];
+  __shared__ int2 s_edge[kTileEdges];          // (byte offset of the slot in s_rows, weight bits)
+  __shared__ int32_t s_rp[kTileRows + 1];
+  __shared__ float s_sd[kTileRows];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, hl = lane & 31;
+  const int tile = (flags & kFlagXcdMap) ? xcd_contiguous(blockIdx.x, ntiles) : (int)blockIdx.x;
+  const int r0 = tile * kTileRows;
+  int nrows = a.n_rows - r0;
+  nrows = nrows > kTileRows ? kTileRows : nrows;
+
+  // ---- tile metadata -> LDS ----
+  for (int l = tid; l <= nrows; l += kBlock) s_rp[l] = a.rowptr[r0 + l];
+  for (int l = tid; l < nrows; l += kBlock) s_sd[l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
+  const int u0 = a.tile_uptr[tile], nu = a.tile_uptr[tile + 1] - u0;
+  for (int l = tid; l < nu; l += kBlock) s_uniq[l] = a.tile_uniq[u0 + l];
+  __syncthreads();
+  const int e0 = s_rp[0], ne = s_rp[nrows] - e0;
+  for (int k = tid; k < ne; k += kBlock) {
+    const int slot = a.tile_eloc[e0 + k];
+    const float w = a.scale_src ? a.scale_src[s_uniq[slot]] : 1.0f;
+    s_edge[k] = make_int2(slot * kSegBytes, __float_as_int(w));
+  }
+  __syncthreads();
+
+  const elem_t* __restrict__ X = (const elem_t*)a.X;
+  const elem_t* __restrict__ X0 = (const elem_t*)a.X0;
+  const elem_t* __restrict__ X1 = (const elem_t*)a.X1;
+  elem_t* __restrict__ Y = (elem_t*)a.Y;
+  const int nseg = (a.C * (int)sizeof(elem_t) + kSegBytes - 1) / kSegBytes;
+
+  for (int seg = 0; seg < nseg; ++seg) {
+    const int c0 = seg * kSegElems;                              // first channel of this segment
+    int cvec = (a.C - c0) / VEC;                                 // 16-B vectors in this segment
+    cvec = cvec > 32 ? 32 : cvec;
+    const int voff = c0 + (hl < cvec ? hl : cvec - 1) * VEC;     // clamped: loads stay inside the row
+    // ---- stage the distinct source rows of this tile (this segment) in LDS, 2 rows per instruction ----
+    for (int q = wave; 2 * q < nu; q += kWaves) {
+      int slot = 2 * q + half;
+      slot = slot < nu ? slot : nu - 1;
+      const elem_t* src = X + (int64_t)s_uniq[slot] * a.ldx + voff;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s_rows + 2 * q * kSegBytes), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- reduce: each half-wavefront owns one output row at a time ----
+    for (int lr = wave * 2 + half; lr < nrows; lr += 2 * kWaves) {
+      const int row = r0 + lr;
+      const int ks = s_rp[lr] - e0, ke = s_rp[lr + 1] - e0;
+      raw_t x0v, x1v;
+      if (NEPI >= 1) x0v = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff);
+      if (NEPI >= 2) x1v = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + voff);
+      float acc[VEC];
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+      int k = ks;
+      for (; k + 4 <= ke; k += 4) {
+        int2 e[4];
+        raw_t xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = s_edge[k + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = *(const raw_t*)(s_rows + e[u].x + hl * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float f[VEC];
+          V::unpack(xv[u], f);
+          const float w = __int_as_float(e[u].y);
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) acc[c] = fmaf(w, f[c], acc[c]);
+        }
+      }
+      for (; k < ke; ++k) {
+        const int2 e = s_edge[k];
+        float f[VEC];
+        V::unpack(*(const raw_t*)(s_rows + e.x + hl * 16), f);
+        const float w = __int_as_float(e.y);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] = fmaf(w, f[c], acc[c]);
+      }
+      const float sdst = a.alpha * s_sd[lr];
+      float y[VEC];
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) y[c] = sdst * acc[c];
+      if (NEPI >= 1) {
+        float f[VEC];
+        V::unpack(x0v, f);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
+      }
+      if (NEPI >= 2) {
+        float f[VEC];
+        V::unpack(x1v, f);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
+      }
+      if (hl < cvec) *(raw_t*)(Y + (int64_t)row * a.ldy + voff) = V::pack(y);
+    }
+    __syncthreads();   // all reads of this segment's rows are done before the next segment lands
+  }
+}
+
 // Any C, any stride, any alignment: one thread per output element, lanes along the channel.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spmm_scalar(const SpmmArgs a) {
@@ -312,6 +442,7 @@ struct Tuning {
   int flags = kFlagXcdMap;        // kFlag* bits
   int unroll = 0;                 // 0 = default per shape
   int slab = 0;                   // channels per column slab; 0 = whole rows
+  int tiled_min_row_bytes = 0;    // > 0: rows at least this wide take the LDS-tiled kernel (experimental, off)
 };
 Tuning g_tuning;
 
@@ -333,6 +464,20 @@ int launch_rows_epi(const SpmmArgs& a, hipStream_t stream) {
   const int64_t chunks = ((int64_t)a.n_rows + ch - 1) / ch;
   const int nblocks = (int)((chunks + kWaves - 1) / kWaves);
   spmm_rows<T, G, R, NEPI><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks, g_tuning.flags);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+template <typename T>
+int launch_tiled(const SpmmArgs& a, hipStream_t stream) {
+  const int ntiles = (a.n_rows + kTileRows - 1) / kTileRows;
+  if (a.X0 && a.X1) spmm_tiled<T, 2><<<ntiles, kBlock, 0, stream>>>(a, ntiles, g_tuning.flags);
+  else if (a.X0) spmm_tiled<T, 1><<<ntiles, kBlock, 0, stream>>>(a, ntiles, g_tuning.flags);
+  else if (a.X1) {
+    SpmmArgs b = a;
+    b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f;
+    spmm_tiled<T, 1><<<ntiles, kBlock, 0, stream>>>(b, ntiles, g_tuning.flags);
+  } else spmm_tiled<T, 0><<<ntiles, kBlock, 0, stream>>>(a, ntiles, g_tuning.flags);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
@@ -366,6 +511,11 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
     return SG_OK;
   }
   const int nvec = a.C / VEC;
+  // wide rows of a tileable graph: stage each distinct source row once in LDS
+  const int row_bytes = a.C * (int)sizeof(typename Vt<T>::elem);
+  if (a.tile_uptr && g_tuning.tiled_min_row_bytes > 0 && row_bytes >= g_tuning.tiled_min_row_bytes &&
+      !(g_tuning.flags & kFlagNoTiles))
+    return launch_tiled<T>(a, stream);
   if (nvec <= 1) return launch_rows<T, 1, 1>(a, stream);
   if (nvec <= 2) return launch_rows<T, 2, 1>(a, stream);
   if (nvec <= 4) return launch_rows<T, 4, 1>(a, stream);
@@ -401,12 +551,15 @@ int launch_typed(const SpmmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+bool tiles_enabled() { return g_tuning.tiled_min_row_bytes > 0; }
+
 int set_tuning(int knob, int value) {
   switch (knob) {
     case SG_TUNE_CHUNK_ROWS: g_tuning.chunk_rows = value; return SG_OK;
     case SG_TUNE_FLAGS: g_tuning.flags = value; return SG_OK;
     case SG_TUNE_UNROLL: g_tuning.unroll = value; return SG_OK;
     case SG_TUNE_SLAB: g_tuning.slab = value; return SG_OK;
+    case SG_TUNE_TILED_MIN_ROW_BYTES: g_tuning.tiled_min_row_bytes = value; return SG_OK;
     default: set_error("unknown tuning knob %d", knob); return SG_ERR_INVALID;
   }
 }

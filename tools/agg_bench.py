@@ -41,11 +41,13 @@ def main():
         from semigcn_amd import reorder
         order, rank = reorder.morton_order(torch.from_numpy(m.vs).to(dev))
         ei = reorder.permute_edge_index(ei, rank)
+    if any("tmin=" in v for v in a.variants):
+        capi.tuning_set(capi.TUNE_TILED_MIN_ROW_BYTES, 512)    # build row tiles for the experimental kernel
     g = MeshGraph.from_edge_index(ei, V)
     variants = []
     for v in a.variants:
         d = dict(kv.split("=") for kv in v.split(","))
-        variants.append((v, int(d.get("ch", 0)), int(d.get("flags", 1)), int(d.get("unroll", 0)), int(d.get("slab", 0))))
+        variants.append((v, int(d.get("ch", 0)), int(d.get("flags", 1)), int(d.get("unroll", 0)), int(d.get("slab", 0)), int(d.get("tmin", 0))))
     out = []
     for dt in a.dtypes.split(","):
         dtype = torch.float32 if dt == "fp32" else torch.bfloat16
@@ -57,11 +59,12 @@ def main():
             for nepi in map(int, a.epilogue.split(",")):
                 times = {v[0]: [] for v in variants}
                 for rnd in range(a.rounds + 1):
-                    for name, ch, flags, unroll, slab in variants:
+                    for name, ch, flags, unroll, slab, tmin in variants:
                         capi.tuning_set(capi.TUNE_CHUNK_ROWS, ch)
                         capi.tuning_set(capi.TUNE_FLAGS, flags)
                         capi.tuning_set(capi.TUNE_UNROLL, unroll)
                         capi.tuning_set(capi.TUNE_SLAB, slab)
+                        capi.tuning_set(capi.TUNE_TILED_MIN_ROW_BYTES, tmin)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
                         for _ in range(a.reps):
