@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="250x200", help="torus for the CPU baseline sample")
     ap.add_argument("--no-launch-timer", action="store_true")
+    ap.add_argument("--model", default="sgcn", choices=["sgcn", "mgcn"],
+                    help="mgcn: BASELINE config c3 (3 pool levels, synthetic hierarchy); not the headline metric")
     return ap.parse_args()
 
 
@@ -184,11 +186,29 @@ def main():
         batch = build_mesh_batch(mesh, device, n_masks=5)
         log("mesh resident on device")
         torch.manual_seed(314)                               # sgcn.py:19-25,76
-        model = SingleScaleGCN(device).to(device)
-        if dtype != torch.float32:
-            model.set_feature_dtype(dtype)
-        trainer = train.SGCNTrainer(model, batch)
-        workload = (f"SGCN train iteration (13 ChebConv K=3 + BN + LeakyReLU, fwd+loss+bwd, Adam every 5th) on a "
+        if args.model == "mgcn":
+            from semigcn_amd.meshnet import MGCN
+            eis, phs, sms, Vl = [mesh.edge_index], [], [mesh.x_pos], mesh.num_vertices
+            for l in range(3):
+                ph, ei_c, Vc = synth.greedy_pool_hierarchy(eis[-1], Vl, seed=319 + l)
+                pos = np.zeros((Vc, 3), np.float32)
+                np.add.at(pos, ph[:, 1], sms[-1])
+                eis.append(ei_c), phs.append(ph), sms.append(pos / np.bincount(ph[:, 1], minlength=Vc)[:, None])
+                Vl = Vc
+            model = MGCN.from_hierarchy(device, [torch.from_numpy(e) for e in eis], phs,
+                                        [torch.from_numpy(np.asarray(x, np.float32)) for x in sms],
+                                        ini_pos=torch.from_numpy(mesh.vs.astype(np.float32)),
+                                        v_mask=torch.from_numpy(mesh.v_mask)).to(device)
+            trainer = train.MGCNTrainer(model, batch)
+            agg_per_iter_edges = 2 * sum(n * e.shape[1] for n, e in zip((6, 11, 11, 5), eis))
+        else:
+            model = SingleScaleGCN(device).to(device)
+            if dtype != torch.float32:
+                model.set_feature_dtype(dtype)
+            trainer = train.SGCNTrainer(model, batch)
+            agg_per_iter_edges = AGG_PER_ITER * E_total
+        workload = (f"{args.model.upper()} train iteration ({13 if args.model == 'sgcn' else 33} ChebConv K=3 + BN + LeakyReLU, "
+                    f"fwd+loss+bwd, Adam every 5th) on a "
                     f"closed torus mesh {nu}x{nv}: V={V_total} E={E_total} directed, "
                     f"{'random' if args.permute else 'grid'} vertex order")
 
@@ -204,7 +224,8 @@ def main():
         trainer.iteration_step()
         torch.cuda.synchronize(device)
         log(f"warm-up iteration {i} done")
-    timer = None if args.no_launch_timer else capi.LaunchTimer()
+    # (per-launch byte accounting below assumes every aggregation runs on the finest mesh: SGCN only)
+    timer = None if (args.no_launch_timer or args.model != "sgcn") else capi.LaunchTimer()
     sync()
     capi.set_launch_timer(timer)
     t0 = time.perf_counter()
@@ -256,8 +277,8 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "bf16 storage / f32 accumulate", "data": "synthetic",
             "config": {"workload": workload, "V": V_total, "E": E_total,
-                       "aggregations_per_iteration": AGG_PER_ITER},
-            "edges_aggregated_per_s": AGG_PER_ITER * E_total * value,
+                       "aggregations_per_iteration": AGG_PER_ITER if args.model == "sgcn" else 66},
+            "edges_aggregated_per_s": (agg_per_iter_edges if world == 1 else AGG_PER_ITER * E_total) * value,
             "optimizer_steps_per_s": value / 5.0,
             "mean_loss": loss_mean,
             "roofline": roof, "aggregation_kernels": kernels,

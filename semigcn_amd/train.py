@@ -86,3 +86,37 @@ class SGCNTrainer:
             self.opt.step()
             self.opt.zero_grad(set_to_none=True)
         return loss
+
+
+class MGCNTrainer:
+    """The loop of /root/reference/mgcn.py:121-160: multi-resolution weighted position RMSE
+    (weights 0.35/0.3/0.2/0.15, mgcn.py:82,138-143) + k1 x normal L1 on the finest level."""
+
+    def __init__(self, model: torch.nn.Module, batch: MeshBatch, lr: float = 0.01, k1: float = 4.0,
+                 accumulate: int = 5, weights=(0.35, 0.3, 0.2, 0.15)):
+        self.model, self.mesh, self.k1, self.accumulate, self.weights = model, batch, k1, accumulate, weights
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr)
+        self.iteration = 0
+        self.loss_sum = torch.zeros((), device=batch.target_pos.device)
+        self.keeps = [m.to(batch.target_pos.device) for m in model.v_masks_list]
+        self.counts = [float(k.sum()) for k in self.keeps]
+        self.opt.zero_grad(set_to_none=True)
+
+    def iteration_step(self, mask_index: Optional[int] = None) -> torch.Tensor:
+        import numpy as np
+        b = self.mesh
+        k = self.iteration % b.dummy_masks.shape[1] if mask_index is None else mask_index
+        self.model.train()
+        # mgcn.py passes a Tensor mask, which MGCN.forward replaces by ones (util/meshnet.py:287-290)
+        poss = self.model(b.data, b.v_keep * b.dummy_masks[:, k:k + 1])
+        loss = sum(w * masked_position_rmse(p, t, keep, n)
+                   for w, p, t, keep, n in zip(self.weights, poss, self.model.poss_list, self.keeps, self.counts))
+        loss = loss + self.k1 * masked_normal_l1(face_normals(poss[0], b.faces), b.target_fn, b.f_keep, b.n_f_keep)
+        loss.backward()
+        self.loss_sum += loss.detach()
+        self.iteration += 1
+        if self.iteration % self.accumulate == 0:
+            self.opt.step()
+            self.opt.zero_grad(set_to_none=True)
+        return loss
+
