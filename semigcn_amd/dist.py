@@ -154,8 +154,8 @@ class DistMeshGraph:
     def exchange(self, blk_ext: torch.Tensor) -> None:
         """Fill rows [n_own:] of ``blk_ext`` ([n_ext, C], unit column stride, any row stride) with
         the neighbours' copies of those vertices; rows [:n_own] must be final."""
-        if self.n_halo == 0 and self.n_send == 0:
-            return
+        if self.world == 1:
+            return                     # (with world > 1 every rank takes part, even with an empty halo: it is a collective)
         own = blk_ext[:self.n_own]
         send = capi.gather_rows(self.send_rows, own)
         recv = torch.empty((self.n_halo, blk_ext.shape[1]), dtype=blk_ext.dtype, device=blk_ext.device)
@@ -164,7 +164,7 @@ class DistMeshGraph:
 
     def exchange_reverse_add(self, grad_halo: torch.Tensor, grad_own: torch.Tensor) -> None:
         """Adjoint of ``exchange``: halo-row gradients travel back to their owners and are added."""
-        if self.n_halo == 0 and self.n_send == 0:
+        if self.world == 1:
             return
         recv = torch.empty((self.n_send, grad_halo.shape[1]), dtype=grad_halo.dtype, device=grad_halo.device)
         self._a2a(recv, grad_halo.contiguous(), self.send_splits, self.recv_splits)
