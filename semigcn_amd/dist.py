@@ -242,7 +242,7 @@ class _DistChebConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        from .functional import weight_grad
+        from .functional import column_sums, weight_grad
         T, wcat = ctx.saved_tensors
         g, K, C, n = ctx.g, ctx.K, ctx.C, ctx.g.n_own
         dout = dout.contiguous()
@@ -251,7 +251,7 @@ class _DistChebConvFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[3:]):
             dwcat = weight_grad(dout, T[:n]).to(ctx.param_dtype)       # partial: summed over ranks later
             dws = [dwcat[:, k * C:(k + 1) * C] for k in range(K)]
-        db = dout.sum(0, dtype=torch.float32).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
+        db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
         dx = None
         if need_x:
             dT = torch.empty((g.n_ext if K > 1 else n, K * C), dtype=dout.dtype, device=dout.device)

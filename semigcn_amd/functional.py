@@ -71,6 +71,40 @@ def _adopt_wide(x: torch.Tensor, K: int):
     return torch.as_strided(x.detach(), (V, K * C), (K * C, 1), 0)
 
 
+def column_sums(x: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of a [V, C] device tensor in ONE streaming pass (the block-moments kernel of
+    csrc/bn_act.hip + its merge: mean * V); ATen's column reduction needs ~3x the time at V = 1 M."""
+    if not x.is_cuda or x.shape[0] < 4096:
+        return x.sum(0, dtype=torch.float32)
+    if x.stride(1) != 1 and x.shape[1] > 1:
+        x = x.contiguous()
+    return capi.bn_merge(capi.col_moments(x), x.shape[0])[0] * float(x.shape[0])
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b for the [V, C] vertex features with fp32 parameters; the weight gradient (a
+    reduction over all V) uses the slab-batched product and the streaming column sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dw = weight_grad(dy, x.contiguous()).to(weight.dtype) if ctx.needs_input_grad[1] else None
+        db = column_sums(dy).to(weight.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear_vertices(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
+    return _LinearFn.apply(x, weight, bias)
+
+
 class _ChebConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph: MeshGraph, x: torch.Tensor, bias: Optional[torch.Tensor], *weights: torch.Tensor):
@@ -112,7 +146,7 @@ class _ChebConvFn(torch.autograd.Function):
         if need_w:
             dwcat = weight_grad(dout, T).to(ctx.param_dtype)  # [Cout, K*C], reduced over V in fp32
             dws = [dwcat[:, k * C:(k + 1) * C] for k in range(K)]
-        db = dout.sum(0, dtype=torch.float32).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
+        db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
         dx = None
         if need_x:
             dT = dout @ wcat  # [V, K*C]; block k = dL/dTx_k before the recurrence is unwound

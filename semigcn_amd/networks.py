@@ -66,10 +66,15 @@ def prepare_input(z1: torch.Tensor, dm: torch.Tensor, lo: Optional[torch.Tensor]
 
 
 class _Fp32Linear(nn.Linear):
-    """nn.Linear whose parameters stay fp32: a reduced-precision input is widened first."""
+    """nn.Linear whose parameters stay fp32: a reduced-precision input is widened first.  On the
+    device its weight gradient (a sum over all V vertices) takes the slab-batched product."""
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return super().forward(x.to(self.weight.dtype))
+        x = x.to(self.weight.dtype)
+        if x.is_cuda and x.dim() == 2:
+            from .functional import linear_vertices
+            return linear_vertices(x, self.weight, self.bias)
+        return super().forward(x)
 
 
 class SingleScaleGCN(nn.Module):

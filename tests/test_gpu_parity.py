@@ -642,3 +642,23 @@ def test_tiled_kernel_bitwise_equals_generic(C, dtype):
             assert torch.equal(t, g)
         want = oracle_lhat(ei, x.float().cpu(), 2.0, x0.float().cpu(), -1.0)
         assert rel(outs[0][1].float(), want) < (KERNEL_TOL if dtype == torch.float32 else 2.0 ** -7)
+
+
+def test_column_sums_and_vertex_linear_match_aten():
+    from semigcn_amd import functional as F_sg
+    for V, C, dtype in ((70001, 48, torch.float32), (200000, 16, torch.bfloat16), (5000, 7, torch.float32)):
+        x = (torch.randn(V, C, device=DEV) + 0.3).to(dtype)
+        want = x.double().sum(0)
+        assert rel(F_sg.column_sums(x), want) < (2e-6 if dtype == torch.float32 else 1e-5)
+    lin = torch.nn.Linear(16, 3).to(DEV)
+    x = torch.randn(50000, 16, device=DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    r = torch.randn(50000, 3, device=DEV)
+    ya = F_sg.linear_vertices(xa, lin.weight, lin.bias)
+    (ya * r).sum().backward()
+    ga = (xa.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    lin.zero_grad()
+    yb = lin(xb)
+    (yb * r).sum().backward()
+    assert torch.allclose(ya, yb, atol=1e-6)
+    assert rel(ga[0], xb.grad) < 1e-6 and rel(ga[1], lin.weight.grad) < 2e-5 and rel(ga[2], lin.bias.grad) < 2e-5
