@@ -192,6 +192,28 @@ SG_API int sg_bn_act_bwd_apply(const void* dA, int64_t ldda, const void* H, int6
                                int64_t C, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Loss step of the training loop, fused -- replaces Models.compute_fn
+ * (util/models.py:121-126), Loss.mask_pos_rec_loss (util/loss.py:14-34, 'rmse')
+ * and Loss.mask_norm_rec_loss (util/loss.py:78-107, 'l1mae') as sgcn.py:130-132
+ * calls them on the positions the network just produced.
+ *   pos [V_ext,3] float32 (V owned rows first, then halo rows when partitioned),
+ *   faces int64 [F,3] indices into pos, target_pos [V,3], v_keep [V] (1 = kept),
+ *   target_fn [F,3] unit normals, f_keep [F].
+ * forward : partial[b] = (sum keep_v |p - t|^2 , sum keep_f |n - n_t|_1) of block b,
+ *           nb = sg_mesh_loss_blocks(V, F) blocks; the caller sums them, then
+ *           loss = sqrt(S_p / n_v + 1e-6) + k1 * S_n / n_f.
+ * backward: grad_pos [V_ext,3] = g[0] * dS_p/dpos + g[1] * dS_n/dpos (g: 2 floats on
+ *           the device); fully overwritten; the face term uses float atomics.
+ * ------------------------------------------------------------------------- */
+SG_API int64_t sg_mesh_loss_blocks(int64_t V, int64_t F);
+SG_API int sg_mesh_loss_fwd(const float* pos, const int64_t* faces, const float* target_pos, const float* v_keep,
+                            const float* target_fn, const float* f_keep, int64_t V, int64_t F, float* partial,
+                            void* stream);
+SG_API int sg_mesh_loss_bwd(const float* pos, const int64_t* faces, const float* target_pos, const float* v_keep,
+                            const float* target_fn, const float* f_keep, const float* g, int64_t V, int64_t V_ext,
+                            int64_t F, float* grad_pos, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Launch tuning of the aggregation kernel (process-wide, not thread-safe; for
  * benchmarking -- results never depend on it).
  * ------------------------------------------------------------------------- */

@@ -49,6 +49,9 @@ _SIGNATURES = {
     "sg_unpool": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sg_unpool_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sg_tuning_set": (c_int, [c_int, c_int]),
+    "sg_mesh_loss_blocks": (c_int64, [c_int64, c_int64]),
+    "sg_mesh_loss_fwd": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_void_p, c_void_p]),
+    "sg_mesh_loss_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "sg_col_blocks": (c_int64, [c_int64]),
     "sg_col_moments": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "sg_bn_merge": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
@@ -411,3 +414,35 @@ def bn_act_bwd_apply(dA, H, scale, shift, mean, invstd, k, c1, c2, slope: float)
                                           float(slope), _ptr(dH), _rows2d(dH, "dH"), V, C, dtype_code(H), _stream(H)),
                "sg_bn_act_bwd_apply")
     return dH
+
+
+# ---- fused loss step ---------------------------------------------------------------------------
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    _require_device(t, name)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise SemigcnLibraryError(f"{name} must be contiguous float32")
+    return t
+
+
+def mesh_loss_fwd(pos, faces, target_pos, v_keep, target_fn, f_keep) -> torch.Tensor:
+    """float32 [nb, 2] block partials of (sum keep_v |p-t|^2, sum keep_f |n-n_t|_1)."""
+    V, F = target_pos.shape[0], faces.shape[0]
+    if faces.dtype != torch.int64 or not faces.is_contiguous():
+        raise SemigcnLibraryError("faces must be contiguous int64 [F, 3]")
+    nb = int(load().sg_mesh_loss_blocks(V, F))
+    part = torch.empty((nb, 2), dtype=torch.float32, device=pos.device)
+    with torch.cuda.device(pos.device):
+        _check(load().sg_mesh_loss_fwd(_ptr(_f32c(pos, "pos")), _ptr(faces), _ptr(_f32c(target_pos, "target_pos")),
+                                       _ptr(_f32c(v_keep, "v_keep")), _ptr(_f32c(target_fn, "target_fn")),
+                                       _ptr(_f32c(f_keep, "f_keep")), V, F, _ptr(part), _stream(pos)), "sg_mesh_loss_fwd")
+    return part
+
+
+def mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, g: torch.Tensor) -> torch.Tensor:
+    V, F = target_pos.shape[0], faces.shape[0]
+    grad = torch.empty_like(pos)
+    with torch.cuda.device(pos.device):
+        _check(load().sg_mesh_loss_bwd(_ptr(_f32c(pos, "pos")), _ptr(faces), _ptr(target_pos), _ptr(v_keep), _ptr(target_fn),
+                                       _ptr(f_keep), _ptr(_f32c(g, "g")), V, pos.shape[0], F, _ptr(grad), _stream(pos)),
+               "sg_mesh_loss_bwd")
+    return grad

@@ -295,6 +295,27 @@ SG_API int sg_unpool_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* d
 
 SG_API int sg_tuning_set(int knob, int value) { return set_tuning(knob, value); }
 
+SG_API int64_t sg_mesh_loss_blocks(int64_t V, int64_t F) { return mesh_loss_blocks(V, F); }
+
+SG_API int sg_mesh_loss_fwd(const float* pos, const int64_t* faces, const float* target_pos, const float* v_keep,
+                            const float* target_fn, const float* f_keep, int64_t V, int64_t F, float* partial,
+                            void* stream) {
+  SG_REQUIRE(V >= 0 && F >= 0 && partial, "sg_mesh_loss_fwd: bad size or null partial");
+  SG_REQUIRE((V == 0 || (pos && target_pos && v_keep)) && (F == 0 || (pos && faces && target_fn && f_keep)),
+             "sg_mesh_loss_fwd: null pointer");
+  return launch_mesh_loss_fwd(pos, faces, target_pos, v_keep, target_fn, f_keep, V, F, partial, (hipStream_t)stream);
+}
+
+SG_API int sg_mesh_loss_bwd(const float* pos, const int64_t* faces, const float* target_pos, const float* v_keep,
+                            const float* target_fn, const float* f_keep, const float* g, int64_t V, int64_t V_ext,
+                            int64_t F, float* grad_pos, void* stream) {
+  SG_REQUIRE(V >= 0 && F >= 0 && V_ext >= V && g && (V_ext == 0 || grad_pos), "sg_mesh_loss_bwd: bad argument");
+  SG_REQUIRE((V == 0 || (pos && target_pos && v_keep)) && (F == 0 || (pos && faces && target_fn && f_keep)),
+             "sg_mesh_loss_bwd: null pointer");
+  return launch_mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, g, V, V_ext, F, grad_pos,
+                              (hipStream_t)stream);
+}
+
 SG_API int64_t sg_col_blocks(int64_t V) { return col_blocks(V); }
 
 SG_API int sg_col_moments(const void* X, int64_t ldx, int64_t V, int64_t C, int dtype, float* partial, int64_t nb,

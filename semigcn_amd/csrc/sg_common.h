@@ -100,6 +100,14 @@ int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_
                      const float* c2, float slope, void* Y, int64_t ldy, int64_t V, int64_t C, int dtype,
                      hipStream_t stream);
 
+// mesh_loss.hip
+int64_t mesh_loss_blocks(int64_t V, int64_t F);
+int launch_mesh_loss_fwd(const float* pos, const int64_t* faces, const float* tpos, const float* vkeep, const float* tfn,
+                         const float* fkeep, int64_t V, int64_t F, float* partial, hipStream_t stream);
+int launch_mesh_loss_bwd(const float* pos, const int64_t* faces, const float* tpos, const float* vkeep, const float* tfn,
+                         const float* fkeep, const float* g, int64_t V, int64_t V_ext, int64_t F, float* grad,
+                         hipStream_t stream);
+
 }  // namespace sg
 
 struct sg_graph {

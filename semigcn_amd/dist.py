@@ -432,6 +432,11 @@ class DistSGCNTrainer:
     def loss(self, pos_own: torch.Tensor) -> torch.Tensor:
         from . import train
         p = self.part
+        if pos_own.is_cuda and pos_own.dtype == torch.float32:     # fused HIP kernels; halo rows via the exchange
+            from .functional import mesh_loss_sums
+            s = mesh_loss_sums(halo_extend(p.graph, pos_own), p.faces_ext, p.target_pos, p.v_keep, p.target_fn, p.f_keep)
+            s = all_reduce_sum(s, self.group)
+            return torch.sqrt(s[0] / p.n_v_keep + 1.0e-6) + self.k1 * (s[1] / p.n_f_keep)
         d = (p.target_pos - pos_own) * p.v_keep
         lp = torch.sqrt(all_reduce_sum((d * d).sum(), self.group) / p.n_v_keep + 1.0e-6)
         pos_ext = halo_extend(p.graph, pos_own)

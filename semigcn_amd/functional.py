@@ -335,3 +335,28 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int =
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return _BNActFn.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, float(slope), group, int(widen))
+
+
+# --------------------------------------------------------------------------------------------
+# fused loss step (csrc/mesh_loss.hip)
+# --------------------------------------------------------------------------------------------
+class _MeshLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, faces, target_pos, v_keep, target_fn, f_keep):
+        pos = pos.contiguous()
+        sums = capi.mesh_loss_fwd(pos, faces, target_pos, v_keep, target_fn, f_keep).double().sum(0).float()
+        ctx.save_for_backward(pos, faces, target_pos, v_keep, target_fn, f_keep)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, faces, target_pos, v_keep, target_fn, f_keep = ctx.saved_tensors
+        grad = capi.mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, g.float().contiguous())
+        return grad, None, None, None, None, None
+
+
+def mesh_loss_sums(pos: torch.Tensor, faces: torch.Tensor, target_pos: torch.Tensor, v_keep: torch.Tensor,
+                   target_fn: torch.Tensor, f_keep: torch.Tensor) -> torch.Tensor:
+    """[S_p, S_n] = [sum_kept |pos - target|^2, sum_kept_faces |n(pos) - n_target|_1], differentiable in
+    ``pos`` ([V_ext, 3]; rows beyond ``target_pos.shape[0]`` are halo rows that only faces read)."""
+    return _MeshLossFn.apply(pos, faces, target_pos, v_keep.reshape(-1), target_fn, f_keep.reshape(-1))

@@ -66,6 +66,10 @@ class SGCNTrainer:
 
     def loss(self, pos: torch.Tensor) -> torch.Tensor:
         b = self.mesh
+        if pos.is_cuda and pos.dtype == torch.float32:     # fused HIP kernels (csrc/mesh_loss.hip)
+            from .functional import mesh_loss_sums
+            s = mesh_loss_sums(pos, b.faces, b.target_pos, b.v_keep, b.target_fn, b.f_keep)
+            return torch.sqrt(s[0] / b.n_v_keep + 1.0e-6) + self.k1 * (s[1] / b.n_f_keep)
         lp = masked_position_rmse(pos, b.target_pos, b.v_keep, b.n_v_keep)
         ln = masked_normal_l1(face_normals(pos, b.faces), b.target_fn, b.f_keep, b.n_f_keep)
         return lp + self.k1 * ln

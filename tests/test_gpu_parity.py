@@ -662,3 +662,27 @@ def test_column_sums_and_vertex_linear_match_aten():
     (yb * r).sum().backward()
     assert torch.allclose(ya, yb, atol=1e-6)
     assert rel(ga[0], xb.grad) < 1e-6 and rel(ga[1], lin.weight.grad) < 2e-5 and rel(ga[2], lin.bias.grad) < 2e-5
+
+
+def test_fused_loss_step_matches_reference_formulas(fixture_meshes):
+    """csrc/mesh_loss.hip vs the oracle's restatement of util/models.py:121-126 and
+    util/loss.py:14-34,78-107 (value and gradient), and vs the golden loss of the reference run."""
+    from semigcn_amd import functional as F_sg
+    g0, g2 = GU.load("g0_mesh_layout.npz"), GU.load("g2_sgcn.npz")
+    for name in ("sphere", "torus"):
+        m = fixture_meshes[name]
+        v_mask = g2[f"{name}/v_mask"]
+        f_mask = v_mask[m.faces].all(1)
+        tgt, tfn = torch.from_numpy(m.vs.astype(np.float32)), torch.from_numpy(g0[f"{name}/fn"])
+        pos = torch.from_numpy(g2[f"{name}/skip0/train_out"]).clone().requires_grad_(True)
+        lo = OM.mask_pos_rec_loss(pos, tgt, v_mask) + 4.0 * OM.mask_norm_rec_loss(OM.compute_fn(pos, m.faces), tfn, f_mask)
+        lo.backward()
+        assert np.allclose(lo.item(), g2[f"{name}/skip0/loss"][2], rtol=1e-5)         # the reference's own number
+        pd = pos.detach().to(DEV).requires_grad_(True)
+        s = F_sg.mesh_loss_sums(pd, torch.from_numpy(m.faces).to(DEV), tgt.to(DEV),
+                                torch.from_numpy(v_mask.astype(np.float32)).to(DEV), tfn.to(DEV),
+                                torch.from_numpy(f_mask.astype(np.float32)).to(DEV))
+        lh = torch.sqrt(s[0] / float(v_mask.sum()) + 1e-6) + 4.0 * s[1] / float(f_mask.sum())
+        lh.backward()
+        assert abs(lh.item() - lo.item()) < 2e-6 * abs(lo.item())
+        assert GU.rel_l2(pd.grad.cpu(), pos.grad) < 2e-5
