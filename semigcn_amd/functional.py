@@ -166,6 +166,62 @@ class _ChebConvFn(torch.autograd.Function):
         return (None, dx, db, *dws)
 
 
+class _ChebConvPostFn(torch.autograd.Function):
+    """The same operator with the aggregation AFTER the GEMM, for layers that narrow (Cout < Cin):
+    L^ is linear, so  sum_k T_k(L^) x W_k^T = sum_k T_k(L^) Z_k  with  Z = x [W_0|..|W_(K-1)]^T,
+    evaluated by Clenshaw's recurrence  b_k = Z_k + 2 L^ b_(k+1) - b_(k+2),  out = Z_0 + L^ b_1 - b_2.
+    The GEMM has the same FLOPs, but every aggregation is Cout wide instead of Cin wide, and only x
+    is kept for backward (not the [V, K*Cin] buffer).  Backward: G = [T_0|T_1|..](L^T) dOut is the
+    forward Chebyshev recurrence applied to dOut, then dx = G Wstack, dWstack = G^T x."""
+
+    @staticmethod
+    def forward(ctx, graph: MeshGraph, x, bias, *weights):
+        K = len(weights)
+        Co = weights[0].shape[0]
+        wstack = torch.cat(list(weights), dim=0).to(x.dtype)          # [K*Cout, Cin]
+        x = x if x.stride(1) == 1 else x.contiguous()
+        Z = x @ wstack.t()                                            # [V, K*Cout]
+        z = [Z[:, k * Co:(k + 1) * Co] for k in range(K)]
+        # Clenshaw, in place in Z: after step k, z[k] holds b_k
+        for k in range(K - 2, 0, -1):
+            x1 = z[k + 2] if k + 2 <= K - 1 else None
+            graph.aggregate(z[k + 1], z[k], alpha=2.0, X0=z[k], beta=1.0, X1=x1, gamma=-1.0)
+        out = torch.empty((x.shape[0], Co), dtype=x.dtype, device=x.device)
+        graph.aggregate(z[1], out, alpha=1.0, X0=z[0], beta=1.0, X1=z[2] if K >= 3 else None, gamma=-1.0)
+        if bias is not None:
+            out += bias.to(x.dtype)
+        ctx.graph, ctx.K, ctx.Co = graph, K, Co
+        ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
+        ctx.save_for_backward(x, wstack)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wstack = ctx.saved_tensors
+        graph, K, Co = ctx.graph, ctx.K, ctx.Co
+        dout = dout.contiguous()
+        V = dout.shape[0]
+        tr = not graph.symmetric
+        G = torch.empty((V, K * Co), dtype=dout.dtype, device=dout.device)
+        g = [G[:, k * Co:(k + 1) * Co] for k in range(K)]
+        g[0].copy_(dout)
+        graph.aggregate(g[0], g[1], alpha=1.0, transpose=tr)
+        for k in range(2, K):
+            graph.aggregate(g[k - 1], g[k], alpha=2.0, X0=g[k - 2], beta=-1.0, transpose=tr)
+        dx = G @ wstack if ctx.needs_input_grad[1] else None
+        dws = [None] * K
+        if any(ctx.needs_input_grad[3:]):
+            dwstack = weight_grad(G, x.contiguous()).to(ctx.param_dtype)   # [K*Cout, Cin]
+            dws = [dwstack[k * Co:(k + 1) * Co] for k in range(K)]
+        db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return (None, dx, db, *dws)
+
+
+#: layers with Cout < Cin aggregate after the GEMM (see _ChebConvPostFn); set False to force the
+#: reference's evaluation order everywhere
+AGGREGATE_AFTER_GEMM_WHEN_NARROWING = True
+
+
 def cheb_conv(graph: MeshGraph, x: torch.Tensor, weights: Sequence[torch.Tensor],
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ChebConv forward on a prepared graph; ``weights[k]`` is ``lins[k].weight`` [Cout, Cin]."""
@@ -176,6 +232,8 @@ def cheb_conv(graph: MeshGraph, x: torch.Tensor, weights: Sequence[torch.Tensor]
         return dist_cheb_conv(graph, x, weights, bias)
     if x.shape[0] != graph.num_vertices:
         raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.num_vertices} vertices")
+    if AGGREGATE_AFTER_GEMM_WHEN_NARROWING and len(weights) >= 2 and weights[0].shape[0] < weights[0].shape[1]:
+        return _ChebConvPostFn.apply(graph, x, bias, *weights)
     return _ChebConvFn.apply(graph, x, bias, *weights)
 
 

@@ -92,12 +92,10 @@ class SingleScaleGCN(nn.Module):
             if i == N_BLOCKS - 1:
                 layers.append((_Fp32Linear(h[i + 1], h[i + 2]), "x -> x"))
             blocks.append(Sequential("x, edge_index", layers))
-        if not skip:   # block i's activation output IS block i+1's Tx0: let it be born inside the [V, 3C] buffer
-            for blk in blocks[:-1]:
-                blk.out_widen = 3
-        else:
-            for blk in blocks[:FIRST_DECODER - 1]:
-                blk.out_widen = 3
+        # block i's activation output IS block i+1's Tx0: let it be born inside that layer's [V, 3C] buffer
+        last_direct = N_BLOCKS - 1 if not skip else FIRST_DECODER - 1     # with skip, decoder inputs come from a Linear
+        for i in range(last_direct):
+            blocks[i].out_widen = blocks[i + 1].module_0.input_buffer_blocks()
         self.blocks = nn.ModuleList(blocks)
         # created unconditionally, after the blocks (RNG order), used only when skip=True (:58-61)
         self.skip_blocks = nn.ModuleList([_Fp32Linear(2 * h[j + 1], h[j + 1]) for j in range(N_ENCODER)])

@@ -70,6 +70,12 @@ class ChebConv(nn.Module):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
 
+    def input_buffer_blocks(self) -> int:
+        """K when this layer evaluates [Tx0|..|Tx(K-1)] next to its input (so a producer may write the
+        input straight into the first block of a [V, K*Cin] buffer), 1 when it aggregates after the GEMM."""
+        post = F_sg.AGGREGATE_AFTER_GEMM_WHEN_NARROWING and self.K >= 2 and self.out_channels < self.in_channels
+        return 1 if (post or self.K == 1) else self.K
+
     def forward(self, x: Tensor, edge_index: Union[Tensor, MeshGraph], edge_weight=None, batch=None,
                 lambda_max=None) -> Tensor:
         if edge_weight is not None or batch is not None or lambda_max is not None:
@@ -150,9 +156,9 @@ class Sequential(nn.Module):
         widen = 1
         if i + 2 < len(self._plan):
             nxt = getattr(self, self._plan[i + 2][0])
-            if isinstance(nxt, ChebConv) and nxt.K > 1 and nxt.in_channels == bn.num_features \
+            if isinstance(nxt, ChebConv) and nxt.in_channels == bn.num_features \
                     and self._plan[i + 2][1][:1] == out1:
-                widen = nxt.K
+                widen = nxt.input_buffer_blocks()
         else:
             widen = self.out_widen
         return slope, widen

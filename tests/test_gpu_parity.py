@@ -216,15 +216,16 @@ def test_chebconv_layer_vs_golden(name, cin, cout, fixture_meshes):
 
 
 @pytest.mark.parametrize("K", [1, 2, 3, 5])
-def test_chebconv_asymmetric_graph_autograd(K):
+@pytest.mark.parametrize("cin,cout", [(12, 20), (20, 12)])     # both evaluation orders (see functional._ChebConvPostFn)
+def test_chebconv_asymmetric_graph_autograd(K, cin, cout):
     ei, V = nasty_graph(), 500
-    mine, ora = sgnn.ChebConv(12, 20, K=K), P.ChebConv(12, 20, K=K)
+    mine, ora = sgnn.ChebConv(cin, cout, K=K), P.ChebConv(cin, cout, K=K)
     GU.fill_state(ora, seed=5)
     mine.load_state_dict(ora.state_dict())
     mine.to(DEV)
     rs = np.random.RandomState(K)
-    x = torch.from_numpy(rs.standard_normal((V, 12)).astype(np.float32))
-    r = torch.from_numpy(rs.standard_normal((V, 20)).astype(np.float32))
+    x = torch.from_numpy(rs.standard_normal((V, cin)).astype(np.float32))
+    r = torch.from_numpy(rs.standard_normal((V, cout)).astype(np.float32))
     xa, xb = x.to(DEV).requires_grad_(True), x.clone().requires_grad_(True)
     ya, yb = mine(xa, ei.to(DEV)), ora(xb, ei)
     assert rel(ya, yb) < KERNEL_TOL
@@ -599,7 +600,7 @@ def test_bn_act_widen_is_adopted_by_the_next_conv(fixture_meshes):
     m = fixture_meshes["torus"]
     ei = torch.from_numpy(m.edge_index).to(DEV)
     bn = torch.nn.BatchNorm1d(32).to(DEV).train()
-    conv = sgnn.ChebConv(32, 8, K=3).to(DEV)
+    conv = sgnn.ChebConv(32, 40, K=3).to(DEV)      # widening layer: evaluates [Tx0|Tx1|Tx2] next to its input
     x = torch.randn(m.num_vertices, 32, device=DEV)
     wide = F_sg.bn_act(x, bn, 0.01, widen=3)
     assert wide.shape == (240, 32) and wide.stride() == (96, 1)
@@ -608,9 +609,10 @@ def test_bn_act_widen_is_adopted_by_the_next_conv(fixture_meshes):
     plain = F_sg.bn_act(x, bn2, 0.01)
     assert torch.equal(wide, plain)
     assert torch.equal(conv(wide, ei), conv(plain, ei))          # same values, one copy less
-    seq = sgnn.Sequential("x, edge_index", [(sgnn.ChebConv(4, 32, K=3), "x, edge_index -> x"), torch.nn.BatchNorm1d(32),
-                                            torch.nn.LeakyReLU(), (sgnn.ChebConv(32, 8, K=3), "x, edge_index -> x")]).to(DEV)
-    assert seq._fusable_at(1) == (0.01, 3) and seq._fusable_at(0) is None
+    for cout, widen in ((40, 3), (8, 1)):          # a narrowing next layer aggregates after its GEMM: nothing to adopt
+        seq = sgnn.Sequential("x, edge_index", [(sgnn.ChebConv(4, 32, K=3), "x, edge_index -> x"), torch.nn.BatchNorm1d(32),
+                                                torch.nn.LeakyReLU(), (sgnn.ChebConv(32, cout, K=3), "x, edge_index -> x")]).to(DEV)
+        assert seq._fusable_at(1) == (0.01, widen) and seq._fusable_at(0) is None
 
 
 # --------------------------------------------------------------------------------------

@@ -26,18 +26,19 @@ def nasty_graph(V=40, E=300, seed=0):
 
 @pytest.mark.parametrize("K", [1, 2, 3, 4])
 @pytest.mark.parametrize("graph", ["torus", "nasty"])
-def test_chebconv_autograd_matches_oracle(cpu_kernels, fixture_meshes, K, graph):
+@pytest.mark.parametrize("cin,cout", [(6, 10), (10, 6)])      # widening: aggregate-then-GEMM; narrowing: GEMM-then-aggregate
+def test_chebconv_autograd_matches_oracle(cpu_kernels, fixture_meshes, K, graph, cin, cout):
     if graph == "torus":
         ei = torch.from_numpy(fixture_meshes["torus"].edge_index)
         V = fixture_meshes["torus"].num_vertices
     else:
         ei, V = nasty_graph(), 40
-    mine, ora = sgnn.ChebConv(6, 10, K=K), P.ChebConv(6, 10, K=K)
+    mine, ora = sgnn.ChebConv(cin, cout, K=K), P.ChebConv(cin, cout, K=K)
     GU.fill_state(ora, seed=3)
     mine.load_state_dict(ora.state_dict())
     rs = np.random.RandomState(1)
-    x = torch.from_numpy(rs.standard_normal((V, 6)).astype(np.float32))
-    r = torch.from_numpy(rs.standard_normal((V, 10)).astype(np.float32))
+    x = torch.from_numpy(rs.standard_normal((V, cin)).astype(np.float32))
+    r = torch.from_numpy(rs.standard_normal((V, cout)).astype(np.float32))
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     ya, yb = mine(xa, ei), ora(xb, ei)
     assert rel(ya.detach(), yb.detach()) < 2e-6
