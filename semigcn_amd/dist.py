@@ -271,9 +271,62 @@ class _DistChebConvFn(torch.autograd.Function):
         return (None, dx, db, *dws)
 
 
+class _DistChebConvPostFn(torch.autograd.Function):
+    """functional._ChebConvPostFn (GEMM first, Clenshaw aggregation after; for Cout < Cin) on a partition:
+    the halo rows exchanged are Cout wide instead of Cin wide."""
+
+    @staticmethod
+    def forward(ctx, g: DistMeshGraph, x, bias, *weights):
+        K, n, Co = len(weights), g.n_own, weights[0].shape[0]
+        wstack = torch.cat(list(weights), dim=0).to(x.dtype)
+        x = x if x.stride(1) == 1 else x.contiguous()
+        Z = torch.empty((g.n_ext, K * Co), dtype=x.dtype, device=x.device)
+        torch.mm(x, wstack.t(), out=Z[:n])
+        z = [Z[:, k * Co:(k + 1) * Co] for k in range(K)]
+        for k in range(K - 2, 0, -1):
+            g.exchange(z[k + 1])
+            x1 = z[k + 2][:n] if k + 2 <= K - 1 else None
+            g.aggregate(z[k + 1], z[k][:n], alpha=2.0, X0=z[k][:n], beta=1.0, X1=x1, gamma=-1.0)
+        g.exchange(z[1])
+        out = torch.empty((n, Co), dtype=x.dtype, device=x.device)
+        g.aggregate(z[1], out, alpha=1.0, X0=z[0][:n], beta=1.0, X1=z[2][:n] if K >= 3 else None, gamma=-1.0)
+        if bias is not None:
+            out += bias.to(x.dtype)
+        ctx.g, ctx.K, ctx.Co = g, K, Co
+        ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
+        ctx.save_for_backward(x, wstack)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .functional import column_sums, weight_grad
+        x, wstack = ctx.saved_tensors
+        g, K, Co, n = ctx.g, ctx.K, ctx.Co, ctx.g.n_own
+        dout = dout.contiguous()
+        G = torch.empty((g.n_ext, K * Co), dtype=dout.dtype, device=dout.device)
+        gk = [G[:, k * Co:(k + 1) * Co] for k in range(K)]
+        gk[0][:n].copy_(dout)
+        g.exchange(gk[0])
+        g.aggregate(gk[0], gk[1][:n], alpha=1.0)
+        for k in range(2, K):
+            g.exchange(gk[k - 1])
+            g.aggregate(gk[k - 1], gk[k][:n], alpha=2.0, X0=gk[k - 2][:n], beta=-1.0)
+        own = G[:n]
+        dx = own @ wstack if ctx.needs_input_grad[1] else None
+        dws = [None] * K
+        if any(ctx.needs_input_grad[3:]):
+            dwstack = weight_grad(own, x.contiguous()).to(ctx.param_dtype)
+            dws = [dwstack[k * Co:(k + 1) * Co] for k in range(K)]
+        db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return (None, dx, db, *dws)
+
+
 def dist_cheb_conv(g: DistMeshGraph, x, weights, bias=None):
+    from . import functional as F_sg
     if x.shape[0] != g.n_own:
         raise ValueError(f"x has {x.shape[0]} rows but this rank owns {g.n_own} vertices")
+    if F_sg.AGGREGATE_AFTER_GEMM_WHEN_NARROWING and len(weights) >= 2 and weights[0].shape[0] < weights[0].shape[1]:
+        return _DistChebConvPostFn.apply(g, x, bias, *weights)
     return _DistChebConvFn.apply(g, x, bias, *weights)
 
 

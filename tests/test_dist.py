@@ -58,8 +58,15 @@ def _run_rank(rank, world, port, out_dir, skip):
     yb = bn(xb)
     (yb * yb * x_all[g.start:g.end, :1]).sum().backward()
     sgdist.all_reduce_gradients(list(bn.parameters()))
+    conv2 = sgnn.ChebConv(20, 12, K=3)                            # narrowing: GEMM first, Clenshaw aggregation after
+    GU.fill_state(conv2, seed=3)
+    x2 = r_all[g.start:g.end].clone().requires_grad_(True)
+    y2 = conv2(x2, g)
+    (y2 * x_all[g.start:g.end]).sum().backward()
+    sgdist.all_reduce_gradients(list(conv2.parameters()))
     lin = {"conv_y": y.detach().clone(), "conv_dx": x.grad.clone(), "conv_dw": conv.lins[2].weight.grad.clone(),
-           "conv_db": conv.bias.grad.clone(), "bn_y": yb.detach().clone(), "bn_dx": xb.grad.clone(),
+           "conv_db": conv.bias.grad.clone(), "conv2_y": y2.detach().clone(), "conv2_dx": x2.grad.clone(),
+           "conv2_dw": conv2.lins[1].weight.grad.clone(), "conv2_db": conv2.bias.grad.clone(), "bn_y": yb.detach().clone(), "bn_dx": xb.grad.clone(),
            "bn_dw": bn.weight.grad.clone(), "bn_db": bn.bias.grad.clone(),
            "bn_rm": bn.running_mean.clone(), "bn_rv": bn.running_var.clone()}
 
@@ -104,9 +111,9 @@ def test_partitioned_training_matches_single_rank(world, skip):
     assert sum(p["range"][1] - p["range"][0] for p in parts) == 384
     assert all(p["n_halo"] > 0 for p in parts)
     # exact pieces: partitioned ChebConv and mesh-wide BatchNorm == their single-rank results
-    for key in ("conv_y", "conv_dx", "bn_y", "bn_dx"):
+    for key in ("conv_y", "conv_dx", "conv2_y", "conv2_dx", "bn_y", "bn_dx"):
         assert rel_l2(torch.cat([p["lin"][key] for p in parts], dim=0), ref["lin"][key]) < 2e-6, key
-    for key in ("conv_dw", "conv_db", "bn_dw", "bn_db", "bn_rm", "bn_rv"):
+    for key in ("conv_dw", "conv_db", "conv2_dw", "conv2_db", "bn_dw", "bn_db", "bn_rm", "bn_rv"):
         for p in parts:
             assert rel_l2(p["lin"][key], ref["lin"][key]) < 5e-6, key
     pos = torch.cat([p["pos"] for p in parts], dim=0)        # blocks are contiguous in processing order
