@@ -281,7 +281,11 @@ class _DistChebConvPostFn(torch.autograd.Function):
         wstack = torch.cat(list(weights), dim=0).to(x.dtype)
         x = x if x.stride(1) == 1 else x.contiguous()
         Z = torch.empty((g.n_ext, K * Co), dtype=x.dtype, device=x.device)
-        torch.mm(x, wstack.t(), out=Z[:n])
+        if bias is not None:      # the bias rides in on Z_0 (see functional._ChebConvPostFn)
+            bias_k = torch.cat([bias.to(x.dtype), bias.new_zeros((K - 1) * Co, dtype=x.dtype)])
+            torch.addmm(bias_k, x, wstack.t(), out=Z[:n])
+        else:
+            torch.mm(x, wstack.t(), out=Z[:n])
         z = [Z[:, k * Co:(k + 1) * Co] for k in range(K)]
         for k in range(K - 2, 0, -1):
             g.exchange(z[k + 1])
@@ -290,8 +294,6 @@ class _DistChebConvPostFn(torch.autograd.Function):
         g.exchange(z[1])
         out = torch.empty((n, Co), dtype=x.dtype, device=x.device)
         g.aggregate(z[1], out, alpha=1.0, X0=z[0][:n], beta=1.0, X1=z[2][:n] if K >= 3 else None, gamma=-1.0)
-        if bias is not None:
-            out += bias.to(x.dtype)
         ctx.g, ctx.K, ctx.Co = g, K, Co
         ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
         ctx.save_for_backward(x, wstack)
@@ -413,7 +415,8 @@ def all_reduce_gradients(params, group=None) -> None:
 
 
 def dist_min_max(z1: torch.Tensor, group=None):
-    lo, hi = z1.min(dim=0, keepdim=True)[0], z1.max(dim=0, keepdim=True)[0]
+    zt = z1.detach().t().contiguous()                       # [3, n]: reduce along the contiguous axis
+    lo, hi = zt.min(dim=1)[0].view(1, -1), zt.max(dim=1)[0].view(1, -1)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         lo, hi = lo.detach().clone(), hi.detach().clone()
         _all_reduce(lo, dist.ReduceOp.MIN, group)

@@ -180,7 +180,11 @@ class _ChebConvPostFn(torch.autograd.Function):
         Co = weights[0].shape[0]
         wstack = torch.cat(list(weights), dim=0).to(x.dtype)          # [K*Cout, Cin]
         x = x if x.stride(1) == 1 else x.contiguous()
-        Z = x @ wstack.t()                                            # [V, K*Cout]
+        if bias is not None:      # the bias rides in on Z_0 (coefficient +1 in the recurrence): free in the GEMM epilogue
+            bias_k = torch.cat([bias.to(x.dtype), bias.new_zeros((K - 1) * Co, dtype=x.dtype)])
+            Z = torch.addmm(bias_k, x, wstack.t())                    # [V, K*Cout]
+        else:
+            Z = x @ wstack.t()
         z = [Z[:, k * Co:(k + 1) * Co] for k in range(K)]
         # Clenshaw, in place in Z: after step k, z[k] holds b_k
         for k in range(K - 2, 0, -1):
@@ -188,8 +192,6 @@ class _ChebConvPostFn(torch.autograd.Function):
             graph.aggregate(z[k + 1], z[k], alpha=2.0, X0=z[k], beta=1.0, X1=x1, gamma=-1.0)
         out = torch.empty((x.shape[0], Co), dtype=x.dtype, device=x.device)
         graph.aggregate(z[1], out, alpha=1.0, X0=z[0], beta=1.0, X1=z[2] if K >= 3 else None, gamma=-1.0)
-        if bias is not None:
-            out += bias.to(x.dtype)
         ctx.graph, ctx.K, ctx.Co = graph, K, Co
         ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
         ctx.save_for_backward(x, wstack)

