@@ -16,7 +16,7 @@ classes directly when /root/reference is present.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import copy
 import os
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch

@@ -174,9 +174,9 @@ class Sequential(nn.Module):
             fused = self._fusable_at(i) if (len(vals) == 1 and torch.is_tensor(vals[0]) and vals[0].is_cuda
                                              and vals[0].dim() == 2) else None
             if fused is not None:      # BatchNorm1d + (Leaky)ReLU in two HIP passes instead of five ATen ones
-                widen = fused[1] if not getattr(scope.get(self._args[1]) if len(self._args) > 1 else None,
-                                                "sg_partitioned", False) else 1
-                result = F_sg.bn_act(vals[0], getattr(self, name), fused[0], widen)
+                # (a partitioned conv needs [owned | halo] rows in its buffer: it cannot adopt a widened one)
+                partitioned = any(getattr(v, "sg_partitioned", False) for v in scope.values())
+                result = F_sg.bn_act(vals[0], getattr(self, name), fused[0], 1 if partitioned else fused[1])
                 i += 1
             else:
                 result = getattr(self, name)(*vals)

@@ -107,7 +107,6 @@ class MGCNTrainer:
         self.opt.zero_grad(set_to_none=True)
 
     def iteration_step(self, mask_index: Optional[int] = None) -> torch.Tensor:
-        import numpy as np
         b = self.mesh
         k = self.iteration % b.dummy_masks.shape[1] if mask_index is None else mask_index
         self.model.train()

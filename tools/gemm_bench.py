@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Times the three dense GEMM shapes of a ChebConv layer at V = 1 M (hipBLASLt through torch) and
 split-K formulations of the weight-gradient product dW = dOut^T T (a reduction over all V)."""
-import sys
 import torch
 
 V = 1_000_000
