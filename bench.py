@@ -162,11 +162,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    # self-test mode for boxes with ONE GPU: every rank uses cuda:0 and talks over gloo (host-staged);
+    # it exercises this N > 1 code path, its numbers mean nothing
+    shared = os.environ.get("SEMIGCN_BENCH_SHARE_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from semigcn_amd import capi, synth, train
     from semigcn_amd.networks import SingleScaleGCN
