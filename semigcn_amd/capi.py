@@ -141,6 +141,25 @@ def _stream(t: torch.Tensor) -> c_void_p:
     return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+class _on_device:
+    """``torch.cuda.device(dev)`` only when ``dev`` is not already current (the context manager costs
+    ~10 us of host time per call, which matters at ~700 launches per training iteration)."""
+    __slots__ = ("_ctx",)
+
+    def __init__(self, device: torch.device):
+        idx = device.index
+        self._ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
 def _ptr(t: Optional[torch.Tensor]) -> c_void_p:
     return c_void_p(0 if t is None else t.data_ptr())
 
@@ -178,7 +197,7 @@ class GraphHandle:
             raise SemigcnLibraryError("edge_index must be int64 [2, E]")
         ei = edge_index.contiguous()
         out = c_void_p()
-        with torch.cuda.device(ei.device):
+        with _on_device(ei.device):
             _check(load().sg_graph_create(_ptr(ei), ei.shape[1], int(num_vertices), _stream(ei), byref(out)),
                    "sg_graph_create")
         return cls(out.value, ei.device)
@@ -192,7 +211,7 @@ class GraphHandle:
         dis_ext = dis_ext.contiguous().float()
         assert dst.dtype == torch.int64 and src.dtype == torch.int64 and dis_ext.numel() == n_ext
         out = c_void_p()
-        with torch.cuda.device(dst.device):
+        with _on_device(dst.device):
             _check(load().sg_graph_create_rect(_ptr(dst), _ptr(src), dst.numel(), int(n_owned), int(n_ext),
                                                _ptr(dis_ext), _stream(dst), byref(out)),
                    "sg_graph_create_rect")
@@ -203,7 +222,7 @@ class GraphHandle:
         rp = torch.empty(self.num_rows + 1, dtype=torch.int32, device=self.device)
         ci = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
         ds = torch.empty(self.num_cols, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             _check(load().sg_graph_export(self._h, _ptr(rp), _ptr(ci), _ptr(ds), _stream(rp)), "sg_graph_export")
         return rp, ci, ds
 
@@ -225,7 +244,7 @@ class GraphHandle:
             if t is not None and t.shape != (n_out, C):
                 raise SemigcnLibraryError(f"{n} shape {tuple(t.shape)} != {(n_out, C)}")
         timer = _timer
-        with torch.cuda.device(X.device):
+        with _on_device(X.device):
             if timer is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
@@ -261,7 +280,7 @@ class PoolHandle:
         fine, coarse = fine.contiguous().long(), coarse.contiguous().long()
         self.device, self.n_fine, self.n_coarse = fine.device, int(n_fine), int(n_coarse)
         out = c_void_p()
-        with torch.cuda.device(fine.device):
+        with _on_device(fine.device):
             _check(load().sg_pool_create(_ptr(fine), _ptr(coarse), fine.numel(), self.n_fine, self.n_coarse,
                                          _stream(fine), byref(out)), "sg_pool_create")
         self._h = out
@@ -273,7 +292,7 @@ class PoolHandle:
         if X.stride(1) != 1 and X.shape[1] > 1:
             X = X.contiguous()
         Y = torch.empty((n_out, X.shape[1]), dtype=X.dtype, device=X.device)
-        with torch.cuda.device(X.device):
+        with _on_device(X.device):
             _check(getattr(load(), fn_name)(self._h, _ptr(X), _rows2d(X, "X"), _ptr(Y), _rows2d(Y, "Y"),
                                             X.shape[1], dtype_code(X), _stream(X)), fn_name)
         return Y
@@ -319,7 +338,7 @@ def gather_rows(rows: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor]
     rows = rows.contiguous()
     if out is None:
         out = torch.empty((rows.numel(), X.shape[1]), dtype=X.dtype, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on_device(X.device):
         _check(load().sg_gather_rows(_ptr(rows), rows.numel(), _ptr(X), _rows2d(X, "X"), _ptr(out),
                                      _rows2d(out, "out"), X.shape[1], dtype_code(X), _stream(X)),
                "sg_gather_rows")
@@ -344,7 +363,7 @@ def col_moments(X: torch.Tensor) -> torch.Tensor:
     V, C = X.shape
     nb = col_blocks(V)
     part = torch.empty((nb, 2, C), dtype=torch.float32, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on_device(X.device):
         _check(load().sg_col_moments(_ptr(X), _rows2d(X, "X"), V, C, dtype_code(X), _ptr(part), nb, _stream(X)),
                "sg_col_moments")
     return part
@@ -354,7 +373,7 @@ def bn_merge(partial: torch.Tensor, num_rows: int) -> torch.Tensor:
     """(mean, M2) [2, C] over all rows from the per-block partials of col_moments."""
     nb, _, C = partial.shape
     stats = torch.empty((2, C), dtype=torch.float32, device=partial.device)
-    with torch.cuda.device(partial.device):
+    with _on_device(partial.device):
         _check(load().sg_bn_merge(_ptr(partial), nb, int(num_rows), C, _ptr(stats), _stream(partial)), "sg_bn_merge")
     return stats
 
@@ -368,7 +387,7 @@ def bn_finalize(stats: torch.Tensor, count: float, gamma: torch.Tensor, beta: to
     for t, n in ((running_mean, "running_mean"), (running_var, "running_var")):
         if t is not None:
             _f32vec(t, C, n)
-    with torch.cuda.device(stats.device):
+    with _on_device(stats.device):
         _check(load().sg_bn_finalize(_ptr(stats), float(count), C, _ptr(_f32vec(gamma, C, "weight")),
                                      _ptr(_f32vec(beta, C, "bias")), _ptr(running_mean), _ptr(running_var),
                                      float(momentum), float(eps), _ptr(out), _stream(stats)), "sg_bn_finalize")
@@ -381,7 +400,7 @@ def scale_shift_act(X: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, s
     V, C = X.shape
     if out is None:
         out = torch.empty((V, C), dtype=X.dtype, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on_device(X.device):
         _check(load().sg_scale_shift_act(_ptr(X), _rows2d(X, "X"), _ptr(_f32vec(scale, C, "scale")),
                                          _ptr(_f32vec(shift, C, "shift")), float(slope), _ptr(out), _rows2d(out, "out"),
                                          V, C, dtype_code(X), _stream(X)), "sg_scale_shift_act")
@@ -393,7 +412,7 @@ def bn_act_bwd_reduce(dA, H, scale, shift, mean, invstd, slope: float) -> torch.
     V, C = H.shape
     nb = col_blocks(V)
     part = torch.empty((nb, 2, C), dtype=torch.float32, device=H.device)
-    with torch.cuda.device(H.device):
+    with _on_device(H.device):
         _check(load().sg_bn_act_bwd_reduce(_ptr(dA), _rows2d(dA, "dA"), _ptr(H), _rows2d(H, "H"),
                                            _ptr(_f32vec(scale, C, "scale")), _ptr(_f32vec(shift, C, "shift")),
                                            _ptr(_f32vec(mean, C, "mean")), _ptr(_f32vec(invstd, C, "invstd")),
@@ -406,7 +425,7 @@ def bn_act_bwd_apply(dA, H, scale, shift, mean, invstd, k, c1, c2, slope: float)
     _require_device(dA, "dA")
     V, C = H.shape
     dH = torch.empty((V, C), dtype=H.dtype, device=H.device)
-    with torch.cuda.device(H.device):
+    with _on_device(H.device):
         _check(load().sg_bn_act_bwd_apply(_ptr(dA), _rows2d(dA, "dA"), _ptr(H), _rows2d(H, "H"),
                                           _ptr(_f32vec(scale, C, "scale")), _ptr(_f32vec(shift, C, "shift")),
                                           _ptr(_f32vec(mean, C, "mean")), _ptr(_f32vec(invstd, C, "invstd")),
@@ -431,7 +450,7 @@ def mesh_loss_fwd(pos, faces, target_pos, v_keep, target_fn, f_keep) -> torch.Te
         raise SemigcnLibraryError("faces must be contiguous int64 [F, 3]")
     nb = int(load().sg_mesh_loss_blocks(V, F))
     part = torch.empty((nb, 2), dtype=torch.float32, device=pos.device)
-    with torch.cuda.device(pos.device):
+    with _on_device(pos.device):
         _check(load().sg_mesh_loss_fwd(_ptr(_f32c(pos, "pos")), _ptr(faces), _ptr(_f32c(target_pos, "target_pos")),
                                        _ptr(_f32c(v_keep, "v_keep")), _ptr(_f32c(target_fn, "target_fn")),
                                        _ptr(_f32c(f_keep, "f_keep")), V, F, _ptr(part), _stream(pos)), "sg_mesh_loss_fwd")
@@ -441,7 +460,7 @@ def mesh_loss_fwd(pos, faces, target_pos, v_keep, target_fn, f_keep) -> torch.Te
 def mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, g: torch.Tensor) -> torch.Tensor:
     V, F = target_pos.shape[0], faces.shape[0]
     grad = torch.empty_like(pos)
-    with torch.cuda.device(pos.device):
+    with _on_device(pos.device):
         _check(load().sg_mesh_loss_bwd(_ptr(_f32c(pos, "pos")), _ptr(faces), _ptr(target_pos), _ptr(v_keep), _ptr(target_fn),
                                        _ptr(f_keep), _ptr(_f32c(g, "g")), V, pos.shape[0], F, _ptr(grad), _stream(pos)),
                "sg_mesh_loss_bwd")
