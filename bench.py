@@ -45,7 +45,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mesh", default="1000x1000", help="torus nu x nv of the whole job (the same mesh at every N: strong scaling)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="feature storage of the measured workload: fp32 = the reference's precision (parity-checked "
+                         "to 1e-5); bf16 = BASELINE configs[3] (fp32 accumulate, fp32 parameters).  At N=1 the other "
+                         "one is measured too and reported as `bf16_features` / `fp32_features`")
+    ap.add_argument("--single-dtype", action="store_true", help="skip the second run at the other precision")
     ap.add_argument("--permute", action="store_true", help="random vertex order (raw-scan like)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="250x200", help="torus for the CPU baseline sample")
@@ -153,6 +157,115 @@ def cpu_baseline(sample: str, full_V: int, budget_s: float = 20.0):
             "edges_aggregated_per_s": AGG_PER_ITER * m.num_edges / dt}
 
 
+def build_trainer(args, dtype, device, world, rank, mesh):
+    """(trainer, workload string, edge-aggregations per iteration) for one feature dtype."""
+    from semigcn_amd import synth, train
+    from semigcn_amd.networks import SingleScaleGCN
+    nu, nv = map(int, args.mesh.split("x"))
+    if world > 1:
+        from semigcn_amd import dist as sgdist
+        job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh)
+        return job.trainer, job.workload, AGG_PER_ITER * mesh.num_edges
+    batch = build_mesh_batch(mesh, device, n_masks=5)
+    torch.manual_seed(314)                               # sgcn.py:19-25,76
+    if args.model == "mgcn":
+        from semigcn_amd.meshnet import MGCN
+        eis, phs, sms, Vl = [mesh.edge_index], [], [mesh.x_pos], mesh.num_vertices
+        for l in range(3):
+            ph, ei_c, Vc = synth.greedy_pool_hierarchy(eis[-1], Vl, seed=319 + l)
+            pos = np.zeros((Vc, 3), np.float32)
+            np.add.at(pos, ph[:, 1], sms[-1])
+            eis.append(ei_c), phs.append(ph), sms.append(pos / np.bincount(ph[:, 1], minlength=Vc)[:, None])
+            Vl = Vc
+        model = MGCN.from_hierarchy(device, [torch.from_numpy(e) for e in eis], phs,
+                                    [torch.from_numpy(np.asarray(x, np.float32)) for x in sms],
+                                    ini_pos=torch.from_numpy(mesh.vs.astype(np.float32)),
+                                    v_mask=torch.from_numpy(mesh.v_mask)).to(device)
+        trainer = train.MGCNTrainer(model, batch)
+        agg_edges = 2 * sum(n * e.shape[1] for n, e in zip((6, 11, 11, 5), eis))
+    else:
+        model = SingleScaleGCN(device).to(device)
+        if dtype != torch.float32:
+            model.set_feature_dtype(dtype)
+        trainer = train.SGCNTrainer(model, batch)
+        agg_edges = AGG_PER_ITER * mesh.num_edges
+    workload = (f"{args.model.upper()} train iteration ({13 if args.model == 'sgcn' else 33} ChebConv K=3 + BN + LeakyReLU, "
+                f"fwd+loss+bwd, Adam every 5th) on a closed torus mesh {nu}x{nv}: V={mesh.num_vertices} "
+                f"E={mesh.num_edges} directed, {'random' if args.permute else 'grid'} vertex order, "
+                f"{'fp32' if dtype == torch.float32 else 'bf16'} features")
+    return trainer, workload, agg_edges
+
+
+def timed_run(trainer, args, device, world, with_timer: bool):
+    """W untimed + exactly K timed iterations between barrier+synchronize brackets; max over ranks."""
+    from semigcn_amd import capi
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        trainer.iteration_step()
+        torch.cuda.synchronize(device)
+        log(f"warm-up iteration {i} done")
+    timer = capi.LaunchTimer() if with_timer else None
+    sync()
+    capi.set_launch_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.iteration_step()
+    sync()
+    dt = time.perf_counter() - t0
+    capi.set_launch_timer(None)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, timer
+
+
+def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
+    """value / ms_per_step / per-kernel roofline numbers of one timed run."""
+    V_total, E_total = mesh.num_vertices, mesh.num_edges
+    value = args.steps / dt
+    elem = 4 if dtype == torch.float32 else 2
+    V_local, E_local = V_total // world, E_total // world
+    nu, nv = map(int, args.mesh.split("x"))
+    kernels, roof = [], None
+    if timer is not None:
+        for (C, dt_name, n_epi), times in sorted(timer.results().items(), key=lambda kv: -sum(kv[1])):
+            mean_ms = float(np.mean(times))
+            B = algorithmic_bytes(V_local, E_local, C, elem, n_epi)
+            kernels.append({"C": C, "dtype": dt_name, "epilogue_operands": n_epi, "launches": len(times),
+                            "mean_ms": round(mean_ms, 4), "total_ms": round(float(np.sum(times)), 3),
+                            "algorithmic_MB": round(B / 1e6, 2), "achieved_GBs": round(B / mean_ms / 1e6, 1)})
+        total_B = sum(k["algorithmic_MB"] * k["launches"] for k in kernels)
+        total_t = sum(k["total_ms"] for k in kernels)
+        dom = kernels[0]
+        traffic = pmc_traffic(dom["C"], dom["dtype"], dom["epilogue_operands"], elem) if (
+            world == 1 and (nu, nv) == (1000, 1000) and not args.permute) else None
+        roof = {"bound": "hbm", "kernel": f"sg::spmm_rows C={dom['C']} {dom['dtype']} (+{dom['epilogue_operands']} epilogue operands)",
+                "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE KiB, separate passes) "
+                                "of this workload, profiles/r01_pmc_traffic_*.json; algorithmic bytes = "
+                                f"{round(dom['algorithmic_MB'] * 1e6)}",
+                "all_aggregations_GBs": round(total_B / total_t, 1),
+                "all_aggregations_frac": round(total_B / total_t / HBM_PEAK_GBS, 4),
+                "aggregation_share_of_step": round(total_t / (dt * 1e3), 4)}
+    return {"value": value, "ms_per_step": dt / args.steps * 1e3,
+            "dtype": "f32" if dtype == torch.float32 else "bf16 storage / f32 accumulate",
+            "edges_aggregated_per_s": agg_edges * value, "optimizer_steps_per_s": value / 5.0,
+            "mean_loss": float(trainer.loss_sum.item()) / max(trainer.iteration, 1),
+            "roofline": roof, "aggregation_kernels": kernels}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -176,125 +289,54 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    from semigcn_amd import capi, synth, train
-    from semigcn_amd.networks import SingleScaleGCN
+    from semigcn_amd import capi, synth
     capi.load()
-
     log("library loaded")
     nu, nv = map(int, args.mesh.split("x"))
-    dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
-    if world > 1:
-        from semigcn_amd import dist as sgdist
-        job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype)
-        trainer, V_total, E_total, workload = job.trainer, job.V_total, job.E_total, job.workload
-    else:
-        mesh = synth.torus_mesh(nu, nv, permute=args.permute)
-        V_total, E_total = mesh.num_vertices, mesh.num_edges
-        log(f"mesh generated V={V_total} E={E_total}")
-        batch = build_mesh_batch(mesh, device, n_masks=5)
-        log("mesh resident on device")
-        torch.manual_seed(314)                               # sgcn.py:19-25,76
-        if args.model == "mgcn":
-            from semigcn_amd.meshnet import MGCN
-            eis, phs, sms, Vl = [mesh.edge_index], [], [mesh.x_pos], mesh.num_vertices
-            for l in range(3):
-                ph, ei_c, Vc = synth.greedy_pool_hierarchy(eis[-1], Vl, seed=319 + l)
-                pos = np.zeros((Vc, 3), np.float32)
-                np.add.at(pos, ph[:, 1], sms[-1])
-                eis.append(ei_c), phs.append(ph), sms.append(pos / np.bincount(ph[:, 1], minlength=Vc)[:, None])
-                Vl = Vc
-            model = MGCN.from_hierarchy(device, [torch.from_numpy(e) for e in eis], phs,
-                                        [torch.from_numpy(np.asarray(x, np.float32)) for x in sms],
-                                        ini_pos=torch.from_numpy(mesh.vs.astype(np.float32)),
-                                        v_mask=torch.from_numpy(mesh.v_mask)).to(device)
-            trainer = train.MGCNTrainer(model, batch)
-            agg_per_iter_edges = 2 * sum(n * e.shape[1] for n, e in zip((6, 11, 11, 5), eis))
-        else:
-            model = SingleScaleGCN(device).to(device)
-            if dtype != torch.float32:
-                model.set_feature_dtype(dtype)
-            trainer = train.SGCNTrainer(model, batch)
-            agg_per_iter_edges = AGG_PER_ITER * E_total
-        workload = (f"{args.model.upper()} train iteration ({13 if args.model == 'sgcn' else 33} ChebConv K=3 + BN + LeakyReLU, "
-                    f"fwd+loss+bwd, Adam every 5th) on a "
-                    f"closed torus mesh {nu}x{nv}: V={V_total} E={E_total} directed, "
-                    f"{'random' if args.permute else 'grid'} vertex order")
+    mesh = synth.torus_mesh(nu, nv, permute=args.permute)
+    log(f"mesh generated V={mesh.num_vertices} E={mesh.num_edges}")
+    dtypes = {"fp32": torch.float32, "bf16": torch.bfloat16}
+    with_timer = not args.no_launch_timer and args.model == "sgcn"   # byte accounting assumes the finest mesh only
 
-    def sync():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize(device)
-
+    trainer, workload, agg_edges = build_trainer(args, dtypes[args.dtype], device, world, rank, mesh)
     log("model built; warm-up")
-    for i in range(args.warmup):
-        trainer.iteration_step()
-        torch.cuda.synchronize(device)
-        log(f"warm-up iteration {i} done")
-    # (per-launch byte accounting below assumes every aggregation runs on the finest mesh: SGCN only)
-    timer = None if (args.no_launch_timer or args.model != "sgcn") else capi.LaunchTimer()
-    sync()
-    capi.set_launch_timer(timer)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.iteration_step()
-    sync()
-    dt = time.perf_counter() - t0
-    capi.set_launch_timer(None)
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss_mean = float(trainer.loss_sum.item()) / max(trainer.iteration, 1)
-    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/iteration")
+    dt, timer = timed_run(trainer, args, device, world, with_timer)
+    main_res = summarize(dt, timer, args, dtypes[args.dtype], mesh, world, agg_edges, trainer)
+    log(f"timed region done: {main_res['ms_per_step']:.2f} ms/iteration ({args.dtype})")
+
+    other = None
+    if world == 1 and args.model == "sgcn" and not args.single_dtype:
+        # the same workload at the other feature precision, for the record (never `value`)
+        del trainer
+        torch.cuda.empty_cache()
+        od = "fp32" if args.dtype == "bf16" else "bf16"
+        tr2, _, agg2 = build_trainer(args, dtypes[od], device, world, rank, mesh)
+        dt2, timer2 = timed_run(tr2, args, device, world, with_timer)
+        other = summarize(dt2, timer2, args, dtypes[od], mesh, world, agg2, tr2)
+        other.pop("aggregation_kernels")
+        log(f"second precision done: {other['ms_per_step']:.2f} ms/iteration ({od})")
+        del tr2
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        value = args.steps / dt
-        elem = 4 if dtype == torch.float32 else 2
-        V_local = V_total // world
-        E_local = E_total // world
-        kernels, roof = [], None
-        if timer is not None:
-            res = timer.results()
-            for (C, dt_name, n_epi), times in sorted(res.items(), key=lambda kv: -sum(kv[1])):
-                mean_ms = float(np.mean(times))
-                B = algorithmic_bytes(V_local, E_local, C, elem, n_epi)
-                kernels.append({"C": C, "dtype": dt_name, "epilogue_operands": n_epi, "launches": len(times),
-                                "mean_ms": round(mean_ms, 4), "total_ms": round(float(np.sum(times)), 3),
-                                "algorithmic_MB": round(B / 1e6, 2), "achieved_GBs": round(B / mean_ms / 1e6, 1)})
-            total_B = sum(k["algorithmic_MB"] * k["launches"] for k in kernels)
-            total_t = sum(k["total_ms"] for k in kernels)
-            dom = kernels[0]
-            traffic = pmc_traffic(dom["C"], dom["dtype"], dom["epilogue_operands"], elem) if (
-                world == 1 and (nu, nv) == (1000, 1000) and not args.permute) else None
-            roof = {"bound": "hbm", "kernel": f"sg::spmm_rows C={dom['C']} {dom['dtype']} (+{dom['epilogue_operands']} epilogue operands)",
-                    "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE KiB, separate passes) "
-                                    "of this workload, profiles/r01_pmc_traffic_*.json; algorithmic bytes = "
-                                    f"{round(dom['algorithmic_MB'] * 1e6)}",
-                    "all_aggregations_GBs": round(total_B / total_t, 1),
-                    "all_aggregations_frac": round(total_B / total_t / HBM_PEAK_GBS, 4),
-                    "aggregation_share_of_step": round(total_t / (dt * 1e3), 4)}
         line = {
             "metric": "GCN train iters/sec + edges-aggregated/sec, 1M-vert mesh",
-            "value": value, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if dtype == torch.float32 else "bf16 storage / f32 accumulate", "data": "synthetic",
-            "config": {"workload": workload, "V": V_total, "E": E_total,
+            "value": main_res["value"], "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": main_res["dtype"], "data": "synthetic",
+            "config": {"workload": workload, "V": mesh.num_vertices, "E": mesh.num_edges,
+                       "baseline_config": ("BASELINE configs[3] (SGCN, 1M-vertex mesh) at the reference's fp32 precision; "
+                                           "the bf16-feature variant named there is in `bf16_features`") if (
+                           args.model == "sgcn" and (nu, nv) == (1000, 1000)) else None,
                        "aggregations_per_iteration": AGG_PER_ITER if args.model == "sgcn" else 66},
-            "edges_aggregated_per_s": (agg_per_iter_edges if world == 1 else AGG_PER_ITER * E_total) * value,
-            "optimizer_steps_per_s": value / 5.0,
-            "mean_loss": loss_mean,
-            "roofline": roof, "aggregation_kernels": kernels,
+            "edges_aggregated_per_s": main_res["edges_aggregated_per_s"],
+            "optimizer_steps_per_s": main_res["optimizer_steps_per_s"], "mean_loss": main_res["mean_loss"],
+            "roofline": main_res["roofline"], "aggregation_kernels": main_res["aggregation_kernels"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, V_total)
-        else:
-            line["cpu_baseline"] = None
+        if other is not None:
+            line["fp32_features" if other["dtype"] == "f32" else "bf16_features"] = other
+        line["cpu_baseline"] = cpu_baseline(args.cpu_sample, mesh.num_vertices) if (
+            world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

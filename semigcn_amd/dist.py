@@ -526,12 +526,13 @@ class _Job:
 
 
 def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permute: bool = False,
-                          dtype=torch.float32, group=None) -> _Job:
+                          dtype=torch.float32, group=None, mesh=None) -> _Job:
     """bench.py's N > 1 leg: the SAME nu x nv mesh as the 1-GPU run, cut into ``world`` blocks
     (strong scaling)."""
     from . import synth
     from .networks import SingleScaleGCN
-    mesh = synth.torus_mesh(nu, nv, permute=permute)
+    if mesh is None:
+        mesh = synth.torus_mesh(nu, nv, permute=permute)
     part = partition_mesh(mesh, rank, world, device, group)
     torch.manual_seed(314)
     model = SingleScaleGCN(device).to(device)
@@ -542,6 +543,7 @@ def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permu
     if world > 1:
         _all_reduce(halo, dist.ReduceOp.MAX, group)
     workload = (f"SGCN train iteration on a closed torus mesh {nu}x{nv} (V={mesh.num_vertices} E={mesh.num_edges}), "
-                f"Morton-ordered and vertex-partitioned into {world} blocks (<= {int(halo)} halo rows per rank), "
+                f"{'fp32' if dtype == torch.float32 else 'bf16'} features, Morton-ordered and vertex-partitioned into "
+                f"{world} blocks (<= {int(halo)} halo rows per rank), "
                 f"halo exchange + mesh-wide BatchNorm + gradient all-reduce over RCCL")
     return _Job(trainer, mesh.num_vertices, mesh.num_edges, workload)
