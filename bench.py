@@ -65,6 +65,13 @@ def algorithmic_bytes(V: int, E: int, C: int, elem: int, n_epilogue: int) -> flo
     return (2 + n_epilogue) * V * C * elem + 4.0 * E + 4.0 * (V + 1) + 4.0 * V
 
 
+def aggregation_kernel_name(C: int, esize: int, n_epi: int) -> str:
+    """Which kernel sg_spmm dispatches to for this shape on a mesh graph (csrc/spmm.hip, launch_typed_one)."""
+    row_bytes = C * esize
+    shared = esize == 4 and row_bytes >= 1024 and (row_bytes >= 2048 or n_epi > 0) and 16 < C // (16 // esize) <= 128
+    return "spmm_shared" if shared else "spmm_rows"
+
+
 def pmc_traffic(C: int, dtype_name: str, n_epi: int, esize: int):
     """HBM-side bytes per launch of the aggregation kernel variant that serves (C, dtype, n_epi), from
     the committed rocprofv3 PMC summary of this same workload (tools/pmc_summary.py; counters cannot be
@@ -78,10 +85,11 @@ def pmc_traffic(C: int, dtype_name: str, n_epi: int, esize: int):
         lanes *= 2
     per_lane = 1 if nvec <= 64 else (2 if nvec <= 128 else 4)
     path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{'fp32' if esize == 4 else 'bf16'}.json")
+    kernel = aggregation_kernel_name(C, esize, n_epi)
     try:
         for k in json.load(open(path))["kernels"]:
-            if (k["dtype"] == dtype_name and k["lanes_per_row"] == lanes and k["vectors_per_lane"] == per_lane
-                    and k["epilogue_operands"] == n_epi):
+            if (k.get("kernel", "spmm_rows") == kernel and k["dtype"] == dtype_name and k["lanes_per_row"] == lanes
+                    and k["vectors_per_lane"] == per_lane and k["epilogue_operands"] == n_epi):
                 return k["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -250,7 +258,8 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
         dom = kernels[0]
         traffic = pmc_traffic(dom["C"], dom["dtype"], dom["epilogue_operands"], elem) if (
             world == 1 and (nu, nv) == (1000, 1000) and not args.permute) else None
-        roof = {"bound": "hbm", "kernel": f"sg::spmm_rows C={dom['C']} {dom['dtype']} (+{dom['epilogue_operands']} epilogue operands)",
+        roof = {"bound": "hbm", "kernel": f"sg::{aggregation_kernel_name(dom['C'], elem, dom['epilogue_operands'])} C={dom['C']} "
+                                          f"{dom['dtype']} (+{dom['epilogue_operands']} epilogue operands)",
                 "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE KiB, separate passes) "

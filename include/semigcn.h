@@ -219,11 +219,13 @@ SG_API int sg_mesh_loss_bwd(const float* pos, const int64_t* faces, const float*
  * ------------------------------------------------------------------------- */
 enum sg_tune_knob {
   SG_TUNE_CHUNK_ROWS = 0, /* rows per wavefront chunk; 0 = automatic */
-  SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map, bit 1: never use the LDS-tiled kernel */
+  SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map, bit 1: never use the shared-gather kernel */
   SG_TUNE_UNROLL = 2,     /* reserved */
   SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */
-  SG_TUNE_TILED_MIN_ROW_BYTES = 4 /* > 0: graphs created from now on carry row tiles and rows at least this
-                                     wide use the experimental LDS-tiled kernel; 0 (default) = off */
+  SG_TUNE_TILED_MIN_ROW_BYTES = 4 /* shared-gather kernel (each distinct source row of a 4-row mini-tile is
+                                     gathered once): default 1024 = fp32 rows of >= 1 KiB where it pays;
+                                     negative = force it for every row of at least |value| bytes and both
+                                     dtypes; 0 = never, and graphs created from now on carry no mini-tiles */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

@@ -101,7 +101,7 @@ struct DeviceBuf {
 // keep the distinct ones.  FILL = false: counts[t] = number of distinct ids, or -1 when the tile has
 // more than kTileEdges edges.  FILL = true: write them to uniq[uptr[t]..] and each edge's slot.
 template <bool FILL>
-__global__ __launch_bounds__(256) void tile_pass(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
+__global__ __launch_bounds__(64) void tile_pass(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
                                                  int64_t n_rows, int tile_rows, int32_t* __restrict__ counts,
                                                  const int32_t* __restrict__ uptr, int32_t* __restrict__ uniq,
                                                  uint8_t* __restrict__ eloc) {
@@ -114,6 +114,19 @@ __global__ __launch_bounds__(256) void tile_pass(const int32_t* __restrict__ row
   if (ne > kTileEdges) {
     if (!FILL && threadIdx.x == 0) counts[blockIdx.x] = -1;
     return;
+  }
+  if (!FILL) {   // a source listed twice in one row (multigraph) cannot be expressed by one slot + one mask bit
+    __shared__ int s_dup;
+    if (threadIdx.x == 0) s_dup = 0;
+    __syncthreads();
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x)
+      for (int e = rowptr[r] + 1; e < rowptr[r + 1]; ++e)
+        if (idx[e] == idx[e - 1]) s_dup = 1;
+    __syncthreads();
+    if (s_dup) {
+      if (threadIdx.x == 0) counts[blockIdx.x] = -1;
+      return;
+    }
   }
   int n2 = 1;
   while (n2 < ne) n2 <<= 1;
@@ -236,7 +249,7 @@ int build_tiles(Csr* c, hipStream_t stream) {
   DeviceBuf counts, temp;
   SG_HIP_TRY(hipMalloc(&counts.p, (nt + 1) * sizeof(int32_t)));
   SG_HIP_TRY(hipMemsetAsync(counts.p, 0, (nt + 1) * sizeof(int32_t), stream));
-  tile_pass<false><<<(int)nt, 256, 0, stream>>>(c->rowptr, c->idx, c->n_rows, kTileRows, (int32_t*)counts.p, nullptr,
+  tile_pass<false><<<(int)nt, 64, 0, stream>>>(c->rowptr, c->idx, c->n_rows, kTileRows, (int32_t*)counts.p, nullptr,
                                                nullptr, nullptr);
   SG_HIP_TRY(hipGetLastError());
   // tileable iff every tile has 0 <= distinct <= kTileSlots: min and max over the counts
@@ -263,7 +276,7 @@ int build_tiles(Csr* c, hipStream_t stream) {
   SG_HIP_TRY(hipStreamSynchronize(stream));
   SG_HIP_TRY(hipMalloc((void**)&c->tile_uniq, (total > 0 ? total : 1) * sizeof(int32_t)));
   SG_HIP_TRY(hipMalloc((void**)&c->tile_eloc, c->nnz));
-  tile_pass<true><<<(int)nt, 256, 0, stream>>>(c->rowptr, c->idx, c->n_rows, kTileRows, nullptr, c->tile_uptr,
+  tile_pass<true><<<(int)nt, 64, 0, stream>>>(c->rowptr, c->idx, c->n_rows, kTileRows, nullptr, c->tile_uptr,
                                               c->tile_uniq, c->tile_eloc);
   SG_HIP_TRY(hipGetLastError());
   SG_HIP_TRY(hipStreamSynchronize(stream));

@@ -35,7 +35,7 @@ struct Csr {
   int32_t* rowptr = nullptr;  // [n_rows + 1] device
   int32_t* idx = nullptr;     // [nnz] device, ascending inside a row
   int32_t max_degree = 0;
-  // Row tiles for the LDS-staged aggregation kernel (optional; null when the graph is not tileable):
+  // Mini-tiles for the shared-gather aggregation kernel (optional; null when the graph does not qualify):
   // tile t = rows [t*tile_rows, (t+1)*tile_rows); its DISTINCT source rows are
   // tile_uniq[tile_uptr[t] .. tile_uptr[t+1]) (ascending) and edge k reads local slot tile_eloc[k].
   int32_t tile_rows = 0;
@@ -45,9 +45,9 @@ struct Csr {
   void release();
 };
 
-constexpr int kTileRows = 32;      // rows per tile
-constexpr int kTileSlots = 128;    // max distinct source rows per tile (LDS slots)
-constexpr int kTileEdges = 512;    // max edges per tile
+constexpr int kTileRows = 4;       // rows per mini-tile (one accumulator set per row in registers)
+constexpr int kTileSlots = 32;     // max distinct source rows per mini-tile
+constexpr int kTileEdges = 128;    // max edges per mini-tile
 int build_tiles(Csr* c, hipStream_t stream);
 
 // Builds a Csr from (dst, src) int64 device pairs. Pairs with dst == src are dropped when

@@ -253,132 +253,191 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-tiled variant for wide rows -- EXPERIMENTAL, off by default (SG_TUNE_TILED_MIN_ROW_BYTES).
-// Measured on the 1 M-vertex mesh it is bit-identical to spmm_rows but 5-25 % SLOWER except at
-// C = 512 fp32 (-6 %): with 69 KB of LDS only two workgroups fit a CU and every tile pays its
-// metadata chain, the DMA wait and the epilogue-operand latency in sequence.  It needs a persistent,
-// double-buffered pipeline across tiles to pay; kept as the starting point for that.
-// With the vertices in a locality order (Morton), the 32 rows
-// of a tile reference only ~70 DISTINCT source rows for their ~192 edges.  The workgroup pulls each
-// distinct row ONCE, straight into LDS with direct-to-LDS loads (global_load_lds_dwordx4: no VGPRs
-// held while in flight, 2 rows x 512 B per wavefront instruction), then every output row is
-// reduced out of LDS (ds_read_b128 per edge).  L2 -> CU traffic drops from 6 to ~2.2 rows per
-// output row.  Rows wider than 512 B are processed in 512-B column segments over the same tile
-// metadata, so the staging buffer stays at kTileSlots x 512 B = 64 KB (two workgroups per CU: one
-// loads while the other reduces).
+// Shared-gather variant for wide rows.  With the vertices in a locality order (Morton), the 4 rows
+// of a mini-tile reference ~17 DISTINCT source rows for their ~24 edges.  A lane group gathers each
+// distinct row ONCE into registers and feeds up to 4 row accumulators from it (a 4-bit adjacency
+// mask per distinct row says which), so the L2 -> CU gather traffic drops from 6.0 to ~4.2 rows per
+// output row.  Per row the neighbours are still visited in ascending-id (CSR) order with the same
+// fma chain, so the result is bit-identical to spmm_rows.  Metadata: Csr::tile_* (csr_build.hip).
 // ---------------------------------------------------------------------------------------------
-constexpr int kSegBytes = 512;
+constexpr int kShTilesPerGroup = 2;                       // mini-tiles a lane group works through per wavefront
 
-template <typename T, int NEPI>
-__global__ __launch_bounds__(kBlock) void spmm_tiled(const SpmmArgs a, const int ntiles, const int flags) {
+template <typename T, int R, int N>
+__device__ __forceinline__ void shared_batch(const int2* __restrict__ su, const uint32_t* __restrict__ sm, int k, int nu,
+                                             const typename Vt<T>::elem* __restrict__ X, int64_t ldx,
+                                             const int (&voff)[R], float (&acc)[kTileRows][R][Vt<T>::VEC]) {
+  using V = Vt<T>;
+  using raw_t = typename V::raw;
+  constexpr int VEC = V::VEC;
+  int2 e[N];
+  uint32_t m[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    int kc = k + u < nu ? k + u : nu - 1;
+    kc = kc < 0 ? 0 : kc;
+    e[u] = su[kc];
+    m[u] = k + u < nu ? sm[kc] : 0u;
+  }
+  raw_t xv[N][R];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const typename V::elem* src = X + (int64_t)e[u].x * ldx;
+#pragma unroll
+    for (int r = 0; r < R; ++r) xv[u][r] = *(const raw_t*)(src + voff[r]);
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const float w = __int_as_float(e[u].y);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float f[VEC];
+      V::unpack(xv[u][r], f);
+#pragma unroll
+      for (int q = 0; q < kTileRows; ++q) {
+        if (m[u] & (1u << q)) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) acc[q][r][c] = fmaf(w, f[c], acc[q][r][c]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int G, int R, int NEPI>
+__global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const int nblocks, const int flags) {
   using V = Vt<T>;
   constexpr int VEC = V::VEC;
+  constexpr int RPW = 64 / G;                              // mini-tiles in flight per wavefront
+  constexpr int MT = RPW * kShTilesPerGroup;               // mini-tiles per wavefront
+  constexpr int ROWS = MT * kTileRows;
+  constexpr int CAPW = MT * kTileSlots;
   using raw_t = typename V::raw;
   using elem_t = typename V::elem;
-  constexpr int kSegElems = kSegBytes / (int)sizeof(elem_t);
 
-  __shared__ __attribute__((aligned(16))) unsigned char s_rows[kTileSlots * kSegBytes];
-  __shared__ int32_t s_uniq[kTileSlots];
-  __shared__ int2 s_edge[kTileEdges];          // (byte offset of the slot in s_rows, weight bits)
-  __shared__ int32_t s_rp[kTileRows + 1];
-  __shared__ float s_sd[kTileRows];
+  __shared__ int32_t s_up[kWaves][MT + 1];
+  __shared__ int32_t s_rp[kWaves][ROWS + 1];
+  __shared__ float s_sd[kWaves][ROWS];
+  __shared__ int2 s_u[kWaves][CAPW];
+  __shared__ uint32_t s_m[kWaves][CAPW];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, hl = lane & 31;
-  const int tile = (flags & kFlagXcdMap) ? xcd_contiguous(blockIdx.x, ntiles) : (int)blockIdx.x;
-  const int r0 = tile * kTileRows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = (flags & kFlagXcdMap) ? xcd_contiguous(blockIdx.x, nblocks) : (int)blockIdx.x;
+  const int n_mt = (a.n_rows + kTileRows - 1) / kTileRows;
+  const int m0 = (blk * kWaves + wave) * MT;
+  int nm = n_mt - m0;
+  nm = nm < 0 ? 0 : (nm > MT ? MT : nm);
+  const int r0 = m0 * kTileRows;
   int nrows = a.n_rows - r0;
-  nrows = nrows > kTileRows ? kTileRows : nrows;
+  nrows = nrows < 0 ? 0 : (nrows > ROWS ? ROWS : nrows);
 
-  // ---- tile metadata -> LDS ----
-  for (int l = tid; l <= nrows; l += kBlock) s_rp[l] = a.rowptr[r0 + l];
-  for (int l = tid; l < nrows; l += kBlock) s_sd[l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
-  const int u0 = a.tile_uptr[tile], nu = a.tile_uptr[tile + 1] - u0;
-  for (int l = tid; l < nu; l += kBlock) s_uniq[l] = a.tile_uniq[u0 + l];
+  // ---- stage mini-tile metadata: distinct-source lists (+ scale), row pointers, adjacency masks ----
+  if (nm > 0) {
+    for (int l = lane; l <= nm; l += 64) s_up[wave][l] = a.tile_uptr[m0 + l];
+    for (int l = lane; l <= nrows; l += 64) s_rp[wave][l] = a.rowptr[r0 + l];
+    for (int l = lane; l < nrows; l += 64) s_sd[wave][l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
+  }
   __syncthreads();
-  const int e0 = s_rp[0], ne = s_rp[nrows] - e0;
-  for (int k = tid; k < ne; k += kBlock) {
-    const int slot = a.tile_eloc[e0 + k];
-    const float w = a.scale_src ? a.scale_src[s_uniq[slot]] : 1.0f;
-    s_edge[k] = make_int2(slot * kSegBytes, __float_as_int(w));
+  int ub = 0, nut = 0, e0 = 0, ne = 0;
+  if (nm > 0) {
+    ub = s_up[wave][0];
+    nut = s_up[wave][nm] - ub;
+    e0 = s_rp[wave][0];
+    ne = s_rp[wave][nrows] - e0;
+  }
+  for (int k = lane; k < nut; k += 64) {
+    const int j = a.tile_uniq[ub + k];
+    s_u[wave][k] = make_int2(j, __float_as_int(a.scale_src ? a.scale_src[j] : 1.0f));
+    s_m[wave][k] = 0u;
+  }
+  __syncthreads();
+  for (int k = lane; k < ne; k += 64) {
+    int lo = 0, hi = nrows;                                 // row of edge e0+k: last lr with s_rp[lr] <= e0+k
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_rp[wave][mid] - e0 <= k) lo = mid; else hi = mid;
+    }
+    const int mt = lo / kTileRows;
+    atomicOr(&s_m[wave][s_up[wave][mt] - ub + a.tile_eloc[e0 + k]], 1u << (lo % kTileRows));
   }
   __syncthreads();
 
+  const int g = lane / G, gl = lane % G;
+  const int nvec = a.C / VEC;
   const elem_t* __restrict__ X = (const elem_t*)a.X;
   const elem_t* __restrict__ X0 = (const elem_t*)a.X0;
   const elem_t* __restrict__ X1 = (const elem_t*)a.X1;
   elem_t* __restrict__ Y = (elem_t*)a.Y;
-  const int nseg = (a.C * (int)sizeof(elem_t) + kSegBytes - 1) / kSegBytes;
+  int voff[R];
+  bool vok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int vi = gl + r * G;
+    vok[r] = vi < nvec;
+    voff[r] = (vok[r] ? vi : nvec - 1) * VEC;
+  }
 
-  for (int seg = 0; seg < nseg; ++seg) {
-    const int c0 = seg * kSegElems;                              // first channel of this segment
-    int cvec = (a.C - c0) / VEC;                                 // 16-B vectors in this segment
-    cvec = cvec > 32 ? 32 : cvec;
-    const int voff = c0 + (hl < cvec ? hl : cvec - 1) * VEC;     // clamped: loads stay inside the row
-    // ---- stage the distinct source rows of this tile (this segment) in LDS, 2 rows per instruction ----
-    for (int q = wave; 2 * q < nu; q += kWaves) {
-      int slot = 2 * q + half;
-      slot = slot < nu ? slot : nu - 1;
-      const elem_t* src = X + (int64_t)s_uniq[slot] * a.ldx + voff;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(s_rows + 2 * q * kSegBytes), 16, 0, 0);
+  for (int it = 0; it * RPW < nm; ++it) {
+    const int mt = it * RPW + g;
+    const bool tvalid = mt < nm;
+    const int mtc = tvalid ? mt : 0;
+    const int u0 = s_up[wave][mtc] - ub;
+    const int nu = tvalid ? s_up[wave][mtc + 1] - s_up[wave][mtc] : 0;
+    const int lr0 = mtc * kTileRows;
+    raw_t x0v[kTileRows][R], x1v[kTileRows][R];
+#pragma unroll
+    for (int q = 0; q < kTileRows; ++q) {
+      int row = r0 + lr0 + q;
+      row = row < a.n_rows ? row : a.n_rows - 1;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (NEPI >= 1) x0v[q][r] = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff[r]);
+        if (NEPI >= 2) x1v[q][r] = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + voff[r]);
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- reduce: each half-wavefront owns one output row at a time ----
-    for (int lr = wave * 2 + half; lr < nrows; lr += 2 * kWaves) {
+    float acc[kTileRows][R][VEC];
+#pragma unroll
+    for (int q = 0; q < kTileRows; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[q][r][c] = 0.f;
+
+    const int2* su = s_u[wave] + u0;
+    const uint32_t* sm = s_m[wave] + u0;
+    int k = 0;
+    while (__any(k < nu)) {
+      const int rem = nu - k;
+      if (R * 8 <= 8 && __any(rem > 4)) { shared_batch<T, R, 8>(su, sm, k, nu, X, a.ldx, voff, acc); k += 8; }
+      else if (__any(rem > 2)) { shared_batch<T, R, 4>(su, sm, k, nu, X, a.ldx, voff, acc); k += 4; }
+      else { shared_batch<T, R, 2>(su, sm, k, nu, X, a.ldx, voff, acc); k += 2; }
+    }
+
+#pragma unroll
+    for (int q = 0; q < kTileRows; ++q) {
+      const int lr = lr0 + q;
+      const bool rvalid = tvalid && lr < nrows;
       const int row = r0 + lr;
-      const int ks = s_rp[lr] - e0, ke = s_rp[lr + 1] - e0;
-      raw_t x0v, x1v;
-      if (NEPI >= 1) x0v = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff);
-      if (NEPI >= 2) x1v = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + voff);
-      float acc[VEC];
+      const float sdst = a.alpha * s_sd[wave][rvalid ? lr : 0];
 #pragma unroll
-      for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
-      int k = ks;
-      for (; k + 4 <= ke; k += 4) {
-        int2 e[4];
-        raw_t xv[4];
+      for (int r = 0; r < R; ++r) {
+        float y[VEC];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = s_edge[k + u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xv[u] = *(const raw_t*)(s_rows + e[u].x + hl * 16);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int c = 0; c < VEC; ++c) y[c] = sdst * acc[q][r][c];
+        if (NEPI >= 1) {
           float f[VEC];
-          V::unpack(xv[u], f);
-          const float w = __int_as_float(e[u].y);
+          V::unpack(x0v[q][r], f);
 #pragma unroll
-          for (int c = 0; c < VEC; ++c) acc[c] = fmaf(w, f[c], acc[c]);
+          for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
         }
-      }
-      for (; k < ke; ++k) {
-        const int2 e = s_edge[k];
-        float f[VEC];
-        V::unpack(*(const raw_t*)(s_rows + e.x + hl * 16), f);
-        const float w = __int_as_float(e.y);
+        if (NEPI >= 2) {
+          float f[VEC];
+          V::unpack(x1v[q][r], f);
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) acc[c] = fmaf(w, f[c], acc[c]);
+          for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
+        }
+        if (rvalid && vok[r]) *(raw_t*)(Y + (int64_t)row * a.ldy + voff[r]) = V::pack(y);
       }
-      const float sdst = a.alpha * s_sd[lr];
-      float y[VEC];
-#pragma unroll
-      for (int c = 0; c < VEC; ++c) y[c] = sdst * acc[c];
-      if (NEPI >= 1) {
-        float f[VEC];
-        V::unpack(x0v, f);
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
-      }
-      if (NEPI >= 2) {
-        float f[VEC];
-        V::unpack(x1v, f);
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
-      }
-      if (hl < cvec) *(raw_t*)(Y + (int64_t)row * a.ldy + voff) = V::pack(y);
     }
-    __syncthreads();   // all reads of this segment's rows are done before the next segment lands
   }
 }
 
@@ -442,7 +501,7 @@ struct Tuning {
   int flags = kFlagXcdMap;        // kFlag* bits
   int unroll = 0;                 // 0 = default per shape
   int slab = 0;                   // channels per column slab; 0 = whole rows
-  int tiled_min_row_bytes = 0;    // > 0: rows at least this wide take the LDS-tiled kernel (experimental, off)
+  int tiled_min_row_bytes = 1024; // shared-gather kernel: see launch_typed_one; 0 = never (and build no mini-tiles)
 };
 Tuning g_tuning;
 
@@ -468,16 +527,16 @@ int launch_rows_epi(const SpmmArgs& a, hipStream_t stream) {
   return SG_OK;
 }
 
-template <typename T>
-int launch_tiled(const SpmmArgs& a, hipStream_t stream) {
-  const int ntiles = (a.n_rows + kTileRows - 1) / kTileRows;
-  if (a.X0 && a.X1) spmm_tiled<T, 2><<<ntiles, kBlock, 0, stream>>>(a, ntiles, g_tuning.flags);
-  else if (a.X0) spmm_tiled<T, 1><<<ntiles, kBlock, 0, stream>>>(a, ntiles, g_tuning.flags);
-  else if (a.X1) {
-    SpmmArgs b = a;
-    b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f;
-    spmm_tiled<T, 1><<<ntiles, kBlock, 0, stream>>>(b, ntiles, g_tuning.flags);
-  } else spmm_tiled<T, 0><<<ntiles, kBlock, 0, stream>>>(a, ntiles, g_tuning.flags);
+template <typename T, int G, int R>
+int launch_shared(const SpmmArgs& a, hipStream_t stream) {
+  constexpr int MT = (64 / G) * kShTilesPerGroup;
+  const int64_t n_mt = ((int64_t)a.n_rows + kTileRows - 1) / kTileRows;
+  const int nblocks = (int)((n_mt + (int64_t)MT * kWaves - 1) / ((int64_t)MT * kWaves));
+  SpmmArgs b = a;
+  if (!a.X0 && a.X1) { b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f; }
+  if (b.X0 && b.X1) spmm_shared<T, G, R, 2><<<nblocks, kBlock, 0, stream>>>(b, nblocks, g_tuning.flags);
+  else if (b.X0) spmm_shared<T, G, R, 1><<<nblocks, kBlock, 0, stream>>>(b, nblocks, g_tuning.flags);
+  else spmm_shared<T, G, R, 0><<<nblocks, kBlock, 0, stream>>>(b, nblocks, g_tuning.flags);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
@@ -511,11 +570,21 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
     return SG_OK;
   }
   const int nvec = a.C / VEC;
-  // wide rows of a tileable graph: stage each distinct source row once in LDS
+  // Wide rows of a graph that carries mini-tiles: gather each distinct source row of 4 rows once.
+  // Measured on the 1 M-vertex Morton-ordered mesh (tools/agg_bench.py): it pays for fp32 rows of
+  // >= 1 KiB with an epilogue operand (0.685 -> 0.643 ms at C=256) and for 2 KiB rows (1.20 -> 1.04 ms
+  // at C=512); it loses on 512-B rows and in bf16 (4 x 8 accumulators per lane cost occupancy), so
+  // those keep spmm_rows unless SG_TUNE_TILED_MIN_ROW_BYTES forces them (negative value = force).
   const int row_bytes = a.C * (int)sizeof(typename Vt<T>::elem);
-  if (a.tile_uptr && g_tuning.tiled_min_row_bytes > 0 && row_bytes >= g_tuning.tiled_min_row_bytes &&
-      !(g_tuning.flags & kFlagNoTiles))
-    return launch_tiled<T>(a, stream);
+  const int tmin = g_tuning.tiled_min_row_bytes;
+  const bool forced = tmin < 0 && row_bytes >= -tmin;
+  const bool pays = tmin > 0 && sizeof(typename Vt<T>::elem) == 4 && row_bytes >= tmin &&
+                    (row_bytes >= 2 * tmin || a.X0 || a.X1);
+  if (a.tile_uptr && (forced || pays) && !(g_tuning.flags & kFlagNoTiles)) {
+    if (nvec > 16 && nvec <= 32) return launch_shared<T, 32, 1>(a, stream);
+    if (nvec > 32 && nvec <= 64) return launch_shared<T, 64, 1>(a, stream);
+    if (nvec > 64 && nvec <= 128) return launch_shared<T, 64, 2>(a, stream);
+  }
   if (nvec <= 1) return launch_rows<T, 1, 1>(a, stream);
   if (nvec <= 2) return launch_rows<T, 2, 1>(a, stream);
   if (nvec <= 4) return launch_rows<T, 4, 1>(a, stream);
@@ -551,7 +620,7 @@ int launch_typed(const SpmmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-bool tiles_enabled() { return g_tuning.tiled_min_row_bytes > 0; }
+bool tiles_enabled() { return g_tuning.tiled_min_row_bytes != 0; }
 
 int set_tuning(int knob, int value) {
   switch (knob) {

@@ -41,13 +41,11 @@ def main():
         from semigcn_amd import reorder
         order, rank = reorder.morton_order(torch.from_numpy(m.vs).to(dev))
         ei = reorder.permute_edge_index(ei, rank)
-    if any("tmin=" in v for v in a.variants):
-        capi.tuning_set(capi.TUNE_TILED_MIN_ROW_BYTES, 512)    # build row tiles for the experimental kernel
     g = MeshGraph.from_edge_index(ei, V)
     variants = []
     for v in a.variants:
         d = dict(kv.split("=") for kv in v.split(","))
-        variants.append((v, int(d.get("ch", 0)), int(d.get("flags", 1)), int(d.get("unroll", 0)), int(d.get("slab", 0)), int(d.get("tmin", 0))))
+        variants.append((v, int(d.get("ch", 0)), int(d.get("flags", 1)), int(d.get("unroll", 0)), int(d.get("slab", 0)), int(d.get("tmin", 1024))))
     out = []
     for dt in a.dtypes.split(","):
         dtype = torch.float32 if dt == "fp32" else torch.bfloat16

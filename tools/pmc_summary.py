@@ -32,17 +32,18 @@ def main():
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         agg = collections.defaultdict(list)
         for r in load(f"{root}/pmc_{cname}"):
-            m = re.search(r"spmm_rows<(.+?), (\d+), (\d+), (\d+)>", r["Kernel_Name"])
+            m = re.search(r"spmm_(rows|shared)<(.+?), (\d+), (\d+), (\d+)>", r["Kernel_Name"])
             if not m or r["Counter_Name"] != cname:
                 continue
-            dt = "bfloat16" if "bf16" in m.group(1) else "float32"
-            agg[(dt, int(m.group(2)), int(m.group(3)), int(m.group(4)))].append(float(r["Counter_Value"]))
+            dt = "bfloat16" if "bf16" in m.group(2) else "float32"
+            agg[(m.group(1), dt, int(m.group(3)), int(m.group(4)), int(m.group(5)))].append(float(r["Counter_Value"]))
         per[cname] = agg
     res = []
     for key in sorted(per["FETCH_SIZE"]):
         f = statistics.mean(per["FETCH_SIZE"][key])
         w = statistics.mean(per["WRITE_SIZE"].get(key, [0.0]))
-        res.append({"dtype": key[0], "lanes_per_row": key[1], "vectors_per_lane": key[2], "epilogue_operands": key[3],
+        res.append({"kernel": "spmm_" + key[0], "dtype": key[1], "lanes_per_row": key[2], "vectors_per_lane": key[3],
+                    "epilogue_operands": key[4],
                     "launches": len(per["FETCH_SIZE"][key]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                     "read_bytes_corrected": round(2 * f * 1024), "write_bytes": round(w * 1024),
                     "traffic_bytes_per_launch": round(2 * f * 1024 + w * 1024)})
