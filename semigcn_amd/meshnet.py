@@ -27,6 +27,8 @@ import torch.nn as nn
 
 from . import capi
 from . import functional as F_sg
+from . import reorder as _reorder
+from .graph import MeshGraph
 from .networks import _Fp32Linear, prepare_input
 from .nn import ChebConv, Sequential
 
@@ -70,6 +72,10 @@ class _HashOp(nn.Module):
         super().__init__()
         self.register_buffer(self._buffer_name, mat)
         self._handle = None
+        # processing-order relabelling of the two vertex sets (set by MGCN when it reorders); the buffer
+        # itself stays in the caller's numbering, so state dicts remain interchangeable with the reference
+        self._rank_fine: Optional[torch.Tensor] = None
+        self._rank_coarse: Optional[torch.Tensor] = None
 
     def _pool(self) -> capi.PoolHandle:
         mat = getattr(self, self._buffer_name)
@@ -78,6 +84,10 @@ class _HashOp(nn.Module):
             r, c, shape = _pairs_from_sparse(mat)
             fine, coarse = (r, c) if self._transposed else (c, r)
             n_fine, n_coarse = (shape[0], shape[1]) if self._transposed else (shape[1], shape[0])
+            if self._rank_fine is not None:
+                fine = self._rank_fine.to(fine.device)[fine]
+            if self._rank_coarse is not None:
+                coarse = self._rank_coarse.to(coarse.device)[coarse]
             h = capi.PoolHandle(fine, coarse, n_fine, n_coarse)
             self._handle = h
         return h
@@ -85,6 +95,10 @@ class _HashOp(nn.Module):
     def _apply(self, fn, *args, **kwargs):   # .to(device) moves the buffer; drop the stale handle
         self._handle = None
         return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):   # a loaded pool_hash invalidates the handle as well
+        self._handle = None
+        return super()._load_from_state_dict(*args, **kwargs)
 
 
 class MeshPool(_HashOp):
@@ -125,7 +139,8 @@ class DownConv(nn.Module):
                                  + _conv_bn_act(c, c, K) + [(nn.Dropout(drop_rate), "x -> x")])
 
     def forward(self, input):
-        return self.model2(self.model1(input, self.edge_index1), self.edge_index2)
+        g1, g2 = getattr(self, "_graphs", (self.edge_index1, self.edge_index2))
+        return self.model2(self.model1(input, g1), g2)
 
 
 class UpConv(nn.Module):
@@ -144,7 +159,8 @@ class UpConv(nn.Module):
                                  + [(nn.Dropout(drop_rate), "x -> x")])
 
     def forward(self, input):
-        return self.model2(self.model1(input, self.edge_index1), self.edge_index2)
+        g1, g2 = getattr(self, "_graphs", (self.edge_index1, self.edge_index2))
+        return self.model2(self.model1(input, g1), g2)
 
 
 def _head(cin: int, K: int) -> Sequential:
@@ -152,8 +168,10 @@ def _head(cin: int, K: int) -> Sequential:
 
 
 class MGCN(nn.Module):
-    def __init__(self, device, smo_mesh, ini_mesh, v_mask, K=3, skip=False, save_pooled: bool = False):
+    def __init__(self, device, smo_mesh, ini_mesh, v_mask, K=3, skip=False, save_pooled: bool = False,
+                 reorder: bool = True):
         super().__init__()
+        self.reorder = reorder
         device = torch.device(device)
         nv = len(smo_mesh.vs)
         self.nvs = [int(nv * (POOL_RATIO ** i)) for i in range(1, POOL_LEVELS + 1)]
@@ -177,11 +195,12 @@ class MGCN(nn.Module):
     def from_hierarchy(cls, device, edge_inds: Sequence[torch.Tensor], pool_hashes: Sequence[np.ndarray],
                        smposs: Sequence[torch.Tensor], ini_pos: Optional[torch.Tensor] = None,
                        v_mask: Optional[torch.Tensor] = None, faces: Optional[Sequence] = None,
-                       K: int = 3, skip: bool = False) -> "MGCN":
+                       K: int = 3, skip: bool = False, reorder: bool = True) -> "MGCN":
         """Build from a precomputed hierarchy: ``edge_inds`` 4 x [2,E_l] (fine..coarse),
         ``pool_hashes`` 3 x int64 [V_l, 2] rows (fine_i, coarse_i), ``smposs`` 4 x [V_l, 3]."""
         self = cls.__new__(cls)
         nn.Module.__init__(self)
+        self.reorder = reorder
         self.nvs = [int(len(smposs[0]) * (POOL_RATIO ** i)) for i in range(1, POOL_LEVELS + 1)]
         self.meshes = None
         if ini_pos is None:
@@ -249,6 +268,24 @@ class MGCN(nn.Module):
                 cnt = torch.zeros(n_c, 1).index_add_(0, coarse, torch.ones(fine.numel(), 1))
                 self.poss_list.append(acc / cnt)
         self.poss = torch.cat(self.poss_list, dim=0)
+        self._orders = None
+        if self.reorder and device.type == "cuda":
+            self._prepare_processing_order()
+
+    def _prepare_processing_order(self):
+        """Every level is processed in Morton order of its smooth positions (like SingleScaleGCN): the
+        per-level graphs are built on relabelled edges, pool/unpool handles relabel both vertex sets,
+        the input is permuted once and the four outputs are returned in the caller's order."""
+        orders = [_reorder.morton_order(p) for p in self.smposs_list]           # (order, rank) per level
+        graphs = [MeshGraph.from_edge_index(_reorder.permute_edge_index(e, r), p.shape[0])
+                  for e, (_, r), p in zip(self.edge_inds, orders, self.smposs_list)]
+        for stage, (lf, lc) in ((self.encoder1, (0, 1)), (self.encoder2, (1, 2)), (self.encoder3, (2, 3))):
+            stage._graphs = (graphs[lf], graphs[lc])
+            stage.model1.module_4._rank_fine, stage.model1.module_4._rank_coarse = orders[lf][1], orders[lc][1]
+        for stage, (lc, lf) in ((self.decoder3, (3, 2)), (self.decoder2, (2, 1)), (self.decoder1[0], (1, 0))):
+            stage._graphs = (graphs[lc], graphs[lf])
+            stage.model1.module_1._rank_fine, stage.model1.module_1._rank_coarse = orders[lf][1], orders[lc][1]
+        self._orders, self._graphs = orders, graphs
 
     def _save_pooled(self, smo_mesh):
         root = os.path.dirname(smo_mesh.path)
@@ -272,25 +309,32 @@ class MGCN(nn.Module):
         else:
             mask = torch.ones((z1.shape[0], 1), dtype=z1.dtype, device=self.device)
         x = prepare_input(z1, mask.to(z1.dtype))
+        heads = self.edge_inds
+        if self._orders is not None:
+            x = x.index_select(0, self._orders[0][0])
+            heads = self._graphs
 
         res1_enc = self.encoder1(x)
         res2_enc = self.encoder2(res1_enc)
         res3_bot = self.encoder3(res2_enc)
-        out3 = self.mcnn3(res3_bot, self.edge_inds[3])
+        out3 = self.mcnn3(res3_bot, heads[3])
 
         res2_dec = self.decoder3(res3_bot)
         if self.skip:
             res2_dec = self.skip2(torch.cat([res2_dec, res2_enc], dim=1))
-        out2 = self.mcnn2(res2_dec, self.edge_inds[2])
+        out2 = self.mcnn2(res2_dec, heads[2])
 
         res1_dec = self.decoder2(res2_dec)
         if self.skip:
             res1_dec = self.skip1(torch.cat([res1_dec, res1_enc], dim=1))
-        out1 = self.mcnn1(res1_dec, self.edge_inds[1])
+        out1 = self.mcnn1(res1_dec, heads[1])
 
         out0 = self.decoder1(res1_dec)
+        outs = [out0, out1, out2, out3]
+        if self._orders is not None:
+            outs = [o.index_select(0, rank) for o, (_, rank) in zip(outs, self._orders)]
         s = self.smposs_list
-        return (s[0] + out0, s[1] + out1, s[2] + out2, s[3] + out3)
+        return (s[0] + outs[0], s[1] + outs[1], s[2] + outs[2], s[3] + outs[3])
 
     # helpers the reference exposes (util/meshnet.py:320-341)
     def pool(self, dx, pool_hash):

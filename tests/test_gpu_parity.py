@@ -532,6 +532,29 @@ def test_mgcn_skip_variant_vs_oracle():
             assert GU.rel_l2(a.cpu(), b) < 5e-5
 
 
+def test_mgcn_reordering_is_transparent():
+    """Per-level Morton processing order changes nothing the caller sees; a state dict written in the
+    caller's numbering (pool_hash buffers included) loads into a reordering model."""
+    from test_host_logic import _mgcn_from_golden
+    from semigcn_amd.meshnet import MGCN
+    g3 = GU.load("g3_mgcn.npz")
+    a = _mgcn_from_golden(DEV, g3)
+    assert a._orders is not None
+    eis = [torch.from_numpy(g3[f"edge_index/{l}"]) for l in range(4)]
+    b = MGCN.from_hierarchy(DEV, eis, [g3[f"pool_hash/{l}"] for l in range(3)],
+                            [torch.from_numpy(g3[f"smposs/{l}"]) for l in range(4)], reorder=False)
+    GU.fill_state(b, seed=12)
+    a.load_state_dict(b.state_dict())
+    a.to(DEV).eval(), b.to(DEV).eval()
+
+    class D:
+        z1 = torch.from_numpy(g3["z1"]).to(DEV)
+        x_pos = None
+    with torch.no_grad():
+        for pa, pb in zip(a(D, g3["dm"]), b(D, g3["dm"])):
+            assert GU.rel_l2(pa.cpu(), pb.cpu()) < 2e-5
+
+
 def test_mgcn_config_c3_size_runs():
     """BASELINE config c3: MGCN, 3 pool levels, 50 K-vertex mesh (synthetic hierarchy)."""
     from semigcn_amd.meshnet import MGCN

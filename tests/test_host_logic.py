@@ -185,7 +185,11 @@ def check_mgcn_against_golden(net, g3, device, out_tol, grad_tight):
     rec_o, rec_h = GU.ActivationMasks(ora), GU.ActivationMasks(net, fused=True)
     ora(torch.from_numpy(g3["z1"]), dm)
     poss = net(D, dm)
-    flips = rec_h.flips_against(rec_o)
+    row_maps = None
+    if getattr(net, "_orders", None) is not None:      # each level is processed in its own Morton order
+        by_size = {rank.numel(): rank.cpu() for _, rank in net._orders}
+        row_maps = [by_size[mk.shape[0]] for mk in rec_h.masks]
+    flips = rec_h.flips_against(rec_o, row_maps)
     rec_o.close(), rec_h.close()
     for l, p in enumerate(poss):
         assert GU.rel_l2(p.detach().cpu(), g3[f"train_out/{l}"]) < out_tol, l
