@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""cProfile of the host side of SGCN training iterations on a small mesh (CPU-launch-bound regime)."""
+import cProfile, os, pstats, sys, io
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.argv = ["bench.py", "--mesh", "250x200"]
+import bench
+from semigcn_amd import synth, train
+from semigcn_amd.networks import SingleScaleGCN
+dev = torch.device("cuda:0")
+mesh = synth.torus_mesh(250, 200)
+batch = bench.build_mesh_batch(mesh, dev, 5)
+model = SingleScaleGCN(dev).to(dev)
+tr = train.SGCNTrainer(model, batch)
+for _ in range(5): tr.iteration_step()
+torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable()
+for _ in range(20): tr.iteration_step()
+torch.cuda.synchronize(); pr.disable()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
