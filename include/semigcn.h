@@ -192,6 +192,34 @@ SG_API int sg_bn_act_bwd_apply(const void* dA, int64_t ldda, const void* H, int6
                                int64_t C, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Mesh connectivity and hole masks -- the producers of the path's inputs, on the
+ * device.  Replace Mesh.build_gemm (util/mesh.py:60-100: self.edges, whose order
+ * edge_index inherits at util/mesh.py:229-230), the face 1-ring f2f
+ * (util/mesh.py:214-227), one ring of dummy-mask dilation
+ * Mv1 = (AdjI @ Mv0) > 0 (util/datamaker.py:123-127) and the vertex->face mask
+ * (f2v_mat @ (1 - vmask)) == 0 (util/datamaker.py:136,156-159;
+ * util/meshnet.py:179,196).  The reference does these with Python loops over
+ * faces and dense V x V matrices.
+ *
+ * sg_mesh_edges: faces int64 [F,3] (device) -> edges_out int64 [n,2] (device,
+ *   capacity 3F rows): the distinct (lo, hi) vertex pairs in the order a
+ *   face-by-face scan of (f0,f1),(f1,f2),(f2,f0) first meets them;
+ *   *n_edges_out (host) = n.  f2f_out (nullable) int64 [F,3]: the faces across
+ *   the face's edges, -1 padded at the end of the row (order inside a row is
+ *   by the face's own edge number; the reference's is Python-set order).
+ *   *manifold_out (host, nullable) = 0 when some edge has more than two faces
+ *   (then f2f is incomplete there).  Synchronises the stream.
+ * sg_mask_dilate: masks are bit-packed, W 64-bit words per vertex (bit b of word w
+ *   = mask 64 w + b); out[v] = in[v] | OR_{j adjacent to v} in[j].  in != out.
+ * sg_face_mask: fbits[f] = vbits[f0] & vbits[f1] & vbits[f2] (bits = "kept").
+ * ------------------------------------------------------------------------- */
+SG_API int sg_mesh_edges(const int64_t* faces, int64_t F, int64_t V, int64_t* edges_out, int64_t* f2f_out,
+                         int64_t* n_edges_out, int* manifold_out, void* stream);
+SG_API int sg_mask_dilate(const sg_graph* g, const uint64_t* in, uint64_t* out, int64_t W, void* stream);
+SG_API int sg_face_mask(const int64_t* faces, int64_t F, int64_t V, const uint64_t* vbits, uint64_t* fbits,
+                        int64_t W, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Loss step of the training loop, fused -- replaces Models.compute_fn
  * (util/models.py:121-126), Loss.mask_pos_rec_loss (util/loss.py:14-34, 'rmse')
  * and Loss.mask_norm_rec_loss (util/loss.py:78-107, 'l1mae') as sgcn.py:130-132

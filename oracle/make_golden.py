@@ -2,7 +2,7 @@
 (/root/reference/util/{mesh,networks,meshnet,loss,models}.py, imported in place
 through oracle/ref_shim.py -- nothing is copied) on small seeded inputs.
 
-    python -m oracle.make_golden            # run in the authoring container only
+    python -m oracle.make_golden [--only g4]     # run in the authoring container only
 
 TEST INFRASTRUCTURE ONLY.  The [3P] torch-geometric operators underneath are
 oracle/pyg_restatement.py (the real package is not installable here); what these
@@ -39,10 +39,10 @@ class _Data:
         self.edge_index = torch.from_numpy(m.edge_index)
 
 
-def _ref_mesh(ref, m, tmp, name):
+def _ref_mesh(ref, m, tmp, name, **kw):
     path = os.path.join(tmp, name + ".obj")
     synth.write_obj(path, m.vs, m.faces)
-    return ref.mesh.Mesh(path)
+    return ref.mesh.Mesh(path, **kw)
 
 
 def g0_layout_and_dense(ref, meshes, tmp):
@@ -202,7 +202,40 @@ def g3_mgcn(ref, m, rm, tmp):
     np.savez_compressed(os.path.join(OUT, "g3_mgcn.npz"), **out)
 
 
+def g4_meshprep(ref, meshes, tmp):
+    """G4: the reference Mesh's own connectivity (util/mesh.py:60-100 edges, :214-227 f2f) and
+    its own ``make_dummy_mask`` / ``vmask_to_fmask`` (util/datamaker.py:110-159) with numpy's
+    global generator seeded, on the closed fixtures and on an open mesh (boundary edges)."""
+    out = {}
+    sph = meshes["sphere"]
+    keep = np.ones(len(sph.faces), bool)
+    keep[[3, 4, 5, 100, 101, 250]] = False
+    cases = {"sphere": (sph.vs, sph.faces), "torus": (meshes["torus"].vs, meshes["torus"].faces),
+             "open": (sph.vs, sph.faces[keep])}
+    for name, (vs, faces) in cases.items():
+        holder = type("M", (), {"vs": vs, "faces": faces})()
+        # the reference's cotangent Laplacian (util/mesh.py:289-317) needs two faces per edge
+        rm = _ref_mesh(ref, holder, tmp, "g4_" + name, build_mat=(name != "open"))
+        os.makedirs(os.path.join(tmp, "dummy_mask"), exist_ok=True)
+        out[f"{name}/faces"] = np.asarray(rm.faces, dtype=np.int64)
+        out[f"{name}/num_vertices"] = np.int64(len(rm.vs))
+        out[f"{name}/edges"] = rm.edges
+        out[f"{name}/edge_index"] = rm.edge_index.numpy()
+        out[f"{name}/f2f"] = rm.f2f.astype(np.int64)
+        np.random.seed(317)
+        vmask, fmask = ref.datamaker.make_dummy_mask(rm, dm_size=3, kn=[1, 2, 3],
+                                                     exist_face=np.ones(len(rm.faces)))
+        out[f"{name}/vmask_dummy"] = vmask.numpy().astype(np.uint8)
+        out[f"{name}/fmask_dummy"] = fmask.numpy().astype(np.uint8)
+        rs = np.random.RandomState(9)
+        vm = rs.random(len(rm.vs)) > 0.1
+        out[f"{name}/vm"] = vm
+        out[f"{name}/fm"] = ref.datamaker.vmask_to_fmask(rm, vm.astype(np.float32)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g4_meshprep.npz"), **out)
+
+
 def main():
+    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
     warnings.simplefilter("ignore")
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -210,11 +243,17 @@ def main():
     ref = ref_shim.load()
     meshes = {"sphere": synth.octahedron_sphere(3), "torus": synth.torus_mesh(20, 12)}
     with tempfile.TemporaryDirectory() as tmp:
-        g0_layout_and_dense(ref, meshes, tmp)
+        if only is None or "g0" in only:
+            g0_layout_and_dense(ref, meshes, tmp)
         ref_meshes = {n: _ref_mesh(ref, m, tmp, n) for n, m in meshes.items()}
-        g1_chebconv(meshes)
-        g2_sgcn(ref, meshes, ref_meshes)
-        g3_mgcn(ref, meshes["sphere"], ref_meshes["sphere"], tmp)
+        if only is None or "g1" in only:
+            g1_chebconv(meshes)
+        if only is None or "g2" in only:
+            g2_sgcn(ref, meshes, ref_meshes)
+        if only is None or "g3" in only:
+            g3_mgcn(ref, meshes["sphere"], ref_meshes["sphere"], tmp)
+        if only is None or "g4" in only:
+            g4_meshprep(ref, meshes, tmp)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

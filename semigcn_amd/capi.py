@@ -66,6 +66,10 @@ _SIGNATURES = {
                                     c_void_p]),
     "sg_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
                                c_void_p]),
+    "sg_mesh_edges": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64), POINTER(c_int),
+                              c_void_p]),
+    "sg_mask_dilate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sg_face_mask": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None
@@ -258,6 +262,18 @@ class GraphHandle:
                 n_epi = int(X0 is not None) + int(X1 is not None)
                 timer.records.append(((C, str(X.dtype).replace("torch.", ""), n_epi), ev0, ev1))
         return Y
+
+    def dilate_bits(self, bits: torch.Tensor) -> torch.Tensor:
+        """One ring of dilation of bit-packed vertex masks: int64 [V, W] -> int64 [V, W]."""
+        _require_device(bits, "bits")
+        if bits.dtype != torch.int64 or bits.dim() != 2 or bits.shape[0] != self.num_rows:
+            raise SemigcnLibraryError(f"bits must be int64 [{self.num_rows}, W], got {bits.dtype} {tuple(bits.shape)}")
+        bits = bits.contiguous()
+        out = torch.empty_like(bits)
+        with _on_device(bits.device):
+            _check(load().sg_mask_dilate(self._h, _ptr(bits), _ptr(out), bits.shape[1], _stream(bits)),
+                   "sg_mask_dilate")
+        return out
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -465,3 +481,33 @@ def mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, g: torch.Te
                                        _ptr(f_keep), _ptr(_f32c(g, "g")), V, pos.shape[0], F, _ptr(grad), _stream(pos)),
                "sg_mesh_loss_bwd")
     return grad
+
+
+def mesh_edges(faces: torch.Tensor, num_vertices: int, with_f2f: bool = True):
+    """(edges int64 [n,2] in first-meeting order, f2f int64 [F,3] or None, manifold: bool)."""
+    _require_device(faces, "faces")
+    if faces.dtype != torch.int64 or faces.dim() != 2 or faces.shape[1] != 3:
+        raise SemigcnLibraryError(f"faces must be int64 [F,3], got {faces.dtype} {tuple(faces.shape)}")
+    faces = faces.contiguous()
+    F = faces.shape[0]
+    edges = torch.empty((3 * F, 2), dtype=torch.int64, device=faces.device)
+    f2f = torch.empty((F, 3), dtype=torch.int64, device=faces.device) if with_f2f else None
+    n, manifold = c_int64(0), c_int(1)
+    with _on_device(faces.device):
+        _check(load().sg_mesh_edges(_ptr(faces), F, int(num_vertices), _ptr(edges), _ptr(f2f), byref(n),
+                                    byref(manifold), _stream(faces)), "sg_mesh_edges")
+    return edges[: n.value].clone(), f2f, bool(manifold.value)
+
+
+def face_mask_bits(faces: torch.Tensor, vbits: torch.Tensor) -> torch.Tensor:
+    """fbits[f] = AND of the three vertices' words; vbits int64 [V, W] -> int64 [F, W]."""
+    _require_device(faces, "faces")
+    _require_device(vbits, "vbits")
+    if faces.dtype != torch.int64 or vbits.dtype != torch.int64 or vbits.dim() != 2:
+        raise SemigcnLibraryError("face_mask_bits: faces int64 [F,3] and vbits int64 [V,W] expected")
+    faces, vbits = faces.contiguous(), vbits.contiguous()
+    out = torch.empty((faces.shape[0], vbits.shape[1]), dtype=torch.int64, device=faces.device)
+    with _on_device(faces.device):
+        _check(load().sg_face_mask(_ptr(faces), faces.shape[0], vbits.shape[0], _ptr(vbits), _ptr(out),
+                                   vbits.shape[1], _stream(faces)), "sg_face_mask")
+    return out

@@ -316,6 +316,29 @@ SG_API int sg_mesh_loss_bwd(const float* pos, const int64_t* faces, const float*
                               (hipStream_t)stream);
 }
 
+SG_API int sg_mesh_edges(const int64_t* faces, int64_t F, int64_t V, int64_t* edges_out, int64_t* f2f_out,
+                         int64_t* n_edges_out, int* manifold_out, void* stream) {
+  SG_REQUIRE(F >= 0 && V >= 0 && n_edges_out, "sg_mesh_edges: bad argument");
+  SG_REQUIRE(F == 0 || (faces && edges_out), "sg_mesh_edges: null pointer");
+  return mesh_edges(faces, F, V, edges_out, f2f_out, n_edges_out, manifold_out, (hipStream_t)stream);
+}
+
+SG_API int sg_mask_dilate(const sg_graph* g, const uint64_t* in, uint64_t* out, int64_t W, void* stream) {
+  SG_REQUIRE(g != nullptr && W >= 0, "sg_mask_dilate: bad argument");
+  SG_REQUIRE(g->square, "sg_mask_dilate: needs a square graph");
+  if (W == 0 || g->fwd.n_rows == 0) return SG_OK;
+  SG_REQUIRE(in && out && in != out, "sg_mask_dilate: null or aliased buffers");
+  return launch_mask_dilate(g->fwd, in, out, W, (hipStream_t)stream);
+}
+
+SG_API int sg_face_mask(const int64_t* faces, int64_t F, int64_t V, const uint64_t* vbits, uint64_t* fbits,
+                        int64_t W, void* stream) {
+  SG_REQUIRE(F >= 0 && V >= 0 && W >= 0, "sg_face_mask: negative size");
+  if (F == 0 || W == 0) return SG_OK;
+  SG_REQUIRE(faces && vbits && fbits, "sg_face_mask: null pointer");
+  return launch_face_mask(faces, F, V, vbits, fbits, W, (hipStream_t)stream);
+}
+
 SG_API int64_t sg_col_blocks(int64_t V) { return col_blocks(V); }
 
 SG_API int sg_col_moments(const void* X, int64_t ldx, int64_t V, int64_t C, int dtype, float* partial, int64_t nb,

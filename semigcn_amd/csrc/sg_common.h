@@ -108,6 +108,13 @@ int launch_mesh_loss_bwd(const float* pos, const int64_t* faces, const float* tp
                          const float* fkeep, const float* g, int64_t V, int64_t V_ext, int64_t F, float* grad,
                          hipStream_t stream);
 
+// mesh_prep.hip
+int mesh_edges(const int64_t* faces, int64_t F, int64_t V, int64_t* edges_out, int64_t* f2f_out,
+               int64_t* n_edges_out, int* manifold_out, hipStream_t stream);
+int launch_mask_dilate(const Csr& c, const uint64_t* in, uint64_t* out, int64_t W, hipStream_t stream);
+int launch_face_mask(const int64_t* faces, int64_t F, int64_t V, const uint64_t* vbits, uint64_t* fbits, int64_t W,
+                     hipStream_t stream);
+
 }  // namespace sg
 
 struct sg_graph {

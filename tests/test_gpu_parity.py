@@ -722,3 +722,98 @@ def test_multigraph_and_hub_rows_fall_back_to_the_generic_kernel():
     capi.tuning_set(capi.TUNE_TILED_MIN_ROW_BYTES, 1024)
     x = torch.randn(V, 256, device=DEV)
     assert rel(h.spmm(x, torch.empty_like(x)), oracle_lhat(ei, x.cpu())) < KERNEL_TOL
+
+
+# --------------------------------------------------------------------------------------
+# mesh connectivity + dummy masks on the device: bit-exact integer work
+# --------------------------------------------------------------------------------------
+def _rows_as_sets(a):
+    return np.sort(np.asarray(a), axis=1)
+
+
+@pytest.mark.parametrize("name", ["sphere", "torus", "open"])
+def test_meshprep_vs_reference_golden(name):
+    """faces -> edges / edge_index / f2f, dummy masks and vertex->face masks equal the outputs of the
+    reference's own Mesh and make_dummy_mask (same numpy seed) bit for bit."""
+    from semigcn_amd import meshprep
+    g = GU.load("g4_meshprep.npz")
+    faces, V = g[f"{name}/faces"], int(g[f"{name}/num_vertices"])
+    topo = meshprep.MeshTopology(faces, V, DEV)
+    assert np.array_equal(topo.edges.cpu().numpy(), g[f"{name}/edges"])
+    assert np.array_equal(topo.edge_index.cpu().numpy(), g[f"{name}/edge_index"])
+    assert np.array_equal(_rows_as_sets(topo.f2f.cpu()), _rows_as_sets(g[f"{name}/f2f"]))
+    f2f = topo.f2f.cpu().numpy()
+    assert ((f2f[:, :-1] >= 0) | (f2f[:, 1:] < 0)).all()          # -1 only as trailing padding
+    assert topo.manifold
+    state = np.random.get_state()
+    try:
+        np.random.seed(317)
+        vm, fm = meshprep.make_dummy_mask(topo, dm_size=3, kn=[1, 2, 3])
+    finally:
+        np.random.set_state(state)
+    assert vm.dtype == torch.float32 and vm.shape == (V, 9) and fm.shape == (len(faces), 9)
+    assert np.array_equal(vm.cpu().numpy(), g[f"{name}/vmask_dummy"])
+    assert np.array_equal(fm.cpu().numpy(), g[f"{name}/fmask_dummy"])
+    assert np.array_equal(meshprep.vmask_to_fmask(topo, g[f"{name}/vm"]).cpu().numpy(), g[f"{name}/fm"])
+
+
+@pytest.mark.parametrize("permute", [False, True])
+def test_meshprep_vs_oracle_medium(permute):
+    """60 K faces, 130 masks (three 64-bit words per vertex), natural and scrambled vertex order."""
+    from oracle import meshprep as MP
+    from semigcn_amd import meshprep
+    m = synth.torus_mesh(200, 150, permute=permute, masks=False)
+    V = m.num_vertices
+    topo = meshprep.MeshTopology(m.faces, V, DEV)
+    edges = MP.edges_first_meeting(m.faces)
+    assert np.array_equal(topo.edges.cpu().numpy(), edges)
+    assert np.array_equal(_rows_as_sets(topo.f2f.cpu()), _rows_as_sets(MP.face_ring(m.faces, V)))
+    vm_o, fm_o = MP.make_dummy_mask(m.faces, edges, V, dm_size=65, kn=(2, 4), rng=np.random.RandomState(5))
+    vm, fm = meshprep.make_dummy_mask(topo, dm_size=65, kn=(2, 4), rng=np.random.RandomState(5))
+    assert np.array_equal(vm.cpu().numpy(), vm_o) and np.array_equal(fm.cpu().numpy(), fm_o)
+    # the graph the topology hands to the convolutions is the one the reference layout gives
+    h = capi.GraphHandle.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), V)
+    for a, b in zip(topo.graph.handle.arrays(), h.arrays()):
+        assert torch.equal(a, b)
+
+
+def test_meshprep_rejects_bad_faces_and_flags_non_manifold():
+    from semigcn_amd import meshprep
+    with pytest.raises(capi.SemigcnLibraryError, match="outside"):
+        meshprep.MeshTopology(np.array([[0, 1, 7]]), 4, DEV)
+    with pytest.raises(capi.SemigcnLibraryError, match="degenerate"):
+        meshprep.MeshTopology(np.array([[0, 1, 1]]), 4, DEV)
+    fan = np.array([[0, 1, 2], [0, 1, 3], [0, 1, 4]])       # edge (0,1) has three faces
+    topo = meshprep.MeshTopology(fan, 5, DEV)
+    assert not topo.manifold and topo.edges.shape[0] == 7
+    empty = meshprep.MeshTopology(np.zeros((0, 3), np.int64), 3, DEV)
+    assert empty.edges.shape == (0, 2) and empty.edge_index.shape == (2, 0)
+
+
+def test_meshprep_full_size_properties():
+    """V = 1 M (BASELINE c4 shape): Euler counts, uniqueness, symmetry of f2f, and ring dilation
+    against an independent float index_add on the device."""
+    from semigcn_amd import meshprep
+    m = synth.torus_mesh(1000, 1000, masks=False)
+    V, F = m.num_vertices, len(m.faces)
+    topo = meshprep.MeshTopology(m.faces, V, DEV)
+    E = topo.edges.shape[0]
+    assert V - E + F == 0 and topo.manifold                     # torus: Euler characteristic 0
+    lo, hi = topo.edges[:, 0], topo.edges[:, 1]
+    assert bool((lo < hi).all()) and torch.unique(lo * V + hi).numel() == E
+    assert torch.equal(topo.edge_index.cpu(), torch.from_numpy(m.edge_index))
+    f2f = topo.f2f
+    assert bool((f2f >= 0).all())
+    me = torch.arange(F, device=DEV).view(-1, 1, 1)
+    assert bool((f2f[f2f] == me).any(dim=2).all())               # f in f2f[g] for every g in f2f[f]
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    seeds = (torch.rand((V, 40), device=DEV, generator=gen) < 0.014)
+    got = meshprep.dilate(topo, seeds, 3)
+    ref = seeds.float()
+    src, dst = topo.edge_index[0], topo.edge_index[1]
+    for _ in range(3):
+        ref = ((ref + torch.zeros_like(ref).index_add_(0, dst, ref[src])) > 0).float()
+    assert torch.equal(got, ref > 0)
+    kept = ~got
+    fm = meshprep.vmask_to_fmask(topo, kept)
+    assert torch.equal(fm, kept[topo.faces].all(dim=1))

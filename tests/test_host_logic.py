@@ -294,3 +294,27 @@ def test_weight_grad_split_reduction_matches_plain_product():
         want = dout.double().t() @ T.double()
         assert rel(weight_grad(dout, T), want) < 1e-5
         assert rel(weight_grad(dout.bfloat16(), T.bfloat16()), dout.bfloat16().double().t() @ T.bfloat16().double()) < 2e-2
+
+
+# --------------------------------------------------------------------------------------
+# mesh preparation host logic (semigcn_amd/meshprep.py): bit packing runs anywhere, the kernels do not
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 40, 64, 65, 130])
+def test_mask_bit_packing_round_trip(n):
+    from semigcn_amd import meshprep
+    rs = np.random.RandomState(n)
+    m = torch.from_numpy((rs.random((37, n)) < 0.4).astype(np.float32))
+    bits = meshprep.pack_bits(m)
+    assert bits.dtype == torch.int64 and bits.shape == (37, (n + 63) // 64)
+    assert torch.equal(meshprep.unpack_bits(bits, n), m != 0)
+    if n >= 64:     # bit 63 lands on the sign bit, not in the next word
+        one = torch.zeros(1, n)
+        one[0, 63] = 1
+        assert meshprep.pack_bits(one)[0, 0].item() == -(1 << 63)
+
+
+def test_meshprep_has_no_cpu_path():
+    from semigcn_amd import capi, meshprep
+    faces = torch.tensor([[0, 1, 2], [0, 2, 3]])
+    with pytest.raises(capi.SemigcnLibraryError, match="HIP device only"):
+        meshprep.MeshTopology(faces, 4, device="cpu")
