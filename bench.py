@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--cpu-sample", default="250x200", help="torus for the CPU baseline sample")
     ap.add_argument("--no-launch-timer", action="store_true")
     ap.add_argument("--model", default="sgcn", choices=["sgcn", "mgcn"],
-                    help="mgcn: BASELINE config c3 (3 pool levels, synthetic hierarchy); not the headline metric")
+                    help="mgcn: BASELINE config c3 (3 pool levels, hierarchy from meshprep.DeviceMesh); not the headline metric")
     return ap.parse_args()
 
 
@@ -178,17 +178,11 @@ def build_trainer(args, dtype, device, world, rank, mesh):
     torch.manual_seed(314)                               # sgcn.py:19-25,76
     if args.model == "mgcn":
         from semigcn_amd.meshnet import MGCN
-        eis, phs, sms, Vl = [mesh.edge_index], [], [mesh.x_pos], mesh.num_vertices
-        for l in range(3):
-            ph, ei_c, Vc = synth.greedy_pool_hierarchy(eis[-1], Vl, seed=319 + l)
-            pos = np.zeros((Vc, 3), np.float32)
-            np.add.at(pos, ph[:, 1], sms[-1])
-            eis.append(ei_c), phs.append(ph), sms.append(pos / np.bincount(ph[:, 1], minlength=Vc)[:, None])
-            Vl = Vc
-        model = MGCN.from_hierarchy(device, [torch.from_numpy(e) for e in eis], phs,
-                                    [torch.from_numpy(np.asarray(x, np.float32)) for x in sms],
-                                    ini_pos=torch.from_numpy(mesh.vs.astype(np.float32)),
-                                    v_mask=torch.from_numpy(mesh.v_mask)).to(device)
+        from semigcn_amd import meshprep
+        smo = meshprep.DeviceMesh(mesh.x_pos, mesh.faces, device)       # hierarchy built on the device
+        ini = meshprep.DeviceMesh(mesh.vs.astype(np.float32), mesh.faces, device)
+        model = MGCN(device, smo, ini, torch.from_numpy(mesh.v_mask)).to(device)   # the reference's signature
+        eis = model.edge_inds
         trainer = train.MGCNTrainer(model, batch)
         agg_edges = 2 * sum(n * e.shape[1] for n, e in zip((6, 11, 11, 5), eis))
     else:

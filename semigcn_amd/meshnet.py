@@ -167,6 +167,11 @@ def _head(cin: int, K: int) -> Sequential:
     return Sequential("x, edge_index", _conv_bn_act(cin, 32, K) + [(_Fp32Linear(32, 3), "x -> x")])
 
 
+def _as_f32(a) -> torch.Tensor:
+    """Mesh attribute (numpy array in the reference's Mesh, device tensor in meshprep.DeviceMesh) -> float32 tensor."""
+    return a.float() if torch.is_tensor(a) else torch.from_numpy(np.asarray(a)).float()
+
+
 class MGCN(nn.Module):
     def __init__(self, device, smo_mesh, ini_mesh, v_mask, K=3, skip=False, save_pooled: bool = False,
                  reorder: bool = True):
@@ -183,9 +188,9 @@ class MGCN(nn.Module):
             meshes.append(s_mesh)
             pool_hashes.append(np.asarray(s_mesh.pool_hash, dtype=np.int64))
         edge_inds = [ini_mesh.edge_index] + [mm.edge_index for mm in meshes[1:]]
-        smposs = [torch.from_numpy(np.asarray(mm.vs)).float() for mm in meshes]
+        smposs = [_as_f32(mm.vs) for mm in meshes]
         faces = [getattr(ini_mesh, "faces", None)] + [getattr(mm, "faces", None) for mm in meshes[1:]]
-        self._build(device, edge_inds, pool_hashes, smposs, torch.from_numpy(np.asarray(ini_mesh.vs)).float(),
+        self._build(device, edge_inds, pool_hashes, smposs, _as_f32(ini_mesh.vs),
                     v_mask, faces, K, skip)
         self.meshes = meshes
         if save_pooled:
@@ -235,7 +240,7 @@ class MGCN(nn.Module):
             if f is None:
                 self.f_masks_list.append(None)
             else:
-                f = torch.as_tensor(np.asarray(f)).long()
+                f = (f if torch.is_tensor(f) else torch.as_tensor(np.asarray(f))).long().cpu()
                 self.f_masks_list.append((self.v_masks_list[l][:, 0][f] > 0).all(dim=1))
         self.f_masks = (torch.cat(self.f_masks_list, dim=0) if all(m is not None for m in self.f_masks_list) else None)
 

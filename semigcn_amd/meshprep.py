@@ -127,3 +127,83 @@ def make_dummy_mask(mesh: MeshTopology, dm_size: int = 40, kn: Sequence[int] = (
     kept = ~hole
     fmask = vmask_to_fmask(mesh, kept)
     return kept.float(), fmask.float()
+
+
+# --------------------------------------------------------------------------------------
+# Pooling hierarchy for MGCN at scale
+# --------------------------------------------------------------------------------------
+def contract_matching(edges: torch.Tensor, priority: torch.Tensor, num_vertices: int, target_v: int):
+    """Choose ``num_vertices - target_v`` vertex-disjoint edges, lowest ``priority`` first, by
+    rounds of locally-dominant matching (an edge is taken when it is the best remaining edge
+    at BOTH of its ends), and contract them.  Returns ``coarse_of`` int64 [V] (cluster id of
+    every vertex; ids ascend with the smallest member, as np.unique numbers them) and V_coarse.
+    Runs on the tensors' device; every round is a handful of scatter-min / gather passes."""
+    dev = edges.device
+    need = int(num_vertices) - int(target_v)
+    rank = torch.empty_like(priority, dtype=torch.int64)
+    rank[torch.argsort(priority, stable=True)] = torch.arange(priority.numel(), device=dev)
+    cand = torch.arange(edges.shape[0], device=dev)
+    used = torch.zeros(num_vertices, dtype=torch.bool, device=dev)
+    parent = torch.arange(num_vertices, device=dev)
+    big = torch.iinfo(torch.int64).max
+    while need > 0 and cand.numel():
+        a, b, r = edges[cand, 0], edges[cand, 1], rank[cand]
+        best = torch.full((num_vertices,), big, dtype=torch.int64, device=dev)
+        best.scatter_reduce_(0, a, r, "amin")
+        best.scatter_reduce_(0, b, r, "amin")
+        win = (best[a] == r) & (best[b] == r)
+        w = cand[win]
+        if w.numel() == 0:
+            break
+        if w.numel() > need:
+            w = w[torch.argsort(rank[w])[:need]]
+        lo, hi = edges[w, 0], edges[w, 1]
+        parent[hi] = lo
+        used[lo] = True
+        used[hi] = True
+        need -= int(w.numel())
+        cand = cand[~win]
+        cand = cand[~(used[edges[cand, 0]] | used[edges[cand, 1]])]
+    is_root = parent == torch.arange(num_vertices, device=dev)
+    root_id = torch.cumsum(is_root.to(torch.int64), 0) - 1
+    return root_id[parent], int(is_root.sum())
+
+
+class DeviceMesh:
+    """What ``MGCN(device, smo_mesh, ini_mesh, v_mask)`` reads from the reference's ``Mesh``
+    (util/meshnet.py:170-199: ``.vs .faces .edge_index .path .simplification(target_v)`` and, on
+    the result, ``.pool_hash``), held on the device so that a 1 M-vertex hierarchy is built in
+    milliseconds.  ``simplification`` is NOT the reference's QEM edge collapse
+    (util/mesh.py:394-482: Python heap loop, minutes at 50 K vertices): it contracts a
+    shortest-edge-first matching, which yields the same artefacts -- ``pool_hash`` rows
+    (fine_i, coarse_i) covering every fine vertex with clusters of one or two, positions at the
+    cluster mean, the surviving triangles, and the quotient graph as ``edge_index``."""
+
+    def __init__(self, vs, faces, device="cuda", path: str = "./mesh.obj", pool_hash=None, edge_index=None):
+        device = torch.device(device)
+        self.vs = torch.as_tensor(vs).to(device=device, dtype=torch.float32)
+        self.topology = MeshTopology(faces, self.vs.shape[0], device, with_f2f=False)
+        self.faces = self.topology.faces
+        self.edge_index = self.topology.edge_index if edge_index is None else edge_index
+        self.pool_hash = pool_hash
+        self.path = path
+
+    def simplification(self, target_v: int) -> "DeviceMesh":
+        V = self.vs.shape[0]
+        half = self.edge_index.shape[1] // 2
+        und = self.edge_index[:, :half].t().contiguous()
+        d = self.vs[und[:, 0]] - self.vs[und[:, 1]]
+        coarse_of, Vc = contract_matching(und, (d * d).sum(1), V, target_v)
+        fine = torch.arange(V, device=self.vs.device)
+        pool = capi.PoolHandle(fine, coarse_of, V, Vc)
+        cvs = pool.pool_mean(self.vs.contiguous())
+        cf = coarse_of[self.faces]
+        alive = (cf[:, 0] != cf[:, 1]) & (cf[:, 1] != cf[:, 2]) & (cf[:, 2] != cf[:, 0])
+        ce = coarse_of[und]
+        ce = ce[ce[:, 0] != ce[:, 1]]
+        key = torch.unique(torch.minimum(ce[:, 0], ce[:, 1]) * Vc + torch.maximum(ce[:, 0], ce[:, 1]))
+        e = torch.stack([key // Vc, key % Vc])
+        out = DeviceMesh(cvs, cf[alive], self.vs.device, self.path,
+                         pool_hash=torch.stack([fine, coarse_of], 1).cpu().numpy(),
+                         edge_index=torch.cat([e, e.flip(0)], dim=1).contiguous())
+        return out

@@ -817,3 +817,92 @@ def test_meshprep_full_size_properties():
     kept = ~got
     fm = meshprep.vmask_to_fmask(topo, kept)
     assert torch.equal(fm, kept[topo.faces].all(dim=1))
+
+
+# --------------------------------------------------------------------------------------
+# pooling hierarchy built on the device and MGCN through the reference's constructor
+# --------------------------------------------------------------------------------------
+def test_device_hierarchy_artefacts():
+    """One contraction level: pool_hash covers every fine vertex, clusters are single vertices or
+    matched EDGES, the level has exactly target_v vertices, positions are cluster means, the coarse
+    graph is the quotient graph, surviving triangles have three distinct corners."""
+    from semigcn_amd import meshprep
+    m = synth.torus_mesh(200, 150, masks=False)
+    V = m.num_vertices
+    fine = meshprep.DeviceMesh(m.x_pos, m.faces, DEV)
+    assert torch.equal(fine.edge_index.cpu(), torch.from_numpy(m.edge_index))
+    target = int(V * 0.6)
+    coarse = fine.simplification(target_v=target)
+    ph = coarse.pool_hash
+    Vc = coarse.vs.shape[0]
+    assert Vc == target and ph.shape == (V, 2) and np.array_equal(ph[:, 0], np.arange(V))
+    sizes = np.bincount(ph[:, 1], minlength=Vc)
+    assert sizes.min() == 1 and sizes.max() == 2
+    order = np.argsort(ph[:, 1], kind="stable")
+    first = np.searchsorted(ph[order, 1], np.arange(Vc))
+    assert (np.diff(order[first]) > 0).all()            # cluster ids ascend with the smallest member
+    und = set(map(tuple, m.edges.tolist()))
+    pairs = order[np.concatenate([first[sizes == 2], first[sizes == 2] + 1])].reshape(2, -1).T
+    assert all((min(a, b), max(a, b)) in und for a, b in pairs.tolist())
+    pos = np.zeros((Vc, 3), np.float64)
+    np.add.at(pos, ph[:, 1], m.x_pos.astype(np.float64))
+    assert np.abs(coarse.vs.cpu().numpy() - pos / sizes[:, None]).max() < 1e-5
+    ce = ph[:, 1][m.edge_index]
+    ce = ce[:, ce[0] != ce[1]]
+    want = np.unique(np.minimum(ce[0], ce[1]) * Vc + np.maximum(ce[0], ce[1]))
+    got = coarse.edge_index.cpu().numpy()
+    half = got.shape[1] // 2
+    assert np.array_equal(got[0, :half] * Vc + got[1, :half], want) and np.array_equal(got[:, half:], got[::-1, :half])
+    cf = coarse.faces.cpu().numpy()
+    assert ((cf[:, 0] != cf[:, 1]) & (cf[:, 1] != cf[:, 2]) & (cf[:, 2] != cf[:, 0])).all() and cf.max() < Vc
+    # shortest edges are preferred: the contracted edges are shorter on average than the rest
+    length = np.linalg.norm(m.x_pos[m.edges[:, 0]] - m.x_pos[m.edges[:, 1]], axis=1)
+    taken = np.linalg.norm(m.x_pos[pairs[:, 0]] - m.x_pos[pairs[:, 1]], axis=1)
+    assert taken.mean() < length.mean()
+
+
+def test_mgcn_reference_constructor_with_device_meshes_vs_oracle():
+    """``MGCN(device, smo_mesh, ini_mesh, v_mask)`` -- the reference's constructor signature -- fed
+    with meshprep.DeviceMesh objects; the forward equals the oracle's MGCN on the same hierarchy."""
+    from semigcn_amd import meshprep
+    from semigcn_amd.meshnet import MGCN
+    m = synth.torus_mesh(40, 30)
+    smo = meshprep.DeviceMesh(m.x_pos, m.faces, DEV)
+    ini = meshprep.DeviceMesh(m.vs.astype(np.float32), m.faces, DEV)
+    net = MGCN(DEV, smo, ini, torch.from_numpy(m.v_mask))
+    sizes = [p.shape[0] for p in net.smposs_list]
+    assert sizes == [1200, 720, 432, 259] and sizes[1:] == net.nvs
+    GU.fill_state(net, seed=77)
+    net.to(DEV).eval()
+    ora = OM.MGCNOracle([e.cpu() for e in net.edge_inds], [np.asarray(mm.pool_hash) for mm in net.meshes[1:]],
+                        [s.cpu() for s in net.smposs_list])
+    ora.load_state_dict({k: v.cpu() for k, v in net.state_dict().items() if not k.endswith("pool_hash")})
+    ora.eval()
+
+    class D:
+        z1 = torch.from_numpy(m.z1).to(DEV)
+        x_pos = None
+    with torch.no_grad():
+        for a, b in zip(net(D, None), ora(torch.from_numpy(m.z1), None)):
+            assert GU.rel_l2(a.cpu(), b) < 5e-5
+    assert len(net.f_masks_list) == 4 and all(fm is not None for fm in net.f_masks_list)
+
+
+def test_mgcn_one_million_vertices_end_to_end_from_faces():
+    """Faces -> hierarchy -> MGCN training iteration at V = 1 M without any host-side mesh code."""
+    from semigcn_amd import meshprep
+    from semigcn_amd.meshnet import MGCN
+    m = synth.torus_mesh(1000, 1000, masks=False)
+    smo = meshprep.DeviceMesh(m.x_pos, m.faces, DEV)
+    net = MGCN(DEV, smo, smo, torch.ones(m.num_vertices, dtype=torch.bool))
+    assert [p.shape[0] for p in net.smposs_list] == [1000000] + net.nvs     # int(V * 0.6**i), util/meshnet.py:172
+    assert net.nvs[:2] == [600000, 360000]
+    net.to(DEV).train()
+
+    class D:
+        z1 = torch.from_numpy(m.z1).to(DEV)
+        x_pos = None
+    outs = net(D, None)
+    sum(w * ((o - t) ** 2).mean() for w, o, t in zip((0.35, 0.3, 0.2, 0.15), outs, net.poss_list)).backward()
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
