@@ -234,6 +234,28 @@ def g4_meshprep(ref, meshes, tmp):
     np.savez_compressed(os.path.join(OUT, "g4_meshprep.npz"), **out)
 
 
+def g5_refine(ref, meshes, ref_meshes):
+    """G5: the reference's own ``Mesh.mesh_merge`` (util/mesh.py:678-698, dense float32 solve) as
+    sgcn.py:189 calls it: Lap and AdjI from the reference Mesh, a perturbed position field as the
+    network output, the fixture's v_mask as ``preserve``, w = mu in {1.0, 0.3}, and one case with a
+    boundary weight."""
+    out = {}
+    for name, m in meshes.items():
+        rm = ref_meshes[name]
+        rs = np.random.RandomState(41)
+        new_pos = torch.from_numpy((m.x_pos + 0.02 * rs.standard_normal(m.x_pos.shape)).astype(np.float32))
+        keep = torch.from_numpy(m.v_mask)
+        out[f"{name}/edge_index"] = rm.edge_index.numpy()
+        out[f"{name}/org_pos"] = rm.vs.astype(np.float32)
+        out[f"{name}/new_pos"] = new_pos.numpy()
+        out[f"{name}/preserve"] = m.v_mask
+        for tag, (w, wb) in {"w1": (1.0, 0.0), "w03": (0.3, 0.0), "wb": (1.0, 0.5)}.items():
+            ref_pos = ref.mesh.Mesh.mesh_merge(rm.Lap, rm, new_pos, keep, w=w, w_b=wb)
+            out[f"{name}/{tag}/ref_pos"] = ref_pos.numpy()
+            out[f"{name}/{tag}/w"] = np.array([w, wb])
+    np.savez_compressed(os.path.join(OUT, "g5_refine.npz"), **out)
+
+
 def main():
     only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
     warnings.simplefilter("ignore")
@@ -254,6 +276,8 @@ def main():
             g3_mgcn(ref, meshes["sphere"], ref_meshes["sphere"], tmp)
         if only is None or "g4" in only:
             g4_meshprep(ref, meshes, tmp)
+        if only is None or "g5" in only:
+            g5_refine(ref, meshes, ref_meshes)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

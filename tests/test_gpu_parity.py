@@ -906,3 +906,77 @@ def test_mgcn_one_million_vertices_end_to_end_from_faces():
     sum(w * ((o - t) ** 2).mean() for w, o, t in zip((0.35, 0.3, 0.2, 0.15), outs, net.poss_list)).backward()
     assert all(bool(torch.isfinite(o).all()) for o in outs)
     assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+
+
+# --------------------------------------------------------------------------------------
+# refinement solve (Mesh.mesh_merge, util/mesh.py:678-698) by CG on the aggregation kernel
+# --------------------------------------------------------------------------------------
+REFINE_TOL = 2e-5     # max|x - ref| / max|ref|: the reference solves densely in fp32 (own error ~4e-6 vs fp64)
+
+
+class _OrgMesh:
+    def __init__(self, vs, edge_index=None):
+        self.vs = vs
+        if edge_index is not None:
+            self.edge_index = edge_index
+
+
+@pytest.mark.parametrize("name", ["sphere", "torus"])
+def test_mesh_merge_vs_reference_golden(name):
+    from semigcn_amd import refine
+    g = GU.load("g5_refine.npz")
+    ei = torch.from_numpy(g[f"{name}/edge_index"])
+    V = g[f"{name}/org_pos"].shape[0]
+    # the reference hands over its sparse Lap = I - D^-1 A (util/mesh.py:262-274); only the pattern is read
+    deg = torch.bincount(ei[0], minlength=V).float()
+    lap = torch.sparse_coo_tensor(torch.cat([ei, torch.arange(V).repeat(2, 1)], 1),
+                                  torch.cat([-1.0 / deg[ei[0]], torch.ones(V)]), (V, V))
+    for tag in ("w1", "w03", "wb"):
+        w, wb = g[f"{name}/{tag}/w"]
+        ref = g[f"{name}/{tag}/ref_pos"]
+        for lap_arg, mesh in ((lap, _OrgMesh(g[f"{name}/org_pos"])), (None, _OrgMesh(g[f"{name}/org_pos"], ei))):
+            x, info = refine.mesh_merge(lap_arg, mesh, torch.from_numpy(g[f"{name}/new_pos"]),
+                                        torch.from_numpy(g[f"{name}/preserve"]), w=w, w_b=wb, device=DEV,
+                                        return_info=True)
+            assert x.dtype == torch.float32 and x.shape == (V, 3) and info["relative_residual"] < 1e-6
+            assert rel(x, ref) < REFINE_TOL, (tag, rel(x, ref), info)
+
+
+def test_mesh_merge_vs_oracle_medium_and_full_size_optimality():
+    from oracle import refine as R
+    from semigcn_amd import refine, meshprep
+    m = synth.torus_mesh(100, 50, permute=True)
+    rs = np.random.RandomState(2)
+    new = (m.x_pos + 0.05 * rs.standard_normal(m.x_pos.shape)).astype(np.float32)
+    want = R.mesh_merge(m.edge_index, m.vs.astype(np.float32), new, m.v_mask, 1.0, 0.0)
+    got = refine.mesh_merge(None, _OrgMesh(m.vs.astype(np.float32), torch.from_numpy(m.edge_index)), new, m.v_mask,
+                            device=DEV)
+    assert rel(got, want) < REFINE_TOL
+    # V = 1 M: the normal equations hold, evaluated with an independent index_add Laplacian in float64
+    m = synth.torus_mesh(1000, 1000)
+    V = m.num_vertices
+    topo = meshprep.MeshTopology(m.faces, V, DEV)
+    org = torch.from_numpy(m.vs.astype(np.float32)).to(DEV)
+    new = torch.from_numpy(m.x_pos).to(DEV) + 0.05 * torch.randn(V, 3, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    keep = torch.from_numpy(m.v_mask).to(DEV)
+
+    class M:
+        vs, topology = org, topo
+    x, info = refine.mesh_merge(None, M, new, keep, w=1.0, return_info=True)
+    assert info["relative_residual"] < 1e-6 and info["iterations"] < 2000
+    src, dst = topo.edge_index[0], topo.edge_index[1]
+    deg = torch.bincount(dst, minlength=V).double().view(-1, 1)
+
+    def L(v):
+        return v - torch.zeros_like(v).index_add_(0, dst, v[src]) / deg
+
+    def Lt(v):
+        return v - torch.zeros_like(v).index_add_(0, dst, (v / deg)[src])
+    holes = (~keep).double().view(-1, 1)
+    inner = (holes + torch.zeros_like(holes).index_add_(0, dst, holes[src])) == 0
+    xd, od, nd = x.double(), org.double(), new.double()
+    b_mix = torch.where(inner, L(od), L(nd))
+    grad = Lt(L(xd) - b_mix) + inner.double() * (xd - od)
+    rhs = Lt(b_mix) + inner.double() * od
+    assert float(grad.norm() / rhs.norm()) < 1e-5
+    assert float((xd - od)[inner.view(-1)].abs().max()) < 0.2 and float((xd - nd).abs().max()) > 1e-3

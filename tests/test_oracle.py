@@ -196,3 +196,16 @@ def test_meshprep_oracle_vs_reference_golden(name):
     # the vectorised builder the synthetic meshes use agrees with the literal scan
     from semigcn_amd import synth
     assert np.array_equal(synth.edges_from_faces(faces, V), edges)
+
+
+@pytest.mark.parametrize("name", ["sphere", "torus"])
+def test_refine_oracle_vs_reference_golden(name):
+    """oracle/refine.py (sparse float64) against the reference's own dense float32 Mesh.mesh_merge."""
+    from oracle import refine as R
+    g = GU.load("g5_refine.npz")
+    for tag in ("w1", "w03", "wb"):
+        w, wb = g[f"{name}/{tag}/w"]
+        x = R.mesh_merge(g[f"{name}/edge_index"], g[f"{name}/org_pos"], g[f"{name}/new_pos"], g[f"{name}/preserve"], w, wb)
+        ref = g[f"{name}/{tag}/ref_pos"]
+        assert np.abs(x - ref).max() / np.abs(ref).max() < 1e-5      # the reference's fp32 dense solve: ~1e-6..4e-6
+        assert np.abs(ref - g[f"{name}/new_pos"]).max() > 1e-2      # the solve moves vertices (not a trivial fixture)

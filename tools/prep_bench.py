@@ -52,6 +52,20 @@ def main():
     meshprep.make_dummy_mask(topo, 40, (3, 4, 5), rng=np.random.RandomState(0))
     torch.cuda.synchronize()
     res["dummy_mask_120_numpy_rng_ms"] = (time.perf_counter() - t) * 1e3
+    # refinement solve (Mesh.mesh_merge) by CG on the aggregation kernel
+    from semigcn_amd import refine
+    mm = synth.torus_mesh(nu, nv)
+    org = torch.from_numpy(mm.vs.astype(np.float32)).cuda()
+    new = torch.from_numpy(mm.x_pos).cuda() + 0.05 * torch.randn(V, 3, device="cuda")
+
+    class M:
+        vs, topology = org, topo
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    _, info = refine.mesh_merge(None, M, new, torch.from_numpy(mm.v_mask).cuda(), return_info=True)
+    torch.cuda.synchronize()
+    res["mesh_merge_ms"] = (time.perf_counter() - t) * 1e3
+    res["mesh_merge_cg_iterations"] = info["iterations"]
     if not a.no_cpu:
         from oracle import meshprep as MP   # checker used as the CPU comparison, as in bench.py's cpu_baseline
         t = time.perf_counter()
