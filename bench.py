@@ -170,7 +170,7 @@ def build_trainer(args, dtype, device, world, rank, mesh):
     from semigcn_amd import synth, train
     from semigcn_amd.networks import SingleScaleGCN
     nu, nv = map(int, args.mesh.split("x"))
-    if world > 1:
+    if world > 1 and args.model == "sgcn":
         from semigcn_amd import dist as sgdist
         job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh)
         return job.trainer, job.workload, AGG_PER_ITER * mesh.num_edges
@@ -183,7 +183,11 @@ def build_trainer(args, dtype, device, world, rank, mesh):
         ini = meshprep.DeviceMesh(mesh.vs.astype(np.float32), mesh.faces, device)
         model = MGCN(device, smo, ini, torch.from_numpy(mesh.v_mask)).to(device)   # the reference's signature
         eis = model.edge_inds
-        trainer = train.MGCNTrainer(model, batch)
+        if world > 1:                                    # every level cut into `world` blocks (dist.partition_mgcn)
+            from semigcn_amd import dist as sgdist
+            trainer = sgdist.DistMGCNTrainer(model, sgdist.partition_mgcn(model, rank, world), batch)
+        else:
+            trainer = train.MGCNTrainer(model, batch)
         agg_edges = 2 * sum(n * e.shape[1] for n, e in zip((6, 11, 11, 5), eis))
     else:
         model = SingleScaleGCN(device).to(device)
@@ -194,7 +198,8 @@ def build_trainer(args, dtype, device, world, rank, mesh):
     workload = (f"{args.model.upper()} train iteration ({13 if args.model == 'sgcn' else 33} ChebConv K=3 + BN + LeakyReLU, "
                 f"fwd+loss+bwd, Adam every 5th) on a closed torus mesh {nu}x{nv}: V={mesh.num_vertices} "
                 f"E={mesh.num_edges} directed, {'random' if args.permute else 'grid'} vertex order, "
-                f"{'fp32' if dtype == torch.float32 else 'bf16'} features")
+                f"{'fp32' if dtype == torch.float32 else 'bf16'} features"
+                + (f", every level vertex-partitioned into {world} blocks" if world > 1 else ""))
     return trainer, workload, agg_edges
 
 

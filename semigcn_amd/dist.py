@@ -85,7 +85,70 @@ def block_bounds(num_vertices: int, world: int) -> List[int]:
     return b
 
 
-class DistMeshGraph:
+class _RowExchange:
+    """Exchange of rows of a block-partitioned [V, C] tensor along a fixed plan.  Needs: ``world, group,
+    n_own, n_halo, n_send, send_rows`` (int32 local row ids, grouped by destination rank, ascending),
+    ``send_splits, recv_splits`` (rows per peer)."""
+
+    def _a2a(self, recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits):
+        if self.world == 1:
+            return
+        _all_to_all_rows(recv, send, recv_splits, send_splits, self.group)
+
+    def exchange(self, blk_ext: torch.Tensor) -> None:
+        """Fill rows [n_own:] of ``blk_ext`` ([n_ext, C], unit column stride, any row stride) with
+        the owners' copies of those rows; rows [:n_own] must be final."""
+        if self.world == 1:
+            return                     # (with world > 1 every rank takes part, even with an empty halo: it is a collective)
+        own = blk_ext[:self.n_own]
+        send = capi.gather_rows(self.send_rows, own)
+        recv = torch.empty((self.n_halo, blk_ext.shape[1]), dtype=blk_ext.dtype, device=blk_ext.device)
+        self._a2a(recv, send, self.recv_splits, self.send_splits)
+        blk_ext[self.n_own:].copy_(recv)
+
+    def exchange_reverse_add(self, grad_halo: torch.Tensor, grad_own: torch.Tensor) -> None:
+        """Adjoint of ``exchange``: halo-row gradients travel back to their owners and are added."""
+        if self.world == 1:
+            return
+        recv = torch.empty((self.n_send, grad_halo.shape[1]), dtype=grad_halo.dtype, device=grad_halo.device)
+        self._a2a(recv, grad_halo.contiguous(), self.send_splits, self.recv_splits)
+        grad_own.index_add_(0, self.send_rows.long(), recv)
+
+
+class HaloPlan(_RowExchange):
+    """Generic plan: "rank ``consumer[i]`` needs global row ``rows[i]``" for a tensor cut into the
+    contiguous blocks ``bounds``.  Every rank builds it from the same global lists, so what to send
+    is known without a handshake.  Pairs whose consumer owns the row are ignored."""
+
+    def __init__(self, consumer: torch.Tensor, rows: torch.Tensor, bounds: Sequence[int], rank: int, world: int,
+                 group=None):
+        dev = rows.device
+        self.group, self.rank, self.world = group, rank, world
+        b = torch.tensor(list(bounds), device=dev, dtype=torch.long)
+        n_rows = int(bounds[-1])
+        self.start, self.end = int(bounds[rank]), int(bounds[rank + 1])
+        self.n_own = self.end - self.start
+        owner = torch.bucketize(rows, b[1:], right=True)
+        remote = owner != consumer
+        pair = torch.unique(consumer[remote] * n_rows + rows[remote])          # sorted by (consumer, row)
+        cons, row = pair // n_rows, pair % n_rows
+        mine = cons == rank
+        self.halo_ids = row[mine]                                              # ascending = grouped by owner
+        self.n_halo = int(self.halo_ids.numel())
+        self.n_ext = self.n_own + self.n_halo
+        self.recv_splits = torch.bincount(torch.bucketize(self.halo_ids, b[1:], right=True), minlength=world).tolist()
+        out = (row >= self.start) & (row < self.end)
+        self.send_splits = torch.bincount(cons[out], minlength=world).tolist()
+        self.send_rows = (row[out] - self.start).to(torch.int32)
+        self.n_send = int(self.send_rows.numel())
+
+    def extended_index(self, rows: torch.Tensor) -> torch.Tensor:
+        """Position of global ``rows`` (owned or in the halo) inside this rank's ``[owned | halo]`` buffer."""
+        own = (rows >= self.start) & (rows < self.end)
+        return torch.where(own, rows - self.start, self.n_own + torch.searchsorted(self.halo_ids, rows))
+
+
+class DistMeshGraph(_RowExchange):
     """One rank's share of the scaled Laplacian plus its halo-exchange plan."""
     sg_partitioned = True
 
@@ -145,37 +208,13 @@ class DistMeshGraph:
     def aggregate(self, X_ext: torch.Tensor, Y_own: torch.Tensor, **kw):
         return self.handle.spmm(X_ext, Y_own, **kw)
 
-    # halo exchange --------------------------------------------------------------------
-    def _a2a(self, recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits):
-        if self.world == 1:
-            return
-        _all_to_all_rows(recv, send, recv_splits, send_splits, self.group)
-
-    def exchange(self, blk_ext: torch.Tensor) -> None:
-        """Fill rows [n_own:] of ``blk_ext`` ([n_ext, C], unit column stride, any row stride) with
-        the neighbours' copies of those vertices; rows [:n_own] must be final."""
-        if self.world == 1:
-            return                     # (with world > 1 every rank takes part, even with an empty halo: it is a collective)
-        own = blk_ext[:self.n_own]
-        send = capi.gather_rows(self.send_rows, own)
-        recv = torch.empty((self.n_halo, blk_ext.shape[1]), dtype=blk_ext.dtype, device=blk_ext.device)
-        self._a2a(recv, send, self.recv_splits, self.send_splits)
-        blk_ext[self.n_own:].copy_(recv)
-
-    def exchange_reverse_add(self, grad_halo: torch.Tensor, grad_own: torch.Tensor) -> None:
-        """Adjoint of ``exchange``: halo-row gradients travel back to their owners and are added."""
-        if self.world == 1:
-            return
-        recv = torch.empty((self.n_send, grad_halo.shape[1]), dtype=grad_halo.dtype, device=grad_halo.device)
-        self._a2a(recv, grad_halo.contiguous(), self.send_splits, self.recv_splits)
-        grad_own.index_add_(0, self.send_rows.long(), recv)
 
 
 class _HaloExtend(torch.autograd.Function):
     """x_own [n,C] -> [x_own ; halo rows] [n_ext, C], differentiable."""
 
     @staticmethod
-    def forward(ctx, g: DistMeshGraph, x: torch.Tensor):
+    def forward(ctx, g: _RowExchange, x: torch.Tensor):
         ext = torch.empty((g.n_ext, x.shape[1]), dtype=x.dtype, device=x.device)
         ext[:g.n_own].copy_(x)
         g.exchange(ext)
@@ -190,7 +229,7 @@ class _HaloExtend(torch.autograd.Function):
         return None, grad_own
 
 
-def halo_extend(g: DistMeshGraph, x: torch.Tensor) -> torch.Tensor:
+def halo_extend(g: _RowExchange, x: torch.Tensor) -> torch.Tensor:
     return _HaloExtend.apply(g, x)
 
 
@@ -547,3 +586,178 @@ def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permu
                 f"{world} blocks (<= {int(halo)} halo rows per rank), "
                 f"halo exchange + mesh-wide BatchNorm + gradient all-reduce over RCCL")
     return _Job(trainer, mesh.num_vertices, mesh.num_edges, workload)
+
+
+# --------------------------------------------------------------------------------------
+# MGCN on a partition (SURVEY.md section 8(e) "MGCN", 8(f)-4): every level is cut into blocks;
+# pool / unpool read the few members / parents that live on another rank through a row exchange
+# --------------------------------------------------------------------------------------
+class DistPool:
+    """MeshPool / MeshUnpool between two partitioned levels.  ``fine``/``coarse``: the pool_hash pairs
+    in PROCESSING numbering (global).  Owner computes: the owner of a coarse vertex averages its
+    members, fetching those owned elsewhere (``fine_plan``); the owner of a fine vertex copies its
+    parent, fetching it when it lives elsewhere (``coarse_plan``).  Backward passes are the autograd
+    transposes: local segment kernels + the reverse row exchange."""
+
+    def __init__(self, fine: torch.Tensor, coarse: torch.Tensor, bounds_f: Sequence[int], bounds_c: Sequence[int],
+                 rank: int, world: int, group=None):
+        dev = fine.device
+        bf = torch.tensor(list(bounds_f), device=dev, dtype=torch.long)
+        bc = torch.tensor(list(bounds_c), device=dev, dtype=torch.long)
+        owner_f = torch.bucketize(fine, bf[1:], right=True)
+        owner_c = torch.bucketize(coarse, bc[1:], right=True)
+        self.fine_plan = HaloPlan(owner_c, fine, bounds_f, rank, world, group)      # coarse owners need fine rows
+        self.coarse_plan = HaloPlan(owner_f, coarse, bounds_c, rank, world, group)  # fine owners need coarse rows
+        mine_c = owner_c == rank
+        self.pool_handle = capi.PoolHandle(self.fine_plan.extended_index(fine[mine_c]),
+                                           coarse[mine_c] - int(bounds_c[rank]),
+                                           self.fine_plan.n_ext, self.coarse_plan.n_own)
+        mine_f = owner_f == rank
+        self.unpool_handle = capi.PoolHandle(fine[mine_f] - int(bounds_f[rank]),
+                                             self.coarse_plan.extended_index(coarse[mine_f]),
+                                             self.fine_plan.n_own, self.coarse_plan.n_ext)
+
+    def pool(self, x_own_fine: torch.Tensor) -> torch.Tensor:
+        from .functional import mesh_pool
+        return mesh_pool(self.pool_handle, halo_extend(self.fine_plan, x_own_fine))
+
+    def unpool(self, x_own_coarse: torch.Tensor) -> torch.Tensor:
+        from .functional import mesh_unpool
+        return mesh_unpool(self.unpool_handle, halo_extend(self.coarse_plan, x_own_coarse))
+
+
+@dataclass
+class MGCNPartition:
+    """This rank's share of an MGCN hierarchy.  ``own_ids[l]``: caller-numbering ids of the level-l
+    vertices this rank owns, in processing order (what ``MGCN.forward`` returns rows for)."""
+    graphs: List[DistMeshGraph]
+    pools: List[DistPool]
+    bounds: List[List[int]]
+    own_ids: List[torch.Tensor]
+    rank_of: List[torch.Tensor]        # per level: processing position of every caller-numbered vertex
+    smposs_own: List[torch.Tensor]
+    rank: int
+    world: int
+    group: object = None
+
+
+def partition_mgcn(model: nn.Module, rank: int, world: int, group=None) -> MGCNPartition:
+    """Switch ``model`` (semigcn_amd.meshnet.MGCN, already on its device) to run on rank ``rank``'s share
+    of every level, in place.  Level 0 is cut into balanced blocks along the Morton curve of its smooth
+    positions; a coarse vertex goes to the owner of its first member (in processing order) and the
+    coarse level is numbered by that member, so blocks stay contiguous and local at every level.
+    Parameters stay replicated; BatchNorm statistics become mesh-wide."""
+    dev = model.smposs_list[0].device
+    n_levels = len(model.smposs_list)
+    order, rank_of = _reorder.morton_order(model.smposs_list[0])
+    orders, ranks = [order], [rank_of]
+    bounds = [block_bounds(model.smposs_list[0].shape[0], world)]
+    pairs = []
+    for l in range(n_levels - 1):
+        ph = torch.as_tensor(np.asarray(model._pool_pairs[l]), dtype=torch.long, device=dev)
+        fine_new = ranks[l][ph[:, 0]]
+        n_c = model.smposs_list[l + 1].shape[0]
+        first = torch.full((n_c,), int(bounds[l][-1]), dtype=torch.long, device=dev)
+        first.scatter_reduce_(0, ph[:, 1], fine_new, "amin")
+        if bool((first == bounds[l][-1]).any()):
+            raise ValueError(f"level {l + 1} has a vertex without members in pool_hash")
+        order_c = torch.argsort(first, stable=True)
+        rank_c = torch.empty_like(order_c)
+        rank_c[order_c] = torch.arange(n_c, device=dev)
+        b = torch.searchsorted(first[order_c], torch.tensor(bounds[l], device=dev, dtype=torch.long)).tolist()
+        b[0], b[-1] = 0, n_c
+        orders.append(order_c), ranks.append(rank_c), bounds.append(b)
+        pairs.append((fine_new, rank_c[ph[:, 1]]))
+    graphs = [DistMeshGraph(_reorder.permute_edge_index(model.edge_inds[l].to(dev), ranks[l]),
+                            model.smposs_list[l].shape[0], rank, world, group, bounds=bounds[l])
+              for l in range(n_levels)]
+    pools = [DistPool(f, c, bounds[l], bounds[l + 1], rank, world, group) for l, (f, c) in enumerate(pairs)]
+    own_ids = [orders[l][bounds[l][rank]:bounds[l][rank + 1]] for l in range(n_levels)]
+    part = MGCNPartition(graphs, pools, bounds, own_ids, ranks,
+                         [model.smposs_list[l].index_select(0, own_ids[l]) for l in range(n_levels)], rank, world, group)
+    for stage, (lf, lc) in ((model.encoder1, (0, 1)), (model.encoder2, (1, 2)), (model.encoder3, (2, 3))):
+        stage._graphs = (graphs[lf], graphs[lc])
+        stage.model1.module_4._dist = pools[lf]
+    for stage, (lc, lf) in ((model.decoder3, (3, 2)), (model.decoder2, (2, 1)), (model.decoder1[0], (1, 0))):
+        stage._graphs = (graphs[lc], graphs[lf])
+        stage.model1.module_1._dist = pools[lf]
+    model._orders = None
+    model._part = part
+    convert_batchnorm(model, group)
+    return part
+
+
+def gather_level(x_own: torch.Tensor, part: MGCNPartition, level: int) -> torch.Tensor:
+    """All ranks' rows of one level, back in the caller's numbering (inference / tests)."""
+    b = part.bounds[level]
+    n_max = max(b[r + 1] - b[r] for r in range(part.world))
+    pad = x_own.new_zeros((n_max, x_own.shape[1]))
+    pad[:x_own.shape[0]] = x_own.detach()
+    ids = torch.full((n_max,), -1, dtype=torch.long, device=x_own.device)
+    ids[:x_own.shape[0]] = part.own_ids[level]
+    if part.world == 1:
+        allx, alli = pad, ids
+    else:
+        allx = pad.new_empty((part.world * n_max, x_own.shape[1]))
+        alli = ids.new_empty((part.world * n_max,))
+        _all_gather_rows(allx, pad, part.group)
+        _all_gather_rows(alli.view(-1, 1), ids.view(-1, 1), part.group)
+    keep = alli >= 0
+    out = x_own.new_empty((b[-1], x_own.shape[1]))
+    out[alli[keep]] = allx[keep]
+    return out
+
+
+class DistMGCNTrainer:
+    """MGCNTrainer (semigcn_amd.train, the loop of mgcn.py:121-160) on a vertex partition: the masked
+    sums of every level are all-reduced; the normal term reads halo positions of the finest level."""
+
+    def __init__(self, model: nn.Module, part: MGCNPartition, batch, lr: float = 0.01, k1: float = 4.0,
+                 accumulate: int = 5, weights=(0.35, 0.3, 0.2, 0.15)):
+        self.model, self.part, self.batch, self.k1, self.accumulate, self.weights = model, part, batch, k1, accumulate, weights
+        self.group = part.group
+        dev = batch.target_pos.device
+        self.params = [p for p in model.parameters()]
+        self.opt = torch.optim.Adam(self.params, lr=lr)
+        self.iteration = 0
+        self.loss_sum = torch.zeros((), device=dev)
+        self.targets = [t.index_select(0, ids) for t, ids in zip(model.poss_list, part.own_ids)]
+        keeps = [m.to(dev) for m in model.v_masks_list]
+        self.counts = [float(k.sum()) for k in keeps]
+        self.keeps = [k.index_select(0, ids) for k, ids in zip(keeps, part.own_ids)]
+        # faces of the finest level whose first corner this rank owns, corners as [owned | halo] positions
+        g0 = part.graphs[0]
+        faces = part.rank_of[0][batch.faces]
+        mine = (faces[:, 0] >= g0.start) & (faces[:, 0] < g0.end)
+        fo = faces[mine]
+        in_own = (fo >= g0.start) & (fo < g0.end)
+        self.faces_ext = torch.where(in_own, fo - g0.start, g0.n_own + torch.searchsorted(g0.halo_ids, fo))
+        self.target_fn = batch.target_fn[mine]
+        self.f_keep = batch.f_keep[mine]
+        self.n_f_keep = float(batch.f_keep.sum())
+        self.opt.zero_grad(set_to_none=True)
+
+    def loss(self, poss) -> torch.Tensor:
+        from . import train
+        total = 0.0
+        for w, p, t, keep, n in zip(self.weights, poss, self.targets, self.keeps, self.counts):
+            d = (t - p) * keep
+            total = total + w * torch.sqrt(all_reduce_sum((d * d).sum(), self.group) / n + 1.0e-6)
+        fn = train.face_normals(halo_extend(self.part.graphs[0], poss[0]), self.faces_ext)
+        ln = all_reduce_sum(((fn - self.target_fn).abs() * self.f_keep).sum(), self.group) / self.n_f_keep
+        return total + self.k1 * ln
+
+    def iteration_step(self, mask_index: Optional[int] = None) -> torch.Tensor:
+        b = self.batch
+        k = self.iteration % b.dummy_masks.shape[1] if mask_index is None else mask_index
+        self.model.train()
+        poss = self.model(b.data, b.v_keep * b.dummy_masks[:, k:k + 1])
+        loss = self.loss(poss)
+        loss.backward()
+        self.loss_sum += loss.detach()
+        self.iteration += 1
+        if self.iteration % self.accumulate == 0:
+            all_reduce_gradients(self.params, self.group)
+            self.opt.step()
+            self.opt.zero_grad(set_to_none=True)
+        return loss

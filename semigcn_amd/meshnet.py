@@ -76,6 +76,7 @@ class _HashOp(nn.Module):
         # itself stays in the caller's numbering, so state dicts remain interchangeable with the reference
         self._rank_fine: Optional[torch.Tensor] = None
         self._rank_coarse: Optional[torch.Tensor] = None
+        self._dist = None      # dist.DistPool when the model runs on a vertex partition
 
     def _pool(self) -> capi.PoolHandle:
         mat = getattr(self, self._buffer_name)
@@ -106,6 +107,8 @@ class MeshPool(_HashOp):
     _buffer_name = "pool_hash"
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if self._dist is not None:
+            return self._dist.pool(input)
         return F_sg.mesh_pool(self._pool(), input)
 
 
@@ -115,6 +118,8 @@ class MeshUnpool(_HashOp):
     _transposed = True
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if self._dist is not None:
+            return self._dist.unpool(input)
         return F_sg.mesh_unpool(self._pool(), input)
 
 
@@ -315,7 +320,13 @@ class MGCN(nn.Module):
             mask = torch.ones((z1.shape[0], 1), dtype=z1.dtype, device=self.device)
         x = prepare_input(z1, mask.to(z1.dtype))
         heads = self.edge_inds
-        if self._orders is not None:
+        part = getattr(self, "_part", None)
+        if part is not None:
+            # vertex-partitioned (dist.partition_mgcn): the input is the whole mesh (replicated, cheap: [V,4]);
+            # every level continues with this rank's rows only and the outputs are this rank's rows
+            x = x.index_select(0, part.own_ids[0])
+            heads = part.graphs
+        elif self._orders is not None:
             x = x.index_select(0, self._orders[0][0])
             heads = self._graphs
 
@@ -336,6 +347,8 @@ class MGCN(nn.Module):
 
         out0 = self.decoder1(res1_dec)
         outs = [out0, out1, out2, out3]
+        if part is not None:
+            return tuple(s_own + o for s_own, o in zip(part.smposs_own, outs))
         if self._orders is not None:
             outs = [o.index_select(0, rank) for o, (_, rank) in zip(outs, self._orders)]
         s = self.smposs_list

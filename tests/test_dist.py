@@ -161,3 +161,117 @@ def test_partition_plan_is_consistent():
         assert torch.allclose(y, y_full[g.start:g.end], atol=1e-6)
     with pytest.raises(ValueError, match="symmetric"):
         sgdist.DistMeshGraph(ei[:, :-1], V, 0, 2)
+
+
+# --------------------------------------------------------------------------------------
+# MGCN on a partition: N ranks == 1 rank == the unpartitioned model, on the REFERENCE's own
+# hierarchy (golden g3: QEM clusters of 1..5 vertices, 258 -> 154 -> 92 -> 55)
+# --------------------------------------------------------------------------------------
+def _run_mgcn_rank(rank, world, port, out_dir, partitioned):
+    _install_doubles()
+    torch.set_num_threads(1)
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import golden_util as GU
+    from test_host_logic import _mgcn_from_golden
+    from semigcn_amd import dist as sgdist, train
+    g3 = GU.load("g3_mgcn.npz")
+    g0 = GU.load("g0_mesh_layout.npz")
+    net = _mgcn_from_golden("cpu", g3, skip=True)
+    GU.fill_state(net, seed=2718)
+    for mod in net.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0                                   # dropout masks are per-rank random streams
+    faces = torch.from_numpy(g0["sphere/faces"]).long()
+    V = g3["z1"].shape[0]
+    v_keep = torch.from_numpy(g3["v_masks/0"]).float()
+    target_pos = torch.from_numpy(g3["poss/0"])
+
+    class D:
+        z1 = torch.from_numpy(g3["z1"])
+        x_pos = None
+    batch = train.MeshBatch(D, faces, target_pos, train.face_normals(target_pos, faces), v_keep,
+                            (v_keep[:, 0][faces] > 0).all(1).float().view(-1, 1), torch.ones(V, 2))
+    out = {}
+    if partitioned:
+        part = sgdist.partition_mgcn(net, rank, world)
+        tr = sgdist.DistMGCNTrainer(net, part, batch, accumulate=2)
+        out["bounds"], out["n_halo"] = part.bounds, [g.n_halo for g in part.graphs]
+        out["pool_halo"] = [(p.fine_plan.n_halo, p.coarse_plan.n_halo) for p in part.pools]
+        # the pool / unpool pair on its own, no kinks: linear in x
+        gen = torch.Generator().manual_seed(9)
+        xf = torch.randn(V, 6, generator=gen)
+        x_own = xf[part.own_ids[0]].clone().requires_grad_(True)
+        pooled = part.pools[0].pool(x_own)
+        back = part.pools[0].unpool(pooled)
+        (back * xf[part.own_ids[0]]).sum().backward()
+        out["pool"] = sgdist.gather_level(pooled, part, 1)
+        out["unpool"] = sgdist.gather_level(back, part, 0)
+        out["pool_dx"] = sgdist.gather_level(x_own.grad, part, 0)
+    else:
+        tr = train.MGCNTrainer(net, batch, accumulate=2)
+        gen = torch.Generator().manual_seed(9)
+        xf = torch.randn(V, 6, generator=gen).requires_grad_(True)
+        pooled = net.encoder1.model1.module_4(xf)
+        back = net.decoder1[0].model1.module_1(pooled)
+        (back * xf.detach()).sum().backward()
+        out["pool"], out["unpool"], out["pool_dx"] = pooled.detach(), back.detach(), xf.grad.clone()
+    net.eval()
+    with torch.no_grad():
+        ev = net(D, None)
+    net.train()
+    poss = net(D, None)
+    loss = tr.loss(poss) if partitioned else sum(
+        w * train.masked_position_rmse(p, t, k, n) for w, p, t, k, n in zip(tr.weights, poss, net.poss_list, tr.keeps, tr.counts)
+    ) + tr.k1 * train.masked_normal_l1(train.face_normals(poss[0], faces), batch.target_fn, batch.f_keep, batch.n_f_keep)
+    loss.backward()
+    if partitioned:
+        sgdist.all_reduce_gradients(tr.params)
+        out["eval"] = [sgdist.gather_level(p, part, l) for l, p in enumerate(ev)]
+        out["train"] = [sgdist.gather_level(p, part, l) for l, p in enumerate(poss)]
+    else:
+        out["eval"], out["train"] = [p.clone() for p in ev], [p.detach().clone() for p in poss]
+    out["loss"] = float(loss.detach())
+    out["grads"] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    out["bn"] = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+    tr.opt.zero_grad(set_to_none=True)
+    out["losses"] = [float(tr.iteration_step().detach()) for _ in range(2)]
+    torch.save(out, os.path.join(out_dir, f"m{int(partitioned)}_w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _launch_mgcn(world, out_dir, partitioned, port):
+    if world == 1:
+        _run_mgcn_rank(0, 1, port, out_dir, partitioned)
+    else:
+        mp.spawn(_run_mgcn_rank, args=(world, port, out_dir, partitioned), nprocs=world, join=True)
+    return [torch.load(os.path.join(out_dir, f"m{int(partitioned)}_w{world}_r{r}.pt")) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_mgcn_matches_unpartitioned(world):
+    with tempfile.TemporaryDirectory() as d:
+        ref = _launch_mgcn(1, d, False, 0)[0]
+        one = _launch_mgcn(1, d, True, 0)[0]
+        parts = _launch_mgcn(world, d, True, 29700 + world)
+    assert [b[-1] for b in parts[0]["bounds"]] == [258, 154, 92, 55]
+    assert all(sum(h) > 0 for p in parts for h in p["pool_halo"][:2])          # clusters do span the cut
+    for p in [one] + parts:
+        for key in ("pool", "unpool", "pool_dx"):
+            assert rel_l2(p[key], ref[key]) < 2e-6, key
+        for l in range(4):
+            assert rel_l2(p["eval"][l], ref["eval"][l]) < 5e-5, l       # the MGCN bar (33 layers; tests/test_gpu_parity.py)
+            assert rel_l2(p["train"][l], ref["train"][l]) < 5e-5, l
+        assert abs(p["loss"] - ref["loss"]) < 2e-5 * abs(ref["loss"])
+        assert np.allclose(p["losses"], ref["losses"], rtol=2e-4)
+        gmax = max(float(v.abs().max()) for v in ref["grads"].values())
+        for n, g in ref["grads"].items():          # kink-limited, as in the SGCN test above
+            scale = max(float(g.norm()), 1e-3 * gmax * g.numel() ** 0.5)
+            assert float((p["grads"][n] - g).norm()) <= 3e-2 * scale, n
+        for k, v in ref["bn"].items():
+            assert rel_l2(p["bn"][k], v) < 1e-5, k
+    for n in parts[0]["grads"]:
+        assert torch.equal(parts[0]["grads"][n], parts[1]["grads"][n]), n

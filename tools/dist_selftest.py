@@ -66,10 +66,67 @@ def main():
     print(f"[rank {rank}/{world}] own={g.n_own} halo={g.n_halo} send={g.n_send}  pos rel-L2 {e_pos:.2e}  "
           f"loss rel {e_loss:.2e}  worst param-grad rel-L2 {worst:.2e}", flush=True)
     assert e_pos < 2e-5 and e_loss < 2e-5 and worst < 3e-2
+    mgcn_selftest(rank, world, dev)
     dist.barrier()
     if rank == 0:
         print("dist_selftest OK")
     dist.destroy_process_group()
+
+
+def mgcn_selftest(rank, world, dev):
+    """Partitioned MGCN (pool / unpool across the cut) against the plain single-GPU MGCN, real kernels."""
+    import numpy as np
+    import golden_util as GU
+    from semigcn_amd import dist as sgdist, meshprep, synth, train
+    from semigcn_amd.meshnet import MGCN
+    import bench
+
+    mesh = synth.torus_mesh(96, 64, permute=True)
+    batch = bench.build_mesh_batch(mesh, dev, n_masks=2)
+
+    def build():
+        smo = meshprep.DeviceMesh(mesh.x_pos, mesh.faces, dev)
+        ini = meshprep.DeviceMesh(mesh.vs.astype(np.float32), mesh.faces, dev)
+        net = MGCN(dev, smo, ini, torch.from_numpy(mesh.v_mask))
+        GU.fill_state(net, seed=5)
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return net.to(dev)
+
+    ref = build()
+    rt = train.MGCNTrainer(ref, batch, accumulate=1000)
+    ref.train()
+    rposs = ref(batch.data, None)
+    rloss = sum(w * train.masked_position_rmse(p, t, k, n)
+                for w, p, t, k, n in zip(rt.weights, rposs, ref.poss_list, rt.keeps, rt.counts)) \
+        + rt.k1 * train.masked_normal_l1(train.face_normals(rposs[0], batch.faces), batch.target_fn, batch.f_keep,
+                                         batch.n_f_keep)
+    rloss.backward()
+
+    net = build()
+    part = sgdist.partition_mgcn(net, rank, world)
+    tr = sgdist.DistMGCNTrainer(net, part, batch, accumulate=1000)
+    net.train()
+    poss = net(batch.data, None)
+    loss = tr.loss(poss)
+    loss.backward()
+    sgdist.all_reduce_gradients(tr.params)
+    e_pos = max(float((p.detach() - r.detach()[ids]).norm() / r.detach()[ids].norm())
+                for p, r, ids in zip(poss, rposs, part.own_ids))
+    e_loss = abs(float(loss) - float(rloss)) / abs(float(rloss))
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    worst = 0.0
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            continue
+        scale = max(float(q.grad.norm()), 1e-3 * gmax * q.grad.numel() ** 0.5)
+        worst = max(worst, float((p.grad - q.grad).norm()) / scale)
+    halos = [(g.n_own, g.n_halo) for g in part.graphs]
+    print(f"[rank {rank}/{world}] MGCN levels (own, halo) {halos} pool halos "
+          f"{[(q.fine_plan.n_halo, q.coarse_plan.n_halo) for q in part.pools]}  pos rel-L2 {e_pos:.2e}  "
+          f"loss rel {e_loss:.2e}  worst param-grad rel-L2 {worst:.2e}", flush=True)
+    assert e_pos < 5e-5 and e_loss < 5e-5 and worst < 3e-2
 
 
 if __name__ == "__main__":
