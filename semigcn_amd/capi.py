@@ -141,7 +141,15 @@ def _require_device(t: torch.Tensor, name: str):
             "(there is no CPU path; move the model and its inputs to cuda)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor) -> c_void_p:
+    """hipStream_t of torch's CURRENT stream on the tensor's device (looked up on every launch: a
+    caller may have switched streams; the raw accessor costs ~0.3 us against ~5 us for the Stream object)."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
     return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

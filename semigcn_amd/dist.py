@@ -543,7 +543,8 @@ class DistSGCNTrainer:
         p = self.part
         k = self.iteration % p.dummy_masks.shape[1] if mask_index is None else mask_index
         dm = p.v_keep * p.dummy_masks[:, k:k + 1]
-        self.model.train()
+        if not self.model.training:
+            self.model.train()
         pos = self.model(p, dm)
         loss = self.loss(pos)
         loss.backward()
@@ -750,7 +751,8 @@ class DistMGCNTrainer:
     def iteration_step(self, mask_index: Optional[int] = None) -> torch.Tensor:
         b = self.batch
         k = self.iteration % b.dummy_masks.shape[1] if mask_index is None else mask_index
-        self.model.train()
+        if not self.model.training:
+            self.model.train()
         poss = self.model(b.data, b.v_keep * b.dummy_masks[:, k:k + 1])
         loss = self.loss(poss)
         loss.backward()

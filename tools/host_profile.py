@@ -3,12 +3,13 @@
 import cProfile, os, pstats, sys, io
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.argv = ["bench.py", "--mesh", "250x200"]
+MESH = sys.argv[1] if len(sys.argv) > 1 else "250x200"
+sys.argv = ["bench.py", "--mesh", MESH]
 import bench
 from semigcn_amd import synth, train
 from semigcn_amd.networks import SingleScaleGCN
 dev = torch.device("cuda:0")
-mesh = synth.torus_mesh(250, 200)
+mesh = synth.torus_mesh(*map(int, MESH.split("x")))
 batch = bench.build_mesh_batch(mesh, dev, 5)
 model = SingleScaleGCN(dev).to(dev)
 tr = train.SGCNTrainer(model, batch)
