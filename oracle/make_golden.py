@@ -256,6 +256,31 @@ def g5_refine(ref, meshes, ref_meshes):
     np.savez_compressed(os.path.join(OUT, "g5_refine.npz"), **out)
 
 
+def g6_bnf(ref, meshes, tmp):
+    """G6: the reference's ``fn_bnf_detach_loss`` (util/loss.py:196-253; the -CAD term of sgcn.py:133-135)
+    with its own ``Mesh.f2f``, on the closed sphere and on the open mesh (rows of f2f padded with -1):
+    loss, filtered normals, and d loss / d pos through ``compute_fn``."""
+    out = {}
+    sph = meshes["sphere"]
+    keep = np.ones(len(sph.faces), bool)
+    keep[[3, 4, 5, 100, 101, 250]] = False
+    for name, faces in (("sphere", sph.faces), ("open", sph.faces[keep])):
+        holder = type("M", (), {"vs": sph.vs, "faces": faces})()
+        rm = _ref_mesh(ref, holder, tmp, "g6_" + name, build_mat=(name != "open"))
+        rs = np.random.RandomState(77)
+        pos = torch.from_numpy((sph.vs + 0.03 * rs.standard_normal(sph.vs.shape)).astype(np.float32)).requires_grad_(True)
+        fn = ref.models.compute_fn(pos, rm.faces)
+        loss, new_fn = ref.loss.fn_bnf_detach_loss(pos, fn, rm, loop=5)
+        loss.backward()
+        out[f"{name}/faces"] = np.asarray(rm.faces, dtype=np.int64)
+        out[f"{name}/f2f"] = rm.f2f.astype(np.int64)
+        out[f"{name}/pos"] = pos.detach().numpy()
+        out[f"{name}/loss"] = np.float64(loss.item())
+        out[f"{name}/new_fn"] = new_fn.numpy()
+        out[f"{name}/dpos"] = pos.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g6_bnf.npz"), **out)
+
+
 def main():
     only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
     warnings.simplefilter("ignore")
@@ -278,6 +303,8 @@ def main():
             g4_meshprep(ref, meshes, tmp)
         if only is None or "g5" in only:
             g5_refine(ref, meshes, ref_meshes)
+        if only is None or "g6" in only:
+            g6_bnf(ref, meshes, tmp)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

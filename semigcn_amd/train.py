@@ -34,6 +34,34 @@ def masked_normal_l1(pred: torch.Tensor, real: torch.Tensor, keep: torch.Tensor,
     return ((pred - real).abs() * keep).sum() / count
 
 
+def bilateral_normal_loss(pos: torch.Tensor, fn: torch.Tensor, faces: torch.Tensor, f2f: torch.Tensor,
+                          loop: int = 5, sigma_s: float = 0.3):
+    """``Loss.fn_bnf_detach_loss`` (util/loss.py:196-253, ltype='l1mae'; the ``-CAD`` term of
+    sgcn.py:133-135 / mgcn.py:146-148): ``loop`` rounds of bilateral filtering of the face normals
+    over the face 1-ring ``f2f`` ([F,3], -1 = no neighbour; semigcn_amd.meshprep.MeshTopology.f2f),
+    weights exp(-|dc|^2 / 2 sigma_c^2) * exp(-|dn|^2 / 2 sigma_s^2) * area, computed on DETACHED
+    geometry; returns (mean_f |filtered_f - fn_f|_1, filtered normals).  Gradients reach ``fn`` only.
+    Plain torch ops (a dozen small face-sized kernels per round): an optional term, not on the
+    default path.  A -1 in ``f2f`` indexes the last face like the reference's numpy-style wrap, and
+    is then weighted by zero area."""
+    p = pos.detach()
+    a, b, c = p[faces[:, 0]], p[faces[:, 1]], p[faces[:, 2]]
+    fc = (a + b + c) / 3.0
+    fa = 0.5 * torch.sqrt((torch.linalg.cross(b - a, c - a, dim=1) ** 2).sum(1) + 1.0e-12)
+    has = (f2f != -1).to(fa.dtype)
+    neig_fa = fa[f2f] * has
+    fc_dist = ((fc[f2f] - fc.unsqueeze(1)) ** 2).sum(2)
+    sigma_c = torch.sqrt(fc_dist + 1.0e-12).sum() / fc_dist.numel()
+    wc = torch.exp(-fc_dist / (2 * sigma_c ** 2))
+    new_fn = fn
+    for _ in range(loop):
+        neig_fn = new_fn[f2f]
+        ws = torch.exp(-((neig_fn - new_fn.unsqueeze(1)) ** 2).sum(2) / (2 * sigma_s ** 2))
+        new_fn = ((wc * ws * neig_fa).unsqueeze(2) * neig_fn).sum(1)
+        new_fn = (new_fn / (torch.sqrt((new_fn ** 2).sum(1, keepdim=True) + 1.0e-12) + 1.0e-12)).detach()
+    return (new_fn - fn).abs().sum(1).sum() / fn.shape[0], new_fn
+
+
 @dataclass
 class MeshBatch:
     """Per-mesh constants of the training loop, resident on the device."""
@@ -46,6 +74,7 @@ class MeshBatch:
     dummy_masks: torch.Tensor    # [V, n_masks] float (vmask_dummy)
     n_v_keep: int = 0
     n_f_keep: int = 0
+    f2f: Optional[torch.Tensor] = None   # [F,3] int64 face 1-ring, -1 padded; only for the -CAD term (k2 > 0)
 
     def __post_init__(self):
         self.n_v_keep = int(self.v_keep.sum().item())
@@ -56,8 +85,12 @@ class SGCNTrainer:
     """optimizer = Adam(lr), StepLR(50, 0.5) as sgcn.py:79-80; k1 = 4 (sgcn.py:47)."""
 
     def __init__(self, model: torch.nn.Module, batch: MeshBatch, lr: float = 0.01, k1: float = 4.0,
-                 accumulate: int = 5):
-        self.model, self.mesh, self.k1, self.accumulate = model, batch, k1, accumulate
+                 accumulate: int = 5, k2: float = 0.0):
+        """``k2 > 0`` adds the bilateral normal term of the reference's ``-CAD`` runs (sgcn.py:133-135, its
+        default weight is 4.0); it needs ``batch.f2f``."""
+        self.model, self.mesh, self.k1, self.accumulate, self.k2 = model, batch, k1, accumulate, k2
+        if k2 > 0 and batch.f2f is None:
+            raise ValueError("k2 > 0 (the -CAD bilateral normal term) needs MeshBatch.f2f")
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=50, gamma=0.5)
         self.iteration = 0
@@ -69,10 +102,16 @@ class SGCNTrainer:
         if pos.is_cuda and pos.dtype == torch.float32:     # fused HIP kernels (csrc/mesh_loss.hip)
             from .functional import mesh_loss_sums
             s = mesh_loss_sums(pos, b.faces, b.target_pos, b.v_keep, b.target_fn, b.f_keep)
-            return torch.sqrt(s[0] / b.n_v_keep + 1.0e-6) + self.k1 * (s[1] / b.n_f_keep)
-        lp = masked_position_rmse(pos, b.target_pos, b.v_keep, b.n_v_keep)
-        ln = masked_normal_l1(face_normals(pos, b.faces), b.target_fn, b.f_keep, b.n_f_keep)
-        return lp + self.k1 * ln
+            loss = torch.sqrt(s[0] / b.n_v_keep + 1.0e-6) + self.k1 * (s[1] / b.n_f_keep)
+            if self.k2 > 0:
+                loss = loss + self.k2 * bilateral_normal_loss(pos, face_normals(pos, b.faces), b.faces, b.f2f)[0]
+            return loss
+        fn = face_normals(pos, b.faces)
+        loss = masked_position_rmse(pos, b.target_pos, b.v_keep, b.n_v_keep) \
+            + self.k1 * masked_normal_l1(fn, b.target_fn, b.f_keep, b.n_f_keep)
+        if self.k2 > 0:
+            loss = loss + self.k2 * bilateral_normal_loss(pos, fn, b.faces, b.f2f)[0]
+        return loss
 
     def iteration_step(self, mask_index: Optional[int] = None) -> torch.Tensor:
         """One forward + loss + backward for one dummy mask (sgcn.py:123-144); every
@@ -98,8 +137,10 @@ class MGCNTrainer:
     (weights 0.35/0.3/0.2/0.15, mgcn.py:82,138-143) + k1 x normal L1 on the finest level."""
 
     def __init__(self, model: torch.nn.Module, batch: MeshBatch, lr: float = 0.01, k1: float = 4.0,
-                 accumulate: int = 5, weights=(0.35, 0.3, 0.2, 0.15)):
-        self.model, self.mesh, self.k1, self.accumulate, self.weights = model, batch, k1, accumulate, weights
+                 accumulate: int = 5, weights=(0.35, 0.3, 0.2, 0.15), k2: float = 0.0):
+        self.model, self.mesh, self.k1, self.accumulate, self.weights, self.k2 = model, batch, k1, accumulate, weights, k2
+        if k2 > 0 and batch.f2f is None:
+            raise ValueError("k2 > 0 (the -CAD bilateral normal term, mgcn.py:146-148) needs MeshBatch.f2f")
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
         self.iteration = 0
         self.loss_sum = torch.zeros((), device=batch.target_pos.device)
@@ -116,7 +157,10 @@ class MGCNTrainer:
         poss = self.model(b.data, b.v_keep * b.dummy_masks[:, k:k + 1])
         loss = sum(w * masked_position_rmse(p, t, keep, n)
                    for w, p, t, keep, n in zip(self.weights, poss, self.model.poss_list, self.keeps, self.counts))
-        loss = loss + self.k1 * masked_normal_l1(face_normals(poss[0], b.faces), b.target_fn, b.f_keep, b.n_f_keep)
+        fn = face_normals(poss[0], b.faces)
+        loss = loss + self.k1 * masked_normal_l1(fn, b.target_fn, b.f_keep, b.n_f_keep)
+        if self.k2 > 0:
+            loss = loss + self.k2 * bilateral_normal_loss(poss[0], fn, b.faces, b.f2f)[0]
         loss.backward()
         self.loss_sum += loss.detach()
         self.iteration += 1

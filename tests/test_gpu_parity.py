@@ -980,3 +980,34 @@ def test_mesh_merge_vs_oracle_medium_and_full_size_optimality():
     rhs = Lt(b_mix) + inner.double() * od
     assert float(grad.norm() / rhs.norm()) < 1e-5
     assert float((xd - od)[inner.view(-1)].abs().max()) < 0.2 and float((xd - nd).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("name", ["sphere", "open"])
+def test_bilateral_normal_loss_with_device_f2f(name):
+    """The -CAD term on the device with the face ring from sg_mesh_edges (row order differs from the reference's
+    Python-set order; the filter sums over the ring, so only rounding changes)."""
+    from semigcn_amd import meshprep, train
+    g = GU.load("g6_bnf.npz")
+    topo = meshprep.MeshTopology(g[f"{name}/faces"], g[f"{name}/pos"].shape[0], DEV)
+    pos = torch.from_numpy(g[f"{name}/pos"]).to(DEV).requires_grad_(True)
+    loss, new_fn = train.bilateral_normal_loss(pos, train.face_normals(pos, topo.faces), topo.faces, topo.f2f)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[f"{name}/loss"])) < 2e-6 * float(g[f"{name}/loss"])
+    assert rel(new_fn, g[f"{name}/new_fn"]) < 2e-6 and rel(pos.grad, g[f"{name}/dpos"]) < 2e-5
+
+
+def test_trainer_with_cad_term_runs():
+    import bench
+    from semigcn_amd import meshprep, train
+    m = synth.torus_mesh(40, 30)
+    batch = bench.build_mesh_batch(m, torch.device(DEV), n_masks=2)
+    with pytest.raises(ValueError, match="f2f"):
+        train.SGCNTrainer(SingleScaleGCN(DEV).to(DEV), batch, k2=4.0)
+    batch.f2f = meshprep.MeshTopology(m.faces, m.num_vertices, DEV).f2f
+    plain = train.SGCNTrainer(SingleScaleGCN(DEV).to(DEV), batch)
+    cad = train.SGCNTrainer(SingleScaleGCN(DEV).to(DEV), batch, k2=4.0)
+    cad.model.load_state_dict(plain.model.state_dict())
+    l0, l1 = float(plain.iteration_step(0).detach()), float(cad.iteration_step(0).detach())
+    pos = cad.model(batch.data, batch.v_keep * batch.dummy_masks[:, :1])
+    extra = float(train.bilateral_normal_loss(pos, train.face_normals(pos, batch.faces), batch.faces, batch.f2f)[0])
+    assert l1 > l0 and abs((l1 - l0) - 4.0 * extra) < 0.05 * (l1 - l0)     # BN statistics moved by one step in between

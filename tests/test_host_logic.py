@@ -318,3 +318,20 @@ def test_meshprep_has_no_cpu_path():
     faces = torch.tensor([[0, 1, 2], [0, 2, 3]])
     with pytest.raises(capi.SemigcnLibraryError, match="HIP device only"):
         meshprep.MeshTopology(faces, 4, device="cpu")
+
+
+@pytest.mark.parametrize("name", ["sphere", "open"])
+def test_bilateral_normal_loss_vs_reference_golden(name):
+    """train.bilateral_normal_loss (plain torch ops) == the reference's fn_bnf_detach_loss (util/loss.py:196-253)
+    with the reference's own f2f: loss value, filtered normals, d loss / d pos (golden g6)."""
+    from semigcn_amd import train
+    g = GU.load("g6_bnf.npz")
+    pos = torch.from_numpy(g[f"{name}/pos"]).requires_grad_(True)
+    faces, f2f = torch.from_numpy(g[f"{name}/faces"]), torch.from_numpy(g[f"{name}/f2f"])
+    loss, new_fn = train.bilateral_normal_loss(pos, train.face_normals(pos, faces), faces, f2f, loop=5)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[f"{name}/loss"])) < 1e-6 * float(g[f"{name}/loss"])
+    assert np.abs(new_fn.numpy() - g[f"{name}/new_fn"]).max() < 1e-6 and not new_fn.requires_grad
+    assert rel(pos.grad, g[f"{name}/dpos"]) < 1e-5
+    if name == "open":
+        assert (g[f"{name}/f2f"] < 0).sum() > 0            # the fixture does exercise the -1 padding
