@@ -108,25 +108,39 @@ __global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda
       }
     }
     if (cok) {
-      for (int64_t r = r_begin + tg; r < r_end; r += groups) {
-        float x[VEC], h[VEC];
-        if (VEC == 1) {
-          x[0] = IO::load1(A + r * lda + cs);
-          if (MODE == 1) h[0] = IO::load1(H + r * ldh + cs);
-        } else {
-          IO::unpack(*(const raw_t*)(A + r * lda + (int64_t)cs * VEC), x);
-          if (MODE == 1) IO::unpack(*(const raw_t*)(H + r * ldh + (int64_t)cs * VEC), h);
+      // U rows in flight per thread (row ids past the end are clamped for the load and masked in the sum):
+      // one 16-B load per thread per trip leaves the CU with too few bytes in flight to cover HBM latency
+      constexpr int U = 4;
+      for (int64_t r = r_begin + tg; r < r_end; r += (int64_t)groups * U) {
+        float x[U][VEC], h[U][VEC];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int64_t ru = r + (int64_t)u * groups;
+          live[u] = ru < r_end;
+          ru = live[u] ? ru : r;
+          if (VEC == 1) {
+            x[u][0] = IO::load1(A + ru * lda + cs);
+            if (MODE == 1) h[u][0] = IO::load1(H + ru * ldh + cs);
+          } else {
+            IO::unpack(*(const raw_t*)(A + ru * lda + (int64_t)cs * VEC), x[u]);
+            if (MODE == 1) IO::unpack(*(const raw_t*)(H + ru * ldh + (int64_t)cs * VEC), h[u]);
+          }
         }
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          if (MODE == 0) {
-            const float d = x[k] - kshift[k];
-            a0[k] += d;
-            a1[k] = fmaf(d, d, a1[k]);
-          } else {
-            const float dz = x[k] * act_slope(fmaf(sc[k], h[k], sh[k]), slope);
-            a0[k] += dz;
-            a1[k] = fmaf(dz, (h[k] - mu[k]) * is[k], a1[k]);
+        for (int u = 0; u < U; ++u) {
+          const float on = live[u] ? 1.f : 0.f;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            if (MODE == 0) {
+              const float d = (x[u][k] - kshift[k]) * on;
+              a0[k] += d;
+              a1[k] = fmaf(d, d, a1[k]);
+            } else {
+              const float dz = x[u][k] * act_slope(fmaf(sc[k], h[u][k], sh[k]), slope) * on;
+              a0[k] += dz;
+              a1[k] = fmaf(dz, (h[u][k] - mu[k]) * is[k], a1[k]);
+            }
           }
         }
       }
@@ -134,11 +148,20 @@ __global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { s_red[0][threadIdx.x][k] = a0[k]; s_red[1][threadIdx.x][k] = a1[k]; }
     __syncthreads();   // (every row group of a column slot used the same shift K: the block's first row)
+    for (int off = groups >> 1; off > 0; off >>= 1) {      // tree over the row groups (groups is a power of two)
+      if (tg < off) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          s_red[0][threadIdx.x][k] += s_red[0][threadIdx.x + off * tpr][k];
+          s_red[1][threadIdx.x][k] += s_red[1][threadIdx.x + off * tpr][k];
+        }
+      }
+      __syncthreads();
+    }
     if (tg == 0 && cok) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int g = 0; g < groups; ++g) { s0 += s_red[0][g * tpr + tc][k]; s1 += s_red[1][g * tpr + tc][k]; }
+        const float s0 = s_red[0][tc][k], s1 = s_red[1][tc][k];
         const int c = cs * VEC + k;
         if (c < C) {
           if (MODE == 0) {
@@ -199,6 +222,74 @@ __global__ __launch_bounds__(kBlock) void col_apply(const void* A_, int64_t lda,
     }
     if (VEC == 1) IO::store1(Y + r * ldy + cs, y[0]);
     else *(raw_t*)(Y + r * ldy + (int64_t)cs * VEC) = IO::pack(y);
+  }
+}
+
+// Same arithmetic as col_apply, for C / VEC <= 256 column slots: a thread keeps ONE column slot for the
+// whole launch, so the per-channel parameters live in registers (col_apply re-reads 2 (MODE 0) or 7
+// (MODE 1) vectors and does a 64-bit division per element group), and it has U rows in flight.
+template <int DT, int MODE>
+__global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t lda, const void* H_, int64_t ldh,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ kk, const float* __restrict__ c1,
+                                                         const float* __restrict__ c2, float slope, void* Y_, int64_t ldy,
+                                                         int64_t V, int C, int tpr_log2) {
+  using IO = Io<DT>;
+  using elem_t = typename IO::elem;
+  using raw_t = typename IO::raw;
+  constexpr int VEC = IO::VEC;
+  constexpr int U = MODE == 0 ? 4 : 2;
+  const elem_t* A = (const elem_t*)A_;
+  const elem_t* H = (const elem_t*)H_;
+  elem_t* Y = (elem_t*)Y_;
+  const int tc = threadIdx.x & ((1 << tpr_log2) - 1);
+  const int tg = threadIdx.x >> tpr_log2;
+  const int groups = kBlock >> tpr_log2;
+  if (tc >= C / VEC) return;
+  const int c0 = tc * VEC;
+  float sc[VEC], sh[VEC], mu[VEC], is[VEC], kc[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    sc[k] = scale[c0 + k];
+    sh[k] = shift[c0 + k];
+    if (MODE == 1) {
+      mu[k] = mean[c0 + k];
+      is[k] = invstd[c0 + k];
+      kc[k] = kk[c0 + k];
+      k1[k] = c1[c0 + k];
+      k2[k] = c2[c0 + k] * is[k];
+    }
+  }
+  const int64_t step = (int64_t)gridDim.x * groups;
+  for (int64_t r = (int64_t)blockIdx.x * groups + tg; r < V; r += step * U) {
+    raw_t xa[U], xh[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t ru = r + u * step;
+      live[u] = ru < V;
+      ru = live[u] ? ru : r;
+      xa[u] = *(const raw_t*)(A + ru * lda + c0);
+      if (MODE == 1) xh[u] = *(const raw_t*)(H + ru * ldh + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float x[VEC], h[VEC], y[VEC];
+      IO::unpack(xa[u], x);
+      if (MODE == 1) IO::unpack(xh[u], h);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (MODE == 0) {
+          const float z = fmaf(sc[k], x[k], sh[k]);
+          y[k] = z > 0.f ? z : z * slope;
+        } else {
+          const float dz = x[k] * act_slope(fmaf(sc[k], h[k], sh[k]), slope);
+          y[k] = kc[k] * (dz - k1[k] - (h[k] - mu[k]) * k2[k]);
+        }
+      }
+      if (live[u]) *(raw_t*)(Y + (r + u * step) * ldy + c0) = IO::pack(y);
+    }
   }
 }
 
@@ -331,6 +422,19 @@ int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_
     constexpr int VEC = Io<DT>::VEC;
     const bool vec = C % VEC == 0 && lda % VEC == 0 && ldy % VEC == 0 && a16(A) && a16(Y) &&
                      (mode == 0 || (ldh % VEC == 0 && a16(H)));
+    if (vec && C / VEC <= kBlock) {
+      const int ncol = (int)(C / VEC);
+      int lg = 0;
+      while ((1 << lg) < ncol) ++lg;
+      const int groups = kBlock >> lg;
+      int64_t nbr = (V + (int64_t)groups * 4 - 1) / ((int64_t)groups * 4);
+      if (nbr > 256 * 16) nbr = 256 * 16;
+      if (nbr < 1) nbr = 1;
+      if (mode == 0) col_apply_rows<DT, 0><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg);
+      else col_apply_rows<DT, 1><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg);
+      SG_HIP_TRY(hipGetLastError());
+      return SG_OK;
+    }
     const int64_t total = V * (vec ? C / VEC : C);
     int64_t nb = (total + kBlock - 1) / kBlock;
     if (nb > 256 * 16) nb = 256 * 16;
