@@ -247,7 +247,10 @@ SG_API int sg_mesh_loss_bwd(const float* pos, const int64_t* faces, const float*
  * ------------------------------------------------------------------------- */
 enum sg_tune_knob {
   SG_TUNE_CHUNK_ROWS = 0, /* rows per wavefront chunk; 0 = automatic */
-  SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map, bit 1: never use the shared-gather kernel */
+  SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map, bit 1: never use the shared-gather kernel,
+                             bit 2: ignore the (id, scale) packed neighbour lists, bit 3: workgroup barriers
+                             between the staging phases instead of wavefront-local ones, bit 4: 64-bit gather addressing
+                             even where 32-bit offsets would do (A/B switches) */
   SG_TUNE_UNROLL = 2,     /* reserved */
   SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */
   SG_TUNE_TILED_MIN_ROW_BYTES = 4 /* shared-gather kernel (each distinct source row of a 4-row mini-tile is

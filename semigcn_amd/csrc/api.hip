@@ -67,11 +67,16 @@ int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64
     a.tile_uniq = c.tile_uniq;
     a.tile_eloc = c.tile_eloc;
   }
+  if (ss != nullptr && ss == c.packed_scale) {
+    a.idx_w = c.idx_w;
+    a.tile_uniq_w = c.tile_uniq_w;
+  }
   a.scale_dst = sd;
   a.scale_src = ss;
   a.X = X; a.X0 = X0; a.X1 = X1; a.Y = Y;
   a.ldx = ldx; a.ldx0 = X0 ? ldx0 : 0; a.ldx1 = X1 ? ldx1 : 0; a.ldy = ldy;
   a.n_rows = (int32_t)c.n_rows;
+  a.n_cols = c.n_cols;
   a.C = (int32_t)C;
   a.alpha = alpha; a.beta = beta; a.gamma = gamma;
   return launch_spmm(a, dtype, stream);
@@ -139,6 +144,8 @@ SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void
       if ((rc = build_tiles(&g->fwd, stream)) != SG_OK) break;
       if (!g->symmetric && (rc = build_tiles(&g->bwd, stream)) != SG_OK) break;
     }
+    if ((rc = pack_source_scale(&g->fwd, g->dis_src, stream)) != SG_OK) break;
+    if (!g->symmetric && (rc = pack_source_scale(&g->bwd, g->dis_src, stream)) != SG_OK) break;
     if (hipStreamSynchronize(stream) != hipSuccess) {
       set_error("stream sync failed in sg_graph_create");
       rc = SG_ERR_HIP;
@@ -174,6 +181,11 @@ SG_API int sg_graph_create_rect(const int64_t* dst, const int64_t* src, int64_t 
           (hipMemcpyAsync(g->dis_src, dis_src, V_src * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess ||
            hipStreamSynchronize(stream) != hipSuccess)) {
         set_error("copy of dis failed");
+        rc = SG_ERR_HIP;
+      }
+      if (rc == SG_OK) rc = pack_source_scale(&g->fwd, g->dis_src, stream);
+      if (rc == SG_OK && hipStreamSynchronize(stream) != hipSuccess) {
+        set_error("stream sync failed in sg_graph_create_rect");
         rc = SG_ERR_HIP;
       }
     }

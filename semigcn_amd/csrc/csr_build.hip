@@ -16,6 +16,11 @@ void Csr::release() {
   if (tile_uptr) (void)hipFree(tile_uptr);
   if (tile_uniq) (void)hipFree(tile_uniq);
   if (tile_eloc) (void)hipFree(tile_eloc);
+  if (idx_w) (void)hipFree(idx_w);
+  if (tile_uniq_w) (void)hipFree(tile_uniq_w);
+  idx_w = nullptr;
+  tile_uniq_w = nullptr;
+  packed_scale = nullptr;
   rowptr = nullptr;
   idx = nullptr;
   tile_uptr = nullptr;
@@ -84,6 +89,14 @@ __global__ void degree_scale_kernel(const int32_t* __restrict__ rowptr, int64_t 
   if (i >= n) return;
   float d = (float)(rowptr[i + 1] - rowptr[i]);
   out[i] = d > 0.f ? (inv_sqrt ? 1.0f / sqrtf(d) : 1.0f / d) : 0.f;
+}
+
+__global__ void pack_scale_kernel(const int32_t* __restrict__ ids, int64_t n, const float* __restrict__ scale,
+                                  int2* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = ids[i];
+  out[i] = make_int2(j, __float_as_int(scale[j]));
 }
 
 __global__ void keys_equal_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
@@ -281,6 +294,26 @@ int build_tiles(Csr* c, hipStream_t stream) {
   SG_HIP_TRY(hipGetLastError());
   SG_HIP_TRY(hipStreamSynchronize(stream));
   c->tile_rows = kTileRows;
+  return SG_OK;
+}
+
+int pack_source_scale(Csr* c, const float* scale, hipStream_t stream) {
+  if (c->nnz == 0 || scale == nullptr) return SG_OK;
+  SG_HIP_TRY(hipMalloc((void**)&c->idx_w, c->nnz * sizeof(int2)));
+  pack_scale_kernel<<<blocks_for(c->nnz), kThreads, 0, stream>>>(c->idx, c->nnz, scale, c->idx_w);
+  SG_HIP_TRY(hipGetLastError());
+  if (c->tile_uptr) {
+    const int64_t nt = (c->n_rows + c->tile_rows - 1) / c->tile_rows;
+    int32_t total = 0;
+    SG_HIP_TRY(hipMemcpyAsync(&total, c->tile_uptr + nt, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    SG_HIP_TRY(hipStreamSynchronize(stream));
+    if (total > 0) {
+      SG_HIP_TRY(hipMalloc((void**)&c->tile_uniq_w, (size_t)total * sizeof(int2)));
+      pack_scale_kernel<<<blocks_for(total), kThreads, 0, stream>>>(c->tile_uniq, total, scale, c->tile_uniq_w);
+      SG_HIP_TRY(hipGetLastError());
+    }
+  }
+  c->packed_scale = scale;
   return SG_OK;
 }
 

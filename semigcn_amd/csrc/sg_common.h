@@ -42,6 +42,12 @@ struct Csr {
   int32_t* tile_uptr = nullptr;   // [n_tiles + 1]
   int32_t* tile_uniq = nullptr;   // [tile_uptr[n_tiles]]
   uint8_t* tile_eloc = nullptr;   // [nnz]
+  // Optional copies of idx / tile_uniq with the source-row scale packed beside each id, (j, bits(scale[j])):
+  // the kernels then stage one 8-byte stream instead of chasing scale[idx[k]] (a dependent gather that
+  // adds a full memory latency to every wavefront's chunk).  Valid for the scale vector `packed_scale`.
+  int2* idx_w = nullptr;          // [nnz]
+  int2* tile_uniq_w = nullptr;    // [tile_uptr[n_tiles]]
+  const float* packed_scale = nullptr;
   void release();
 };
 
@@ -49,6 +55,8 @@ constexpr int kTileRows = 4;       // rows per mini-tile (one accumulator set pe
 constexpr int kTileSlots = 32;     // max distinct source rows per mini-tile
 constexpr int kTileEdges = 128;    // max edges per mini-tile
 int build_tiles(Csr* c, hipStream_t stream);
+// Fills Csr::idx_w (and tile_uniq_w when the CSR carries tiles) for the source scale vector `scale` [n_cols].
+int pack_source_scale(Csr* c, const float* scale, hipStream_t stream);
 
 // Builds a Csr from (dst, src) int64 device pairs. Pairs with dst == src are dropped when
 // drop_self. If keys_out != nullptr the sorted (dst << 32 | src) keys (n entries, dropped
@@ -67,6 +75,8 @@ struct SpmmArgs {
   const int32_t* tile_uptr = nullptr;   // non-null: the CSR carries row tiles (see Csr)
   const int32_t* tile_uniq = nullptr;
   const uint8_t* tile_eloc = nullptr;
+  const int2* idx_w = nullptr;          // non-null: (id, scale bits) pairs replace idx + scale_src lookups
+  const int2* tile_uniq_w = nullptr;
   const float* scale_dst;  // nullable, [n_rows]
   const float* scale_src;  // nullable, [n_cols]
   const void* X;
@@ -75,6 +85,7 @@ struct SpmmArgs {
   void* Y;
   int64_t ldx, ldx0, ldx1, ldy;
   int32_t n_rows;
+  int64_t n_cols = 0;   // rows of X (bounds the gather offsets)
   int32_t C;
   float alpha, beta, gamma;
 };

@@ -35,7 +35,21 @@ struct bf16_tag {};
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2 };
+enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16 };
+
+// Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
+// one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
+// A workgroup barrier here would march the four wavefronts of a block through the metadata / gather / store
+// phases in lock-step (kFlagBlockBarrier restores that for A/B timing).
+__device__ __forceinline__ void wave_sync(int flags) {
+  if (flags & kFlagBlockBarrier) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
 
 template <typename T> struct Vt;
 template <> struct Vt<float> {
@@ -92,42 +106,69 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
 // dropped by a select): hipcc puts `s_waitcnt vmcnt(0)` in front of every load that sits behind
 // a branch, which serialises the gathers -- the batch must be branch-free to keep N*R*16 B per
 // lane in flight.
-template <typename T, int R, int N>
-__device__ __forceinline__ void gather_batch(const int2* __restrict__ edges, int k, int ke,
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc += w * f over VEC values as VEC/2 packed v_pk_fma_f32 (two fp32 FMAs per issued instruction)
+template <int VEC>
+__device__ __forceinline__ void axpy(float w, const float (&f)[VEC], float (&acc)[VEC]) {
+  const f32x2 w2 = {w, w};
+#pragma unroll
+  for (int c = 0; c < VEC; c += 2) {
+    const f32x2 v = {f[c], f[c + 1]};
+    f32x2 a = {acc[c], acc[c + 1]};
+    a = __builtin_elementwise_fma(w2, v, a);
+    acc[c] = a.x;
+    acc[c + 1] = a.y;
+  }
+}
+
+template <typename T, int R, int N, bool NARROW>
+__device__ __forceinline__ void gather_batch(const int2* __restrict__ edges, int k, int ke, int klast,
                                              const typename Vt<T>::elem* __restrict__ X, int64_t ldx,
                                              const int (&voff)[R], float (&acc)[R][Vt<T>::VEC]) {
   using V = Vt<T>;
   using raw_t = typename V::raw;
+  using elem_t = typename V::elem;
   constexpr int VEC = V::VEC;
+  // Slots past the end of this lane group's row re-read the row's LAST neighbour (klast; an L1 hit) and are
+  // switched off through the weight: one select per slot instead of one per accumulated value.  An empty
+  // row has klast = its start, i.e. the next row's first neighbour or the sentinel behind the list (row 0,
+  // weight 0).  Consequence: a non-finite value in such a re-read row surfaces as NaN (0 * inf).
   int2 e[N];
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    int kc = k + u < ke ? k + u : ke - 1;
-    kc = kc < 0 ? 0 : kc;
+    const int kc = k + u < klast ? k + u : klast;
     e[u] = edges[kc];
   }
   raw_t xv[N][R];
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    const typename V::elem* src = X + (int64_t)e[u].x * ldx;
+    if (NARROW) {
+      // byte offsets fit 32 bits, row ids and the row pitch fit 24: one full-rate v_mad_u32_u24 per gather
+      // instead of a 64-bit multiply-add chain (quarter rate) -- this kernel is VALU-issue-bound
+      const uint32_t base = __umul24((uint32_t)e[u].x, (uint32_t)ldx * (uint32_t)sizeof(elem_t));
 #pragma unroll
-    for (int r = 0; r < R; ++r) xv[u][r] = *(const raw_t*)(src + voff[r]);
+      for (int r = 0; r < R; ++r)
+        xv[u][r] = *(const raw_t*)((const char*)X + (base + (uint32_t)voff[r] * (uint32_t)sizeof(elem_t)));
+    } else {
+      const elem_t* src = X + (int64_t)e[u].x * ldx;
+#pragma unroll
+      for (int r = 0; r < R; ++r) xv[u][r] = *(const raw_t*)(src + voff[r]);
+    }
   }
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    const bool valid = k + u < ke;
-    const float w = __int_as_float(e[u].y);
+    const float w = k + u < ke ? __int_as_float(e[u].y) : 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float f[VEC];
       V::unpack(xv[u][r], f);
-#pragma unroll
-      for (int c = 0; c < VEC; ++c) acc[r][c] = valid ? fmaf(w, f[c], acc[r][c]) : acc[r][c];
+      axpy<VEC>(w, f, acc[r]);
     }
   }
 }
 
-template <typename T, int G, int R, int NEPI>
+template <typename T, int G, int R, int NEPI, bool NARROW>
 __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int ch, const int nblocks,
                                                      const int flags) {
   using V = Vt<T>;
@@ -138,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 
   __shared__ int32_t s_rp[kWaves][kChMax + 1];
   __shared__ float s_sd[kWaves][kChMax];
-  __shared__ int2 s_e[kWaves][kCap];
+  __shared__ int2 s_e[kWaves][kCap + 1];   // + the sentinel slot of gather_batch
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -152,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
     for (int l = lane; l <= nrows; l += 64) s_rp[wave][l] = a.rowptr[r0 + l];
     for (int l = lane; l < nrows; l += 64) s_sd[wave][l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
   }
-  __syncthreads();
+  wave_sync(flags);
   int e0 = 0, ne = 0;
   if (nrows > 0) {
     e0 = s_rp[wave][0];
@@ -160,13 +201,18 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
   }
   const bool staged = ne <= kCap;  // wave-uniform; a chunk holding a huge row takes the slow path
   if (staged) {
-    for (int k = lane; k < ne; k += 64) {
-      const int j = a.idx[e0 + k];
-      const float w = a.scale_src ? a.scale_src[j] : 1.0f;
-      s_e[wave][k] = make_int2(j, __float_as_int(w));
+    if (a.idx_w) {
+      for (int k = lane; k < ne; k += 64) s_e[wave][k] = a.idx_w[e0 + k];
+    } else {
+      for (int k = lane; k < ne; k += 64) {
+        const int j = a.idx[e0 + k];
+        const float w = a.scale_src ? a.scale_src[j] : 1.0f;
+        s_e[wave][k] = make_int2(j, __float_as_int(w));
+      }
     }
+    if (lane == 0) s_e[wave][ne] = make_int2(0, 0);
   }
-  __syncthreads();
+  wave_sync(flags);
 
   const int g = lane / G;   // which of the RPW simultaneous rows
   const int gl = lane % G;  // lane inside the row group
@@ -209,12 +255,15 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 
     if (staged) {
       int k = ks;
+      // narrow rows: slots past the row's end run on into the next rows' neighbours (a free prefetch of what this
+      // wavefront gathers next, measured faster up to 256-B rows); wide rows: re-read the row's last neighbour
+      const int klast = a.C * (int)sizeof(elem_t) <= 256 ? ne : (ke - 1 > ks ? ke - 1 : ks);
       while (__any(k < ke)) {                 // wave-uniform trip count: the longest row decides
         const int rem = ke - k;
-        if (R * 8 <= 16 && __any(rem > 6)) { gather_batch<T, R, 8>(edges, k, ke, X, a.ldx, voff, acc); k += 8; }
-        else if (R * 6 <= 16 && __any(rem > 4)) { gather_batch<T, R, 6>(edges, k, ke, X, a.ldx, voff, acc); k += 6; }
-        else if (R * 4 <= 16 && __any(rem > 2)) { gather_batch<T, R, 4>(edges, k, ke, X, a.ldx, voff, acc); k += 4; }
-        else { gather_batch<T, R, 2>(edges, k, ke, X, a.ldx, voff, acc); k += 2; }
+        if (R * 8 <= 16 && __any(rem > 6)) { gather_batch<T, R, 8, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 8; }
+        else if (R * 6 <= 16 && __any(rem > 4)) { gather_batch<T, R, 6, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 6; }
+        else if (R * 4 <= 16 && __any(rem > 2)) { gather_batch<T, R, 4, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 4; }
+        else { gather_batch<T, R, 2, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 2; }
       }
     } else {
       for (int k = ks; k < ke; ++k) {         // rare: more than kCap neighbours in one chunk
@@ -262,12 +311,13 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 // ---------------------------------------------------------------------------------------------
 constexpr int kShTilesPerGroup = 2;                       // mini-tiles a lane group works through per wavefront
 
-template <typename T, int R, int N>
+template <typename T, int R, int N, bool NARROW>
 __device__ __forceinline__ void shared_batch(const int2* __restrict__ su, const uint32_t* __restrict__ sm, int k, int nu,
                                              const typename Vt<T>::elem* __restrict__ X, int64_t ldx,
                                              const int (&voff)[R], float (&acc)[kTileRows][R][Vt<T>::VEC]) {
   using V = Vt<T>;
   using raw_t = typename V::raw;
+  using elem_t = typename V::elem;
   constexpr int VEC = V::VEC;
   int2 e[N];
   uint32_t m[N];
@@ -281,29 +331,34 @@ __device__ __forceinline__ void shared_batch(const int2* __restrict__ su, const 
   raw_t xv[N][R];
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    const typename V::elem* src = X + (int64_t)e[u].x * ldx;
+    if (NARROW) {
+      const uint32_t base = __umul24((uint32_t)e[u].x, (uint32_t)ldx * (uint32_t)sizeof(elem_t));
 #pragma unroll
-    for (int r = 0; r < R; ++r) xv[u][r] = *(const raw_t*)(src + voff[r]);
+      for (int r = 0; r < R; ++r)
+        xv[u][r] = *(const raw_t*)((const char*)X + (base + (uint32_t)voff[r] * (uint32_t)sizeof(elem_t)));
+    } else {
+      const elem_t* src = X + (int64_t)e[u].x * ldx;
+#pragma unroll
+      for (int r = 0; r < R; ++r) xv[u][r] = *(const raw_t*)(src + voff[r]);
+    }
   }
 #pragma unroll
   for (int u = 0; u < N; ++u) {
     const float w = __int_as_float(e[u].y);
+    float wq[kTileRows];      // the source's weight for each of the tile's rows, 0 where it is no neighbour
+#pragma unroll
+    for (int q = 0; q < kTileRows; ++q) wq[q] = (m[u] >> q) & 1u ? w : 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float f[VEC];
       V::unpack(xv[u][r], f);
 #pragma unroll
-      for (int q = 0; q < kTileRows; ++q) {
-        if (m[u] & (1u << q)) {
-#pragma unroll
-          for (int c = 0; c < VEC; ++c) acc[q][r][c] = fmaf(w, f[c], acc[q][r][c]);
-        }
-      }
+      for (int q = 0; q < kTileRows; ++q) axpy<VEC>(wq[q], f, acc[q][r]);
     }
   }
 }
 
-template <typename T, int G, int R, int NEPI>
+template <typename T, int G, int R, int NEPI, bool NARROW>
 __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const int nblocks, const int flags) {
   using V = Vt<T>;
   constexpr int VEC = V::VEC;
@@ -336,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
     for (int l = lane; l <= nrows; l += 64) s_rp[wave][l] = a.rowptr[r0 + l];
     for (int l = lane; l < nrows; l += 64) s_sd[wave][l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
   }
-  __syncthreads();
+  wave_sync(flags);
   int ub = 0, nut = 0, e0 = 0, ne = 0;
   if (nm > 0) {
     ub = s_up[wave][0];
@@ -345,11 +400,15 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
     ne = s_rp[wave][nrows] - e0;
   }
   for (int k = lane; k < nut; k += 64) {
-    const int j = a.tile_uniq[ub + k];
-    s_u[wave][k] = make_int2(j, __float_as_int(a.scale_src ? a.scale_src[j] : 1.0f));
+    if (a.tile_uniq_w) {
+      s_u[wave][k] = a.tile_uniq_w[ub + k];
+    } else {
+      const int j = a.tile_uniq[ub + k];
+      s_u[wave][k] = make_int2(j, __float_as_int(a.scale_src ? a.scale_src[j] : 1.0f));
+    }
     s_m[wave][k] = 0u;
   }
-  __syncthreads();
+  wave_sync(flags);
   for (int k = lane; k < ne; k += 64) {
     int lo = 0, hi = nrows;                                 // row of edge e0+k: last lr with s_rp[lr] <= e0+k
     while (hi - lo > 1) {
@@ -359,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
     const int mt = lo / kTileRows;
     atomicOr(&s_m[wave][s_up[wave][mt] - ub + a.tile_eloc[e0 + k]], 1u << (lo % kTileRows));
   }
-  __syncthreads();
+  wave_sync(flags);
 
   const int g = lane / G, gl = lane % G;
   const int nvec = a.C / VEC;
@@ -383,17 +442,6 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
     const int u0 = s_up[wave][mtc] - ub;
     const int nu = tvalid ? s_up[wave][mtc + 1] - s_up[wave][mtc] : 0;
     const int lr0 = mtc * kTileRows;
-    raw_t x0v[kTileRows][R], x1v[kTileRows][R];
-#pragma unroll
-    for (int q = 0; q < kTileRows; ++q) {
-      int row = r0 + lr0 + q;
-      row = row < a.n_rows ? row : a.n_rows - 1;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (NEPI >= 1) x0v[q][r] = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff[r]);
-        if (NEPI >= 2) x1v[q][r] = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + voff[r]);
-      }
-    }
     float acc[kTileRows][R][VEC];
 #pragma unroll
     for (int q = 0; q < kTileRows; ++q)
@@ -407,9 +455,22 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
     int k = 0;
     while (__any(k < nu)) {
       const int rem = nu - k;
-      if (R * 8 <= 8 && __any(rem > 4)) { shared_batch<T, R, 8>(su, sm, k, nu, X, a.ldx, voff, acc); k += 8; }
-      else if (__any(rem > 2)) { shared_batch<T, R, 4>(su, sm, k, nu, X, a.ldx, voff, acc); k += 4; }
-      else { shared_batch<T, R, 2>(su, sm, k, nu, X, a.ldx, voff, acc); k += 2; }
+      if (R * 8 <= 8 && __any(rem > 4)) { shared_batch<T, R, 8, NARROW>(su, sm, k, nu, X, a.ldx, voff, acc); k += 8; }
+      else if (__any(rem > 2)) { shared_batch<T, R, 4, NARROW>(su, sm, k, nu, X, a.ldx, voff, acc); k += 4; }
+      else { shared_batch<T, R, 2, NARROW>(su, sm, k, nu, X, a.ldx, voff, acc); k += 2; }
+    }
+    // epilogue operands AFTER the gathers: holding 4 rows x NEPI vectors across the gather loop costs a whole
+    // occupancy step (130 -> ~100 VGPRs at C = 256 fp32); other wavefronts cover this one extra latency
+    raw_t x0v[kTileRows][R], x1v[kTileRows][R];
+#pragma unroll
+    for (int q = 0; q < kTileRows; ++q) {
+      int row = r0 + lr0 + q;
+      row = row < a.n_rows ? row : a.n_rows - 1;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (NEPI >= 1) x0v[q][r] = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff[r]);
+        if (NEPI >= 2) x1v[q][r] = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + voff[r]);
+      }
     }
 
 #pragma unroll
@@ -522,7 +583,12 @@ int launch_rows_epi(const SpmmArgs& a, hipStream_t stream) {
   ch = (ch / RPW) * RPW;
   const int64_t chunks = ((int64_t)a.n_rows + ch - 1) / ch;
   const int nblocks = (int)((chunks + kWaves - 1) / kWaves);
-  spmm_rows<T, G, R, NEPI><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks, g_tuning.flags);
+  // 24-bit row ids / row pitch and 32-bit byte offsets into X: the cheap gather addressing (see gather_batch)
+  constexpr int64_t esz = sizeof(typename Vt<T>::elem);
+  const bool narrow = !(g_tuning.flags & kFlagWideAddr) && a.n_cols > 0 && a.n_cols < (1 << 24) &&
+                      a.ldx * esz < (1 << 24) && a.n_cols * a.ldx * esz < ((int64_t)1 << 32);
+  if (narrow) spmm_rows<T, G, R, NEPI, true><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks, g_tuning.flags);
+  else spmm_rows<T, G, R, NEPI, false><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks, g_tuning.flags);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
@@ -534,9 +600,14 @@ int launch_shared(const SpmmArgs& a, hipStream_t stream) {
   const int nblocks = (int)((n_mt + (int64_t)MT * kWaves - 1) / ((int64_t)MT * kWaves));
   SpmmArgs b = a;
   if (!a.X0 && a.X1) { b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f; }
-  if (b.X0 && b.X1) spmm_shared<T, G, R, 2><<<nblocks, kBlock, 0, stream>>>(b, nblocks, g_tuning.flags);
-  else if (b.X0) spmm_shared<T, G, R, 1><<<nblocks, kBlock, 0, stream>>>(b, nblocks, g_tuning.flags);
-  else spmm_shared<T, G, R, 0><<<nblocks, kBlock, 0, stream>>>(b, nblocks, g_tuning.flags);
+  constexpr int64_t esz = sizeof(typename Vt<T>::elem);
+  const bool narrow = !(g_tuning.flags & kFlagWideAddr) && a.n_cols > 0 && a.n_cols < (1 << 24) &&
+                      a.ldx * esz < (1 << 24) && a.n_cols * a.ldx * esz < ((int64_t)1 << 32);
+#define SG_SHARED(NE, NW) spmm_shared<T, G, R, NE, NW><<<nblocks, kBlock, 0, stream>>>(b, nblocks, g_tuning.flags)
+  if (b.X0 && b.X1) { if (narrow) SG_SHARED(2, true); else SG_SHARED(2, false); }
+  else if (b.X0) { if (narrow) SG_SHARED(1, true); else SG_SHARED(1, false); }
+  else { if (narrow) SG_SHARED(0, true); else SG_SHARED(0, false); }
+#undef SG_SHARED
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
@@ -571,15 +642,15 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
   }
   const int nvec = a.C / VEC;
   // Wide rows of a graph that carries mini-tiles: gather each distinct source row of 4 rows once.
-  // Measured on the 1 M-vertex Morton-ordered mesh (tools/agg_bench.py): it pays for fp32 rows of
-  // >= 1 KiB with an epilogue operand (0.685 -> 0.643 ms at C=256) and for 2 KiB rows (1.20 -> 1.04 ms
-  // at C=512); it loses on 512-B rows and in bf16 (4 x 8 accumulators per lane cost occupancy), so
-  // those keep spmm_rows unless SG_TUNE_TILED_MIN_ROW_BYTES forces them (negative value = force).
+  // Measured on the 1 M-vertex Morton-ordered mesh (tools/agg_bench.py): it pays for fp32 rows of >= 1 KiB
+  // (C=256: 0.546 -> 0.506 ms plain, 0.683 -> 0.667 ms with an epilogue operand; C=512: 1.065 -> 0.964 /
+  // 1.354 -> 1.286 ms); it loses in bf16 (4 x 8 accumulators per lane cost an occupancy step: 0.31 -> 0.43 ms
+  // at C=256) and on narrower rows, so those keep spmm_rows unless SG_TUNE_TILED_MIN_ROW_BYTES forces
+  // them (negative value = force).
   const int row_bytes = a.C * (int)sizeof(typename Vt<T>::elem);
   const int tmin = g_tuning.tiled_min_row_bytes;
   const bool forced = tmin < 0 && row_bytes >= -tmin;
-  const bool pays = tmin > 0 && sizeof(typename Vt<T>::elem) == 4 && row_bytes >= tmin &&
-                    (row_bytes >= 2 * tmin || a.X0 || a.X1);
+  const bool pays = tmin > 0 && sizeof(typename Vt<T>::elem) == 4 && row_bytes >= tmin;
   if (a.tile_uptr && (forced || pays) && !(g_tuning.flags & kFlagNoTiles)) {
     if (nvec > 16 && nvec <= 32) return launch_shared<T, 32, 1>(a, stream);
     if (nvec > 32 && nvec <= 64) return launch_shared<T, 64, 1>(a, stream);
@@ -633,8 +704,13 @@ int set_tuning(int knob, int value) {
   }
 }
 
-int launch_spmm(const SpmmArgs& a, int dtype, hipStream_t stream) {
-  if (a.n_rows == 0 || a.C == 0) return SG_OK;
+int launch_spmm(const SpmmArgs& a_in, int dtype, hipStream_t stream) {
+  if (a_in.n_rows == 0 || a_in.C == 0) return SG_OK;
+  SpmmArgs a = a_in;
+  if (g_tuning.flags & kFlagNoPackedScale) {     // A/B switch: chase scale_src[idx[k]] as before
+    a.idx_w = nullptr;
+    a.tile_uniq_w = nullptr;
+  }
   switch (dtype) {
     case SG_F32: return launch_typed<float>(a, stream);
     case SG_BF16: return launch_typed<bf16_tag>(a, stream);
