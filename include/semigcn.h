@@ -250,7 +250,8 @@ enum sg_tune_knob {
   SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map, bit 1: never use the shared-gather kernel,
                              bit 2: ignore the (id, scale) packed neighbour lists, bit 3: workgroup barriers
                              between the staging phases instead of wavefront-local ones, bit 4: 64-bit gather addressing
-                             even where 32-bit offsets would do (A/B switches) */
+                             even where 32-bit offsets would do, bit 5: fixed-size gather batches also where the
+                             row length is wave-uniform (A/B switches) */
   SG_TUNE_UNROLL = 2,     /* reserved */
   SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */
   SG_TUNE_TILED_MIN_ROW_BYTES = 4 /* shared-gather kernel (each distinct source row of a 4-row mini-tile is

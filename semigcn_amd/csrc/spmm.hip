@@ -35,7 +35,7 @@ struct bf16_tag {};
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16 };
+enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32 };
 
 // Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
 // one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
@@ -122,7 +122,7 @@ __device__ __forceinline__ void axpy(float w, const float (&f)[VEC], float (&acc
   }
 }
 
-template <typename T, int R, int N, bool NARROW>
+template <typename T, int R, int N, bool NARROW, bool EXACT = false>
 __device__ __forceinline__ void gather_batch(const int2* __restrict__ edges, int k, int ke, int klast,
                                              const typename Vt<T>::elem* __restrict__ X, int64_t ldx,
                                              const int (&voff)[R], float (&acc)[R][Vt<T>::VEC]) {
@@ -134,10 +134,12 @@ __device__ __forceinline__ void gather_batch(const int2* __restrict__ edges, int
   // switched off through the weight: one select per slot instead of one per accumulated value.  An empty
   // row has klast = its start, i.e. the next row's first neighbour or the sentinel behind the list (row 0,
   // weight 0).  Consequence: a non-finite value in such a re-read row surfaces as NaN (0 * inf).
+  // EXACT (one row per wavefront, so the caller can size the batch to the row): every slot is live -- no clamp,
+  // no select, and the N list entries are read at immediate offsets from one LDS address.
   int2 e[N];
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    const int kc = k + u < klast ? k + u : klast;
+    const int kc = EXACT ? k + u : (k + u < klast ? k + u : klast);
     e[u] = edges[kc];
   }
   raw_t xv[N][R];
@@ -158,7 +160,7 @@ __device__ __forceinline__ void gather_batch(const int2* __restrict__ edges, int
   }
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    const float w = k + u < ke ? __int_as_float(e[u].y) : 0.f;
+    const float w = (EXACT || k + u < ke) ? __int_as_float(e[u].y) : 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float f[VEC];
@@ -255,6 +257,26 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 
     if (staged) {
       int k = ks;
+      if (RPW == 1 && !(flags & kFlagNoExact)) {
+        // the whole wavefront is on ONE row: its length is wave-uniform, so the batches are cut to fit exactly
+        constexpr int NMAX = R * 8 <= 16 ? 8 : (R * 4 <= 16 ? 4 : 2);
+        int rem = __builtin_amdgcn_readfirstlane(ke - ks);
+        while (rem > 0) {
+          const int n = rem < NMAX ? rem : NMAX;
+          switch (n) {
+            case 8: if (NMAX >= 8) gather_batch<T, R, 8, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+            case 7: if (NMAX >= 8) gather_batch<T, R, 7, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+            case 6: if (NMAX >= 8) gather_batch<T, R, 6, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+            case 5: if (NMAX >= 8) gather_batch<T, R, 5, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+            case 4: if (NMAX >= 4) gather_batch<T, R, 4, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+            case 3: if (NMAX >= 4) gather_batch<T, R, 3, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+            case 2: gather_batch<T, R, 2, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+            default: gather_batch<T, R, 1, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+          }
+          k += n;
+          rem -= n;
+        }
+      } else {
       // narrow rows: slots past the row's end run on into the next rows' neighbours (a free prefetch of what this
       // wavefront gathers next, measured faster up to 256-B rows); wide rows: re-read the row's last neighbour
       const int klast = a.C * (int)sizeof(elem_t) <= 256 ? ne : (ke - 1 > ks ? ke - 1 : ks);
@@ -264,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
         else if (R * 6 <= 16 && __any(rem > 4)) { gather_batch<T, R, 6, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 6; }
         else if (R * 4 <= 16 && __any(rem > 2)) { gather_batch<T, R, 4, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 4; }
         else { gather_batch<T, R, 2, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 2; }
+      }
       }
     } else {
       for (int k = ks; k < ke; ++k) {         // rare: more than kCap neighbours in one chunk
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 // ---------------------------------------------------------------------------------------------
 constexpr int kShTilesPerGroup = 2;                       // mini-tiles a lane group works through per wavefront
 
-template <typename T, int R, int N, bool NARROW>
+template <typename T, int R, int N, bool NARROW, bool EXACT = false>
 __device__ __forceinline__ void shared_batch(const int2* __restrict__ su, const uint32_t* __restrict__ sm, int k, int nu,
                                              const typename Vt<T>::elem* __restrict__ X, int64_t ldx,
                                              const int (&voff)[R], float (&acc)[kTileRows][R][Vt<T>::VEC]) {
@@ -323,10 +346,15 @@ __device__ __forceinline__ void shared_batch(const int2* __restrict__ su, const 
   uint32_t m[N];
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    int kc = k + u < nu ? k + u : nu - 1;
-    kc = kc < 0 ? 0 : kc;
-    e[u] = su[kc];
-    m[u] = k + u < nu ? sm[kc] : 0u;
+    if (EXACT) {        // the caller cut the batch to the tile's source list: every slot is live
+      e[u] = su[k + u];
+      m[u] = sm[k + u];
+    } else {
+      int kc = k + u < nu ? k + u : nu - 1;
+      kc = kc < 0 ? 0 : kc;
+      e[u] = su[kc];
+      m[u] = k + u < nu ? sm[kc] : 0u;
+    }
   }
   raw_t xv[N][R];
 #pragma unroll
@@ -453,11 +481,31 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
     const int2* su = s_u[wave] + u0;
     const uint32_t* sm = s_m[wave] + u0;
     int k = 0;
-    while (__any(k < nu)) {
-      const int rem = nu - k;
-      if (R * 8 <= 8 && __any(rem > 4)) { shared_batch<T, R, 8, NARROW>(su, sm, k, nu, X, a.ldx, voff, acc); k += 8; }
-      else if (__any(rem > 2)) { shared_batch<T, R, 4, NARROW>(su, sm, k, nu, X, a.ldx, voff, acc); k += 4; }
-      else { shared_batch<T, R, 2, NARROW>(su, sm, k, nu, X, a.ldx, voff, acc); k += 2; }
+    if (RPW == 1 && !(flags & kFlagNoExact)) {     // one mini-tile per wavefront at a time: its source count is wave-uniform -> exact batches
+      constexpr int NMAX = R * 8 <= 8 ? 8 : 4;
+      int rem = __builtin_amdgcn_readfirstlane(nu);
+      while (rem > 0) {
+        const int n = rem < NMAX ? rem : NMAX;
+        switch (n) {
+          case 8: if (NMAX >= 8) shared_batch<T, R, 8, NARROW, true>(su, sm, k, nu, X, a.ldx, voff, acc); break;
+          case 7: if (NMAX >= 8) shared_batch<T, R, 7, NARROW, true>(su, sm, k, nu, X, a.ldx, voff, acc); break;
+          case 6: if (NMAX >= 8) shared_batch<T, R, 6, NARROW, true>(su, sm, k, nu, X, a.ldx, voff, acc); break;
+          case 5: if (NMAX >= 8) shared_batch<T, R, 5, NARROW, true>(su, sm, k, nu, X, a.ldx, voff, acc); break;
+          case 4: shared_batch<T, R, 4, NARROW, true>(su, sm, k, nu, X, a.ldx, voff, acc); break;
+          case 3: shared_batch<T, R, 3, NARROW, true>(su, sm, k, nu, X, a.ldx, voff, acc); break;
+          case 2: shared_batch<T, R, 2, NARROW, true>(su, sm, k, nu, X, a.ldx, voff, acc); break;
+          default: shared_batch<T, R, 1, NARROW, true>(su, sm, k, nu, X, a.ldx, voff, acc); break;
+        }
+        k += n;
+        rem -= n;
+      }
+    } else {
+      while (__any(k < nu)) {
+        const int rem = nu - k;
+        if (R * 8 <= 8 && __any(rem > 4)) { shared_batch<T, R, 8, NARROW>(su, sm, k, nu, X, a.ldx, voff, acc); k += 8; }
+        else if (__any(rem > 2)) { shared_batch<T, R, 4, NARROW>(su, sm, k, nu, X, a.ldx, voff, acc); k += 4; }
+        else { shared_batch<T, R, 2, NARROW>(su, sm, k, nu, X, a.ldx, voff, acc); k += 2; }
+      }
     }
     // epilogue operands AFTER the gathers: holding 4 rows x NEPI vectors across the gather loop costs a whole
     // occupancy step (130 -> ~100 VGPRs at C = 256 fp32); other wavefronts cover this one extra latency
@@ -642,15 +690,16 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
   }
   const int nvec = a.C / VEC;
   // Wide rows of a graph that carries mini-tiles: gather each distinct source row of 4 rows once.
-  // Measured on the 1 M-vertex Morton-ordered mesh (tools/agg_bench.py): it pays for fp32 rows of >= 1 KiB
-  // (C=256: 0.546 -> 0.506 ms plain, 0.683 -> 0.667 ms with an epilogue operand; C=512: 1.065 -> 0.964 /
-  // 1.354 -> 1.286 ms); it loses in bf16 (4 x 8 accumulators per lane cost an occupancy step: 0.31 -> 0.43 ms
-  // at C=256) and on narrower rows, so those keep spmm_rows unless SG_TUNE_TILED_MIN_ROW_BYTES forces
-  // them (negative value = force).
+  // Measured on the 1 M-vertex Morton-ordered mesh (tools/agg_bench.py, variants interleaved in one process):
+  // it pays for fp32 rows of 2 KiB (C=512: 1.13 -> 0.97 ms plain, 1.40 -> 1.31 ms with an epilogue operand) and
+  // for plain 1 KiB rows (C=256: 0.571 -> 0.515 ms); with an epilogue operand the 1 KiB case is a wash
+  // (0.687 vs 0.708 ms) and bf16 loses (4 x 8 accumulators per lane cost an occupancy step: 0.31 -> 0.43 ms at
+  // C=256), so those keep spmm_rows unless SG_TUNE_TILED_MIN_ROW_BYTES forces them (negative value = force).
   const int row_bytes = a.C * (int)sizeof(typename Vt<T>::elem);
   const int tmin = g_tuning.tiled_min_row_bytes;
   const bool forced = tmin < 0 && row_bytes >= -tmin;
-  const bool pays = tmin > 0 && sizeof(typename Vt<T>::elem) == 4 && row_bytes >= tmin;
+  const bool pays = tmin > 0 && sizeof(typename Vt<T>::elem) == 4 && row_bytes >= tmin &&
+                    (row_bytes >= 2 * tmin || !(a.X0 || a.X1));
   if (a.tile_uptr && (forced || pays) && !(g_tuning.flags & kFlagNoTiles)) {
     if (nvec > 16 && nvec <= 32) return launch_shared<T, 32, 1>(a, stream);
     if (nvec > 32 && nvec <= 64) return launch_shared<T, 64, 1>(a, stream);
