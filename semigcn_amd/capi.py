@@ -445,10 +445,11 @@ def bn_act_bwd_reduce(dA, H, scale, shift, mean, invstd, slope: float) -> torch.
     return part
 
 
-def bn_act_bwd_apply(dA, H, scale, shift, mean, invstd, k, c1, c2, slope: float) -> torch.Tensor:
+def bn_act_bwd_apply(dA, H, scale, shift, mean, invstd, k, c1, c2, slope: float,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _require_device(dA, "dA")
     V, C = H.shape
-    dH = torch.empty((V, C), dtype=H.dtype, device=H.device)
+    dH = torch.empty((V, C), dtype=H.dtype, device=H.device) if out is None else out
     with _on_device(H.device):
         _check(load().sg_bn_act_bwd_apply(_ptr(dA), _rows2d(dA, "dA"), _ptr(H), _rows2d(H, "H"),
                                           _ptr(_f32vec(scale, C, "scale")), _ptr(_f32vec(shift, C, "shift")),

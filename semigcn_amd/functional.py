@@ -201,12 +201,15 @@ class _ChebConvPostFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, wstack = ctx.saved_tensors
         graph, K, Co = ctx.graph, ctx.K, ctx.Co
-        dout = dout.contiguous()
         V = dout.shape[0]
         tr = not graph.symmetric
-        G = torch.empty((V, K * Co), dtype=dout.dtype, device=dout.device)
+        G = _adopt_wide(dout, K)          # the fused BatchNorm backward writes dout into block 0 of a [V, K*Co] buffer
+        if G is None:
+            dout = dout.contiguous()
+            G = torch.empty((V, K * Co), dtype=dout.dtype, device=dout.device)
+            G[:, :Co].copy_(dout)
         g = [G[:, k * Co:(k + 1) * Co] for k in range(K)]
-        g[0].copy_(dout)
+        dout = g[0]
         graph.aggregate(g[0], g[1], alpha=1.0, transpose=tr)
         for k in range(2, K):
             graph.aggregate(g[k - 1], g[k], alpha=2.0, X0=g[k - 2], beta=-1.0, transpose=tr)
@@ -303,7 +306,8 @@ def _merge_moments(counts: torch.Tensor, means: torch.Tensor, m2s: torch.Tensor)
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, group, widen):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, group, widen,
+                grad_widen=1):
         V, C = x.shape
         if x.stride(1) != 1 and C > 1:
             x = x.contiguous()
@@ -341,6 +345,7 @@ class _BNActFn(torch.autograd.Function):
             obs(y)
         ctx.save_for_backward(x, scale, shift, mean, invstd, w32)
         ctx.training, ctx.slope, ctx.group, ctx.param_dtype = training, slope, group, weight.dtype
+        ctx.grad_widen = grad_widen
         return y
 
     @staticmethod
@@ -363,8 +368,11 @@ class _BNActFn(torch.autograd.Function):
             c1 = torch.zeros_like(scale)
             c2 = c1
             k = scale
-        dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        out = None
+        if ctx.grad_widen > 1:     # born as block 0 of the conv's [V, K*C] gradient buffer (see _ChebConvPostFn.backward)
+            out = torch.empty((x.shape[0], ctx.grad_widen * x.shape[1]), dtype=x.dtype, device=x.device)[:, :x.shape[1]]
+        dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope, out=out)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 #: callables invoked with every fused BN+activation output (sign(y) == sign of the BatchNorm output);
@@ -380,7 +388,8 @@ def ctx_group_active(group) -> bool:
     return tdist.is_initialized() and tdist.get_world_size(group) > 1
 
 
-def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int = 1) -> torch.Tensor:
+def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int = 1,
+           grad_widen: int = 1) -> torch.Tensor:
     """``leaky_relu(bn(x), slope)`` with nn.BatchNorm1d semantics (batch statistics and running-stat
     updates in training mode, running statistics in eval mode) in two HIP passes.  ``widen = K``
     returns a view of the first C columns of a fresh [V, K*C] buffer, which the next ChebConv
@@ -394,7 +403,8 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int =
     group = getattr(bn, "group", False) if getattr(bn, "sg_mesh_wide", False) else False
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BNActFn.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, float(slope), group, int(widen))
+    return _BNActFn.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, float(slope), group, int(widen),
+                          int(grad_widen))
 
 
 # --------------------------------------------------------------------------------------------

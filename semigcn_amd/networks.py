@@ -52,17 +52,31 @@ class _DeviceCache:
         return dev
 
 
+def _column_min_max(z1: torch.Tensor, block: int = 4096):
+    """min / max over dim 0 of [V, 3] as [1, 3] tensors, with the values and gradient routing of
+    ``torch.min(z1, dim=0)`` (one arg-extreme per column).  ATen's strided column reduction takes 1.3 ms at
+    V = 1 M and a 3-row reduction of the transposed copy 0.25 ms per call (three workgroups); two stages over
+    ``block``-wide pieces of the transposed copy keep the whole chip busy (~0.03 ms)."""
+    zt = z1.t().contiguous()                       # [3, V]
+    V = zt.shape[1]
+    n = (V // block) * block
+    if n == 0:
+        return torch.min(zt, dim=1)[0].view(1, -1), torch.max(zt, dim=1)[0].view(1, -1)
+    body = zt[:, :n].view(zt.shape[0], -1, block)
+    lo, hi = torch.min(body, dim=2)[0], torch.max(body, dim=2)[0]
+    if n < V:
+        lo = torch.cat([lo, torch.min(zt[:, n:], dim=1, keepdim=True)[0]], dim=1)
+        hi = torch.cat([hi, torch.max(zt[:, n:], dim=1, keepdim=True)[0]], dim=1)
+    return torch.min(lo, dim=1)[0].view(1, -1), torch.max(hi, dim=1)[0].view(1, -1)
+
+
 def prepare_input(z1: torch.Tensor, dm: torch.Tensor, lo: Optional[torch.Tensor] = None,
                   hi: Optional[torch.Tensor] = None) -> torch.Tensor:
     """util/networks.py:67-79 -- bounding-box normalisation with ONE scalar scale and a
     per-axis centre, masking of all three coordinates, mask appended as 4th channel.
     ``lo`` / ``hi`` [1,3]: mesh-wide bounds when z1 is only one rank's share."""
     if lo is None:
-        # same values and gradients as min/max over dim 0 of [V,3]; reducing the transposed copy along its
-        # contiguous axis is ~30x faster than ATen's strided column reduction at V = 1 M (1.3 ms -> 0.04 ms)
-        zt = z1.t().contiguous()
-        lo = torch.min(zt, dim=1)[0].view(1, -1)
-        hi = torch.max(zt, dim=1)[0].view(1, -1)
+        lo, hi = _column_min_max(z1)
     extent = torch.max(hi - lo)
     centred = (z1 - (lo + hi) * 0.5) / extent
     return torch.cat([dm * centred, dm], dim=1)

@@ -76,6 +76,12 @@ class ChebConv(nn.Module):
         post = F_sg.AGGREGATE_AFTER_GEMM_WHEN_NARROWING and self.K >= 2 and self.out_channels < self.in_channels
         return 1 if (post or self.K == 1) else self.K
 
+    def grad_buffer_blocks(self) -> int:
+        """K when the backward pass runs the Chebyshev recurrence on the OUTPUT gradient (aggregate-after-GEMM
+        layers): the producer of that gradient may then write it straight into block 0 of a [V, K*Cout] buffer."""
+        post = F_sg.AGGREGATE_AFTER_GEMM_WHEN_NARROWING and self.K >= 2 and self.out_channels < self.in_channels
+        return self.K if post else 1
+
     def forward(self, x: Tensor, edge_index: Union[Tensor, MeshGraph], edge_weight=None, batch=None,
                 lambda_max=None) -> Tensor:
         if edge_weight is not None or batch is not None or lambda_max is not None:
@@ -140,7 +146,7 @@ class Sequential(nn.Module):
     out_widen = 1
 
     def _fusable_at(self, i: int):
-        """(slope, widen) when entries i, i+1 are BatchNorm1d -> LeakyReLU/ReLU on one variable."""
+        """(slope, widen, grad_widen) when entries i, i+1 are BatchNorm1d -> LeakyReLU/ReLU on one variable."""
         if i + 1 >= len(self._plan):
             return None
         (n0, in0, out0), (n1, in1, out1) = self._plan[i], self._plan[i + 1]
@@ -161,7 +167,12 @@ class Sequential(nn.Module):
                 widen = nxt.input_buffer_blocks()
         else:
             widen = self.out_widen
-        return slope, widen
+        grad_widen = 1       # the conv in front takes its output gradient as block 0 of a [V, K*Cout] buffer?
+        if i >= 1:
+            prv = getattr(self, self._plan[i - 1][0])
+            if isinstance(prv, ChebConv) and prv.out_channels == bn.num_features and self._plan[i - 1][2] == in0:
+                grad_widen = prv.grad_buffer_blocks()
+        return slope, widen, grad_widen
 
     def forward(self, *args, **kwargs):
         scope = dict(zip(self._args, args))
@@ -176,7 +187,8 @@ class Sequential(nn.Module):
             if fused is not None:      # BatchNorm1d + (Leaky)ReLU in two HIP passes instead of five ATen ones
                 # (a partitioned conv needs [owned | halo] rows in its buffer: it cannot adopt a widened one)
                 partitioned = any(getattr(v, "sg_partitioned", False) for v in scope.values())
-                result = F_sg.bn_act(vals[0], getattr(self, name), fused[0], 1 if partitioned else fused[1])
+                result = F_sg.bn_act(vals[0], getattr(self, name), fused[0], 1 if partitioned else fused[1],
+                                     1 if partitioned else fused[2])
                 i += 1
             else:
                 result = getattr(self, name)(*vals)

@@ -635,7 +635,30 @@ def test_bn_act_widen_is_adopted_by_the_next_conv(fixture_meshes):
     for cout, widen in ((40, 3), (8, 1)):          # a narrowing next layer aggregates after its GEMM: nothing to adopt
         seq = sgnn.Sequential("x, edge_index", [(sgnn.ChebConv(4, 32, K=3), "x, edge_index -> x"), torch.nn.BatchNorm1d(32),
                                                 torch.nn.LeakyReLU(), (sgnn.ChebConv(32, cout, K=3), "x, edge_index -> x")]).to(DEV)
-        assert seq._fusable_at(1) == (0.01, widen) and seq._fusable_at(0) is None
+        assert seq._fusable_at(1) == (0.01, widen, 1) and seq._fusable_at(0) is None
+    # backward: a narrowing conv (aggregate-after-GEMM) takes its output gradient as block 0 of a [V, K*Cout] buffer,
+    # which the fused BatchNorm backward behind it writes directly; same gradients as with the copy
+    seq = sgnn.Sequential("x, edge_index", [(sgnn.ChebConv(32, 8, K=3), "x, edge_index -> x"), torch.nn.BatchNorm1d(8),
+                                            torch.nn.LeakyReLU()]).to(DEV)
+    assert seq._fusable_at(1) == (0.01, 1, 3) and seq.module_0.grad_buffer_blocks() == 3
+    xa = x.clone().requires_grad_(True)
+    r = torch.randn(m.num_vertices, 8, device=DEV)
+    (seq(xa, ei) * r).sum().backward()
+    got = [xa.grad.clone()] + [p.grad.clone() for p in seq.parameters()]
+    seen = []
+    orig = F_sg._adopt_wide
+    F_sg._adopt_wide = lambda t, K: (seen.append(orig(t, K) is not None), None)[1]      # force the copying path
+    try:
+        for p in seq.parameters():
+            p.grad = None
+        xb = x.clone().requires_grad_(True)
+        seq.module_1.reset_running_stats()
+        (seq(xb, ei) * r).sum().backward()
+    finally:
+        F_sg._adopt_wide = orig
+    assert any(seen)                                      # the adoptable buffer did arrive at the conv's backward
+    for a, b in zip(got, [xb.grad] + [p.grad for p in seq.parameters()]):
+        assert torch.equal(a, b)
 
 
 # --------------------------------------------------------------------------------------
