@@ -105,9 +105,15 @@ SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, 
  * aggregations.  X [V_src, C], X0/X1/Y [V_dst, C] (transpose swaps the roles),
  * row-major with row strides ldx/ldx0/ldx1/ldy in ELEMENTS (so column blocks of
  * a wider [V, 3C] buffer can be read and written in place); X0/X1 may be NULL
- * (then beta/gamma are ignored).  Y must not alias X.  Edge weights
- * -dis[i]*dis[j] are recomputed, never stored.  Deterministic: one owner per
- * output row, fixed summation order, no atomics.
+ * (then beta/gamma are ignored).  Y must not alias X.  Edge weights are the
+ * products -dis[i]*dis[j] of the per-vertex scales (dis[j] rides beside the
+ * neighbour id in the CSR; no per-edge weight array).  Deterministic: one owner
+ * per output row, fixed summation order, no atomics.
+ * Non-finite inputs: the gathers run in fixed-size batches whose unused slots
+ * are switched off by a ZERO WEIGHT on a row that is read anyway (a neighbour of
+ * one of the rows the same wavefront works on, or row 0), so an Inf/NaN in X can
+ * turn into NaN in a few output rows that are not its neighbours; for finite X
+ * the result is exactly the CSR sum.
  * ------------------------------------------------------------------------- */
 SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx, const void* X0,
             int64_t ldx0, const void* X1, int64_t ldx1, void* Y, int64_t ldy, int64_t C, int dtype,
