@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
   using elem_t = typename IO::elem;
   using raw_t = typename IO::raw;
   constexpr int VEC = IO::VEC;
-  constexpr int U = MODE == 0 ? 4 : 2;
+  constexpr int U = (MODE == 0 && DT == SG_F32) ? 4 : 2;   // rows in flight per thread (bf16 rows carry 8 values per vector)
   const elem_t* A = (const elem_t*)A_;
   const elem_t* H = (const elem_t*)H_;
   elem_t* Y = (elem_t*)Y_;
