@@ -178,12 +178,21 @@ SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t
  *                         mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; when
  *                         running_mean / running_var are not NULL they are updated like
  *                         nn.BatchNorm1d does (momentum, unbiased variance)
+ *   sg_bn_stats_finalize  sg_bn_merge + sg_bn_finalize in one launch for N = V (one device)
+ *   sg_bn_bwd_coeffs      from the nb partials of sg_bn_act_bwd_reduce: out[0][c] = sum dz (= d bias),
+ *                         out[1][c] = sum dz*xhat (= d weight), out[2] = out[0]/N, out[3] = out[1]/N
+ *                         (the c1, c2 of sg_bn_act_bwd_apply), out[4][c] = gamma*invstd (its k)
  * partial is float32 [nb, 2, C].
  * ------------------------------------------------------------------------- */
 SG_API int64_t sg_col_blocks(int64_t V);
 SG_API int sg_col_moments(const void* X, int64_t ldx, int64_t V, int64_t C, int dtype, float* partial,
                           int64_t nb, void* stream);
 SG_API int sg_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, float* stats, void* stream);
+SG_API int sg_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_t C, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                float* out, void* stream);
+SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
+                            const float* invstd, float* out, void* stream);
 SG_API int sg_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps, float* out,
                           void* stream);

@@ -55,6 +55,9 @@ _SIGNATURES = {
     "sg_col_blocks": (c_int64, [c_int64]),
     "sg_col_moments": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "sg_bn_merge": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "sg_bn_stats_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                     c_float, c_void_p, c_void_p]),
+    "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_bn_finalize": (c_int, [c_void_p, ctypes.c_double, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_float, c_void_p, c_void_p]),
     "sg_scale_shift_act": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
@@ -415,6 +418,34 @@ def bn_finalize(stats: torch.Tensor, count: float, gamma: torch.Tensor, beta: to
         _check(load().sg_bn_finalize(_ptr(stats), float(count), C, _ptr(_f32vec(gamma, C, "weight")),
                                      _ptr(_f32vec(beta, C, "bias")), _ptr(running_mean), _ptr(running_var),
                                      float(momentum), float(eps), _ptr(out), _stream(stats)), "sg_bn_finalize")
+    return out
+
+
+def bn_stats_finalize(partial: torch.Tensor, num_rows: int, gamma: torch.Tensor, beta: torch.Tensor,
+                      running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], momentum: float,
+                      eps: float) -> torch.Tensor:
+    """bn_merge + bn_finalize in one launch (statistics over this device's rows only): [4, C]."""
+    nb, _, C = partial.shape
+    out = torch.empty((4, C), dtype=torch.float32, device=partial.device)
+    for t, n in ((running_mean, "running_mean"), (running_var, "running_var")):
+        if t is not None:
+            _f32vec(t, C, n)
+    with _on_device(partial.device):
+        _check(load().sg_bn_stats_finalize(_ptr(partial), nb, int(num_rows), C, _ptr(_f32vec(gamma, C, "weight")),
+                                           _ptr(_f32vec(beta, C, "bias")), _ptr(running_mean), _ptr(running_var),
+                                           float(momentum), float(eps), _ptr(out), _stream(partial)),
+               "sg_bn_stats_finalize")
+    return out
+
+
+def bn_bwd_coeffs(partial: torch.Tensor, count: float, gamma: torch.Tensor, invstd: torch.Tensor) -> torch.Tensor:
+    """[5, C] = (sum dz, sum dz*xhat, c1, c2, k) from the partials of bn_act_bwd_reduce."""
+    nb, _, C = partial.shape
+    out = torch.empty((5, C), dtype=torch.float32, device=partial.device)
+    with _on_device(partial.device):
+        _check(load().sg_bn_bwd_coeffs(_ptr(partial), nb, C, float(count), _ptr(_f32vec(gamma, C, "weight")),
+                                       _ptr(_f32vec(invstd, C, "invstd")), _ptr(out), _stream(partial)),
+               "sg_bn_bwd_coeffs")
     return out
 
 

@@ -367,6 +367,22 @@ SG_API int sg_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, f
   return launch_bn_merge(partial, nb, V, C, stats, (hipStream_t)stream);
 }
 
+SG_API int sg_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_t C, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                float* out, void* stream) {
+  SG_REQUIRE(V > 1 && C >= 0 && partial && gamma && beta && out, "sg_bn_stats_finalize: bad argument");
+  SG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+             "sg_bn_stats_finalize: give both running buffers or none");
+  return launch_bn_stats_finalize(partial, nb, V, C, gamma, beta, running_mean, running_var, momentum, eps, out,
+                                  (hipStream_t)stream);
+}
+
+SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
+                            const float* invstd, float* out, void* stream) {
+  SG_REQUIRE(nb > 0 && C >= 0 && N > 0 && partial && gamma && invstd && out, "sg_bn_bwd_coeffs: bad argument");
+  return launch_bn_bwd_coeffs(partial, nb, C, N, gamma, invstd, out, (hipStream_t)stream);
+}
+
 SG_API int sg_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps, float* out,
                           void* stream) {

@@ -351,6 +351,86 @@ __global__ void bn_finalize(const float* __restrict__ stats, double N, int C, co
   }
 }
 
+// bn_merge + bn_finalize in one launch for the single-device case (N = V), and the per-channel coefficients of the
+// backward pass from the partial sums of col_reduce<MODE 1>: two tiny kernels instead of six launches per
+// BatchNorm (merge, finalize; sum over blocks, /N, gamma*invstd) -- they matter where an iteration is launch-bound.
+__global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ partial, int64_t nb, int64_t V, int C,
+                                                         int rpb, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* running_mean,
+                                                         float* running_var, float momentum, float eps,
+                                                         float* __restrict__ out /*[4][C]*/) {
+  const int lane = threadIdx.x & 31;
+  const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  if (c < C) {
+    for (int64_t b = lane; b < nb; b += 32) {
+      int64_t rows = V - b * rpb;
+      rows = rows > rpb ? rpb : rows;
+      if (rows <= 0) break;
+      const double nbk = (double)rows, mb = partial[(b * 2 + 0) * C + c], qb = partial[(b * 2 + 1) * C + c];
+      const double tot = n + nbk, delta = mb - mean;
+      mean += delta * (nbk / tot);
+      m2 += qb + delta * delta * (n * nbk / tot);
+      n = tot;
+    }
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    const double n2 = __shfl_down(n, off, 32), mean2 = __shfl_down(mean, off, 32), m22 = __shfl_down(m2, off, 32);
+    const double tot = n + n2;
+    if (tot > 0.0) {
+      const double delta = mean2 - mean;
+      mean += delta * (n2 / tot);
+      m2 += m22 + delta * delta * (n * n2 / tot);
+      n = tot;
+    }
+  }
+  if (c < C && lane == 0) {
+    // through float, exactly as bn_merge hands (mean, M2) to bn_finalize
+    const float meanf = (float)mean;
+    const double m2d = (double)(float)m2;
+    const double N = (double)V;
+    const float invstd = rsqrtf((float)(m2d / N) + eps);
+    const float scale = gamma[c] * invstd;
+    out[c] = meanf;
+    out[C + c] = invstd;
+    out[2 * C + c] = scale;
+    out[3 * C + c] = beta[c] - meanf * scale;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2d / (N - 1.0));
+    }
+  }
+}
+
+// out[0] = sum dz, out[1] = sum dz*xhat (the bias / weight gradients), out[2] = out[0]/N, out[3] = out[1]/N, out[4] = gamma*invstd
+__global__ __launch_bounds__(256) void bn_bwd_coeffs(const float* __restrict__ partial, int64_t nb, int C, double N,
+                                                     const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                     float* __restrict__ out /*[5][C]*/) {
+  const int lane = threadIdx.x & 31;
+  const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    for (int64_t b = lane; b < nb; b += 32) {
+      s0 += partial[(b * 2 + 0) * C + c];
+      s1 += partial[(b * 2 + 1) * C + c];
+    }
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off, 32);
+    s1 += __shfl_down(s1, off, 32);
+  }
+  if (c < C && lane == 0) {
+    const float f0 = (float)s0, f1 = (float)s1;
+    out[c] = f0;
+    out[C + c] = f1;
+    out[2 * C + c] = (float)((double)f0 / N);
+    out[3 * C + c] = (float)((double)f1 / N);
+    out[4 * C + c] = gamma[c] * invstd[c];
+  }
+}
+
 inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 int threads_per_row(int ncol) {
@@ -373,6 +453,26 @@ int launch_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, floa
   SG_REQUIRE(nb == col_blocks(V), "partial buffer must have sg_col_blocks(V) blocks");
   const int rpb = (int)((V + nb - 1) / nb);
   bn_merge<<<(int)((C + 7) / 8), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, stats);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_t C, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                             float* out, hipStream_t stream) {
+  if (C == 0) return SG_OK;
+  SG_REQUIRE(nb == col_blocks(V), "partial buffer must have sg_col_blocks(V) blocks");
+  const int rpb = (int)((V + nb - 1) / nb);
+  bn_stats_finalize<<<(int)((C + 7) / 8), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, gamma, beta, running_mean,
+                                                            running_var, momentum, eps, out);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
+                         const float* invstd, float* out, hipStream_t stream) {
+  if (C == 0) return SG_OK;
+  bn_bwd_coeffs<<<(int)((C + 7) / 8), 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

@@ -103,6 +103,11 @@ int launch_col_reduce(int mode, const void* A, int64_t lda, const void* H, int64
                       const float* shift, const float* mean, const float* invstd, float slope, float* out,
                       int64_t nblk, int64_t V, int64_t C, int dtype, hipStream_t stream);
 int launch_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, float* stats, hipStream_t stream);
+int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_t C, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                             float* out, hipStream_t stream);
+int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
+                         const float* invstd, float* out, hipStream_t stream);
 int launch_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, float* out,
                        hipStream_t stream);

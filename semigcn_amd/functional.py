@@ -314,7 +314,11 @@ class _BNActFn(torch.autograd.Function):
         dev = x.device
         w32 = weight if weight.dtype == torch.float32 else weight.float()
         b32 = bias if bias.dtype == torch.float32 else bias.float()
-        if training:
+        if training and V > 1 and not ctx_group_active(group):
+            fin = capi.bn_stats_finalize(capi.col_moments(x), V, w32, b32, running_mean, running_var, momentum, eps)
+            mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+            ctx.N = float(V)
+        elif training:
             stats = capi.bn_merge(capi.col_moments(x), V)            # [2, C]: mean, M2 of this rank's rows
             N = float(V)
             if ctx_group_active(group):
@@ -353,7 +357,16 @@ class _BNActFn(torch.autograd.Function):
         x, scale, shift, mean, invstd, w32 = ctx.saved_tensors
         if dy.stride(1) != 1 and dy.shape[1] > 1:
             dy = dy.contiguous()
-        s = capi.bn_act_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.slope).sum(0)   # [2, C]: sum dz, sum dz*xhat
+        part = capi.bn_act_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.slope)
+        if ctx.training and not ctx_group_active(ctx.group):       # one launch: block sums, /N and gamma*invstd
+            co = capi.bn_bwd_coeffs(part, ctx.N, w32, invstd)
+            out = None
+            if ctx.grad_widen > 1:
+                out = torch.empty((x.shape[0], ctx.grad_widen * x.shape[1]), dtype=x.dtype, device=x.device)[:, :x.shape[1]]
+            dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, co[4], co[2], co[3], ctx.slope, out=out)
+            return (dx, co[1].to(ctx.param_dtype), co[0].to(ctx.param_dtype), None, None, None, None, None, None, None,
+                    None, None)
+        s = part.sum(0)                                                                # [2, C]: sum dz, sum dz*xhat
         dbeta, dgamma = s[0].to(ctx.param_dtype), s[1].to(ctx.param_dtype)            # this rank's partial sums
         if ctx.training:
             if ctx_group_active(ctx.group):
