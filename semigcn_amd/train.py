@@ -2,13 +2,16 @@
 (/root/reference/sgcn.py:118-147): for each optimiser step, ``batch`` masked
 forward + loss + backward passes are accumulated, then Adam steps once.
 
-The losses run right after the network each iteration; they are plain
-torch-ROCm ops here (SURVEY.md section 8(f)-1 ranks fusing them as "next"):
+The losses run right after the network each iteration:
   face normals          util/models.py:121-126 (compute_fn)
   masked position RMSE  util/loss.py:14-34     (mask_pos_rec_loss, ltype='rmse')
   masked normal L1      util/loss.py:78-107    (mask_norm_rec_loss, ltype='l1mae')
-Unlike the reference no ``.item()`` is taken inside the loop (sgcn.py:140-144 forces
-3-4 device syncs per iteration); loss values are accumulated on the device.
+  bilateral normal term util/loss.py:196-253   (fn_bnf_detach_loss; the -CAD option, off by default)
+On the device in fp32 the first three are one fused HIP forward and two backward kernels
+(functional.mesh_loss_sums, csrc/mesh_loss.hip); the plain-torch versions below serve other
+dtypes, MGCN's coarse levels and the tests.  Unlike the reference no ``.item()`` is taken
+inside the loop (sgcn.py:140-144 forces 3-4 device syncs per iteration); loss values are
+accumulated on the device.
 """
 from __future__ import annotations
 
