@@ -294,14 +294,14 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
 }
 
 // stats[0][c] = mean, stats[1][c] = M2 over all V rows, from the per-block partials (Chan et al.,
-// in double).  32 lanes per channel: each merges every 32nd block, then a shuffle tree merges lanes.
+// in double).  One wavefront per channel: each lane merges every 64th block, then a shuffle tree merges lanes.
 __global__ __launch_bounds__(256) void bn_merge(const float* __restrict__ partial, int64_t nb, int64_t V, int C,
                                                 int rpb, float* __restrict__ stats) {
-  const int lane = threadIdx.x & 31;
-  const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   double n = 0.0, mean = 0.0, m2 = 0.0;
   if (c < C) {
-    for (int64_t b = lane; b < nb; b += 32) {
+    for (int64_t b = lane; b < nb; b += 64) {
       int64_t rows = V - b * rpb;
       rows = rows > rpb ? rpb : rows;
       if (rows <= 0) break;
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void bn_merge(const float* __restrict__ partia
     }
   }
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {       // lanes l and l+off sit in the same 32-lane half of the wavefront
-    const double n2 = __shfl_down(n, off, 32), mean2 = __shfl_down(mean, off, 32), m22 = __shfl_down(m2, off, 32);
+  for (int off = 32; off > 0; off >>= 1) {       // lanes l and l+off sit in the same 32-lane half of the wavefront
+    const double n2 = __shfl_down(n, off, 64), mean2 = __shfl_down(mean, off, 64), m22 = __shfl_down(m2, off, 64);
     const double tot = n + n2;
     if (tot > 0.0) {
       const double delta = mean2 - mean;
@@ -359,11 +359,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
                                                          const float* __restrict__ beta, float* running_mean,
                                                          float* running_var, float momentum, float eps,
                                                          float* __restrict__ out /*[4][C]*/) {
-  const int lane = threadIdx.x & 31;
-  const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   double n = 0.0, mean = 0.0, m2 = 0.0;
   if (c < C) {
-    for (int64_t b = lane; b < nb; b += 32) {
+    for (int64_t b = lane; b < nb; b += 64) {
       int64_t rows = V - b * rpb;
       rows = rows > rpb ? rpb : rows;
       if (rows <= 0) break;
@@ -375,8 +375,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
     }
   }
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
-    const double n2 = __shfl_down(n, off, 32), mean2 = __shfl_down(mean, off, 32), m22 = __shfl_down(m2, off, 32);
+  for (int off = 32; off > 0; off >>= 1) {
+    const double n2 = __shfl_down(n, off, 64), mean2 = __shfl_down(mean, off, 64), m22 = __shfl_down(m2, off, 64);
     const double tot = n + n2;
     if (tot > 0.0) {
       const double delta = mean2 - mean;
@@ -407,19 +407,19 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
 __global__ __launch_bounds__(256) void bn_bwd_coeffs(const float* __restrict__ partial, int64_t nb, int C, double N,
                                                      const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                      float* __restrict__ out /*[5][C]*/) {
-  const int lane = threadIdx.x & 31;
-  const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   double s0 = 0.0, s1 = 0.0;
   if (c < C) {
-    for (int64_t b = lane; b < nb; b += 32) {
+    for (int64_t b = lane; b < nb; b += 64) {
       s0 += partial[(b * 2 + 0) * C + c];
       s1 += partial[(b * 2 + 1) * C + c];
     }
   }
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
-    s0 += __shfl_down(s0, off, 32);
-    s1 += __shfl_down(s1, off, 32);
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64);
+    s1 += __shfl_down(s1, off, 64);
   }
   if (c < C && lane == 0) {
     const float f0 = (float)s0, f1 = (float)s1;
@@ -452,7 +452,7 @@ int launch_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, floa
   if (C == 0) return SG_OK;
   SG_REQUIRE(nb == col_blocks(V), "partial buffer must have sg_col_blocks(V) blocks");
   const int rpb = (int)((V + nb - 1) / nb);
-  bn_merge<<<(int)((C + 7) / 8), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, stats);
+  bn_merge<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, stats);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
@@ -463,7 +463,7 @@ int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_
   if (C == 0) return SG_OK;
   SG_REQUIRE(nb == col_blocks(V), "partial buffer must have sg_col_blocks(V) blocks");
   const int rpb = (int)((V + nb - 1) / nb);
-  bn_stats_finalize<<<(int)((C + 7) / 8), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, gamma, beta, running_mean,
+  bn_stats_finalize<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, gamma, beta, running_mean,
                                                             running_var, momentum, eps, out);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
@@ -472,7 +472,7 @@ int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_
 int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
                          const float* invstd, float* out, hipStream_t stream) {
   if (C == 0) return SG_OK;
-  bn_bwd_coeffs<<<(int)((C + 7) / 8), 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out);
+  bn_bwd_coeffs<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

@@ -158,11 +158,21 @@ class MGCNTrainer:
             self.model.train()
         # mgcn.py passes a Tensor mask, which MGCN.forward replaces by ones (util/meshnet.py:287-290)
         poss = self.model(b.data, b.v_keep * b.dummy_masks[:, k:k + 1])
-        loss = sum(w * masked_position_rmse(p, t, keep, n)
-                   for w, p, t, keep, n in zip(self.weights, poss, self.model.poss_list, self.keeps, self.counts))
-        fn = face_normals(poss[0], b.faces)
-        loss = loss + self.k1 * masked_normal_l1(fn, b.target_fn, b.f_keep, b.n_f_keep)
+        if poss[0].is_cuda and poss[0].dtype == torch.float32:
+            # finest level: position and normal terms from the fused HIP kernels (csrc/mesh_loss.hip), as in SGCNTrainer
+            from .functional import mesh_loss_sums
+            s0 = mesh_loss_sums(poss[0], b.faces, self.model.poss_list[0], self.keeps[0], b.target_fn, b.f_keep)
+            loss = self.weights[0] * torch.sqrt(s0[0] / self.counts[0] + 1.0e-6) + self.k1 * (s0[1] / b.n_f_keep)
+            fn = None
+            coarse = list(zip(self.weights, poss, self.model.poss_list, self.keeps, self.counts))[1:]
+        else:
+            fn = face_normals(poss[0], b.faces)
+            loss = self.k1 * masked_normal_l1(fn, b.target_fn, b.f_keep, b.n_f_keep)
+            coarse = list(zip(self.weights, poss, self.model.poss_list, self.keeps, self.counts))
+        for w, p, t, keep, n in coarse:
+            loss = loss + w * masked_position_rmse(p, t, keep, n)
         if self.k2 > 0:
+            fn = face_normals(poss[0], b.faces) if fn is None else fn
             loss = loss + self.k2 * bilateral_normal_loss(poss[0], fn, b.faces, b.f2f)[0]
         loss.backward()
         self.loss_sum += loss.detach()
