@@ -740,13 +740,21 @@ class DistMGCNTrainer:
 
     def loss(self, poss) -> torch.Tensor:
         from . import train
-        total = 0.0
-        for w, p, t, keep, n in zip(self.weights, poss, self.targets, self.keeps, self.counts):
+        total, first = 0.0, 0
+        pos_ext = halo_extend(self.part.graphs[0], poss[0])
+        if poss[0].is_cuda and poss[0].dtype == torch.float32:       # finest level: fused HIP kernels, as DistSGCNTrainer
+            from .functional import mesh_loss_sums
+            s0 = all_reduce_sum(mesh_loss_sums(pos_ext, self.faces_ext, self.targets[0], self.keeps[0], self.target_fn,
+                                               self.f_keep), self.group)
+            total = self.weights[0] * torch.sqrt(s0[0] / self.counts[0] + 1.0e-6) + self.k1 * (s0[1] / self.n_f_keep)
+            first = 1
+        else:
+            fn = train.face_normals(pos_ext, self.faces_ext)
+            total = self.k1 * all_reduce_sum(((fn - self.target_fn).abs() * self.f_keep).sum(), self.group) / self.n_f_keep
+        for w, p, t, keep, n in list(zip(self.weights, poss, self.targets, self.keeps, self.counts))[first:]:
             d = (t - p) * keep
             total = total + w * torch.sqrt(all_reduce_sum((d * d).sum(), self.group) / n + 1.0e-6)
-        fn = train.face_normals(halo_extend(self.part.graphs[0], poss[0]), self.faces_ext)
-        ln = all_reduce_sum(((fn - self.target_fn).abs() * self.f_keep).sum(), self.group) / self.n_f_keep
-        return total + self.k1 * ln
+        return total
 
     def iteration_step(self, mask_index: Optional[int] = None) -> torch.Tensor:
         b = self.batch
