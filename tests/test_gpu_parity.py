@@ -1034,3 +1034,34 @@ def test_trainer_with_cad_term_runs():
     pos = cad.model(batch.data, batch.v_keep * batch.dummy_masks[:, :1])
     extra = float(train.bilateral_normal_loss(pos, train.face_normals(pos, batch.faces), batch.faces, batch.f2f)[0])
     assert l1 > l0 and abs((l1 - l0) - 4.0 * extra) < 0.05 * (l1 - l0)     # BN statistics moved by one step in between
+
+
+# --------------------------------------------------------------------------------------
+# every code path of the aggregation kernels gives the same bits: the A/B switches of SG_TUNE_FLAGS select the
+# 64-bit addressing fallback, fixed-size batches, workgroup barriers, the unpacked neighbour lists
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,dtype", [(4, torch.float32), (24, torch.float32), (64, torch.float32), (256, torch.float32),
+                                     (512, torch.float32), (64, torch.bfloat16), (256, torch.bfloat16), (512, torch.bfloat16)])
+def test_aggregation_code_paths_are_bit_identical(C, dtype):
+    graphs = [(nasty_graph(), 500)]                      # hubs, duplicates, self loops, isolated vertices
+    m = synth.torus_mesh(48, 40, permute=True)
+    graphs.append((torch.from_numpy(m.edge_index), m.num_vertices))
+    try:
+        for ei, V in graphs:
+            h = capi.GraphHandle.from_edge_index(ei.to(DEV), V)
+            x = torch.randn(V, C, device=DEV).to(dtype)
+            x0 = torch.randn(V, C, device=DEV).to(dtype)
+            ref = None
+            for flags in (1, 1 | 16, 1 | 32, 1 | 8, 1 | 4, 1 | 2, 0):
+                capi.tuning_set(capi.TUNE_FLAGS, flags)
+                y = h.spmm(x, torch.empty_like(x), alpha=2.0, X0=x0, beta=-1.0)
+                z = h.spmm(x, torch.empty_like(x))
+                if ref is None:
+                    ref = (y.clone(), z.clone())
+                    want = oracle_lhat(ei, x.float().cpu(), 2.0, x0.float().cpu(), -1.0)
+                    tol = KERNEL_TOL if dtype == torch.float32 else 2.0 ** -6
+                    assert rel(y.float(), want) < tol
+                else:
+                    assert torch.equal(y, ref[0]) and torch.equal(z, ref[1]), flags
+    finally:
+        capi.tuning_set(capi.TUNE_FLAGS, 1)
