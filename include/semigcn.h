@@ -247,11 +247,19 @@ SG_API int sg_face_mask(const int64_t* faces, int64_t F, int64_t V, const uint64
  *           loss = sqrt(S_p / n_v + 1e-6) + k1 * S_n / n_f.
  * backward: grad_pos [V_ext,3] = g[0] * dS_p/dpos + g[1] * dS_n/dpos (g: 2 floats on
  *           the device); fully overwritten; the face term uses float atomics.
+ * sg_mesh_loss_bwd_det: the same gradient without atomics (bit-reproducible): the three
+ *           corner gradients of every face are written to corner_scratch [3F,3] and summed
+ *           per vertex in ascending corner order through `incidence`, an sg_pool created
+ *           with fine = 0..3F-1 (corner ids 3f+i), coarse = faces[f][i], n_fine = 3F,
+ *           n_coarse = V_ext.
  * ------------------------------------------------------------------------- */
 SG_API int64_t sg_mesh_loss_blocks(int64_t V, int64_t F);
 SG_API int sg_mesh_loss_fwd(const float* pos, const int64_t* faces, const float* target_pos, const float* v_keep,
                             const float* target_fn, const float* f_keep, int64_t V, int64_t F, float* partial,
                             void* stream);
+SG_API int sg_mesh_loss_bwd_det(const float* pos, const int64_t* faces, const float* target_pos, const float* v_keep,
+                                const float* target_fn, const float* f_keep, const float* g, int64_t V, int64_t V_ext,
+                                int64_t F, const sg_pool* incidence, float* corner_scratch, float* grad_pos, void* stream);
 SG_API int sg_mesh_loss_bwd(const float* pos, const int64_t* faces, const float* target_pos, const float* v_keep,
                             const float* target_fn, const float* f_keep, const float* g, int64_t V, int64_t V_ext,
                             int64_t F, float* grad_pos, void* stream);

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "sg_mesh_loss_blocks": (c_int64, [c_int64, c_int64]),
     "sg_mesh_loss_fwd": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_void_p, c_void_p]),
     "sg_mesh_loss_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "sg_mesh_loss_bwd_det": (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_col_blocks": (c_int64, [c_int64]),
     "sg_col_moments": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "sg_bn_merge": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
@@ -521,6 +522,26 @@ def mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, g: torch.Te
                                        _ptr(f_keep), _ptr(_f32c(g, "g")), V, pos.shape[0], F, _ptr(grad), _stream(pos)),
                "sg_mesh_loss_bwd")
     return grad
+
+
+def mesh_loss_bwd_det(pos, faces, target_pos, v_keep, target_fn, f_keep, g: torch.Tensor,
+                      incidence: "PoolHandle") -> torch.Tensor:
+    """mesh_loss_bwd without atomics: per-corner gradients + a CSR sum over ``incidence`` (see face_incidence)."""
+    V, F = target_pos.shape[0], faces.shape[0]
+    grad = torch.empty_like(pos)
+    corner = torch.empty((3 * F, 3), dtype=torch.float32, device=pos.device)
+    with _on_device(pos.device):
+        _check(load().sg_mesh_loss_bwd_det(_ptr(_f32c(pos, "pos")), _ptr(faces), _ptr(target_pos), _ptr(v_keep),
+                                           _ptr(target_fn), _ptr(f_keep), _ptr(_f32c(g, "g")), V, pos.shape[0], F,
+                                           incidence._h, _ptr(corner), _ptr(grad), _stream(pos)), "sg_mesh_loss_bwd_det")
+    return grad
+
+
+def face_incidence(faces: torch.Tensor, num_rows: int) -> "PoolHandle":
+    """vertex -> incident face corners (corner id = 3 f + i) as an sg_pool, for mesh_loss_bwd_det."""
+    F = faces.shape[0]
+    corners = torch.arange(3 * F, device=faces.device, dtype=torch.int64)
+    return PoolHandle(corners, faces.reshape(-1), 3 * F, int(num_rows))
 
 
 def mesh_edges(faces: torch.Tensor, num_vertices: int, with_f2f: bool = True):

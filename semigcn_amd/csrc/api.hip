@@ -351,6 +351,29 @@ SG_API int sg_face_mask(const int64_t* faces, int64_t F, int64_t V, const uint64
   return launch_face_mask(faces, F, V, vbits, fbits, W, (hipStream_t)stream);
 }
 
+SG_API int sg_mesh_loss_bwd_det(const float* pos, const int64_t* faces, const float* target_pos, const float* v_keep,
+                                const float* target_fn, const float* f_keep, const float* g, int64_t V, int64_t V_ext,
+                                int64_t F, const sg_pool* incidence, float* corner_scratch, float* grad_pos, void* stream_) {
+  SG_REQUIRE(V >= 0 && F >= 0 && V_ext >= V && g && (V_ext == 0 || grad_pos), "sg_mesh_loss_bwd_det: bad argument");
+  SG_REQUIRE((V == 0 || (pos && target_pos && v_keep)) && (F == 0 || (pos && faces && target_fn && f_keep)),
+             "sg_mesh_loss_bwd_det: null pointer");
+  SG_REQUIRE(incidence && incidence->by_coarse.n_rows == V_ext && incidence->by_coarse.n_cols == 3 * F &&
+                 (F == 0 || corner_scratch),
+             "sg_mesh_loss_bwd_det: incidence must map the 3F face corners onto V_ext vertices");
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = launch_mesh_loss_bwd_corners(pos, faces, target_fn, f_keep, g, F, corner_scratch, stream);
+  if (rc != SG_OK) return rc;
+  if (V_ext == 0) return SG_OK;
+  if (F == 0) {
+    SG_HIP_TRY(hipMemsetAsync(grad_pos, 0, (size_t)V_ext * 3 * sizeof(float), stream));
+  } else {   // grad[v] = sum over the corners incident to v, in CSR (ascending corner id) order
+    rc = run_csr(incidence->by_coarse, nullptr, nullptr, corner_scratch, 3, nullptr, 0, nullptr, 0, grad_pos, 3, 3, SG_F32,
+                 1.f, 0.f, 0.f, stream);
+    if (rc != SG_OK) return rc;
+  }
+  return launch_mesh_loss_bwd_vertex_add(pos, target_pos, v_keep, g, V, grad_pos, stream);
+}
+
 SG_API int64_t sg_col_blocks(int64_t V) { return col_blocks(V); }
 
 SG_API int sg_col_moments(const void* X, int64_t ldx, int64_t V, int64_t C, int dtype, float* partial, int64_t nb,

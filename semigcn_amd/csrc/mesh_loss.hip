@@ -106,7 +106,67 @@ __global__ __launch_bounds__(kBlock) void mesh_loss_bwd_face(const float* __rest
   atomicAdd(&grad[3 * ia + 2], -(g1.z + g2.z));
 }
 
+// Deterministic variant of the face term: the three corner gradients of every face go to corner[3f + i] (zeros
+// for a masked face); a CSR gather over the vertex -> corner incidence (sg_unpool_bwd of the incidence handle)
+// then sums them per vertex in a fixed order, and mesh_loss_bwd_vertex_add puts the vertex term on top.
+__global__ __launch_bounds__(kBlock) void mesh_loss_bwd_corners(const float* __restrict__ pos, const int64_t* __restrict__ faces,
+                                                                const float* __restrict__ tfn, const float* __restrict__ fkeep,
+                                                                const float* __restrict__ g, int64_t F,
+                                                                float* __restrict__ corner) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= F) return;
+  F3 ga = F3{0.f, 0.f, 0.f}, g1 = ga, g2 = ga;
+  const float k = g[1] * fkeep[i];
+  if (k != 0.f) {
+    const F3 a = ld3(pos, faces[3 * i]), b = ld3(pos, faces[3 * i + 1]), c = ld3(pos, faces[3 * i + 2]);
+    const F3 e1 = sub(b, a), e2 = sub(c, a);
+    const F3 cr = cross(e1, e2);
+    const float inv = 1.0f / sqrtf(dot(cr, cr));
+    const F3 n = F3{cr.x * inv, cr.y * inv, cr.z * inv};
+    const F3 t = ld3(tfn, i);
+    const F3 s = F3{k * sgn(n.x - t.x), k * sgn(n.y - t.y), k * sgn(n.z - t.z)};
+    const float ns = dot(n, s);
+    const F3 gc = F3{(s.x - n.x * ns) * inv, (s.y - n.y * ns) * inv, (s.z - n.z * ns) * inv};
+    g1 = cross(e2, gc);
+    g2 = cross(gc, e1);
+    ga = F3{-(g1.x + g2.x), -(g1.y + g2.y), -(g1.z + g2.z)};
+  }
+  float* o = corner + 9 * i;
+  o[0] = ga.x; o[1] = ga.y; o[2] = ga.z;
+  o[3] = g1.x; o[4] = g1.y; o[5] = g1.z;
+  o[6] = g2.x; o[7] = g2.y; o[8] = g2.z;
+}
+
+__global__ __launch_bounds__(kBlock) void mesh_loss_bwd_vertex_add(const float* __restrict__ pos, const float* __restrict__ tpos,
+                                                                   const float* __restrict__ vkeep, const float* __restrict__ g,
+                                                                   int64_t V, float* __restrict__ grad) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= V) return;
+  const float k = 2.0f * g[0] * vkeep[i];
+  if (k == 0.f) return;
+  const F3 d = sub(ld3(pos, i), ld3(tpos, i));
+  grad[3 * i] += k * d.x; grad[3 * i + 1] += k * d.y; grad[3 * i + 2] += k * d.z;
+}
+
 }  // namespace
+
+int launch_mesh_loss_bwd_corners(const float* pos, const int64_t* faces, const float* tfn, const float* fkeep, const float* g,
+                                 int64_t F, float* corner, hipStream_t stream) {
+  if (F > 0) {
+    mesh_loss_bwd_corners<<<(int)((F + kBlock - 1) / kBlock), kBlock, 0, stream>>>(pos, faces, tfn, fkeep, g, F, corner);
+    SG_HIP_TRY(hipGetLastError());
+  }
+  return SG_OK;
+}
+
+int launch_mesh_loss_bwd_vertex_add(const float* pos, const float* tpos, const float* vkeep, const float* g, int64_t V,
+                                    float* grad, hipStream_t stream) {
+  if (V > 0) {
+    mesh_loss_bwd_vertex_add<<<(int)((V + kBlock - 1) / kBlock), kBlock, 0, stream>>>(pos, tpos, vkeep, g, V, grad);
+    SG_HIP_TRY(hipGetLastError());
+  }
+  return SG_OK;
+}
 
 int64_t mesh_loss_blocks(int64_t V, int64_t F) {
   const int64_t n = V > F ? V : F;

@@ -131,6 +131,11 @@ int launch_mask_dilate(const Csr& c, const uint64_t* in, uint64_t* out, int64_t 
 int launch_face_mask(const int64_t* faces, int64_t F, int64_t V, const uint64_t* vbits, uint64_t* fbits, int64_t W,
                      hipStream_t stream);
 
+int launch_mesh_loss_bwd_corners(const float* pos, const int64_t* faces, const float* tfn, const float* fkeep, const float* g,
+                                 int64_t F, float* corner, hipStream_t stream);
+int launch_mesh_loss_bwd_vertex_add(const float* pos, const float* tpos, const float* vkeep, const float* g, int64_t V,
+                                    float* grad, hipStream_t stream);
+
 }  // namespace sg
 
 struct sg_graph {

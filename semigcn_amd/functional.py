@@ -423,6 +423,28 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int =
 # --------------------------------------------------------------------------------------------
 # fused loss step (csrc/mesh_loss.hip)
 # --------------------------------------------------------------------------------------------
+_incidence_cache: dict = {}
+
+
+def _face_incidence(faces: torch.Tensor, num_rows: int) -> capi.PoolHandle:
+    """One vertex -> face-corner incidence handle per (faces tensor, row count); a reference to the tensor is
+    held so that its id is not recycled."""
+    key = (id(faces), num_rows)
+    ent = _incidence_cache.get(key)
+    if ent is not None and ent[0] is faces and ent[1] == faces._version:
+        return ent[2]
+    if len(_incidence_cache) > 8:
+        _incidence_cache.clear()
+    h = capi.face_incidence(faces, num_rows)
+    _incidence_cache[key] = (faces, faces._version, h)
+    return h
+
+
+#: the normal term's gradient through per-corner buffers and a fixed-order CSR sum (bit-reproducible, and faster
+#: than 9 float atomics per face); False restores the atomic kernel
+DETERMINISTIC_LOSS_BACKWARD = True
+
+
 class _MeshLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos, faces, target_pos, v_keep, target_fn, f_keep):
@@ -434,7 +456,11 @@ class _MeshLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         pos, faces, target_pos, v_keep, target_fn, f_keep = ctx.saved_tensors
-        grad = capi.mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, g.float().contiguous())
+        if DETERMINISTIC_LOSS_BACKWARD:
+            grad = capi.mesh_loss_bwd_det(pos, faces, target_pos, v_keep, target_fn, f_keep, g.float().contiguous(),
+                                          _face_incidence(faces, pos.shape[0]))
+        else:
+            grad = capi.mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, g.float().contiguous())
         return grad, None, None, None, None, None
 
 

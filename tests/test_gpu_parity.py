@@ -1065,3 +1065,55 @@ def test_aggregation_code_paths_are_bit_identical(C, dtype):
                     assert torch.equal(y, ref[0]) and torch.equal(z, ref[1]), flags
     finally:
         capi.tuning_set(capi.TUNE_FLAGS, 1)
+
+
+def test_loss_backward_without_atomics_is_reproducible_and_matches_atomic_kernel():
+    """functional.DETERMINISTIC_LOSS_BACKWARD: per-corner gradients + fixed-order CSR sum == the atomic kernel up to
+    fp32 summation order, and identical bits from run to run (with halo rows: V_ext > V)."""
+    from semigcn_amd import functional as F_sg, train
+    m = synth.torus_mesh(120, 90)
+    V = m.num_vertices
+    faces = torch.from_numpy(m.faces).to(DEV)
+    n_own = V - 700                                            # pretend the last 700 rows are halo rows
+    own_faces = faces[(faces[:, 0] < n_own)]
+    pos = (torch.from_numpy(m.vs.astype(np.float32)).to(DEV) + 0.01 * torch.randn(V, 3, device=DEV))
+    tpos = torch.from_numpy(m.vs.astype(np.float32)).to(DEV)[:n_own]
+    tfn = train.face_normals(torch.from_numpy(m.vs.astype(np.float32)).to(DEV), own_faces)
+    vk = (torch.rand(n_own, device=DEV) > 0.1).float()
+    fk = (torch.rand(own_faces.shape[0], device=DEV) > 0.1).float()
+
+    def grad(det):
+        F_sg.DETERMINISTIC_LOSS_BACKWARD = det
+        p = pos.clone().requires_grad_(True)
+        s = F_sg.mesh_loss_sums(p, own_faces, tpos, vk, tfn, fk)
+        (0.7 * torch.sqrt(s[0] / 1000.0 + 1e-6) + 4.0 * s[1] / 2000.0).backward()
+        return p.grad.clone()
+    try:
+        a, b, c = grad(True), grad(True), grad(False)
+    finally:
+        F_sg.DETERMINISTIC_LOSS_BACKWARD = True
+    assert torch.equal(a, b)
+    assert rel(a, c) < 2e-6 and bool((a[n_own:] != 0).any())      # halo rows receive face contributions only
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_is_bit_reproducible(dtype):
+    """No atomics anywhere on the iteration path (CSR-owned aggregation rows, fixed-order reductions, the loss backward
+    through the corner incidence): two runs from the same state give identical bits after an optimiser step."""
+    import bench
+    from semigcn_amd import train
+    m = synth.torus_mesh(200, 150)
+    batch = bench.build_mesh_batch(m, torch.device(DEV), n_masks=3)
+
+    def run():
+        net = SingleScaleGCN(DEV)
+        GU.fill_state(net, seed=9)
+        net.to(DEV).set_feature_dtype(dtype)
+        tr = train.SGCNTrainer(net, batch)
+        losses = [tr.iteration_step().detach().clone() for _ in range(6)]
+        return torch.stack(losses), {k: v.clone() for k, v in net.state_dict().items()}
+    la, sa = run()
+    lb, sb = run()
+    assert torch.equal(la, lb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
