@@ -47,6 +47,17 @@ def test_argument_validation_without_gpu():
     assert lib.sg_spmm(None, 0, None, 0, None, 0, None, 0, None, 0, 4, 0, 1.0, 0.0, 0.0, None) == -1
     assert b"null graph" in lib.sg_last_error()
     assert lib.sg_graph_destroy(None) == 0 and lib.sg_pool_destroy(None) == 0
+    # newer entry points reject bad arguments before touching a device as well
+    n, man = ctypes.c_int64(0), ctypes.c_int(0)
+    assert lib.sg_mesh_edges(None, 5, 10, None, None, ctypes.byref(n), ctypes.byref(man), None) == -1
+    assert b"null pointer" in lib.sg_last_error()
+    assert lib.sg_mask_dilate(None, None, None, 1, None) == -1
+    assert lib.sg_face_mask(None, 3, 4, None, None, 1, None) == -1
+    g2 = (ctypes.c_float * 2)(1.0, 1.0)
+    assert lib.sg_mesh_loss_bwd_det(None, None, None, None, None, None, g2, 0, 0, 0, None, None, None, None) == -1
+    assert b"incidence" in lib.sg_last_error()
+    assert lib.sg_bn_bwd_coeffs(None, 0, 4, 1.0, None, None, None, None) == -1
+    assert lib.sg_bn_stats_finalize(None, 1, 1, 4, None, None, None, None, 0.1, 1e-5, None, None) == -1
 
 
 def test_no_cpu_fallback():
