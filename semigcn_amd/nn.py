@@ -89,7 +89,10 @@ class ChebConv(nn.Module):
                                       "and are not implemented")
         prepared = isinstance(edge_index, MeshGraph) or getattr(edge_index, "sg_partitioned", False)
         graph = edge_index if prepared else graph_for(edge_index, x.shape[0])
-        return F_sg.cheb_conv(graph, x, [lin.weight for lin in self.lins], self.bias)
+        cache = self.__dict__.get("_weight_cache")
+        if cache is None:
+            cache = self.__dict__["_weight_cache"] = F_sg.WeightCache()
+        return F_sg.cheb_conv(graph, x, [lin.weight for lin in self.lins], self.bias, cache)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, K={self.K}, "
