@@ -623,7 +623,7 @@ int launch_rows_epi(const SpmmArgs& a, hipStream_t stream) {
   if (ch <= 0) {
     // measured on the 1 M-vertex mesh (tools/agg_bench.py): wide rows want a thin sweep front
     const int row_bytes = a.C * (int)sizeof(typename Vt<T>::elem);
-    ch = row_bytes >= 2048 ? 4 : row_bytes >= 1024 ? (sizeof(typename Vt<T>::elem) == 4 ? 4 : 8) : 16;
+    ch = row_bytes >= 2048 ? 4 : row_bytes >= 1024 ? (sizeof(typename Vt<T>::elem) == 4 ? 4 : 8) : row_bytes >= 512 ? 8 : 16;
     while (ch > RPW && (int64_t)a.n_rows / ch < 4096) ch >>= 1;
   }
   if (ch < RPW) ch = RPW;
