@@ -257,8 +257,14 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 
     if (staged) {
       int k = ks;
-      if (RPW == 1 && !(flags & kFlagNoExact)) {
-        // the whole wavefront is on ONE row: its length is wave-uniform, so the batches are cut to fit exactly
+      bool uniform = RPW == 1;
+      if (RPW == 2) {   // two rows side by side: when they happen to have the same length the exact path serves both
+        const int d = ke - ks;
+        uniform = __builtin_amdgcn_readlane(d, 0) == __builtin_amdgcn_readlane(d, 32);
+      }
+      if (uniform && !(flags & kFlagNoExact)) {
+        // every lane group of the wavefront has the same row length: it is wave-uniform, so the batches are cut
+        // to fit exactly (always the case with one row per wavefront)
         constexpr int NMAX = R * 8 <= 16 ? 8 : (R * 4 <= 16 ? 4 : 2);
         int rem = __builtin_amdgcn_readfirstlane(ke - ks);
         while (rem > 0) {
