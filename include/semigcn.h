@@ -182,6 +182,9 @@ SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t
  *   sg_bn_bwd_coeffs      from the nb partials of sg_bn_act_bwd_reduce: out[0][c] = sum dz (= d bias),
  *                         out[1][c] = sum dz*xhat (= d weight), out[2] = out[0]/N, out[3] = out[1]/N
  *                         (the c1, c2 of sg_bn_act_bwd_apply), out[4][c] = gamma*invstd (its k)
+ *   sg_bn_finalize_ranks  vertex partition: all [world, 2C+1] = every rank's (mean[C], M2[C], row count) after an
+ *                         all-gather -> out [4,C] as sg_bn_finalize for the whole mesh, out_n[0] = total row count
+ *                         (kept on the device: no host round trip per BatchNorm)
  * partial is float32 [nb, 2, C].
  * ------------------------------------------------------------------------- */
 SG_API int64_t sg_col_blocks(int64_t V);
@@ -193,6 +196,9 @@ SG_API int sg_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int
                                 float* out, void* stream);
 SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
                             const float* invstd, float* out, void* stream);
+SG_API int sg_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* out,
+                                float* out_n, void* stream);
 SG_API int sg_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps, float* out,
                           void* stream);

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "sg_bn_stats_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                      c_float, c_void_p, c_void_p]),
     "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sg_bn_finalize_ranks": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                     c_void_p, c_void_p, c_void_p]),
     "sg_bn_finalize": (c_int, [c_void_p, ctypes.c_double, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_float, c_void_p, c_void_p]),
     "sg_scale_shift_act": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
@@ -397,10 +399,10 @@ def col_moments(X: torch.Tensor) -> torch.Tensor:
     return part
 
 
-def bn_merge(partial: torch.Tensor, num_rows: int) -> torch.Tensor:
-    """(mean, M2) [2, C] over all rows from the per-block partials of col_moments."""
+def bn_merge(partial: torch.Tensor, num_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(mean, M2) [2, C] over all rows from the per-block partials of col_moments (``out``: 2C contiguous floats)."""
     nb, _, C = partial.shape
-    stats = torch.empty((2, C), dtype=torch.float32, device=partial.device)
+    stats = torch.empty((2, C), dtype=torch.float32, device=partial.device) if out is None else out
     with _on_device(partial.device):
         _check(load().sg_bn_merge(_ptr(partial), nb, int(num_rows), C, _ptr(stats), _stream(partial)), "sg_bn_merge")
     return stats
@@ -420,6 +422,23 @@ def bn_finalize(stats: torch.Tensor, count: float, gamma: torch.Tensor, beta: to
                                      _ptr(_f32vec(beta, C, "bias")), _ptr(running_mean), _ptr(running_var),
                                      float(momentum), float(eps), _ptr(out), _stream(stats)), "sg_bn_finalize")
     return out
+
+
+def bn_finalize_ranks(all_stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                      running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], momentum: float,
+                      eps: float):
+    """[world, 2C+1] gathered rows of (mean, M2, count) -> ([4, C] mean/invstd/scale/shift of the whole mesh,
+    [1] total row count), everything on the device."""
+    world, w = all_stats.shape
+    C = (w - 1) // 2
+    out = torch.empty((4, C), dtype=torch.float32, device=all_stats.device)
+    n = torch.empty((1,), dtype=torch.float32, device=all_stats.device)
+    with _on_device(all_stats.device):
+        _check(load().sg_bn_finalize_ranks(_ptr(all_stats), world, C, _ptr(_f32vec(gamma, C, "weight")),
+                                           _ptr(_f32vec(beta, C, "bias")), _ptr(running_mean), _ptr(running_var),
+                                           float(momentum), float(eps), _ptr(out), _ptr(n), _stream(all_stats)),
+               "sg_bn_finalize_ranks")
+    return out, n
 
 
 def bn_stats_finalize(partial: torch.Tensor, num_rows: int, gamma: torch.Tensor, beta: torch.Tensor,

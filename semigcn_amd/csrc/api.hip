@@ -406,6 +406,16 @@ SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double 
   return launch_bn_bwd_coeffs(partial, nb, C, N, gamma, invstd, out, (hipStream_t)stream);
 }
 
+SG_API int sg_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* out,
+                                float* out_n, void* stream) {
+  SG_REQUIRE(world > 0 && C >= 0 && all && gamma && beta && out && out_n, "sg_bn_finalize_ranks: bad argument");
+  SG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+             "sg_bn_finalize_ranks: give both running buffers or none");
+  return launch_bn_finalize_ranks(all, world, C, gamma, beta, running_mean, running_var, momentum, eps, out, out_n,
+                                  (hipStream_t)stream);
+}
+
 SG_API int sg_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps, float* out,
                           void* stream) {

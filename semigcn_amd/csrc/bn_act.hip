@@ -431,6 +431,41 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs(const float* __restrict__ p
   }
 }
 
+// Mesh-wide statistics on a vertex partition: every rank's (mean[C], M2[C], row count) row of `all` [world, 2C+1]
+// (after an all-gather) is merged per channel (Chan et al., in double) and finalised like bn_finalize, with the
+// total row count N taken from the gathered counts ON THE DEVICE (out_n[0] = N: the backward pass divides by it
+// as a device scalar too), so the partitioned BatchNorm needs no host round trip.  One thread per channel.
+__global__ void bn_finalize_ranks(const float* __restrict__ all, int world, int C, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* running_mean, float* running_var,
+                                  float momentum, float eps, float* __restrict__ out /*[4][C]*/,
+                                  float* __restrict__ out_n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const float* row = all + (int64_t)r * (2 * C + 1);
+    const double nr = row[2 * C];
+    if (nr <= 0.0) continue;
+    const double tot = n + nr, delta = (double)row[c] - mean;
+    mean += delta * (nr / tot);
+    m2 += (double)row[C + c] + delta * delta * (n * nr / tot);
+    n = tot;
+  }
+  const float meanf = (float)mean;
+  const double m2d = (double)(float)m2;
+  const float invstd = rsqrtf((float)(m2d / n) + eps);
+  const float scale = gamma[c] * invstd;
+  out[c] = meanf;
+  out[C + c] = invstd;
+  out[2 * C + c] = scale;
+  out[3 * C + c] = beta[c] - meanf * scale;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2d / (n - 1.0));
+  }
+  if (c == 0) out_n[0] = (float)n;
+}
+
 inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 int threads_per_row(int ncol) {
@@ -473,6 +508,16 @@ int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, 
                          const float* invstd, float* out, hipStream_t stream) {
   if (C == 0) return SG_OK;
   bn_bwd_coeffs<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int launch_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, float* out,
+                             float* out_n, hipStream_t stream) {
+  if (C == 0) return SG_OK;
+  bn_finalize_ranks<<<(int)((C + 127) / 128), 128, 0, stream>>>(all, (int)world, (int)C, gamma, beta, running_mean,
+                                                               running_var, momentum, eps, out, out_n);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

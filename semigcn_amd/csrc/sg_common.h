@@ -108,6 +108,9 @@ int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_
                              float* out, hipStream_t stream);
 int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
                          const float* invstd, float* out, hipStream_t stream);
+int launch_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, float* out,
+                             float* out_n, hipStream_t stream);
 int launch_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, float* out,
                        hipStream_t stream);

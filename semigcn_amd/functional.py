@@ -326,15 +326,6 @@ def mesh_unpool(pool: capi.PoolHandle, x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 # BatchNorm over the vertex axis + LeakyReLU, fused (csrc/bn_act.hip)
 # --------------------------------------------------------------------------------------------
-def _merge_moments(counts: torch.Tensor, means: torch.Tensor, m2s: torch.Tensor):
-    """Chan et al.: combine per-block (n, mean, M2) along dim 0, in float64."""
-    n = counts.double().view(-1, 1)
-    N = n.sum()
-    mean = (n * means.double()).sum(0) / N
-    m2 = (m2s.double() + n * (means.double() - mean) ** 2).sum(0)
-    return N, mean, m2
-
-
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, group, widen,
@@ -349,22 +340,25 @@ class _BNActFn(torch.autograd.Function):
             fin = capi.bn_stats_finalize(capi.col_moments(x), V, w32, b32, running_mean, running_var, momentum, eps)
             mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
             ctx.N = float(V)
-        elif training:
-            stats = capi.bn_merge(capi.col_moments(x), V)            # [2, C]: mean, M2 of this rank's rows
-            N = float(V)
-            if ctx_group_active(group):
-                from . import dist as _d
-                import torch.distributed as tdist
-                world = tdist.get_world_size(group)
-                local = torch.cat([stats.view(-1), stats.new_tensor([N])]).unsqueeze(0)
-                allst = torch.empty((world, 2 * C + 1), dtype=torch.float32, device=dev)
-                _d._all_gather_rows(allst, local.contiguous(), group)
-                Nt, mean, m2 = _merge_moments(allst[:, 2 * C], allst[:, :C], allst[:, C:2 * C])
-                stats = torch.stack([mean, m2]).float()
-                N = float(Nt)
-            fin = capi.bn_finalize(stats, N, w32, b32, running_mean, running_var, momentum, eps)
+        elif training and ctx_group_active(group):
+            # vertex partition: (mean, M2, count) of this rank's rows -> all-gather -> merged and finalised in one
+            # kernel; the total row count stays on the device (no host round trip per BatchNorm)
+            from . import dist as _d
+            import torch.distributed as tdist
+            world = tdist.get_world_size(group)
+            local = torch.empty((1, 2 * C + 1), dtype=torch.float32, device=dev)
+            capi.bn_merge(capi.col_moments(x), V, out=local[0, :2 * C])
+            local[0, 2 * C:].fill_(float(V))
+            allst = torch.empty((world, 2 * C + 1), dtype=torch.float32, device=dev)
+            _d._all_gather_rows(allst, local, group)
+            fin, n_dev = capi.bn_finalize_ranks(allst, w32, b32, running_mean, running_var, momentum, eps)
             mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
-            ctx.N = N
+            ctx.N = n_dev
+        elif training:      # a single row: nothing to merge
+            stats = capi.bn_merge(capi.col_moments(x), V)
+            fin = capi.bn_finalize(stats, float(V), w32, b32, running_mean, running_var, momentum, eps)
+            mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+            ctx.N = float(V)
         else:
             mean = running_mean.float()
             invstd = torch.rsqrt(running_var.float() + eps)
