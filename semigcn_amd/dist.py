@@ -259,10 +259,12 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 class _DistChebConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, g: DistMeshGraph, x, bias, *weights):
+    def forward(ctx, g: DistMeshGraph, cache, x, bias, *weights):
         K, n = len(weights), g.n_own
         C = x.shape[1]
-        wcat = (weights[0] if K == 1 else torch.cat(list(weights), dim=1)).to(x.dtype)
+        from .functional import _wcat
+        wcat = (_wcat(weights, x.dtype) if cache is None
+                else cache.get("cat", x.dtype, weights, None, lambda: _wcat(weights, x.dtype)))
         T = torch.empty((g.n_ext if K > 1 else n, K * C), dtype=x.dtype, device=x.device)
         blk = [T[:, k * C:(k + 1) * C] for k in range(K)]
         blk[0][:n].copy_(x)
@@ -285,9 +287,9 @@ class _DistChebConvFn(torch.autograd.Function):
         T, wcat = ctx.saved_tensors
         g, K, C, n = ctx.g, ctx.K, ctx.C, ctx.g.n_own
         dout = dout.contiguous()
-        need_x, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_x, need_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         dws = [None] * K
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[4:]):
             dwcat = weight_grad(dout, T[:n]).to(ctx.param_dtype)       # partial: summed over ranks later
             dws = [dwcat[:, k * C:(k + 1) * C] for k in range(K)]
         db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
@@ -307,7 +309,7 @@ class _DistChebConvFn(torch.autograd.Function):
                 dx = torch.empty((n, C), dtype=dout.dtype, device=dout.device)
                 x1 = gk[2][:n] if K >= 3 else None
                 g.aggregate(gk[1], dx, alpha=1.0, X0=gk[0][:n], beta=1.0, X1=x1, gamma=-1.0)
-        return (None, dx, db, *dws)
+        return (None, None, dx, db, *dws)
 
 
 class _DistChebConvPostFn(torch.autograd.Function):
@@ -315,13 +317,18 @@ class _DistChebConvPostFn(torch.autograd.Function):
     the halo rows exchanged are Cout wide instead of Cin wide."""
 
     @staticmethod
-    def forward(ctx, g: DistMeshGraph, x, bias, *weights):
+    def forward(ctx, g: DistMeshGraph, cache, x, bias, *weights):
         K, n, Co = len(weights), g.n_own, weights[0].shape[0]
-        wstack = torch.cat(list(weights), dim=0).to(x.dtype)
+        def build():
+            ws = torch.cat(list(weights), dim=0).to(x.dtype)
+            bk = None
+            if bias is not None:      # the bias rides in on Z_0 (see functional._ChebConvPostFn)
+                bk = torch.cat([bias.to(x.dtype), bias.new_zeros((K - 1) * Co, dtype=x.dtype)])
+            return ws, bk
+        wstack, bias_k = build() if cache is None else cache.get("stack", x.dtype, weights, bias, build)
         x = x if x.stride(1) == 1 else x.contiguous()
         Z = torch.empty((g.n_ext, K * Co), dtype=x.dtype, device=x.device)
-        if bias is not None:      # the bias rides in on Z_0 (see functional._ChebConvPostFn)
-            bias_k = torch.cat([bias.to(x.dtype), bias.new_zeros((K - 1) * Co, dtype=x.dtype)])
+        if bias is not None:
             torch.addmm(bias_k, x, wstack.t(), out=Z[:n])
         else:
             torch.mm(x, wstack.t(), out=Z[:n])
@@ -353,22 +360,22 @@ class _DistChebConvPostFn(torch.autograd.Function):
             g.exchange(gk[k - 1])
             g.aggregate(gk[k - 1], gk[k][:n], alpha=2.0, X0=gk[k - 2][:n], beta=-1.0)
         own = G[:n]
-        dx = own @ wstack if ctx.needs_input_grad[1] else None
+        dx = own @ wstack if ctx.needs_input_grad[2] else None
         dws = [None] * K
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[4:]):
             dwstack = weight_grad(own, x.contiguous()).to(ctx.param_dtype)
             dws = [dwstack[k * Co:(k + 1) * Co] for k in range(K)]
-        db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return (None, dx, db, *dws)
+        db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        return (None, None, dx, db, *dws)
 
 
-def dist_cheb_conv(g: DistMeshGraph, x, weights, bias=None):
+def dist_cheb_conv(g: DistMeshGraph, x, weights, bias=None, cache=None):
     from . import functional as F_sg
     if x.shape[0] != g.n_own:
         raise ValueError(f"x has {x.shape[0]} rows but this rank owns {g.n_own} vertices")
     if F_sg.AGGREGATE_AFTER_GEMM_WHEN_NARROWING and len(weights) >= 2 and weights[0].shape[0] < weights[0].shape[1]:
-        return _DistChebConvPostFn.apply(g, x, bias, *weights)
-    return _DistChebConvFn.apply(g, x, bias, *weights)
+        return _DistChebConvPostFn.apply(g, cache, x, bias, *weights)
+    return _DistChebConvFn.apply(g, cache, x, bias, *weights)
 
 
 # --------------------------------------------------------------------------------------
@@ -454,8 +461,8 @@ def all_reduce_gradients(params, group=None) -> None:
 
 
 def dist_min_max(z1: torch.Tensor, group=None):
-    zt = z1.detach().t().contiguous()                       # [3, n]: reduce along the contiguous axis
-    lo, hi = zt.min(dim=1)[0].view(1, -1), zt.max(dim=1)[0].view(1, -1)
+    from .networks import _column_min_max
+    lo, hi = _column_min_max(z1.detach())
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         lo, hi = lo.detach().clone(), hi.detach().clone()
         _all_reduce(lo, dist.ReduceOp.MIN, group)

@@ -265,7 +265,7 @@ def cheb_conv(graph: MeshGraph, x: torch.Tensor, weights: Sequence[torch.Tensor]
         raise ValueError(f"x must be [V, C], got {tuple(x.shape)}")
     if getattr(graph, "sg_partitioned", False):
         from .dist import dist_cheb_conv
-        return dist_cheb_conv(graph, x, weights, bias)
+        return dist_cheb_conv(graph, x, weights, bias, cache)
     if x.shape[0] != graph.num_vertices:
         raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.num_vertices} vertices")
     if AGGREGATE_AFTER_GEMM_WHEN_NARROWING and len(weights) >= 2 and weights[0].shape[0] < weights[0].shape[1]:
