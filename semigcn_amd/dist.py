@@ -265,9 +265,14 @@ class _DistChebConvFn(torch.autograd.Function):
         from .functional import _wcat
         wcat = (_wcat(weights, x.dtype) if cache is None
                 else cache.get("cat", x.dtype, weights, None, lambda: _wcat(weights, x.dtype)))
-        T = torch.empty((g.n_ext if K > 1 else n, K * C), dtype=x.dtype, device=x.device)
+        from .functional import _adopt_wide
+        T = _adopt_wide(x, K, g.n_ext) if K > 1 else None     # the fused BatchNorm in front may have written x in place
+        fresh = T is None
+        if fresh:
+            T = torch.empty((g.n_ext if K > 1 else n, K * C), dtype=x.dtype, device=x.device)
         blk = [T[:, k * C:(k + 1) * C] for k in range(K)]
-        blk[0][:n].copy_(x)
+        if fresh:
+            blk[0][:n].copy_(x)
         if K > 1:
             g.exchange(blk[0])
             g.aggregate(blk[0], blk[1][:n], alpha=1.0)

@@ -61,14 +61,16 @@ def weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _adopt_wide(x: torch.Tensor, K: int):
-    """If ``x`` is the first C columns of an otherwise unused [V, K*C] buffer (what ``bn_act(...,
-    widen=K)`` returns), hand back that buffer so Tx1..Tx(K-1) are written next to it without a copy."""
+def _adopt_wide(x: torch.Tensor, K: int, rows: Optional[int] = None):
+    """If ``x`` is the first C columns (and first V rows) of an otherwise unused [rows, K*C] buffer (what
+    ``bn_act(..., widen=K, rows=...)`` returns; rows = V by default, V + halo rows on a partition), hand back that
+    buffer so Tx1..Tx(K-1) are written next to it without a copy."""
     V, C = x.shape
+    rows = V if rows is None else rows
     if (x.stride(1) != 1 or x.stride(0) != K * C or x.storage_offset() != 0
-            or x.untyped_storage().nbytes() != V * K * C * x.element_size()):
+            or x.untyped_storage().nbytes() != rows * K * C * x.element_size()):
         return None
-    return torch.as_strided(x.detach(), (V, K * C), (K * C, 1), 0)
+    return torch.as_strided(x.detach(), (rows, K * C), (K * C, 1), 0)
 
 
 def column_sums(x: torch.Tensor) -> torch.Tensor:
@@ -329,7 +331,7 @@ def mesh_unpool(pool: capi.PoolHandle, x: torch.Tensor) -> torch.Tensor:
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, group, widen,
-                grad_widen=1):
+                grad_widen=1, rows=0):
         V, C = x.shape
         if x.stride(1) != 1 and C > 1:
             x = x.contiguous()
@@ -365,8 +367,8 @@ class _BNActFn(torch.autograd.Function):
             scale = (w32 * invstd).contiguous()
             shift = (b32 - mean * scale).contiguous()
             ctx.N = float(V)
-        if widen > 1:
-            y = torch.empty((V, widen * C), dtype=x.dtype, device=dev)[:, :C]
+        if widen > 1:     # rows > V: the consumer is a partitioned conv whose buffer also holds the halo rows
+            y = torch.empty((max(rows, V), widen * C), dtype=x.dtype, device=dev)[:V, :C]
         else:
             y = torch.empty((V, C), dtype=x.dtype, device=dev)
         capi.scale_shift_act(x, scale, shift, slope, out=y)
@@ -390,7 +392,7 @@ class _BNActFn(torch.autograd.Function):
                 out = torch.empty((x.shape[0], ctx.grad_widen * x.shape[1]), dtype=x.dtype, device=x.device)[:, :x.shape[1]]
             dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, co[4], co[2], co[3], ctx.slope, out=out)
             return (dx, co[1].to(ctx.param_dtype), co[0].to(ctx.param_dtype), None, None, None, None, None, None, None,
-                    None, None)
+                    None, None, None)
         s = part.sum(0)                                                                # [2, C]: sum dz, sum dz*xhat
         dbeta, dgamma = s[0].to(ctx.param_dtype), s[1].to(ctx.param_dtype)            # this rank's partial sums
         if ctx.training:
@@ -410,7 +412,7 @@ class _BNActFn(torch.autograd.Function):
         if ctx.grad_widen > 1:     # born as block 0 of the conv's [V, K*C] gradient buffer (see _ChebConvPostFn.backward)
             out = torch.empty((x.shape[0], ctx.grad_widen * x.shape[1]), dtype=x.dtype, device=x.device)[:, :x.shape[1]]
         dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope, out=out)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 #: callables invoked with every fused BN+activation output (sign(y) == sign of the BatchNorm output);
@@ -427,7 +429,7 @@ def ctx_group_active(group) -> bool:
 
 
 def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int = 1,
-           grad_widen: int = 1) -> torch.Tensor:
+           grad_widen: int = 1, rows: int = 0) -> torch.Tensor:
     """``leaky_relu(bn(x), slope)`` with nn.BatchNorm1d semantics (batch statistics and running-stat
     updates in training mode, running statistics in eval mode) in two HIP passes.  ``widen = K``
     returns a view of the first C columns of a fresh [V, K*C] buffer, which the next ChebConv
@@ -442,7 +444,7 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int =
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return _BNActFn.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, float(slope), group, int(widen),
-                          int(grad_widen))
+                          int(grad_widen), int(rows))
 
 
 # --------------------------------------------------------------------------------------------

@@ -188,10 +188,10 @@ class Sequential(nn.Module):
             fused = self._fusable_at(i) if (len(vals) == 1 and torch.is_tensor(vals[0]) and vals[0].is_cuda
                                              and vals[0].dim() == 2) else None
             if fused is not None:      # BatchNorm1d + (Leaky)ReLU in two HIP passes instead of five ATen ones
-                # (a partitioned conv needs [owned | halo] rows in its buffer: it cannot adopt a widened one)
-                partitioned = any(getattr(v, "sg_partitioned", False) for v in scope.values())
-                result = F_sg.bn_act(vals[0], getattr(self, name), fused[0], 1 if partitioned else fused[1],
-                                     1 if partitioned else fused[2])
+                # (a partitioned conv keeps [owned | halo] rows in its buffer: the widened output gets the halo rows too)
+                part = next((v for v in scope.values() if getattr(v, "sg_partitioned", False)), None)
+                result = F_sg.bn_act(vals[0], getattr(self, name), fused[0], fused[1],
+                                     1 if part is not None else fused[2], 0 if part is None else part.n_ext)
                 i += 1
             else:
                 result = getattr(self, name)(*vals)
