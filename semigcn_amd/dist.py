@@ -466,12 +466,14 @@ def all_reduce_gradients(params, group=None) -> None:
 
 
 def dist_min_max(z1: torch.Tensor, group=None):
+    """Per-axis min / max of the whole mesh's z1 ([1, 3] each) from this rank's rows: ONE all-reduce (max of [-lo | hi])."""
     from .networks import _column_min_max
     lo, hi = _column_min_max(z1.detach())
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        lo, hi = lo.detach().clone(), hi.detach().clone()
-        _all_reduce(lo, dist.ReduceOp.MIN, group)
-        _all_reduce(hi, dist.ReduceOp.MAX, group)
+        both = torch.cat([-lo, hi], dim=1).contiguous()
+        _all_reduce(both, dist.ReduceOp.MAX, group)
+        n = lo.shape[1]
+        lo, hi = -both[:, :n], both[:, n:]
     return lo, hi
 
 
