@@ -23,6 +23,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if "--graph" in sys.argv:      # must be in the environment before the first HIP call (semigcn_amd.train.GRAPH_ENV)
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import numpy as np
 import torch
@@ -54,6 +56,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="250x200", help="torus for the CPU baseline sample")
     ap.add_argument("--no-launch-timer", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay each iteration from a hipGraph (1 GPU; pays off on launch-bound meshes <= ~200 K "
+                         "vertices and MGCN; sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, see DESIGN.md section 8); "
+                         "per-launch kernel timing is off in this mode")
     ap.add_argument("--model", default="sgcn", choices=["sgcn", "mgcn"],
                     help="mgcn: BASELINE config c3 (3 pool levels, hierarchy from meshprep.DeviceMesh); not the headline metric")
     return ap.parse_args()
@@ -187,18 +193,19 @@ def build_trainer(args, dtype, device, world, rank, mesh):
             from semigcn_amd import dist as sgdist
             trainer = sgdist.DistMGCNTrainer(model, sgdist.partition_mgcn(model, rank, world), batch)
         else:
-            trainer = train.MGCNTrainer(model, batch)
+            trainer = train.MGCNTrainer(model, batch, capture=args.graph)
         agg_edges = 2 * sum(n * e.shape[1] for n, e in zip((6, 11, 11, 5), eis))
     else:
         model = SingleScaleGCN(device).to(device)
         if dtype != torch.float32:
             model.set_feature_dtype(dtype)
-        trainer = train.SGCNTrainer(model, batch)
+        trainer = train.SGCNTrainer(model, batch, capture=args.graph)
         agg_edges = AGG_PER_ITER * mesh.num_edges
     workload = (f"{args.model.upper()} train iteration ({13 if args.model == 'sgcn' else 33} ChebConv K=3 + BN + LeakyReLU, "
                 f"fwd+loss+bwd, Adam every 5th) on a closed torus mesh {nu}x{nv}: V={mesh.num_vertices} "
                 f"E={mesh.num_edges} directed, {'random' if args.permute else 'grid'} vertex order, "
                 f"{'fp32' if dtype == torch.float32 else 'bf16'} features"
+                + (", iteration replayed from a hipGraph" if args.graph else "")
                 + (f", every level vertex-partitioned into {world} blocks" if world > 1 else ""))
     return trainer, workload, agg_edges
 
@@ -304,7 +311,9 @@ def main():
     mesh = synth.torus_mesh(nu, nv, permute=args.permute)
     log(f"mesh generated V={mesh.num_vertices} E={mesh.num_edges}")
     dtypes = {"fp32": torch.float32, "bf16": torch.bfloat16}
-    with_timer = not args.no_launch_timer and args.model == "sgcn"   # byte accounting assumes the finest mesh only
+    if args.graph and (world > 1 or args.warmup < 4):
+        raise SystemExit("--graph: single GPU only, and --warmup must be >= 4 (3 eager iterations + the capture)")
+    with_timer = not args.no_launch_timer and args.model == "sgcn" and not args.graph   # byte accounting assumes the finest mesh only
 
     trainer, workload, agg_edges = build_trainer(args, dtypes[args.dtype], device, world, rank, mesh)
     log("model built; warm-up")

@@ -118,6 +118,8 @@ class WeightCache:
         self._val = None
 
     def get(self, kind: str, dtype: torch.dtype, weights, bias, build):
+        if weights[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            return build()     # inside a hipGraph capture the cat/cast must be part of the graph (replays see new weights)
         key = (kind, dtype, tuple((w.data_ptr(), w._version) for w in weights),
                None if bias is None else (bias.data_ptr(), bias._version))
         if key != self._key:

@@ -15,6 +15,7 @@ accumulated on the device.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -84,13 +85,87 @@ class MeshBatch:
         self.n_f_keep = int(self.f_keep.sum().item())
 
 
+#: ROCm 7.2's graph "packet capture" fast path replays stale packets after an eager kernel has run on an idle
+#: GPU (wrong gradients; bisected in tools/graph_replay_check.py).  With this runtime flag off, replays are exact.
+GRAPH_ENV = ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
+def graphs_usable() -> bool:
+    return os.environ.get(GRAPH_ENV[0]) == GRAPH_ENV[1]
+
+
+class _PrivateData:
+    """The caller's ``data`` with ``z1`` replaced by a leaf of the trainer's own (same values, same
+    requires_grad): autograd keeps a leaf's AccumulateGrad node on the stream of its first use, and one
+    that has lived on another stream (an eager run on the default stream, say) would fork the capture."""
+
+    def __init__(self, data):
+        for name in ("x_pos", "edge_index", "graph"):
+            if hasattr(data, name):
+                setattr(self, name, getattr(data, name))
+        self.z1 = data.z1.detach().clone().requires_grad_(data.z1.requires_grad)
+
+
+class _GraphedIteration:
+    """One training iteration (forward + loss + backward) captured into a hipGraph (``torch.cuda.CUDAGraph``) and
+    replayed: one host call instead of ~650 (SGCN) / ~1300 (MGCN) kernel launches.  Pays off where the iteration is
+    launch-bound -- meshes of <= ~200 K vertices and MGCN's small coarse levels; at V = 1 M the GPU is busy anyway.
+
+    Contract of ``body(mask)``: reads only tensors that keep their storage between calls (model parameters and
+    buffers, the trainer's constants, the static ``mask`` handed in), returns the detached scalar loss.  Parameter
+    gradients accumulate into ``.grad`` tensors that exist before the capture, so the optimiser must zero them in
+    place (``set_to_none=False``).  Needs ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` in the environment BEFORE the first
+    HIP call of the process (see GRAPH_ENV); refuses to run otherwise."""
+
+    WARMUP = 3          # eager iterations first: allocator, graph/CSR caches, hipBLASLt heuristics
+
+    def __init__(self, params, mask_like: torch.Tensor, body):
+        if not graphs_usable():
+            raise RuntimeError(f"hipGraph replay needs {GRAPH_ENV[0]}={GRAPH_ENV[1]} set before the process first touches "
+                               "the GPU: with ROCm 7.2's default graph packet capture a replay that follows an eager "
+                               "kernel on an idle GPU returns wrong gradients (tools/graph_replay_check.py)")
+        self.params, self.body = [p for p in params], body
+        self.mask = torch.zeros_like(mask_like)
+        self.graph = None
+        self.loss = None
+        self.calls = 0
+        # ONE side stream for the warm-ups and the capture: autograd's AccumulateGrad nodes run on the stream they
+        # were first used on, and a node left over from another stream would fork the capture
+        self.stream = torch.cuda.Stream(mask_like.device)
+
+    def __call__(self, mask: torch.Tensor) -> torch.Tensor:
+        self.mask.copy_(mask)
+        if self.graph is not None:
+            self.graph.replay()
+            return self.loss
+        self.calls += 1
+        if self.calls <= self.WARMUP:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                loss = self.body(self.mask)
+            torch.cuda.current_stream().wait_stream(self.stream)
+            return loss
+        for p in self.params:                      # AccumulateGrad must add in place inside the graph
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p)
+        import gc
+        gc.collect()                               # a dead CUDAGraph collected DURING a capture aborts the process
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=self.stream):
+            self.loss = self.body(self.mask)
+        self.graph = graph                         # the capture itself executed nothing: replay it for this call
+        graph.replay()
+        return self.loss
+
+
 class SGCNTrainer:
     """optimizer = Adam(lr), StepLR(50, 0.5) as sgcn.py:79-80; k1 = 4 (sgcn.py:47)."""
 
     def __init__(self, model: torch.nn.Module, batch: MeshBatch, lr: float = 0.01, k1: float = 4.0,
-                 accumulate: int = 5, k2: float = 0.0):
+                 accumulate: int = 5, k2: float = 0.0, capture: bool = False):
         """``k2 > 0`` adds the bilateral normal term of the reference's ``-CAD`` runs (sgcn.py:133-135, its
-        default weight is 4.0); it needs ``batch.f2f``."""
+        default weight is 4.0); it needs ``batch.f2f``.  ``capture=True`` replays the iteration from a hipGraph
+        after three eager ones (see _GraphedIteration)."""
         self.model, self.mesh, self.k1, self.accumulate, self.k2 = model, batch, k1, accumulate, k2
         if k2 > 0 and batch.f2f is None:
             raise ValueError("k2 > 0 (the -CAD bilateral normal term) needs MeshBatch.f2f")
@@ -99,6 +174,15 @@ class SGCNTrainer:
         self.iteration = 0
         self.loss_sum = torch.zeros((), device=batch.target_pos.device)
         self.opt.zero_grad(set_to_none=True)
+        self._graphed = _GraphedIteration(model.parameters(), batch.v_keep, self._forward_backward) if capture else None
+        self._data = _PrivateData(batch.data) if capture else batch.data
+
+    def _forward_backward(self, dm: torch.Tensor) -> torch.Tensor:
+        if not self.model.training:      # the recursive mode switch costs ~0.5 ms of host time per call
+            self.model.train()
+        loss = self.loss(self.model(self._data, dm))
+        loss.backward()
+        return loss.detach()
 
     def loss(self, pos: torch.Tensor) -> torch.Tensor:
         b = self.mesh
@@ -122,16 +206,12 @@ class SGCNTrainer:
         b = self.mesh
         k = self.iteration % b.dummy_masks.shape[1] if mask_index is None else mask_index
         dm = b.v_keep * b.dummy_masks[:, k:k + 1]
-        if not self.model.training:      # the recursive mode switch costs ~0.5 ms of host time per call
-            self.model.train()
-        pos = self.model(b.data, dm)
-        loss = self.loss(pos)
-        loss.backward()
-        self.loss_sum += loss.detach()
+        loss = self._graphed(dm) if self._graphed is not None else self._forward_backward(dm)
+        self.loss_sum += loss
         self.iteration += 1
         if self.iteration % self.accumulate == 0:
             self.opt.step()
-            self.opt.zero_grad(set_to_none=True)
+            self.opt.zero_grad(set_to_none=self._graphed is None)
         return loss
 
 
@@ -140,7 +220,7 @@ class MGCNTrainer:
     (weights 0.35/0.3/0.2/0.15, mgcn.py:82,138-143) + k1 x normal L1 on the finest level."""
 
     def __init__(self, model: torch.nn.Module, batch: MeshBatch, lr: float = 0.01, k1: float = 4.0,
-                 accumulate: int = 5, weights=(0.35, 0.3, 0.2, 0.15), k2: float = 0.0):
+                 accumulate: int = 5, weights=(0.35, 0.3, 0.2, 0.15), k2: float = 0.0, capture: bool = False):
         self.model, self.mesh, self.k1, self.accumulate, self.weights, self.k2 = model, batch, k1, accumulate, weights, k2
         if k2 > 0 and batch.f2f is None:
             raise ValueError("k2 > 0 (the -CAD bilateral normal term, mgcn.py:146-148) needs MeshBatch.f2f")
@@ -150,14 +230,27 @@ class MGCNTrainer:
         self.keeps = [m.to(batch.target_pos.device) for m in model.v_masks_list]
         self.counts = [float(k.sum()) for k in self.keeps]
         self.opt.zero_grad(set_to_none=True)
+        self._graphed = _GraphedIteration(model.parameters(), batch.v_keep, self._forward_backward) if capture else None
+        self._data = _PrivateData(batch.data) if capture else batch.data
 
     def iteration_step(self, mask_index: Optional[int] = None) -> torch.Tensor:
         b = self.mesh
         k = self.iteration % b.dummy_masks.shape[1] if mask_index is None else mask_index
+        dm = b.v_keep * b.dummy_masks[:, k:k + 1]
+        loss = self._graphed(dm) if self._graphed is not None else self._forward_backward(dm)
+        self.loss_sum += loss
+        self.iteration += 1
+        if self.iteration % self.accumulate == 0:
+            self.opt.step()
+            self.opt.zero_grad(set_to_none=self._graphed is None)
+        return loss
+
+    def _forward_backward(self, dm: torch.Tensor) -> torch.Tensor:
+        b = self.mesh
         if not self.model.training:      # the recursive mode switch costs ~0.5 ms of host time per call
             self.model.train()
         # mgcn.py passes a Tensor mask, which MGCN.forward replaces by ones (util/meshnet.py:287-290)
-        poss = self.model(b.data, b.v_keep * b.dummy_masks[:, k:k + 1])
+        poss = self.model(self._data, dm)
         if poss[0].is_cuda and poss[0].dtype == torch.float32:
             # finest level: position and normal terms from the fused HIP kernels (csrc/mesh_loss.hip), as in SGCNTrainer
             from .functional import mesh_loss_sums
@@ -175,10 +268,5 @@ class MGCNTrainer:
             fn = face_normals(poss[0], b.faces) if fn is None else fn
             loss = loss + self.k2 * bilateral_normal_loss(poss[0], fn, b.faces, b.f2f)[0]
         loss.backward()
-        self.loss_sum += loss.detach()
-        self.iteration += 1
-        if self.iteration % self.accumulate == 0:
-            self.opt.step()
-            self.opt.zero_grad(set_to_none=True)
-        return loss
+        return loss.detach()
 

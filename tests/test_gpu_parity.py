@@ -1117,3 +1117,29 @@ def test_training_is_bit_reproducible(dtype):
     assert torch.equal(la, lb)
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+# --------------------------------------------------------------------------------------
+# hipGraph replay of the training iteration (opt-in; needs a runtime flag from process start)
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["sgcn", "mgcn"])
+def test_graphed_training_matches_eager(kind):
+    import os
+    import subprocess
+    import sys
+    from semigcn_amd import train
+    env = dict(os.environ)
+    env[train.GRAPH_ENV[0]] = train.GRAPH_ENV[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_replay_script.py")
+    out = subprocess.run([sys.executable, script, kind], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "GRAPH_REPLAY_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_graph_capture_refuses_without_the_runtime_flag(monkeypatch):
+    import bench
+    from semigcn_amd import train
+    monkeypatch.delenv(train.GRAPH_ENV[0], raising=False)
+    m = synth.torus_mesh(20, 12)
+    batch = bench.build_mesh_batch(m, torch.device(DEV), n_masks=2)
+    with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
+        train.SGCNTrainer(SingleScaleGCN(DEV).to(DEV), batch, capture=True)

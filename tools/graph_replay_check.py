@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment behind DESIGN.md section 8 ("hipGraph replay of the training iteration"): why the
-product does not replay iterations from a hipGraph on this ROCm 7.2 / PyTorch 2.10 image.
+"""Experiment behind DESIGN.md section 8 / 3.10: why hipGraph replay of the training iteration is opt-in and tied to
+DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 on this ROCm 7.2 / PyTorch 2.10 image.
 
 An MGCN training iteration (forward + loss + backward, ~1280 kernel nodes, captured as ONE linear chain:
 hipGraphGetEdges shows 1 root, 1 leaf, no fan-out) is replayed five times and the accumulated parameter
@@ -8,7 +8,9 @@ gradients are compared with five eager iterations.
 
     python tools/graph_replay_check.py
 
-Observed on MI355X:
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 python tools/graph_replay_check.py      # all four cases exact
+
+Observed on MI355X with the runtime's defaults:
   * replays launched back to back, or preceded only by device-to-device memcpys:      identical to eager
   * an unrelated eager elementwise kernel on the same stream + an idle GPU before the
     replay (device or stream synchronize between iterations):                         gradients wrong
