@@ -47,14 +47,18 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mesh", default="1000x1000", help="torus nu x nv of the whole job (the same mesh at every N: strong scaling)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="feature storage of the measured workload: fp32 = the reference's precision (parity-checked "
-                         "to 1e-5); bf16 = BASELINE configs[3] (fp32 accumulate, fp32 parameters).  At N=1 the other "
-                         "one is measured too and reported as `bf16_features` / `fp32_features`")
+    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16"],
+                    help="feature storage of the measured workload: bf16 = what BASELINE configs[3] names (bf16 features, "
+                         "fp32 accumulate, fp32 parameters and output); fp32 = the reference's own precision "
+                         "(parity-checked to 1e-5).  At N=1 the other one is measured too and reported as "
+                         "`fp32_features` / `bf16_features`")
     ap.add_argument("--single-dtype", action="store_true", help="skip the second run at the other precision")
     ap.add_argument("--permute", action="store_true", help="random vertex order (raw-scan like)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="250x200", help="torus for the CPU baseline sample")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="CPU baseline: additionally time ONE oracle iteration at the full mesh size (BASELINE.md section 3; "
+                         "~2 min and ~50 GB of host memory at V = 1 M)")
     ap.add_argument("--no-launch-timer", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay each iteration from a hipGraph (1 GPU; pays off on launch-bound meshes <= ~200 K "
@@ -119,14 +123,17 @@ def build_mesh_batch(mesh, device, n_masks: int):
     return train.MeshBatch(Data, faces, target, train.face_normals(target, faces), v_keep, f_keep, dm)
 
 
-def cpu_baseline(sample: str, full_V: int, budget_s: float = 20.0):
-    """Oracle (PyG-equivalent ATen ops on CPU) SGCN iteration on a smaller torus, scaled
-    linearly in V (the path is O(V) at fixed valence).  Bounded: a 5 K-vertex probe picks the
-    largest sample (<= `sample`) whose iterations fit `budget_s` seconds."""
+def cpu_baseline(sample: str, full_V: int, budget_s: float = 25.0, full: bool = False):
+    """Oracle (PyG-equivalent ATen ops on CPU: index_select -> multiply -> scatter_add_, normalisation per call, three
+    linears, BatchNorm1d, LeakyReLU -- BASELINE.md section 3) SGCN iteration on the host cores of this box.
+    Default: a BOUNDED sample (a smaller torus whose iterations fit `budget_s` seconds), scaled linearly in V (the
+    path is O(V) at fixed valence).  `full=True` (--cpu-full): ONE timed iteration at the full V as BASELINE.md
+    section 3 specifies (~2 min and ~50 GB of host memory at V = 1 M), the scaled figure kept beside it.
+    Threads: os.cpu_count() unless a probe shows that fewer are faster (ATen's scatter/index kernels stop scaling
+    early); both probe timings are reported in `sample`."""
     from oracle import models as OM            # cpu_baseline leg: the only oracle use in bench.py
     from semigcn_amd import synth
-    cores = min(os.cpu_count() or 1, 32)       # ATen's scatter/index kernels stop scaling long before that
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     torch.manual_seed(314)
     net = OM.SGCNOracle().train()
 
@@ -147,12 +154,24 @@ def cpu_baseline(sample: str, full_V: int, budget_s: float = 20.0):
             loss.backward()
         return m, it
 
+    def timed(it, n=1):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            it()
+        return (time.perf_counter() - t0) / n
+
     t_start = time.perf_counter()
     m, it = make(100, 50)
-    it()
-    t0 = time.perf_counter(); it(); probe = time.perf_counter() - t0
+    probes = {}
+    for c in sorted({min(32, ncpu), ncpu}):
+        torch.set_num_threads(c)
+        it()
+        probes[c] = timed(it, 2)
+    cores = min(probes, key=probes.get)
+    torch.set_num_threads(cores)
+    probe_note = ", ".join(f"{probes[c]:.2f} s on {c} threads" for c in sorted(probes))
     nu, nv = map(int, sample.split("x"))
-    per_vertex = probe / m.num_vertices
+    per_vertex = probes[cores] / m.num_vertices
     while nu * nv * per_vertex * 3 > budget_s and nu * nv > 2 * m.num_vertices:
         nu, nv = max(nu * 3 // 4, 16), max(nv * 3 // 4, 16)
     if nu * nv > m.num_vertices:
@@ -164,11 +183,23 @@ def cpu_baseline(sample: str, full_V: int, budget_s: float = 20.0):
         n += 1
     dt = (time.perf_counter() - t0) / n
     scaled = (1.0 / dt) * (m.num_vertices / full_V)
-    return {"value": scaled, "unit": "iter/s", "cores": cores, "kind": "port",
-            "sample": f"{n} timed SGCN iterations (fwd+loss+bwd, fp32) of the oracle on a {m.nu}x{m.nv} torus "
-                      f"(V={m.num_vertices}, E={m.num_edges}), {dt:.2f} s each on {cores} threads "
-                      f"(host has {os.cpu_count()} logical CPUs), scaled linearly in V to V={full_V}",
-            "edges_aggregated_per_s": AGG_PER_ITER * m.num_edges / dt}
+    out = {"value": scaled, "unit": "iter/s", "cores": cores, "kind": "port",
+           "sample": f"{n} timed SGCN iterations (fwd+loss+bwd, fp32) of the oracle on a {m.nu}x{m.nv} torus "
+                     f"(V={m.num_vertices}, E={m.num_edges}), {dt:.2f} s each on {cores} of {ncpu} logical CPUs "
+                     f"(5K-vertex probe: {probe_note}), scaled linearly in V to V={full_V}",
+           "edges_aggregated_per_s": AGG_PER_ITER * m.num_edges / dt}
+    if full:
+        import math
+        side = int(round(math.sqrt(full_V)))
+        mf, itf = make(side, full_V // side)
+        dtf = timed(itf, 1)
+        out["scaled_from_sample"] = scaled
+        out["value"] = 1.0 / dtf
+        out["edges_aggregated_per_s"] = AGG_PER_ITER * mf.num_edges / dtf
+        out["sample"] = (f"ONE timed SGCN iteration (fwd+loss+bwd, fp32, no warm-up) of the oracle at the full size "
+                         f"V={mf.num_vertices} E={mf.num_edges}: {dtf:.1f} s on {cores} of {ncpu} logical CPUs; "
+                         f"beside it: " + out["sample"])
+    return out
 
 
 def build_trainer(args, dtype, device, world, rank, mesh):
@@ -281,13 +312,43 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
             "roofline": roof, "aggregation_kernels": kernels}
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  Runs BEFORE this process has
+    made any HIP call (torch.cuda.device_count() does not initialise the GPU on this image); the ranks are child
+    processes of `python -m torch.distributed.run`, nothing is exec'ed over a process that touched the GPU."""
+    import socket
+    import subprocess
+    shared = os.environ.get("SEMIGCN_BENCH_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not shared:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} HIP device(s) are visible; refusing to fall back to fewer "
+              "ranks (SEMIGCN_BENCH_SHARE_GPU=1 runs the N-rank code path on one device over gloo as a self-test)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log(f"--gpus {args.gpus} without a launcher: starting {args.gpus} ranks with torch.distributed.run on port {port}")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, launched as "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     # self-test mode for boxes with ONE GPU: every rank uses cuda:0 and talks over gloo (host-staged);
@@ -342,9 +403,16 @@ def main():
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": main_res["dtype"], "data": "synthetic",
             "config": {"workload": workload, "V": mesh.num_vertices, "E": mesh.num_edges,
-                       "baseline_config": ("BASELINE configs[3] (SGCN, 1M-vertex mesh) at the reference's fp32 precision; "
-                                           "the bf16-feature variant named there is in `bf16_features`") if (
+                       "baseline_config": (("BASELINE configs[3] (SGCN, 1M-vertex mesh, bf16 features: bf16 storage of the "
+                                            "per-vertex features, fp32 accumulation, fp32 parameters / loss / output); the "
+                                            "same workload at the reference's fp32 precision is in `fp32_features`")
+                                           if args.dtype == "bf16" else
+                                           ("BASELINE configs[3]'s mesh (SGCN, 1M vertices) at the reference's fp32 "
+                                            "precision; the bf16-feature variant named there is in `bf16_features`")) if (
                            args.model == "sgcn" and (nu, nv) == (1000, 1000)) else None,
+                       "mesh_recipe": "closed torus grid, quad diagonals flipped independently with p=0.45 (valence 4..8; "
+                                      "SURVEY 8(d) words it as 0.15*E_und random edge flips, valence 4..9), jitter N(0,0.05^2), "
+                                      "x_pos = positions - z1, seeds 314-317 (semigcn_amd/synth.py)",
                        "aggregations_per_iteration": AGG_PER_ITER if args.model == "sgcn" else 66},
             "edges_aggregated_per_s": main_res["edges_aggregated_per_s"],
             "optimizer_steps_per_s": main_res["optimizer_steps_per_s"], "mean_loss": main_res["mean_loss"],
@@ -352,7 +420,7 @@ def main():
         }
         if other is not None:
             line["fp32_features" if other["dtype"] == "f32" else "bf16_features"] = other
-        line["cpu_baseline"] = cpu_baseline(args.cpu_sample, mesh.num_vertices) if (
+        line["cpu_baseline"] = cpu_baseline(args.cpu_sample, mesh.num_vertices, full=args.cpu_full) if (
             world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -465,16 +465,39 @@ def all_reduce_gradients(params, group=None) -> None:
         off += g.numel()
 
 
-def dist_min_max(z1: torch.Tensor, group=None):
-    """Per-axis min / max of the whole mesh's z1 ([1, 3] each) from this rank's rows: ONE all-reduce (max of [-lo | hi])."""
-    from .networks import _column_min_max
-    lo, hi = _column_min_max(z1.detach())
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        both = torch.cat([-lo, hi], dim=1).contiguous()
+class _GlobalMinMax(torch.autograd.Function):
+    """(lo_local, hi_local) [1, n] -> mesh-wide (lo, hi): ONE all-reduce (max of [-lo | hi]).  Every rank goes on with
+    the replicated bounds, so d loss / d bound is the SUM over ranks of the local terms (one all-reduce of 2n floats
+    in backward); it is then handed to the rank(s) whose local extreme IS the global one, where ``_column_min_max``'s
+    own backward routes it to the arg-extreme vertex -- as torch.min/max(z1, dim=0) does on a single device."""
+
+    @staticmethod
+    def forward(ctx, lo_l, hi_l, group):
+        n = lo_l.shape[1]
+        both = torch.cat([-lo_l, hi_l], dim=1).contiguous()
         _all_reduce(both, dist.ReduceOp.MAX, group)
-        n = lo.shape[1]
-        lo, hi = -both[:, :n], both[:, n:]
-    return lo, hi
+        lo_g, hi_g = -both[:, :n], both[:, n:].clone()
+        ctx.group = group
+        ctx.save_for_backward(lo_l == lo_g, hi_l == hi_g)
+        return lo_g, hi_g
+
+    @staticmethod
+    def backward(ctx, g_lo, g_hi):
+        own_lo, own_hi = ctx.saved_tensors
+        g = torch.cat([g_lo, g_hi], dim=1).contiguous()
+        _all_reduce(g, dist.ReduceOp.SUM, ctx.group)
+        n = g_lo.shape[1]
+        return g[:, :n] * own_lo.to(g.dtype), g[:, n:] * own_hi.to(g.dtype), None
+
+
+def dist_min_max(z1: torch.Tensor, group=None):
+    """Per-axis min / max of the whole mesh's z1 ([1, 3] each) from this rank's rows, differentiable like the
+    single-device ``torch.min/max(z1, dim=0)`` (see _GlobalMinMax): dz1 of the partitioned run equals the 1-GPU run's."""
+    from .networks import _column_min_max
+    lo_l, hi_l = _column_min_max(z1)
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return lo_l, hi_l
+    return _GlobalMinMax.apply(lo_l, hi_l, group)
 
 
 # --------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@ otherwise the transposed CSR kept by sg_graph_create is used).
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -61,16 +62,34 @@ def weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     return out
 
 
+#: wide [rows, K*C] buffers handed out by ``bn_act(..., widen=K)`` / the fused BatchNorm backward (``grad_widen``),
+#: keyed by the address of their storage.  Values are weak: an entry lives exactly as long as the buffer (which
+#: the [:V, :C] view handed to the caller keeps alive), so a recycled address can never match a dead entry.
+_wide_buffers: "weakref.WeakValueDictionary[int, torch.Tensor]" = weakref.WeakValueDictionary()
+
+
+def _new_wide(rows: int, V: int, C: int, K: int, dtype, device) -> torch.Tensor:
+    """View [:V, :C] of a fresh, registered [rows, K*C] buffer: block 0 for the caller, blocks 1..K-1 reserved for
+    the ChebConv that adopts it (``_adopt_wide``)."""
+    base = torch.empty((rows, K * C), dtype=dtype, device=device)
+    _wide_buffers[base.untyped_storage().data_ptr()] = base
+    return base[:V, :C]
+
+
 def _adopt_wide(x: torch.Tensor, K: int, rows: Optional[int] = None):
-    """If ``x`` is the first C columns (and first V rows) of an otherwise unused [rows, K*C] buffer (what
+    """If ``x`` is the block-0 view of a [rows, K*C] buffer that ``_new_wide`` handed out (what
     ``bn_act(..., widen=K, rows=...)`` returns; rows = V by default, V + halo rows on a partition), hand back that
-    buffer so Tx1..Tx(K-1) are written next to it without a copy."""
+    buffer so Tx1..Tx(K-1) are written next to it without a copy.  Only REGISTERED buffers qualify: a tensor that
+    merely has the same strides (a column slice of a caller's tensor, the gradient view ``torch.cat`` hands to a
+    backward) owns its neighbouring columns and is copied instead."""
     V, C = x.shape
     rows = V if rows is None else rows
-    if (x.stride(1) != 1 or x.stride(0) != K * C or x.storage_offset() != 0
-            or x.untyped_storage().nbytes() != rows * K * C * x.element_size()):
+    if x.stride(1) != 1 or x.stride(0) != K * C or x.storage_offset() != 0:
         return None
-    return torch.as_strided(x.detach(), (rows, K * C), (K * C, 1), 0)
+    base = _wide_buffers.get(x.untyped_storage().data_ptr())
+    if base is None or base.shape != (rows, K * C) or base.dtype != x.dtype or V > rows:
+        return None
+    return base
 
 
 def column_sums(x: torch.Tensor) -> torch.Tensor:
@@ -370,7 +389,7 @@ class _BNActFn(torch.autograd.Function):
             shift = (b32 - mean * scale).contiguous()
             ctx.N = float(V)
         if widen > 1:     # rows > V: the consumer is a partitioned conv whose buffer also holds the halo rows
-            y = torch.empty((max(rows, V), widen * C), dtype=x.dtype, device=dev)[:V, :C]
+            y = _new_wide(max(rows, V), V, C, widen, x.dtype, dev)
         else:
             y = torch.empty((V, C), dtype=x.dtype, device=dev)
         capi.scale_shift_act(x, scale, shift, slope, out=y)
@@ -391,7 +410,7 @@ class _BNActFn(torch.autograd.Function):
             co = capi.bn_bwd_coeffs(part, ctx.N, w32, invstd)
             out = None
             if ctx.grad_widen > 1:
-                out = torch.empty((x.shape[0], ctx.grad_widen * x.shape[1]), dtype=x.dtype, device=x.device)[:, :x.shape[1]]
+                out = _new_wide(x.shape[0], x.shape[0], x.shape[1], ctx.grad_widen, x.dtype, x.device)
             dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, co[4], co[2], co[3], ctx.slope, out=out)
             return (dx, co[1].to(ctx.param_dtype), co[0].to(ctx.param_dtype), None, None, None, None, None, None, None,
                     None, None, None)
@@ -412,7 +431,7 @@ class _BNActFn(torch.autograd.Function):
             k = scale
         out = None
         if ctx.grad_widen > 1:     # born as block 0 of the conv's [V, K*C] gradient buffer (see _ChebConvPostFn.backward)
-            out = torch.empty((x.shape[0], ctx.grad_widen * x.shape[1]), dtype=x.dtype, device=x.device)[:, :x.shape[1]]
+            out = _new_wide(x.shape[0], x.shape[0], x.shape[1], ctx.grad_widen, x.dtype, x.device)
         dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope, out=out)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 

@@ -70,6 +70,20 @@ class ChebConv(nn.Module):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
 
+    def invalidate_weight_cache(self) -> None:
+        """Drop the cached concatenated / cast copy of ``lins[k].weight``.  The cache follows the parameters' version
+        counters, which optimiser steps and every autograd-visible in-place update bump; writes through ``.data``
+        (``p.data.copy_(ema)``, manual clipping) do NOT bump them -- call this after such a write."""
+        self.__dict__.pop("_weight_cache", None)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_weight_cache()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_weight_cache()
+        return super()._apply(fn, *args, **kwargs)
+
     def input_buffer_blocks(self) -> int:
         """K when this layer evaluates [Tx0|..|Tx(K-1)] next to its input (so a producer may write the
         input straight into the first block of a [V, K*Cin] buffer), 1 when it aggregates after the GEMM."""

@@ -90,8 +90,35 @@ class MeshBatch:
 GRAPH_ENV = ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
+#: value of GRAPH_ENV[0] at the moment the HIP runtime was initialised in this process (the runtime reads the flag
+#: once, then): recorded by a callback queued on torch's lazy CUDA initialisation when this module is imported
+#: before the first GPU call, else the value found at import time (the best that can still be known).
+_flag_at_gpu_init = {"value": None, "known": False}
+
+
+def _record_flag_at_init():
+    _flag_at_gpu_init["value"] = os.environ.get(GRAPH_ENV[0])
+    _flag_at_gpu_init["known"] = True
+
+
+if torch.cuda.is_initialized():
+    _record_flag_at_init()
+else:
+    try:
+        torch.cuda._lazy_call(_record_flag_at_init)
+    except Exception:      # no lazy-init hook on this build: fall back to the value seen at first use
+        pass
+
+
 def graphs_usable() -> bool:
-    return os.environ.get(GRAPH_ENV[0]) == GRAPH_ENV[1]
+    """True only if DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was in the environment when the HIP runtime initialised (setting
+    it afterwards has no effect on the runtime and would let a corrupting replay through)."""
+    if not _flag_at_gpu_init["known"]:
+        if torch.cuda.is_initialized():
+            _record_flag_at_init()
+        else:
+            return os.environ.get(GRAPH_ENV[0]) == GRAPH_ENV[1]     # the runtime has yet to read it
+    return _flag_at_gpu_init["value"] == GRAPH_ENV[1] and os.environ.get(GRAPH_ENV[0]) == GRAPH_ENV[1]
 
 
 class _PrivateData:
@@ -121,7 +148,7 @@ class _GraphedIteration:
 
     def __init__(self, params, mask_like: torch.Tensor, body):
         if not graphs_usable():
-            raise RuntimeError(f"hipGraph replay needs {GRAPH_ENV[0]}={GRAPH_ENV[1]} set before the process first touches "
+            raise RuntimeError(f"hipGraph replay needs {GRAPH_ENV[0]}={GRAPH_ENV[1]} in the environment BEFORE the process first touches "
                                "the GPU: with ROCm 7.2's default graph packet capture a replay that follows an eager "
                                "kernel on an idle GPU returns wrong gradients (tools/graph_replay_check.py)")
         self.params, self.body = [p for p in params], body
@@ -137,7 +164,7 @@ class _GraphedIteration:
         self.mask.copy_(mask)
         if self.graph is not None:
             self.graph.replay()
-            return self.loss
+            return self.loss.clone()       # a fresh tensor per call, as in eager mode (the static one is overwritten by the next replay)
         self.calls += 1
         if self.calls <= self.WARMUP:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -155,7 +182,7 @@ class _GraphedIteration:
             self.loss = self.body(self.mask)
         self.graph = graph                         # the capture itself executed nothing: replay it for this call
         graph.replay()
-        return self.loss
+        return self.loss.clone()
 
 
 class SGCNTrainer:

@@ -64,7 +64,11 @@ def _run_rank(rank, world, port, out_dir, skip):
     y2 = conv2(x2, g)
     (y2 * x_all[g.start:g.end]).sum().backward()
     sgdist.all_reduce_gradients(list(conv2.parameters()))
-    lin = {"conv_y": y.detach().clone(), "conv_dx": x.grad.clone(), "conv_dw": conv.lins[2].weight.grad.clone(),
+    zz = part.z1.detach().clone().requires_grad_(True)             # bounding box: gradient reaches the arg-extreme's owner
+    lo_mm, hi_mm = sgdist.dist_min_max(zz)
+    ((2.0 * lo_mm.sum() + 3.0 * hi_mm.sum()) / world).backward()      # each rank holds 1/world of the replicated term
+    lin = {"mm_lo": lo_mm.detach().clone(), "mm_hi": hi_mm.detach().clone(), "mm_dz": zz.grad.clone(),
+           "conv_y": y.detach().clone(), "conv_dx": x.grad.clone(), "conv_dw": conv.lins[2].weight.grad.clone(),
            "conv_db": conv.bias.grad.clone(), "conv2_y": y2.detach().clone(), "conv2_dx": x2.grad.clone(),
            "conv2_dw": conv2.lins[1].weight.grad.clone(), "conv2_db": conv2.bias.grad.clone(), "bn_y": yb.detach().clone(), "bn_dx": xb.grad.clone(),
            "bn_dw": bn.weight.grad.clone(), "bn_db": bn.bias.grad.clone(),
@@ -78,10 +82,20 @@ def _run_rank(rank, world, port, out_dir, skip):
     loss.backward()
     sgdist.all_reduce_gradients(tr.params)
     g = part.graph
-    out = {"lin": lin, "loss0": float(loss.detach()), "pos": pos.detach().clone(), "range": (g.start, g.end), "n_halo": g.n_halo,
+    out = {"lin": lin, "dz1": part.z1.grad.clone(), "loss0": float(loss.detach()), "pos": pos.detach().clone(), "range": (g.start, g.end), "n_halo": g.n_halo,
            "grads": {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
            "bn": {k: v.clone() for k, v in model.state_dict().items() if "running" in k}}
     tr.opt.zero_grad(set_to_none=True)
+    # (1b) the input gradient without activation kinks (slope 1: LeakyReLU is the identity), mask all ones, on a copy
+    #      of the model: every cross-rank term of dz1 (halo exchanges, mesh-wide BatchNorm, bounding box, loss sums)
+    #      must then agree closely with the single-rank run
+    import copy
+    smooth = copy.deepcopy(model)
+    smooth.blocks[0].module_2.negative_slope = 1.0           # ONE shared instance (util/networks.py:17-18)
+    part.z1.grad = None
+    tr.loss(smooth(part, torch.ones_like(part.v_keep))).backward()
+    out["dz1_smooth"] = part.z1.grad.clone()
+    part.z1.grad = None
     # (2) the training loop proper: two accumulated iterations, then Adam on the reduced gradients
     out["losses"] = [float(tr.iteration_step().detach()) for _ in range(2)]
     out["params"] = {n: p.detach().clone() for n, p in model.named_parameters()}
@@ -116,8 +130,15 @@ def test_partitioned_training_matches_single_rank(world, skip):
     for key in ("conv_dw", "conv_db", "conv2_dw", "conv2_db", "bn_dw", "bn_db", "bn_rm", "bn_rv"):
         for p in parts:
             assert rel_l2(p["lin"][key], ref["lin"][key]) < 5e-6, key
+    for p in parts:
+        assert torch.equal(p["lin"]["mm_lo"], ref["lin"]["mm_lo"]) and torch.equal(p["lin"]["mm_hi"], ref["lin"]["mm_hi"])
+    mm_dz = torch.cat([p["lin"]["mm_dz"] for p in parts], dim=0)
+    assert torch.equal(mm_dz, ref["lin"]["mm_dz"]) and int((mm_dz != 0).sum()) == 6      # one arg-min and one arg-max per axis
     pos = torch.cat([p["pos"] for p in parts], dim=0)        # blocks are contiguous in processing order
     assert rel_l2(pos, ref["pos"]) < 2e-5
+    dz1 = torch.cat([p["dz1_smooth"] for p in parts], dim=0)  # input gradient incl. the bounding-box terms, no LeakyReLU kinks
+    assert rel_l2(dz1, ref["dz1_smooth"]) < 1e-3
+    assert float(ref["dz1_smooth"].abs().max()) > 0
     gmax = max(float(v.abs().max()) for v in ref["grads"].values())
     for p in parts:
         assert abs(p["loss0"] - ref["loss0"]) < 2e-5 * abs(ref["loss0"])

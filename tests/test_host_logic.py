@@ -335,3 +335,58 @@ def test_bilateral_normal_loss_vs_reference_golden(name):
     assert rel(pos.grad, g[f"{name}/dpos"]) < 1e-5
     if name == "open":
         assert (g[f"{name}/f2f"] < 0).sum() > 0            # the fixture does exercise the -1 padding
+
+
+def test_wide_buffer_adoption_needs_a_registered_buffer(cpu_kernels):
+    """a tensor that merely LOOKS like block 0 of a [V, K*C] buffer (a column slice of the caller's tensor,
+    the gradient view torch.cat hands to a backward) must not be adopted -- its neighbouring columns are live data."""
+    from semigcn_amd import functional as F_sg, nn as sgnn, synth
+    m = synth.torus_mesh(12, 8)
+    ei = torch.from_numpy(m.edge_index)
+    V = m.num_vertices
+    torch.manual_seed(0)
+    # forward: a user slice big[:, :C] of a [V, 3C] tensor keeps its other columns
+    conv = sgnn.ChebConv(6, 10, K=3)
+    big = torch.randn(V, 18)
+    keep = big.clone()
+    assert F_sg._adopt_wide(big[:, :6], 3) is None
+    y = conv(big[:, :6], ei)
+    assert torch.equal(big, keep)
+    assert torch.allclose(y, conv(keep[:, :6].contiguous(), ei), atol=1e-6)
+    # backward: cat([conv_out, b, c]).backward() hands the narrowing conv a (3C,1)-strided gradient view
+    conv2 = sgnn.ChebConv(10, 6, K=3)                     # Cout < Cin -> _ChebConvPostFn, which adopts its dout
+    x = torch.randn(V, 10, requires_grad=True)
+    b = torch.randn(V, 6, requires_grad=True)
+    c = torch.randn(V, 6, requires_grad=True)
+    r = torch.randn(V, 18)
+    (torch.cat([conv2(x, ei), b, c], 1) * r).sum().backward()
+    assert torch.equal(b.grad, r[:, 6:12]) and torch.equal(c.grad, r[:, 12:])
+    x2 = x.detach().clone().requires_grad_(True)
+    (conv2(x2, ei) * r[:, :6]).sum().backward()
+    assert torch.allclose(x.grad, x2.grad, atol=1e-6)
+    # the registered buffer IS adopted, exactly once per buffer shape
+    wide = F_sg._new_wide(V, V, 6, 3, torch.float32, "cpu")
+    assert F_sg._adopt_wide(wide, 3) is not None and F_sg._adopt_wide(wide, 2) is None
+    assert F_sg._adopt_wide(wide.clone(), 3) is None
+
+
+def test_weight_cache_invalidation(cpu_kernels):
+    """writes through .data do not bump the version counter; invalidate_weight_cache / load_state_dict do."""
+    from semigcn_amd import nn as sgnn, synth
+    m = synth.torus_mesh(12, 8)
+    ei = torch.from_numpy(m.edge_index)
+    conv = sgnn.ChebConv(5, 7, K=3)
+    x = torch.randn(m.num_vertices, 5)
+    y0 = conv(x, ei).detach()
+    with torch.no_grad():
+        conv.lins[0].weight.mul_(2.0)                      # autograd-visible in-place update: picked up by itself
+    y1 = conv(x, ei).detach()
+    assert not torch.allclose(y0, y1)
+    conv.lins[0].weight.data.mul_(0.5)                     # invisible to the version counter
+    conv.invalidate_weight_cache()
+    assert torch.allclose(conv(x, ei).detach(), y0, atol=1e-6)
+    sd = {k: v.clone() for k, v in conv.state_dict().items()}
+    sd["lins.1.weight"] = sd["lins.1.weight"] * 3.0
+    conv.load_state_dict(sd)
+    assert "_weight_cache" not in conv.__dict__
+    assert not torch.allclose(conv(x, ei).detach(), y0)
