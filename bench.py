@@ -259,12 +259,17 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     timer = capi.LaunchTimer() if with_timer else None
     sync()
     capi.set_launch_timer(timer)
+    if world > 1:
+        from semigcn_amd import dist as sgdist
+        c0 = dict(sgdist.collective_counts)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.iteration_step()
     sync()
     dt = time.perf_counter() - t0
     capi.set_launch_timer(None)
+    if world > 1:
+        timed_run.collectives = {k: (v - c0[k]) / args.steps for k, v in sgdist.collective_counts.items()}
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -420,6 +425,15 @@ def main():
         }
         if other is not None:
             line["fp32_features" if other["dtype"] == "f32" else "bf16_features"] = other
+        if world > 1:
+            import torch.distributed as dist
+            g = trainer.part.graph if hasattr(trainer, "part") and hasattr(trainer.part, "graph") else None
+            coll = getattr(timed_run, "collectives", {})
+            line["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                   "devices_visible": torch.cuda.device_count(), "ranks_share_one_gpu": shared,
+                                   "collectives_per_iteration": round(sum(coll.values()), 1), "collectives_by_kind": coll,
+                                   "rank0_owned_rows": None if g is None else g.n_own,
+                                   "rank0_halo_rows": None if g is None else g.n_halo}
         line["cpu_baseline"] = cpu_baseline(args.cpu_sample, mesh.num_vertices, full=args.cpu_full) if (
             world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(line), flush=True)

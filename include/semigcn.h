@@ -274,6 +274,27 @@ SG_API int sg_mesh_loss_bwd(const float* pos, const int64_t* faces, const float*
  * Launch tuning of the aggregation kernel (process-wide, not thread-safe; for
  * benchmarking -- results never depend on it).
  * ------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------- *
+ * Dense per-vertex feature x weight product on the matrix cores (MFMA):
+ *     C[M, N] = A[M, K] * B[N, K]^T (+ bias[N])     bf16 operands and result, fp32 accumulate
+ * Replaces the K bias-free `lins[k](Tx_k)` + `out += bias` of ChebConv.forward [3P torch_geometric 2.2.0]
+ * (call sites util/networks.py:42,49; util/meshnet.py:40-240): A = [Tx0|Tx1|Tx2] ([V, K*Cin], written by sg_spmm),
+ * B = [W0|W1|W2] ([Cout, K*Cin]); with B = the transposed weights it is their input gradient dT = dOut * Wcat
+ * (autograd of the same call sites).  Row strides lda / ldb / ldc are in elements; A, B, C 16-byte aligned,
+ * K, N and the strides multiples of 8 (otherwise SG_ERR_UNSUPPORTED: the caller keeps its BLAS call).
+ * moments (nullable): float32 [sg_gemm_row_tiles(M), 2, N]; tile t receives the per-column mean and
+ * sum (x - mean)^2 of rows [t*R, (t+1)*R) of the ROUNDED result, R = sg_gemm_tile_rows() -- the block moments
+ * sg_bn_stats_finalize_tiles merges, so BatchNorm needs no separate pass over C (util/networks.py:43).
+ * ------------------------------------------------------------------------- */
+SG_API int64_t sg_gemm_tile_rows(void);
+SG_API int64_t sg_gemm_row_tiles(int64_t M);
+SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
+                      int64_t M, int64_t N, int64_t K, int dtype, float* moments, void* stream);
+/* sg_bn_stats_finalize for partials cut into uniform tiles of rows_per_tile rows (the last one shorter) */
+SG_API int sg_bn_stats_finalize_tiles(const float* partial, int64_t n_tiles, int64_t rows_per_tile, int64_t V, int64_t C,
+                                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                      float momentum, float eps, float* out, void* stream);
+
 enum sg_tune_knob {
   SG_TUNE_CHUNK_ROWS = 0, /* rows per wavefront chunk; 0 = automatic */
   SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map, bit 1: never use the shared-gather kernel,

@@ -58,6 +58,12 @@ _SIGNATURES = {
     "sg_bn_merge": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "sg_bn_stats_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                      c_float, c_void_p, c_void_p]),
+    "sg_bn_stats_finalize_tiles": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "sg_gemm_tile_rows": (c_int64, []),
+    "sg_gemm_row_tiles": (c_int64, [c_int64]),
+    "sg_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                           c_int, c_void_p, c_void_p]),
     "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_bn_finalize_ranks": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                      c_void_p, c_void_p, c_void_p]),
@@ -456,6 +462,63 @@ def bn_stats_finalize(partial: torch.Tensor, num_rows: int, gamma: torch.Tensor,
                                            float(momentum), float(eps), _ptr(out), _stream(partial)),
                "sg_bn_stats_finalize")
     return out
+
+
+def bn_stats_finalize_tiles(partial: torch.Tensor, rows_per_tile: int, num_rows: int, gamma: torch.Tensor,
+                            beta: torch.Tensor, running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
+                            momentum: float, eps: float) -> torch.Tensor:
+    """bn_stats_finalize for the per-tile moments the MFMA GEMM emits (uniform tiles of ``rows_per_tile`` rows)."""
+    nb, _, C = partial.shape
+    out = torch.empty((4, C), dtype=torch.float32, device=partial.device)
+    for t, n in ((running_mean, "running_mean"), (running_var, "running_var")):
+        if t is not None:
+            _f32vec(t, C, n)
+    with _on_device(partial.device):
+        _check(load().sg_bn_stats_finalize_tiles(_ptr(partial), nb, int(rows_per_tile), int(num_rows), C,
+                                                 _ptr(_f32vec(gamma, C, "weight")), _ptr(_f32vec(beta, C, "bias")),
+                                                 _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+                                                 _ptr(out), _stream(partial)), "sg_bn_stats_finalize_tiles")
+    return out
+
+
+# ---- dense feature x weight product on the matrix cores ------------------------------------------
+def gemm_tile_rows() -> int:
+    return int(load().sg_gemm_tile_rows())
+
+
+def gemm_nt_supported(A: torch.Tensor, B: torch.Tensor, ldc: int) -> bool:
+    """Shapes sg_gemm_nt takes: bf16, unit column strides, K / N / row strides multiples of 8, 16-byte aligned."""
+    if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16 or not A.is_cuda or A.dim() != 2 or B.dim() != 2:
+        return False
+    if A.shape[1] != B.shape[1] or A.stride(1) != 1 or B.stride(1) != 1 or A.shape[0] == 0:
+        return False
+    K, N = A.shape[1], B.shape[0]
+    return (K % 8 == 0 and N % 8 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and ldc % 8 == 0
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+            moments: bool = False):
+    """``out = A @ B.T (+ bias)`` on the MFMA kernel (csrc/gemm_mfma.hip): A [M, K] and B [N, K] bf16 with unit column
+    stride, bias fp32 [N], out bf16 [M, N] (any row stride that is a multiple of 8).  ``moments=True`` also returns
+    the float32 [ceil(M / gemm_tile_rows()), 2, N] per-tile column (mean, M2) of the rounded result."""
+    _require_device(A, "A")
+    _require_device(B, "B")
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    if out.shape != (M, N) or out.dtype != torch.bfloat16 or B.shape[1] != K:
+        raise SemigcnLibraryError(f"gemm_nt shape mismatch: A {tuple(A.shape)} B {tuple(B.shape)} out {tuple(out.shape)}")
+    if bias is not None:
+        _f32vec(bias, N, "bias")
+    mom = None
+    if moments:
+        mom = torch.empty((int(load().sg_gemm_row_tiles(M)), 2, N), dtype=torch.float32, device=A.device)
+    with _on_device(A.device):
+        _check(load().sg_gemm_nt(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), _ptr(bias), _ptr(out),
+                                 _rows2d(out, "out"), M, N, K, SG_BF16, _ptr(mom), _stream(A)), "sg_gemm_nt")
+    return (out, mom) if moments else out
 
 
 def bn_bwd_coeffs(partial: torch.Tensor, count: float, gamma: torch.Tensor, invstd: torch.Tensor) -> torch.Tensor:

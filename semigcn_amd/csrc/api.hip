@@ -400,6 +400,29 @@ SG_API int sg_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int
                                   (hipStream_t)stream);
 }
 
+SG_API int sg_bn_stats_finalize_tiles(const float* partial, int64_t n_tiles, int64_t rows_per_tile, int64_t V, int64_t C,
+                                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                      float momentum, float eps, float* out, void* stream) {
+  SG_REQUIRE(V > 1 && C >= 0 && partial && gamma && beta && out, "sg_bn_stats_finalize_tiles: bad argument");
+  SG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+             "sg_bn_stats_finalize_tiles: give both running buffers or none");
+  return launch_bn_stats_finalize_tiles(partial, n_tiles, rows_per_tile, V, C, gamma, beta, running_mean, running_var,
+                                        momentum, eps, out, (hipStream_t)stream);
+}
+
+SG_API int64_t sg_gemm_tile_rows(void) { return kGemmTileRows; }
+
+SG_API int64_t sg_gemm_row_tiles(int64_t M) { return M <= 0 ? 0 : (M + kGemmTileRows - 1) / kGemmTileRows; }
+
+SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
+                      int64_t M, int64_t N, int64_t K, int dtype, float* moments, void* stream) {
+  SG_REQUIRE(M >= 0 && N >= 0 && K >= 0, "sg_gemm_nt: negative size");
+  if (M == 0 || N == 0) return SG_OK;
+  SG_REQUIRE(A && B && C && K > 0, "sg_gemm_nt: null operand or K = 0");
+  SG_REQUIRE(lda >= K && ldb >= K && ldc >= N, "sg_gemm_nt: row stride shorter than the row");
+  return launch_gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, dtype, moments, (hipStream_t)stream);
+}
+
 SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
                             const float* invstd, float* out, void* stream) {
   SG_REQUIRE(nb > 0 && C >= 0 && N > 0 && partial && gamma && invstd && out, "sg_bn_bwd_coeffs: bad argument");

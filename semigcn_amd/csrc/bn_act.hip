@@ -504,6 +504,17 @@ int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_
   return SG_OK;
 }
 
+int launch_bn_stats_finalize_tiles(const float* partial, int64_t nb, int64_t rpb, int64_t V, int64_t C, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                   float* out, hipStream_t stream) {
+  if (C == 0) return SG_OK;
+  SG_REQUIRE(rpb > 0 && rpb <= INT32_MAX && nb == (V + rpb - 1) / rpb, "partial buffer must have ceil(V / rows_per_tile) tiles");
+  bn_stats_finalize<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, V, (int)C, (int)rpb, gamma, beta, running_mean,
+                                                            running_var, momentum, eps, out);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
 int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
                          const float* invstd, float* out, hipStream_t stream) {
   if (C == 0) return SG_OK;

@@ -1,0 +1,275 @@
+// Dense per-vertex feature x weight product on the gfx950 matrix cores:
+//
+//     C[M, N] = A[M, K] * B[N, K]^T (+ bias[N]),  bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16)
+//
+// Replaces the three `lins[k](Tx_k)` of ChebConv.forward [3P torch_geometric 2.2.0] (reached from
+// util/networks.py:42,49 and util/meshnet.py:40-240) -- A = [Tx0|Tx1|Tx2] (one [V, 3 Cin] buffer written by the
+// aggregation kernel), B = [W0|W1|W2] -- and, with the transposed weights as B, their input gradient
+// dT = dOut * Wcat.  M is the vertex count (1 M .. 4 M), N and K are channel counts (16 .. 768): the product is a
+// STREAM over A and C with a small L2-resident B, so for most layers the bound is HBM, not the MFMA rate
+// (DESIGN.md section 3.3 has the per-layer byte / flop counts).
+//
+// Structure (CDNA4 guide, section 5: the 128-row tile, two barriers per K step, ~3 workgroups per CU):
+//  * one workgroup = 4 wavefronts = one 128 x BN tile of C (BN = 16/32/64/128 by N); K is walked in steps of
+//    64 bf16 = 128-byte rows of the LDS tiles;
+//  * global -> registers -> LDS staging (16 B per lane, whole 128-B lines per 8 lanes): the loads of step t+1 are
+//    issued BEFORE the MFMAs of step t and written to LDS after them, so HBM latency hides behind the matrix work
+//    and behind the other workgroups of the CU; register staging (not LDS-DMA) because the K tail and the M / N
+//    edges are zero-filled / clamped per lane;
+//  * LDS rows are XOR-swizzled in 16-B chunks (chunk ^ (row & 7)): the ds_read_b128 fragment reads (16 rows x one
+//    chunk per 16 lanes) and the ds_write_b128 fills are both bank-conflict-free;
+//  * epilogue: accumulators (+ bias) are rounded to bf16 into an LDS image of the C tile and leave as 16-byte row
+//    segments (the MFMA result layout holds one COLUMN per lane -- stored directly it would write 2-byte pieces);
+//    optionally the tile's per-column (mean, M2) go out beside it, so BatchNorm needs no separate moments pass;
+//  * workgroups that share an XCD (blockIdx % 8) take consecutive tiles, column tile fastest: the column tiles of
+//    one row tile run side by side on one L2, so A leaves HBM once.
+#include "sg_common.h"
+
+namespace sg {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment: 8 consecutive k (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kBK = 64;           // bf16 per K step
+constexpr int kRowBytes = 128;    // kBK * 2
+
+struct GemmArgs {
+  const uint16_t* A; int64_t lda;
+  const uint16_t* B; int64_t ldb;
+  const float* bias;              // nullable
+  uint16_t* C; int64_t ldc;
+  float* moments;                 // nullable: [row tiles][2][N] = per-tile column (mean, M2) of the ROUNDED output
+  int M, N, K;
+  int n_col_tiles, n_tiles;
+};
+
+__device__ __forceinline__ int xcd_run(int b, int nblocks) {   // blocks b, b+8, .. (one XCD) get one contiguous run
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = b & 7, slot = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool MOMENTS>
+__global__ __launch_bounds__(kThreads) void gemm_nt_bf16(const GemmArgs g) {
+  static_assert(WAVES_M * WAVES_N == 4, "four wavefronts per workgroup");
+  constexpr int BM = WAVES_M * MT * 16, BN = WAVES_N * NT * 16;
+  constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes;
+  constexpr int C_PITCH = BN * 2 + 16;                         // padded: the column-per-lane writes spread over banks
+  constexpr int C_BYTES = BM * C_PITCH;
+  constexpr int RED_BYTES = MOMENTS ? kThreads * 4 : 0;
+  constexpr int LDS_BYTES = (A_BYTES + B_BYTES > C_BYTES ? A_BYTES + B_BYTES : C_BYTES) + RED_BYTES;
+  constexpr int A_CH = BM * 8 / kThreads;                      // 16-B chunks of the A tile per thread (4)
+  constexpr int B_CH = (BN * 8 + kThreads - 1) / kThreads;     // of the B tile (4 / 2 / 1 / 1)
+  __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+  uint8_t* const ldsA = lds;
+  uint8_t* const ldsB = lds + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int tile = xcd_run(blockIdx.x, g.n_tiles);
+  const int row0 = (tile / g.n_col_tiles) * BM;
+  const int col0 = (tile % g.n_col_tiles) * BN;
+
+  // ---- staging addresses: chunk q = tid + 256 i -> tile row q / 8, 16-B chunk q % 8 -------------------------------
+  const int s_c = tid & 7;
+  const uint16_t* a_src[A_CH];
+  int a_dst[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int r = (tid >> 3) + 32 * i;
+    int gr = row0 + r;
+    gr = gr < g.M ? gr : g.M - 1;                              // clamped: in bounds, masked at the store
+    a_src[i] = g.A + (int64_t)gr * g.lda;
+    a_dst[i] = r * kRowBytes + ((s_c ^ (r & 7)) << 4);
+  }
+  const uint16_t* b_src[B_CH];
+  int b_dst[B_CH];
+  bool b_on[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int r = (tid >> 3) + 32 * i;
+    b_on[i] = r < BN;
+    int gr = col0 + r;
+    gr = gr < g.N ? gr : g.N - 1;
+    b_src[i] = g.B + (int64_t)gr * g.ldb;
+    b_dst[i] = (b_on[i] ? r : 0) * kRowBytes + ((s_c ^ (r & 7)) << 4);
+  }
+
+  // Loads are UNCONDITIONAL (a chunk past K re-reads the start of its row and is zeroed on its way to LDS): hipcc
+  // puts every load that sits behind a branch into its own basic block, which breaks up the batch of loads in flight.
+  u32x4 ra[A_CH], rb[B_CH];
+  bool kin = true;                                             // does the fetched chunk lie inside K?
+  auto fetch = [&](int k0) {                                   // global -> registers
+    kin = k0 + s_c * 8 < g.K;                                  // K % 8 == 0: a chunk is wholly inside or outside
+    const int koff = kin ? k0 + s_c * 8 : 0;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i] + koff);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) rb[i] = *(const u32x4*)(b_src[i] + koff);
+  };
+  auto stash = [&]() {                                         // registers -> LDS, zero past K
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) *(u32x4*)(ldsA + a_dst[i]) = kin ? ra[i] : zero;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      if (b_on[i]) *(u32x4*)(ldsB + b_dst[i]) = kin ? rb[i] : zero;
+  };
+
+  // ---- fragment addresses: lane -> (row = lane & 15, chunk = lane >> 4 (+4 for the second half of the K step)) ---
+  const int f_r = lane & 15, f_c = lane >> 4;
+  int a_off[MT], b_off[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) a_off[i] = ((wm * MT + i) * 16 + f_r) * kRowBytes;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) b_off[j] = ((wn * NT + j) * 16 + f_r) * kRowBytes;
+  const int sw = f_r & 7;                                      // (row & 7): tile bases are multiples of 16
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + kBK - 1) / kBK;
+  fetch(0);
+  stash();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) fetch((kt + 1) * kBK);                    // in flight during the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = (((ks << 2) | f_c) ^ sw) << 4;
+      bf16x8 af[MT], bfr[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(ldsA + a_off[i] + ch);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(ldsB + b_off[j] + ch);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                           // every wavefront is done reading this step's tiles
+    if (kt + 1 < nk) {
+      stash();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: (+ bias) -> bf16 -> LDS image of the C tile [BM][BN] (pitch C_PITCH) ------------------------------
+  // accumulator layout of the 16x16 MFMA: column = lane & 15, rows = 4 (lane >> 4) + reg
+  uint8_t* const ldsC = lds;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int cl = (wn * NT + j) * 16 + f_r;
+    const int gc = col0 + cl;
+    const float bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int rl = (wm * MT + i) * 16 + f_c * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(uint16_t*)(ldsC + (rl + q) * C_PITCH + cl * 2) = __builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][q] + bv));
+    }
+  }
+  __syncthreads();
+
+  // 16-B row segments out: BN / 8 chunks per row
+  constexpr int CPR = BN / 8;
+  int rows_valid = g.M - row0;
+  rows_valid = rows_valid > BM ? BM : rows_valid;
+#pragma unroll
+  for (int i = 0; i < BM * CPR / kThreads; ++i) {
+    const int q = tid + kThreads * i;
+    const int r = q / CPR, c = q % CPR;
+    const int gc = col0 + c * 8;
+    if (r < rows_valid && gc < g.N)                           // N % 8 == 0: a chunk is wholly inside or outside
+      *(u32x4*)(g.C + (int64_t)(row0 + r) * g.ldc + gc) = *(const u32x4*)(ldsC + r * C_PITCH + c * 16);
+  }
+
+  if (MOMENTS) {
+    // per-column (mean, M2) of this tile's rows, from the ROUNDED values BatchNorm will read back: kThreads / BN
+    // row groups per column, merged through LDS; two passes (mean first) so nothing cancels
+    constexpr int GROUPS = kThreads / BN;
+    float* const red = (float*)(lds + LDS_BYTES - RED_BYTES);
+    const int c = tid % BN, gsel = tid / BN;
+    const bool con = col0 + c < g.N;
+    float s = 0.f;
+    for (int r = gsel; r < rows_valid; r += GROUPS)
+      s += __uint_as_float((uint32_t)(*(const uint16_t*)(ldsC + r * C_PITCH + c * 2)) << 16);
+    red[tid] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < GROUPS; ++k) tot += red[k * BN + c];
+    const float mean = tot / (float)rows_valid;
+    __syncthreads();
+    float m2 = 0.f;
+    for (int r = gsel; r < rows_valid; r += GROUPS) {
+      const float d = __uint_as_float((uint32_t)(*(const uint16_t*)(ldsC + r * C_PITCH + c * 2)) << 16) - mean;
+      m2 = fmaf(d, d, m2);
+    }
+    red[tid] = m2;
+    __syncthreads();
+    if (gsel == 0 && con) {
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < GROUPS; ++k) q += red[k * BN + c];
+      float* out = g.moments + (int64_t)(tile / g.n_col_tiles) * 2 * g.N;
+      out[col0 + c] = mean;
+      out[g.N + col0 + c] = q;
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int MT, int NT>
+int launch(GemmArgs g, hipStream_t stream) {
+  constexpr int BM = WAVES_M * MT * 16, BN = WAVES_N * NT * 16;
+  static_assert(BM == kGemmTileRows, "moments are per kGemmTileRows-row tile");
+  g.n_col_tiles = (g.N + BN - 1) / BN;
+  const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * g.n_col_tiles;
+  SG_REQUIRE(tiles <= INT32_MAX, "sg_gemm_nt: too many tiles");
+  g.n_tiles = (int)tiles;
+  if (g.moments) gemm_nt_bf16<WAVES_M, WAVES_N, MT, NT, true><<<g.n_tiles, kThreads, 0, stream>>>(g);
+  else gemm_nt_bf16<WAVES_M, WAVES_N, MT, NT, false><<<g.n_tiles, kThreads, 0, stream>>>(g);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream) {
+  if (dtype != SG_BF16) {
+    set_error("sg_gemm_nt: bf16 operands only (dtype %d); fp32 products stay with the BLAS library", dtype);
+    return SG_ERR_UNSUPPORTED;
+  }
+  if (K % 8 || N % 8 || lda % 8 || ldb % 8 || ldc % 8 || !a16(A) || !a16(B) || !a16(C)) {
+    set_error("sg_gemm_nt: needs K, N and the row strides to be multiples of 8 and 16-byte aligned operands "
+              "(K=%lld N=%lld lda=%lld ldb=%lld ldc=%lld)", (long long)K, (long long)N, (long long)lda, (long long)ldb,
+              (long long)ldc);
+    return SG_ERR_UNSUPPORTED;
+  }
+  SG_REQUIRE(M <= INT32_MAX && N <= INT32_MAX && K <= INT32_MAX, "sg_gemm_nt: size out of range");
+  GemmArgs g;
+  g.A = (const uint16_t*)A; g.lda = lda;
+  g.B = (const uint16_t*)B; g.ldb = ldb;
+  g.bias = bias;
+  g.C = (uint16_t*)C; g.ldc = ldc;
+  g.moments = moments;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.n_col_tiles = g.n_tiles = 0;
+  if (N > 64) return launch<2, 2, 4, 4>(g, stream);     // 128 x 128, wavefront tile 64 x 64
+  if (N > 32) return launch<4, 1, 2, 4>(g, stream);     // 128 x 64,  wavefront tile 32 x 64
+  if (N > 16) return launch<4, 1, 2, 2>(g, stream);     // 128 x 32
+  return launch<4, 1, 2, 1>(g, stream);                 // 128 x 16
+}
+
+}  // namespace sg

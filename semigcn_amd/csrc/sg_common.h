@@ -119,6 +119,15 @@ int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_
                      const float* c2, float slope, void* Y, int64_t ldy, int64_t V, int64_t C, int dtype,
                      hipStream_t stream);
 
+int launch_bn_stats_finalize_tiles(const float* partial, int64_t nb, int64_t rpb, int64_t V, int64_t C, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                   float* out, hipStream_t stream);
+
+// gemm_mfma.hip
+constexpr int kGemmTileRows = 128;
+int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream);
+
 // mesh_loss.hip
 int64_t mesh_loss_blocks(int64_t V, int64_t F);
 int launch_mesh_loss_fwd(const float* pos, const int64_t* faces, const float* tpos, const float* vkeep, const float* tfn,

@@ -42,11 +42,16 @@ from . import reorder as _reorder
 # single-GPU self-test where several ranks share one device -- device tensors are staged through
 # host memory, because gloo moves host buffers only.
 # --------------------------------------------------------------------------------------
+#: collectives issued by this rank since import, by kind (bench.py reports the per-iteration count)
+collective_counts = {"all_reduce": 0, "all_gather": 0, "all_to_all": 0}
+
+
 def _staged(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
 def _all_reduce(t: torch.Tensor, op, group) -> None:
+    collective_counts["all_reduce"] += 1
     if _staged(t, group):
         h = t.cpu()
         dist.all_reduce(h, op=op, group=group)
@@ -56,6 +61,7 @@ def _all_reduce(t: torch.Tensor, op, group) -> None:
 
 
 def _all_gather_rows(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    collective_counts["all_gather"] += 1
     if _staged(inp, group):
         ho, hi = out.cpu(), inp.cpu()
         dist.all_gather_into_tensor(ho, hi, group=group)
@@ -65,6 +71,7 @@ def _all_gather_rows(out: torch.Tensor, inp: torch.Tensor, group) -> None:
 
 
 def _all_to_all_rows(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits, group) -> None:
+    collective_counts["all_to_all"] += 1
     if _staged(send, group):
         hr, hs = recv.cpu(), send.cpu()
         dist.all_to_all_single(hr, hs, list(recv_splits), list(send_splits), group=group)
@@ -149,7 +156,13 @@ class HaloPlan(_RowExchange):
 
 
 class DistMeshGraph(_RowExchange):
-    """One rank's share of the scaled Laplacian plus its halo-exchange plan."""
+    """One rank's share of the scaled Laplacian plus its halo-exchange plan.
+
+    The halo is TWO rings deep: ``[owned | halo]`` holds the owned rows, their remote neighbours (ring 1) and those
+    neighbours' remote neighbours (ring 2), halo rows in ascending global id (= grouped by owner, so a peer's rows
+    land contiguously).  ONE exchange then serves both aggregations of a K = 3 ChebConv: ``handle_wide`` applies
+    L^ on the owned AND ring-1 rows (Tx1 recomputed redundantly on ring 1 -- a few per cent of the rows), ``handle``
+    on the owned rows only (Tx2).  Ring-2 rows carry no edges in ``handle_wide`` (their output rows are not used)."""
     sg_partitioned = True
 
     def __init__(self, edge_index: torch.Tensor, num_vertices: int, rank: int, world: int,
@@ -158,12 +171,11 @@ class DistMeshGraph(_RowExchange):
         (callers renumber with reorder.morton_order first); every rank passes the full graph."""
         dev = edge_index.device
         self.group, self.rank, self.world = group, rank, world
-        self.num_vertices_global = int(num_vertices)
+        self.num_vertices_global = V = int(num_vertices)
         bounds = list(bounds) if bounds is not None else block_bounds(num_vertices, world)
         self.bounds = bounds
         start, end = bounds[rank], bounds[rank + 1]
         self.start, self.end, self.n_own = start, end, end - start
-        b = torch.tensor(bounds, device=dev, dtype=torch.long)
 
         ei = edge_index[:, edge_index[0] != edge_index[1]]
         src, dst = ei[0], ei[1]
@@ -174,31 +186,58 @@ class DistMeshGraph(_RowExchange):
         deg = torch.bincount(src, minlength=num_vertices).float()
         dis = torch.where(deg > 0, deg.rsqrt(), torch.zeros_like(deg))
 
-        owner_dst = torch.bucketize(dst, b[1:], right=True)
-        owner_src = torch.bucketize(src, b[1:], right=True)
-        mine = owner_dst == rank
-        d_loc = dst[mine] - start
-        s_glob = src[mine]
-        s_own = owner_src[mine] == rank
-        halo = torch.unique(s_glob[~s_own])                      # sorted global ids = grouped by owner
+        def rings_of(lo: int, hi: int):
+            """(ring 1, ring 2) of the block [lo, hi) as boolean vertex masks: a row gathers from the SOURCES of the
+            edges that end in it."""
+            own = torch.zeros(V, dtype=torch.bool, device=dev)
+            own[lo:hi] = True
+            r1 = torch.zeros(V, dtype=torch.bool, device=dev)
+            r1[src[own[dst]]] = True
+            r1 &= ~own
+            r2 = torch.zeros(V, dtype=torch.bool, device=dev)
+            r2[src[r1[dst]]] = True
+            r2 &= ~(own | r1)
+            return own, r1, r2
+
+        own, r1, r2 = rings_of(start, end)
+        halo = torch.nonzero(r1 | r2).flatten()                  # ascending global ids = grouped by owner
         self.halo_ids = halo
         self.n_halo = int(halo.numel())
+        self.n_halo1 = int(r1.sum())
         self.n_ext = self.n_own + self.n_halo
-        s_ext = torch.where(s_own, s_glob - start, self.n_own + torch.searchsorted(halo, s_glob))
+        ext_of = torch.full((V,), -1, dtype=torch.long, device=dev)
+        ext_of[start:end] = torch.arange(self.n_own, device=dev)
+        ext_of[halo] = self.n_own + torch.arange(self.n_halo, device=dev)
+        self._ext_of = ext_of
         dis_ext = torch.cat([dis[start:end], dis[halo]])
-        self.handle = capi.GraphHandle.from_partition(d_loc, s_ext, self.n_own, self.n_ext, dis_ext)
+        e_own = own[dst]                                          # edges that end in an owned row
+        self.handle = capi.GraphHandle.from_partition(dst[e_own] - start, ext_of[src[e_own]], self.n_own, self.n_ext, dis_ext)
+        e_wide = e_own | r1[dst]                                  # ... or in a ring-1 row (complete rows: global degrees)
+        self.handle_wide = capi.GraphHandle.from_partition(ext_of[dst[e_wide]], ext_of[src[e_wide]], self.n_ext, self.n_ext,
+                                                           dis_ext)
 
         # what I receive from each peer: my halo ids that it owns (contiguous runs of `halo`)
-        halo_owner = torch.bucketize(halo, b[1:], right=True)
-        self.recv_splits = torch.bincount(halo_owner, minlength=world).tolist()
-        # what I send to peer q: my rows that are sources of edges into q's rows, ascending
-        out_edges = (owner_src == rank) & (owner_dst != rank)
-        pair = torch.unique(owner_dst[out_edges] * num_vertices + src[out_edges])   # sorted by (q, row)
-        self.send_splits = torch.bincount(pair // num_vertices, minlength=world).tolist()
-        self.send_rows = (pair % num_vertices - start).to(torch.int32)
+        b = torch.tensor(bounds, device=dev, dtype=torch.long)
+        self.recv_splits = torch.bincount(torch.bucketize(halo, b[1:], right=True), minlength=world).tolist()
+        # what I send to peer q: my rows inside q's two rings, ascending -- q's receive order
+        send_rows, send_splits = [], []
+        for q in range(world):
+            if q == rank or bounds[q + 1] == bounds[q]:
+                send_splits.append(0)
+                continue
+            _, q1, q2 = rings_of(bounds[q], bounds[q + 1])
+            rows = torch.nonzero((q1 | q2)[start:end]).flatten()
+            send_rows.append(rows)
+            send_splits.append(int(rows.numel()))
+        self.send_splits = send_splits
+        self.send_rows = (torch.cat(send_rows) if send_rows else torch.zeros(0, dtype=torch.long, device=dev)).to(torch.int32)
         self.n_send = int(self.send_rows.numel())
         self.device = dev
         self.symmetric = True
+
+    def extended_index(self, rows: torch.Tensor) -> torch.Tensor:
+        """Position of global ``rows`` (owned or in the halo) inside this rank's ``[owned | halo]`` buffer."""
+        return self._ext_of[rows]
 
     # MeshGraph-compatible surface -----------------------------------------------------
     @property
@@ -206,8 +245,13 @@ class DistMeshGraph(_RowExchange):
         return self.n_own
 
     def aggregate(self, X_ext: torch.Tensor, Y_own: torch.Tensor, **kw):
+        """L^ on the owned rows: X on ``[owned | halo]`` (ring 1 valid), Y on the owned rows."""
         return self.handle.spmm(X_ext, Y_own, **kw)
 
+    def aggregate_wide(self, X_ext: torch.Tensor, Y_ext: torch.Tensor, **kw):
+        """L^ on the owned and ring-1 rows: X on ``[owned | halo]`` (both rings valid), Y on all ``n_ext`` rows (its
+        ring-2 rows receive only the epilogue terms and are not to be used)."""
+        return self.handle_wide.spmm(X_ext, Y_ext, **kw)
 
 
 class _HaloExtend(torch.autograd.Function):
@@ -262,9 +306,9 @@ class _DistChebConvFn(torch.autograd.Function):
     def forward(ctx, g: DistMeshGraph, cache, x, bias, *weights):
         K, n = len(weights), g.n_own
         C = x.shape[1]
-        from .functional import _wcat
-        wcat = (_wcat(weights, x.dtype) if cache is None
-                else cache.get("cat", x.dtype, weights, None, lambda: _wcat(weights, x.dtype)))
+        from .functional import _wcat_pair, dense_nt
+        wcat, wcat_t = (_wcat_pair(weights, x.dtype) if cache is None
+                        else cache.get("cat", x.dtype, weights, None, lambda: _wcat_pair(weights, x.dtype)))
         from .functional import _adopt_wide
         T = _adopt_wide(x, K, g.n_ext) if K > 1 else None     # the fused BatchNorm in front may have written x in place
         fresh = T is None
@@ -273,22 +317,27 @@ class _DistChebConvFn(torch.autograd.Function):
         blk = [T[:, k * C:(k + 1) * C] for k in range(K)]
         if fresh:
             blk[0][:n].copy_(x)
-        if K > 1:
+        if K == 3:       # ONE exchange (two rings of x): Tx1 on owned + ring-1 rows, Tx2 on the owned rows
             g.exchange(blk[0])
-            g.aggregate(blk[0], blk[1][:n], alpha=1.0)
-        for k in range(2, K):
-            g.exchange(blk[k - 1])
-            g.aggregate(blk[k - 1], blk[k][:n], alpha=2.0, X0=blk[k - 2][:n], beta=-1.0)
-        own = T[:n]
-        out = torch.addmm(bias.to(x.dtype), own, wcat.t()) if bias is not None else own @ wcat.t()
+            g.aggregate_wide(blk[0], blk[1], alpha=1.0)
+            g.aggregate(blk[1], blk[2][:n], alpha=2.0, X0=blk[0][:n], beta=-1.0)
+        else:
+            if K > 1:
+                g.exchange(blk[0])
+                g.aggregate(blk[0], blk[1][:n], alpha=1.0)
+            for k in range(2, K):
+                g.exchange(blk[k - 1])
+                g.aggregate(blk[k - 1], blk[k][:n], alpha=2.0, X0=blk[k - 2][:n], beta=-1.0)
+        out = dense_nt(T[:n], wcat, bias)
         ctx.g, ctx.K, ctx.C = g, K, C
         ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
+        ctx.wcat_t = wcat_t
         ctx.save_for_backward(T, wcat)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        from .functional import column_sums, weight_grad
+        from .functional import column_sums, dense_nt, weight_grad
         T, wcat = ctx.saved_tensors
         g, K, C, n = ctx.g, ctx.K, ctx.C, ctx.g.n_own
         dout = dout.contiguous()
@@ -301,19 +350,27 @@ class _DistChebConvFn(torch.autograd.Function):
         dx = None
         if need_x:
             dT = torch.empty((g.n_ext if K > 1 else n, K * C), dtype=dout.dtype, device=dout.device)
-            torch.mm(dout, wcat, out=dT[:n])
+            if ctx.wcat_t is not None:
+                dense_nt(dout, ctx.wcat_t, out=dT[:n])
+            else:
+                torch.mm(dout, wcat, out=dT[:n])
             if K == 1:
                 dx = dT
             else:
                 gk = [dT[:, k * C:(k + 1) * C] for k in range(K)]
-                for k in range(K - 2, 0, -1):
-                    g.exchange(gk[k + 1])
-                    x1 = gk[k + 2][:n] if k + 2 <= K - 1 else None
-                    g.aggregate(gk[k + 1], gk[k][:n], alpha=2.0, X0=gk[k][:n], beta=1.0, X1=x1, gamma=-1.0)
-                g.exchange(gk[1])
                 dx = torch.empty((n, C), dtype=dout.dtype, device=dout.device)
-                x1 = gk[2][:n] if K >= 3 else None
-                g.aggregate(gk[1], dx, alpha=1.0, X0=gk[0][:n], beta=1.0, X1=x1, gamma=-1.0)
+                if K == 3:   # ONE exchange of the [g1 | g2] column blocks on both rings; g1 += 2 L g2 on owned + ring 1
+                    g.exchange(dT[:, C:3 * C])
+                    g.aggregate_wide(gk[2], gk[1], alpha=2.0, X0=gk[1], beta=1.0)
+                    g.aggregate(gk[1], dx, alpha=1.0, X0=gk[0][:n], beta=1.0, X1=gk[2][:n], gamma=-1.0)
+                else:
+                    for k in range(K - 2, 0, -1):
+                        g.exchange(gk[k + 1])
+                        x1 = gk[k + 2][:n] if k + 2 <= K - 1 else None
+                        g.aggregate(gk[k + 1], gk[k][:n], alpha=2.0, X0=gk[k][:n], beta=1.0, X1=x1, gamma=-1.0)
+                    g.exchange(gk[1])
+                    x1 = gk[2][:n] if K >= 3 else None
+                    g.aggregate(gk[1], dx, alpha=1.0, X0=gk[0][:n], beta=1.0, X1=x1, gamma=-1.0)
         return (None, None, dx, db, *dws)
 
 
@@ -324,35 +381,36 @@ class _DistChebConvPostFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g: DistMeshGraph, cache, x, bias, *weights):
         K, n, Co = len(weights), g.n_own, weights[0].shape[0]
-        def build():
-            ws = torch.cat(list(weights), dim=0).to(x.dtype)
-            bk = None
-            if bias is not None:      # the bias rides in on Z_0 (see functional._ChebConvPostFn)
-                bk = torch.cat([bias.to(x.dtype), bias.new_zeros((K - 1) * Co, dtype=x.dtype)])
-            return ws, bk
-        wstack, bias_k = build() if cache is None else cache.get("stack", x.dtype, weights, bias, build)
+        from .functional import _wstack_set, dense_nt
+
+        def build():      # the bias rides in on Z_0 (see functional._ChebConvPostFn)
+            return _wstack_set(weights, bias, x.dtype)
+        wstack, bias_k, wstack_t = build() if cache is None else cache.get("stack", x.dtype, weights, bias, build)
         x = x if x.stride(1) == 1 else x.contiguous()
         Z = torch.empty((g.n_ext, K * Co), dtype=x.dtype, device=x.device)
-        if bias is not None:
-            torch.addmm(bias_k, x, wstack.t(), out=Z[:n])
-        else:
-            torch.mm(x, wstack.t(), out=Z[:n])
+        dense_nt(x, wstack, bias_k, out=Z[:n])
         z = [Z[:, k * Co:(k + 1) * Co] for k in range(K)]
-        for k in range(K - 2, 0, -1):
-            g.exchange(z[k + 1])
-            x1 = z[k + 2][:n] if k + 2 <= K - 1 else None
-            g.aggregate(z[k + 1], z[k][:n], alpha=2.0, X0=z[k][:n], beta=1.0, X1=x1, gamma=-1.0)
-        g.exchange(z[1])
         out = torch.empty((n, Co), dtype=x.dtype, device=x.device)
-        g.aggregate(z[1], out, alpha=1.0, X0=z[0][:n], beta=1.0, X1=z[2][:n] if K >= 3 else None, gamma=-1.0)
+        if K == 3:       # ONE exchange of [Z1 | Z2] on both rings; b1 = Z1 + 2 L Z2 on owned + ring 1
+            g.exchange(Z[:, Co:3 * Co])
+            g.aggregate_wide(z[2], z[1], alpha=2.0, X0=z[1], beta=1.0)
+            g.aggregate(z[1], out, alpha=1.0, X0=z[0][:n], beta=1.0, X1=z[2][:n], gamma=-1.0)
+        else:
+            for k in range(K - 2, 0, -1):
+                g.exchange(z[k + 1])
+                x1 = z[k + 2][:n] if k + 2 <= K - 1 else None
+                g.aggregate(z[k + 1], z[k][:n], alpha=2.0, X0=z[k][:n], beta=1.0, X1=x1, gamma=-1.0)
+            g.exchange(z[1])
+            g.aggregate(z[1], out, alpha=1.0, X0=z[0][:n], beta=1.0, X1=z[2][:n] if K >= 3 else None, gamma=-1.0)
         ctx.g, ctx.K, ctx.Co = g, K, Co
         ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
+        ctx.wstack_t = wstack_t
         ctx.save_for_backward(x, wstack)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        from .functional import column_sums, weight_grad
+        from .functional import column_sums, dense_nt, weight_grad
         x, wstack = ctx.saved_tensors
         g, K, Co, n = ctx.g, ctx.K, ctx.Co, ctx.g.n_own
         dout = dout.contiguous()
@@ -360,12 +418,18 @@ class _DistChebConvPostFn(torch.autograd.Function):
         gk = [G[:, k * Co:(k + 1) * Co] for k in range(K)]
         gk[0][:n].copy_(dout)
         g.exchange(gk[0])
-        g.aggregate(gk[0], gk[1][:n], alpha=1.0)
-        for k in range(2, K):
-            g.exchange(gk[k - 1])
-            g.aggregate(gk[k - 1], gk[k][:n], alpha=2.0, X0=gk[k - 2][:n], beta=-1.0)
+        if K == 3:       # one exchange (two rings of dOut), as in _DistChebConvFn.forward
+            g.aggregate_wide(gk[0], gk[1], alpha=1.0)
+            g.aggregate(gk[1], gk[2][:n], alpha=2.0, X0=gk[0][:n], beta=-1.0)
+        else:
+            g.aggregate(gk[0], gk[1][:n], alpha=1.0)
+            for k in range(2, K):
+                g.exchange(gk[k - 1])
+                g.aggregate(gk[k - 1], gk[k][:n], alpha=2.0, X0=gk[k - 2][:n], beta=-1.0)
         own = G[:n]
-        dx = own @ wstack if ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[2]:
+            dx = dense_nt(own, ctx.wstack_t) if ctx.wstack_t is not None else own @ wstack
         dws = [None] * K
         if any(ctx.needs_input_grad[4:]):
             dwstack = weight_grad(own, x.contiguous()).to(ctx.param_dtype)
@@ -374,7 +438,9 @@ class _DistChebConvPostFn(torch.autograd.Function):
         return (None, None, dx, db, *dws)
 
 
-def dist_cheb_conv(g: DistMeshGraph, x, weights, bias=None, cache=None):
+def dist_cheb_conv(g: DistMeshGraph, x, weights, bias=None, cache=None, moments=None):
+    """``moments`` is accepted for signature parity with functional.cheb_conv and left empty: mesh-wide BatchNorm
+    statistics are merged across ranks from each rank's own moments pass."""
     from . import functional as F_sg
     if x.shape[0] != g.n_own:
         raise ValueError(f"x has {x.shape[0]} rows but this rank owns {g.n_own} vertices")
@@ -533,8 +599,7 @@ def partition_mesh(mesh, rank: int, world: int, device, group=None, n_masks: int
     faces = rank_of[torch.from_numpy(mesh.faces).to(device)]     # new ids
     f_mine = (faces[:, 0] >= g.start) & (faces[:, 0] < g.end)
     fo = faces[f_mine]
-    in_own = (fo >= g.start) & (fo < g.end)
-    faces_ext = torch.where(in_own, fo - g.start, g.n_own + torch.searchsorted(g.halo_ids, fo))
+    faces_ext = g.extended_index(fo)
     vs_all = torch.from_numpy(mesh.vs.astype(np.float32)).to(device)
     tfn_all = train.face_normals(vs_all, torch.from_numpy(mesh.faces).to(device))
     v_keep_all = torch.from_numpy(mesh.v_mask.astype(np.float32)).to(device)
@@ -768,8 +833,7 @@ class DistMGCNTrainer:
         faces = part.rank_of[0][batch.faces]
         mine = (faces[:, 0] >= g0.start) & (faces[:, 0] < g0.end)
         fo = faces[mine]
-        in_own = (fo >= g0.start) & (fo < g0.end)
-        self.faces_ext = torch.where(in_own, fo - g0.start, g0.n_own + torch.searchsorted(g0.halo_ids, fo))
+        self.faces_ext = g0.extended_index(fo)
         self.target_fn = batch.target_fn[mine]
         self.f_keep = batch.f_keep[mine]
         self.n_f_keep = float(batch.f_keep.sum())

@@ -151,14 +151,48 @@ def _wcat(weights, dtype):
     return w.to(dtype)
 
 
+#: bf16 features: the dense products run on the library's own MFMA kernel (csrc/gemm_mfma.hip) wherever its shape
+#: rules allow; False sends every product back to the BLAS library (hipBLASLt through torch), e.g. for A/B timing
+USE_MFMA_GEMM = True
+
+
+def _mfma_ok(a: torch.Tensor, b: torch.Tensor, ldc: int) -> bool:
+    return USE_MFMA_GEMM and a.is_cuda and a.dtype == torch.bfloat16 and capi.gemm_nt_supported(a, b, ldc)
+
+
+def _wcat_pair(weights, dtype):
+    """(Wcat [Cout, K*C], its transposed copy [K*C, Cout] for the input-gradient product on the MFMA kernel -- only
+    built for bf16 features, where that kernel serves)."""
+    w = _wcat(weights, dtype)
+    return w, (w.t().contiguous() if dtype == torch.bfloat16 and w.is_cuda and USE_MFMA_GEMM else None)
+
+
+def dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+             moments: Optional[dict] = None) -> torch.Tensor:
+    """``a @ b.T (+ bias)`` for the [V, C] vertex features: the MFMA kernel for bf16 operands it accepts, else the BLAS
+    library.  ``bias`` is the fp32 parameter.  ``moments`` (a dict): on the MFMA path it receives ``"tiles"`` = the
+    per-row-tile column (mean, M2) of the result and ``"rows"`` = rows per tile, for the BatchNorm that follows."""
+    ldc = b.shape[0] if out is None else out.stride(0)
+    if _mfma_ok(a, b, ldc) and (out is None or (out.stride(1) == 1 and out.data_ptr() % 16 == 0)):
+        bias32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float()).contiguous()
+        if moments is not None:
+            res, mom = capi.gemm_nt(a, b, bias32, out=out, moments=True)
+            moments["tiles"], moments["rows"] = mom, capi.gemm_tile_rows()
+            return res
+        return capi.gemm_nt(a, b, bias32, out=out)
+    if bias is not None:
+        return torch.addmm(bias.to(a.dtype), a, b.t()) if out is None else torch.addmm(bias.to(a.dtype), a, b.t(), out=out)
+    return a @ b.t() if out is None else torch.mm(a, b.t(), out=out)
+
+
 class _ChebConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, graph: MeshGraph, cache: Optional[WeightCache], x: torch.Tensor, bias: Optional[torch.Tensor],
-                *weights: torch.Tensor):
+    def forward(ctx, graph: MeshGraph, cache: Optional[WeightCache], moments: Optional[dict], x: torch.Tensor,
+                bias: Optional[torch.Tensor], *weights: torch.Tensor):
         K = len(weights)
         V, C = x.shape
-        wcat = (_wcat(weights, x.dtype) if cache is None
-                else cache.get("cat", x.dtype, weights, None, lambda: _wcat(weights, x.dtype)))
+        wcat, wcat_t = (_wcat_pair(weights, x.dtype) if cache is None
+                        else cache.get("cat", x.dtype, weights, None, lambda: _wcat_pair(weights, x.dtype)))
         if K == 1:
             T = x.contiguous()
         else:
@@ -172,13 +206,11 @@ class _ChebConvFn(torch.autograd.Function):
             graph.aggregate(blk[0], blk[1], alpha=1.0)
             for k in range(2, K):
                 graph.aggregate(blk[k - 1], blk[k], alpha=2.0, X0=blk[k - 2], beta=-1.0)
-        if bias is not None:
-            out = torch.addmm(bias.to(x.dtype), T, wcat.t())
-        else:
-            out = T @ wcat.t()
+        out = dense_nt(T, wcat, bias, moments=moments)
         ctx.graph, ctx.K, ctx.C = graph, K, C
         ctx.has_bias = bias is not None
         ctx.param_dtype = weights[0].dtype
+        ctx.wcat_t = wcat_t
         ctx.save_for_backward(T, wcat)
         return out
 
@@ -187,8 +219,8 @@ class _ChebConvFn(torch.autograd.Function):
         T, wcat = ctx.saved_tensors
         graph, K, C = ctx.graph, ctx.K, ctx.C
         dout = dout.contiguous()
-        need_x, need_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        need_w = any(ctx.needs_input_grad[4:])
+        need_x, need_b = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        need_w = any(ctx.needs_input_grad[5:])
         dws = [None] * K
         if need_w:
             dwcat = weight_grad(dout, T).to(ctx.param_dtype)  # [Cout, K*C], reduced over V in fp32
@@ -196,7 +228,8 @@ class _ChebConvFn(torch.autograd.Function):
         db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
         dx = None
         if need_x:
-            dT = dout @ wcat  # [V, K*C]; block k = dL/dTx_k before the recurrence is unwound
+            # [V, K*C]; block k = dL/dTx_k before the recurrence is unwound
+            dT = dense_nt(dout, ctx.wcat_t) if ctx.wcat_t is not None else dout @ wcat
             if K == 1:
                 dx = dT
             else:
@@ -210,7 +243,19 @@ class _ChebConvFn(torch.autograd.Function):
                 dx = torch.empty((T.shape[0], C), dtype=dout.dtype, device=dout.device)
                 x1 = g[2] if K >= 3 else None
                 graph.aggregate(g[1], dx, alpha=1.0, X0=g[0], beta=1.0, X1=x1, gamma=-1.0, transpose=tr)
-        return (None, None, dx, db, *dws)
+        return (None, None, None, dx, db, *dws)
+
+
+def _wstack_set(weights, bias, dtype):
+    """(Wstack [K*Cout, Cin] in the feature dtype, the fp32 bias padded to K*Cout (it rides in on Z_0), the transposed
+    copy [Cin, K*Cout] for the input-gradient product on the MFMA kernel or None)."""
+    K, Co = len(weights), weights[0].shape[0]
+    ws = torch.cat(list(weights), dim=0).to(dtype)
+    bk = None
+    if bias is not None:
+        bk = torch.cat([bias.float(), bias.new_zeros((K - 1) * Co, dtype=torch.float32)])
+    wt = ws.t().contiguous() if dtype == torch.bfloat16 and ws.is_cuda and USE_MFMA_GEMM else None
+    return ws, bk, wt
 
 
 class _ChebConvPostFn(torch.autograd.Function):
@@ -227,17 +272,11 @@ class _ChebConvPostFn(torch.autograd.Function):
         Co = weights[0].shape[0]
 
         def build():
-            ws = torch.cat(list(weights), dim=0).to(x.dtype)          # [K*Cout, Cin]
-            bk = None
-            if bias is not None:
-                bk = torch.cat([bias.to(x.dtype), bias.new_zeros((K - 1) * Co, dtype=x.dtype)])
-            return ws, bk
-        wstack, bias_k = build() if cache is None else cache.get("stack", x.dtype, weights, bias, build)
+            return _wstack_set(weights, bias, x.dtype)
+        wstack, bias_k, wstack_t = build() if cache is None else cache.get("stack", x.dtype, weights, bias, build)
         x = x if x.stride(1) == 1 else x.contiguous()
-        if bias is not None:      # the bias rides in on Z_0 (coefficient +1 in the recurrence): free in the GEMM epilogue
-            Z = torch.addmm(bias_k, x, wstack.t())                    # [V, K*Cout]
-        else:
-            Z = x @ wstack.t()
+        # the bias rides in on Z_0 (coefficient +1 in the recurrence): free in the GEMM epilogue
+        Z = dense_nt(x, wstack, bias_k)                              # [V, K*Cout]
         z = [Z[:, k * Co:(k + 1) * Co] for k in range(K)]
         # Clenshaw, in place in Z: after step k, z[k] holds b_k
         for k in range(K - 2, 0, -1):
@@ -247,6 +286,7 @@ class _ChebConvPostFn(torch.autograd.Function):
         graph.aggregate(z[1], out, alpha=1.0, X0=z[0], beta=1.0, X1=z[2] if K >= 3 else None, gamma=-1.0)
         ctx.graph, ctx.K, ctx.Co = graph, K, Co
         ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
+        ctx.wstack_t = wstack_t
         ctx.save_for_backward(x, wstack)
         return out
 
@@ -266,7 +306,9 @@ class _ChebConvPostFn(torch.autograd.Function):
         graph.aggregate(g[0], g[1], alpha=1.0, transpose=tr)
         for k in range(2, K):
             graph.aggregate(g[k - 1], g[k], alpha=2.0, X0=g[k - 2], beta=-1.0, transpose=tr)
-        dx = G @ wstack if ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[2]:
+            dx = dense_nt(G, ctx.wstack_t) if ctx.wstack_t is not None else G @ wstack
         dws = [None] * K
         if any(ctx.needs_input_grad[4:]):
             dwstack = weight_grad(G, x.contiguous()).to(ctx.param_dtype)   # [K*Cout, Cin]
@@ -281,19 +323,22 @@ AGGREGATE_AFTER_GEMM_WHEN_NARROWING = True
 
 
 def cheb_conv(graph: MeshGraph, x: torch.Tensor, weights: Sequence[torch.Tensor],
-              bias: Optional[torch.Tensor] = None, cache: Optional[WeightCache] = None) -> torch.Tensor:
+              bias: Optional[torch.Tensor] = None, cache: Optional[WeightCache] = None,
+              moments: Optional[dict] = None) -> torch.Tensor:
     """ChebConv forward on a prepared graph; ``weights[k]`` is ``lins[k].weight`` [Cout, Cin].  ``cache``: the
-    calling layer's WeightCache (optional)."""
+    calling layer's WeightCache (optional).  ``moments``: a dict that receives the output's per-row-tile column
+    moments when the layer's last step is the MFMA product (see dense_nt) -- the BatchNorm behind it then skips its
+    own moments pass; it stays empty otherwise."""
     if x.dim() != 2:
         raise ValueError(f"x must be [V, C], got {tuple(x.shape)}")
     if getattr(graph, "sg_partitioned", False):
         from .dist import dist_cheb_conv
-        return dist_cheb_conv(graph, x, weights, bias, cache)
+        return dist_cheb_conv(graph, x, weights, bias, cache, moments)
     if x.shape[0] != graph.num_vertices:
         raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.num_vertices} vertices")
     if AGGREGATE_AFTER_GEMM_WHEN_NARROWING and len(weights) >= 2 and weights[0].shape[0] < weights[0].shape[1]:
         return _ChebConvPostFn.apply(graph, cache, x, bias, *weights)
-    return _ChebConvFn.apply(graph, cache, x, bias, *weights)
+    return _ChebConvFn.apply(graph, cache, moments, x, bias, *weights)
 
 
 class _LaplacianFn(torch.autograd.Function):
@@ -352,7 +397,7 @@ def mesh_unpool(pool: capi.PoolHandle, x: torch.Tensor) -> torch.Tensor:
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, group, widen,
-                grad_widen=1, rows=0):
+                grad_widen=1, rows=0, tile_moments=None):
         V, C = x.shape
         if x.stride(1) != 1 and C > 1:
             x = x.contiguous()
@@ -360,7 +405,11 @@ class _BNActFn(torch.autograd.Function):
         w32 = weight if weight.dtype == torch.float32 else weight.float()
         b32 = bias if bias.dtype == torch.float32 else bias.float()
         if training and V > 1 and not ctx_group_active(group):
-            fin = capi.bn_stats_finalize(capi.col_moments(x), V, w32, b32, running_mean, running_var, momentum, eps)
+            if tile_moments is not None:       # left behind by the MFMA product that wrote x: no pass over x needed
+                fin = capi.bn_stats_finalize_tiles(tile_moments["tiles"], tile_moments["rows"], V, w32, b32, running_mean,
+                                                   running_var, momentum, eps)
+            else:
+                fin = capi.bn_stats_finalize(capi.col_moments(x), V, w32, b32, running_mean, running_var, momentum, eps)
             mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
             ctx.N = float(V)
         elif training and ctx_group_active(group):
@@ -413,7 +462,7 @@ class _BNActFn(torch.autograd.Function):
                 out = _new_wide(x.shape[0], x.shape[0], x.shape[1], ctx.grad_widen, x.dtype, x.device)
             dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, co[4], co[2], co[3], ctx.slope, out=out)
             return (dx, co[1].to(ctx.param_dtype), co[0].to(ctx.param_dtype), None, None, None, None, None, None, None,
-                    None, None, None)
+                    None, None, None, None)
         s = part.sum(0)                                                                # [2, C]: sum dz, sum dz*xhat
         dbeta, dgamma = s[0].to(ctx.param_dtype), s[1].to(ctx.param_dtype)            # this rank's partial sums
         if ctx.training:
@@ -433,7 +482,7 @@ class _BNActFn(torch.autograd.Function):
         if ctx.grad_widen > 1:     # born as block 0 of the conv's [V, K*C] gradient buffer (see _ChebConvPostFn.backward)
             out = _new_wide(x.shape[0], x.shape[0], x.shape[1], ctx.grad_widen, x.dtype, x.device)
         dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope, out=out)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 #: callables invoked with every fused BN+activation output (sign(y) == sign of the BatchNorm output);
@@ -450,11 +499,12 @@ def ctx_group_active(group) -> bool:
 
 
 def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int = 1,
-           grad_widen: int = 1, rows: int = 0) -> torch.Tensor:
+           grad_widen: int = 1, rows: int = 0, tile_moments: Optional[dict] = None) -> torch.Tensor:
     """``leaky_relu(bn(x), slope)`` with nn.BatchNorm1d semantics (batch statistics and running-stat
     updates in training mode, running statistics in eval mode) in two HIP passes.  ``widen = K``
     returns a view of the first C columns of a fresh [V, K*C] buffer, which the next ChebConv
-    adopts as its [Tx0|Tx1|..] buffer instead of copying."""
+    adopts as its [Tx0|Tx1|..] buffer instead of copying.  ``tile_moments``: {"tiles": [nt, 2, C] per-row-tile
+    (mean, M2) of x, "rows": rows per tile} when the kernel that produced x already took them (dense_nt)."""
     training = bn.training or not bn.track_running_stats
     momentum = 0.0
     if bn.training and bn.track_running_stats:
@@ -465,7 +515,7 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int =
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return _BNActFn.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, float(slope), group, int(widen),
-                          int(grad_widen), int(rows))
+                          int(grad_widen), int(rows), tile_moments)
 
 
 # --------------------------------------------------------------------------------------------

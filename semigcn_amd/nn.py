@@ -97,7 +97,9 @@ class ChebConv(nn.Module):
         return self.K if post else 1
 
     def forward(self, x: Tensor, edge_index: Union[Tensor, MeshGraph], edge_weight=None, batch=None,
-                lambda_max=None) -> Tensor:
+                lambda_max=None, moments: Optional[dict] = None) -> Tensor:
+        """``moments`` (not part of the torch_geometric signature; used by ``Sequential``): a dict that receives the
+        output's per-row-tile column moments when the MFMA product emits them (functional.dense_nt)."""
         if edge_weight is not None or batch is not None or lambda_max is not None:
             raise NotImplementedError("edge_weight / batch / lambda_max are not used by the reference "
                                       "and are not implemented")
@@ -106,7 +108,7 @@ class ChebConv(nn.Module):
         cache = self.__dict__.get("_weight_cache")
         if cache is None:
             cache = self.__dict__["_weight_cache"] = F_sg.WeightCache()
-        return F_sg.cheb_conv(graph, x, [lin.weight for lin in self.lins], self.bias, cache)
+        return F_sg.cheb_conv(graph, x, [lin.weight for lin in self.lins], self.bias, cache, moments)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, K={self.K}, "
@@ -195,20 +197,29 @@ class Sequential(nn.Module):
         scope = dict(zip(self._args, args))
         scope.update(kwargs)
         result = None
+        pending = None             # (conv output, its tile moments) from the ChebConv just run, for the BatchNorm behind it
         i, n = 0, len(self._plan)
         while i < n:
             name, ins, outs = self._plan[i]
             vals = [scope[a] for a in ins]
-            fused = self._fusable_at(i) if (len(vals) == 1 and torch.is_tensor(vals[0]) and vals[0].is_cuda
-                                             and vals[0].dim() == 2) else None
+            on_dev = len(vals) >= 1 and torch.is_tensor(vals[0]) and vals[0].is_cuda and vals[0].dim() == 2
+            fused = self._fusable_at(i) if (len(vals) == 1 and on_dev) else None
+            mod = getattr(self, name)
             if fused is not None:      # BatchNorm1d + (Leaky)ReLU in two HIP passes instead of five ATen ones
                 # (a partitioned conv keeps [owned | halo] rows in its buffer: the widened output gets the halo rows too)
                 part = next((v for v in scope.values() if getattr(v, "sg_partitioned", False)), None)
-                result = F_sg.bn_act(vals[0], getattr(self, name), fused[0], fused[1],
-                                     1 if part is not None else fused[2], 0 if part is None else part.n_ext)
+                tiles = pending[1] if (pending is not None and pending[0] is vals[0]) else None
+                result = F_sg.bn_act(vals[0], mod, fused[0], fused[1],
+                                     1 if part is not None else fused[2], 0 if part is None else part.n_ext,
+                                     tile_moments=tiles)
                 i += 1
+            elif isinstance(mod, ChebConv) and on_dev and mod.training and self._fusable_at(i + 1) is not None \
+                    and self._plan[i + 1][1] == outs:
+                mom = {}              # the MFMA product leaves the BatchNorm's block moments behind (when it serves)
+                result = mod(*vals, moments=mom)
+                pending = (result, mom) if "tiles" in mom else None
             else:
-                result = getattr(self, name)(*vals)
+                result = mod(*vals)
             if len(outs) == 1:
                 scope[outs[0]] = result
             else:

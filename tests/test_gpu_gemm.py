@@ -1,0 +1,127 @@
+"""``-m gpu``: the MFMA product sg_gemm_nt (csrc/gemm_mfma.hip) -- the dense per-vertex feature x weight GEMM of
+ChebConv.forward [3P] (util/networks.py:42,49) and its input gradient -- against fp32 matmul on the same bf16 inputs,
+bit-exact on integer data, plus the BatchNorm tile moments it leaves behind and the layer-level wiring."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as GU
+from semigcn_amd import capi, functional as F_sg, nn as sgnn, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(a, b, bias=None):
+    r = a.float() @ b.float().t()
+    return r if bias is None else r + bias
+
+
+SHAPES = [  # (M, N, K)
+    (1, 16, 8), (127, 16, 48), (128, 24, 16), (129, 32, 96), (1000, 48, 32), (4097, 64, 72), (300, 96, 64),
+    (513, 128, 192), (2050, 192, 128), (777, 256, 384), (640, 384, 256), (300, 512, 768), (260, 768, 512),
+]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_nt_integer_data_is_bit_exact(M, N, K):
+    """Small-integer operands: every product and partial sum is exact in fp32, so the result must EQUAL the
+    reference (rounded once to bf16) bit for bit -- catches any fragment / accumulator layout or K-tail mistake.
+    B is asymmetric (A = I with a symmetric B would hide a transposed C write: CDNA guide section 3)."""
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N * 3 + K)
+    lim = 2 if K > 64 else 3
+    a = torch.randint(-lim, lim + 1, (M, K), device=DEV, generator=g).to(torch.bfloat16)
+    b = torch.randint(-1, 2, (N, K), device=DEV, generator=g).to(torch.bfloat16)
+    b[:, 0] = torch.arange(N, device=DEV).remainder(5).to(torch.bfloat16) - 2       # column pattern that is not symmetric
+    ref = _ref(a, b)                                          # exact integers in fp32
+    out = capi.gemm_nt(a, b)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, ref.to(torch.bfloat16))
+    # identity rows pick out columns of B: out[i] == B[:, i]
+    if M >= K:
+        eye = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16)
+        eye[torch.arange(K), torch.arange(K)] = 1
+        assert torch.equal(capi.gemm_nt(eye, b)[:K].float(), b.float().t())
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_nt_random_data_bias_strides_and_moments(M, N, K):
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    wide = torch.randn(M, K + 24, device=DEV, generator=g).to(torch.bfloat16)
+    a = wide[:, 8:8 + K]                                       # a column block of a wider buffer (row stride K + 24)
+    b = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = _ref(a, b, bias)
+    outw = torch.full((M, N + 16), 7.0, device=DEV, dtype=torch.bfloat16)
+    out, mom = capi.gemm_nt(a, b, bias, out=outw[:, 8:8 + N], moments=True)
+    # one rounding of the fp32 result to bf16 (2^-9 relative) + fp32 summation-order noise
+    err = (out.float() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2.0 ** -8, float(err)
+    assert GU.rel_l2(out.float().cpu(), ref.cpu()) < 2.0 ** -8
+    assert bool((outw[:, :8] == 7).all()) and bool((outw[:, 8 + N:] == 7).all())      # neighbours untouched
+    # tile moments == moments of the ROUNDED output over rows [128 t, 128 t + 128)
+    R = capi.gemm_tile_rows()
+    assert R == 128 and mom.shape == ((M + R - 1) // R, 2, N)
+    o = out.float()
+    for t in range(mom.shape[0]):
+        blk = o[t * R:(t + 1) * R]
+        mean = blk.mean(0)
+        m2 = ((blk - mean) ** 2).sum(0)
+        assert float((mom[t, 0] - mean).abs().max()) <= 1e-5 * max(float(mean.abs().max()), 1.0)
+        assert float((mom[t, 1] - m2).abs().max()) <= 1e-4 * max(float(m2.max()), 1e-3)
+    # merged with the tile finalizer == BatchNorm statistics of the output
+    if M > 1:
+        gam, bet = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV)
+        fin = capi.bn_stats_finalize_tiles(mom, R, M, gam, bet, None, None, 0.1, 1e-5)
+        var, mean = torch.var_mean(o.double(), dim=0, unbiased=False)
+        assert float((fin[0].double() - mean).abs().max()) < 1e-5
+        assert float((fin[1].double() - (var + 1e-5).rsqrt()).abs().max() / (var + 1e-5).rsqrt().abs().max()) < 1e-4
+
+
+def test_gemm_nt_rejects_what_it_cannot_take():
+    a = torch.zeros(64, 12, device=DEV, dtype=torch.bfloat16)
+    b = torch.zeros(16, 12, device=DEV, dtype=torch.bfloat16)
+    assert not capi.gemm_nt_supported(a, b, 16)                 # K = 12 (the 4 -> 16 layer's [V, 12] operand)
+    with pytest.raises(capi.SemigcnLibraryError, match="multiples of 8"):
+        capi.gemm_nt(a, b)
+    a32 = torch.zeros(64, 16, device=DEV)
+    assert not capi.gemm_nt_supported(a32, a32, 16)
+    # the host wrapper routes such products to the BLAS library instead
+    y = F_sg.dense_nt(a, b)
+    assert y.shape == (64, 16) and y.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 16), (16, 32), (256, 128)])
+def test_chebconv_bf16_layer_same_result_on_mfma_and_blas_paths(cin, cout):
+    """One ChebConv + BatchNorm + LeakyReLU block, bf16 features, forward and backward: the MFMA path (own GEMM, BatchNorm
+    moments from its epilogue) against the BLAS path (hipBLASLt + separate moments pass) -- same math, one bf16
+    rounding apart at most per stored value."""
+    m = synth.torus_mesh(40, 24)
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    seq = sgnn.Sequential("x, edge_index", [(sgnn.ChebConv(cin, cout, K=3), "x, edge_index -> x"), torch.nn.BatchNorm1d(cout),
+                                            torch.nn.LeakyReLU()])
+    GU.fill_state(seq, seed=cin + cout)
+    seq.to(DEV).train()
+    x0 = torch.randn(m.num_vertices, cin, device=DEV).to(torch.bfloat16)
+    r = torch.randn(m.num_vertices, cout, device=DEV).to(torch.bfloat16)
+    res = {}
+    for mfma in (True, False):
+        F_sg.USE_MFMA_GEMM = mfma
+        try:
+            for mod in seq.modules():
+                if isinstance(mod, sgnn.ChebConv):
+                    mod.invalidate_weight_cache()
+            seq.module_1.reset_running_stats()
+            seq.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y = seq(x, ei)
+            (y.float() * r.float()).sum().backward()
+            res[mfma] = (y.detach().float(), x.grad.float(), [p.grad.clone() for p in seq.parameters()],
+                         seq.module_1.running_mean.clone(), seq.module_1.running_var.clone())
+        finally:
+            F_sg.USE_MFMA_GEMM = True
+    a, b = res[True], res[False]
+    assert GU.rel_l2(a[0].cpu(), b[0].cpu()) < 2e-2 and GU.rel_l2(a[1].cpu(), b[1].cpu()) < 3e-2
+    for pa, pb in zip(a[2], b[2]):
+        scale = max(float(pb.norm()), 1e-3 * float(max(q.abs().max() for q in b[2])) * pb.numel() ** 0.5)
+        assert float((pa - pb).norm()) <= 3e-2 * scale
+    assert GU.rel_l2(a[3].cpu(), b[3].cpu()) < 1e-2 and GU.rel_l2(a[4].cpu(), b[4].cpu()) < 1e-2

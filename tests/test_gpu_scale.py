@@ -1,0 +1,232 @@
+"""``-m gpu`` tests at the benchmark sizes and of the N > 1 path with the real kernels.
+
+  * V = 1 M (BASELINE config c4): SGCN outputs on sampled rows against the ORACLE evaluated on the
+    rows' dependency neighbourhood (fp32, 1e-5), the bf16-feature run against the fp32 one;
+  * V = 4 M (config c5's mesh, 2000 x 2000) on one GPU: aggregation properties and one training
+    iteration in fp32 and with bf16 features;
+  * the vertex-partitioned path (sg_graph_create_rect, sg_bn_finalize_ranks, DistPool, halo exchange)
+    with 2 and 4 ranks sharing cuda:0 over gloo == the single-rank model on the device;
+  * ``bench.py --gpus N`` starting its own ranks.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as GU
+from oracle import models as OM          # checker only
+from semigcn_amd import synth, train
+from semigcn_amd.graph import MeshGraph
+from semigcn_amd.networks import SingleScaleGCN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _child_env(**extra):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "4"
+    env.update(extra)
+    return env
+
+
+# --------------------------------------------------------------------------------------
+# V = 1 M: model outputs on sampled rows vs the oracle on their dependency neighbourhood
+# --------------------------------------------------------------------------------------
+RADIUS = 34          # grid half-width of a patch
+VALID = 6            # rows within this grid distance of the patch centre are exact (see below)
+
+
+def _patch(m, cu, cv):
+    """Sub-mesh of the nu x nv torus grid around grid position (cu, cv), away from the periodic seam: vertex ids
+    (global), induced directed edges relabelled to patch ids, and the patch ids of the rows whose 13-layer K=3
+    dependency cone lies inside the patch.  One ChebConv reads 2 rings, so 13 layers read 26 rings; an edge weight
+    -dis[i]*dis[j] needs the FULL degree of j, i.e. j's neighbours: rows within RADIUS - 28 of the centre are exact
+    (a flipped quad diagonal still joins grid neighbours, so one ring <= one grid step)."""
+    nu, nv = m.nu, m.nv
+    assert RADIUS <= cu < nu - RADIUS and RADIUS <= cv < nv - RADIUS and RADIUS - 28 >= VALID
+    uu, vv = np.meshgrid(np.arange(cu - RADIUS, cu + RADIUS + 1), np.arange(cv - RADIUS, cv + RADIUS + 1), indexing="ij")
+    ids = (uu * nv + vv).ravel()
+    local = np.full(m.num_vertices, -1, np.int64)
+    local[ids] = np.arange(ids.size)
+    ei = m.edge_index
+    keep = (local[ei[0]] >= 0) & (local[ei[1]] >= 0)
+    ei_loc = np.stack([local[ei[0][keep]], local[ei[1][keep]]])
+    centre = (np.abs(uu - cu) <= VALID) & (np.abs(vv - cv) <= VALID)
+    return ids, ei_loc, np.nonzero(centre.ravel())[0]
+
+
+def test_full_size_sgcn_rows_vs_oracle_and_bf16_step():
+    """SGCN at V = 1 M in eval mode (BatchNorm on running statistics that one full-size training pass has moved):
+    338 output rows against the oracle run on two 69 x 69 patches, 1e-5; then the same forward with bf16 feature
+    storage against the fp32 one (13 layers x ~5 roundings to 8 bits, BatchNorm-amplified: rel-L2 of the offsets
+    < 0.2, the bound of test_sgcn_bf16_features_close_to_fp32) and a bf16 training step."""
+    m = synth.torus_mesh(1000, 1000)
+    V = m.num_vertices
+    net = SingleScaleGCN(DEV)
+    GU.fill_state(net, seed=1234)
+    net.to(DEV)
+    # the model returns x_pos + offset in fp32; with |x_pos| ~ 500 the sum carries 3e-5 of rounding, which would hide
+    # the network's own error: shrink the positions (same Morton order) so that out - x_pos IS the offset to ~1e-8
+    xp_small = (m.x_pos * np.float32(1e-3)).astype(np.float32)
+
+    class D:
+        z1 = torch.from_numpy(m.z1).to(DEV).requires_grad_(True)
+        x_pos = torch.from_numpy(xp_small).to(DEV)
+        edge_index = torch.from_numpy(m.edge_index).to(DEV)
+    dm_np = synth.make_dummy_masks(m.edge_index, V, 1, k=4, p=0.014, seed=317)
+    dm = torch.from_numpy(dm_np).to(DEV)
+    net.train()
+    net(D, dm)                                         # moves every running_mean / running_var off its initial value
+    net.eval()
+    with torch.no_grad():
+        out = net(D, dm)
+    assert out.shape == (V, 3) and bool(torch.isfinite(out).all())
+
+    ora = OM.SGCNOracle()
+    ora.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    ora.eval()
+    lo, hi = m.z1.min(0), m.z1.max(0)
+    checked, worst = 0, 0.0
+    for cu, cv in ((300, 300), (700, 640)):
+        ids, ei_loc, rows = _patch(m, cu, cv)
+        n = ids.size
+        # two isolated extra vertices carry the mesh-wide bounding box into the oracle's own normalisation
+        z1 = np.concatenate([m.z1[ids], lo[None], hi[None]]).astype(np.float32)
+        xp = np.concatenate([xp_small[ids], np.zeros((2, 3), np.float32)])
+        dmp = np.concatenate([dm_np[ids], np.ones((2, 1), np.float32)])
+        with torch.no_grad():
+            ref = ora(torch.from_numpy(z1), torch.from_numpy(xp), torch.from_numpy(ei_loc), torch.from_numpy(dmp))[:n]
+        got = out[torch.from_numpy(ids[rows]).to(DEV)].cpu()
+        off_ref = ref[rows] - torch.from_numpy(xp_small[ids[rows]])         # compare the network's offsets, not x_pos + offset
+        off_got = got - torch.from_numpy(xp_small[ids[rows]])
+        err = float((off_got - off_ref).abs().max() / off_ref.abs().max())
+        worst = max(worst, err)
+        assert err < 1e-5, (cu, cv, err)
+        assert GU.rel_l2(off_got, off_ref) < 1e-5
+        checked += rows.size
+    assert checked >= 256
+    print(f"V=1M eval rows vs oracle patches: {checked} rows, worst max-rel error {worst:.2e}")
+
+    # bf16 feature storage at full size: forward against fp32, then one training step
+    net.set_feature_dtype(torch.bfloat16)
+    with torch.no_grad():
+        out16 = net(D, dm)
+    e16 = GU.rel_l2((out16 - D.x_pos).cpu(), (out - D.x_pos).cpu())
+    assert out16.dtype == torch.float32 and e16 < 0.2, e16
+    net.train()
+    pos = net(D, dm)
+    (pos - D.x_pos).square().mean().backward()
+    assert all(p.grad is not None and p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all())
+               for nme, p in net.named_parameters() if not nme.startswith("skip_blocks"))
+    assert bool(torch.isfinite(D.z1.grad).all())
+    print(f"V=1M bf16-feature forward vs fp32: rel-L2 of the offsets {e16:.3e}")
+
+
+# --------------------------------------------------------------------------------------
+# config c5's mesh (2000 x 2000, V = 4 M, E = 24 M) on ONE GPU
+# --------------------------------------------------------------------------------------
+def test_c5_mesh_aggregation_properties_and_training_step():
+    m = synth.torus_mesh(2000, 2000, masks=False)
+    V = m.num_vertices
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    g = MeshGraph.from_edge_index(ei, V)
+    assert V == 4_000_000 and ei.shape[1] == 24_000_000 and g.symmetric
+    deg = torch.bincount(ei[0], minlength=V).float()
+    for C, dtype in ((64, torch.float32), (256, torch.bfloat16)):
+        f32 = dtype == torch.float32
+        gen = torch.Generator(device=DEV).manual_seed(C)
+        x = torch.randn(V, C, device=DEV, generator=gen).to(dtype)
+        y = torch.randn(V, C, device=DEV, generator=gen).to(dtype)
+        Lx, Ly = g.aggregate(x, torch.empty_like(x)), g.aggregate(y, torch.empty_like(y))
+        s = deg.sqrt().view(-1, 1).expand(V, C).contiguous().to(dtype)              # eigenvector: L^ D^1/2 1 = -D^1/2 1
+        Ls = g.aggregate(s, torch.empty_like(s))
+        assert float((Ls.float() + s.float()).abs().max() / s.float().abs().max()) < (2e-6 if f32 else 2e-2)
+        a = float((y.double() * Lx.double()).sum())                                   # symmetry <y, Lx> = <Ly, x>
+        b = float((Ly.double() * x.double()).sum())
+        assert abs(a - b) <= (1e-7 if f32 else 1e-4) * float(x.double().norm() * y.double().norm())
+        fused = g.aggregate(x, torch.empty_like(x), alpha=2.0, X0=y, beta=-1.0)       # fused epilogue == separate ops
+        sep = 2 * Lx.float() - y.float()
+        assert float((fused.float() - sep).abs().max() / sep.abs().max()) < (1e-5 if f32 else 3e-2)
+        rp, ci, dis = g.handle.arrays()                                               # spot rows against a direct gather
+        for rr in torch.randint(0, V, (32,), generator=torch.Generator().manual_seed(2)).tolist():
+            nb = ci[int(rp[rr]):int(rp[rr + 1])].long()
+            want = -(dis[rr] * (dis[nb].view(-1, 1) * x[nb].float()).sum(0))
+            assert float((Lx[rr].float() - want).abs().max()) <= (4e-5 if f32 else 3e-2) * max(float(want.abs().max()), 1e-3)
+        del x, y, Lx, Ly, s, Ls, fused, sep
+    torch.cuda.empty_cache()
+
+    faces = torch.from_numpy(m.faces).to(DEV)
+    target = torch.from_numpy(m.vs.astype(np.float32)).to(DEV)
+    v_keep = torch.ones(V, 1, device=DEV)
+
+    class D:
+        z1 = torch.from_numpy(m.z1).to(DEV).requires_grad_(True)
+        x_pos = torch.from_numpy(m.x_pos).to(DEV)
+        edge_index = ei
+    batch = train.MeshBatch(D, faces, target, train.face_normals(target, faces), v_keep,
+                            torch.ones(faces.shape[0], 1, device=DEV), torch.ones(V, 1, device=DEV))
+    losses = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        net = SingleScaleGCN(DEV)
+        GU.fill_state(net, seed=99)
+        net.to(DEV)
+        net.set_feature_dtype(dtype)
+        tr = train.SGCNTrainer(net, batch)
+        loss = tr.iteration_step()
+        torch.cuda.synchronize()
+        losses[dtype] = float(loss)
+        assert np.isfinite(losses[dtype])
+        assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+        del net, tr
+        torch.cuda.empty_cache()
+    # same weights, same inputs: the bf16-feature loss sits within the bf16 forward error of the fp32 one
+    assert abs(losses[torch.bfloat16] - losses[torch.float32]) < 0.1 * abs(losses[torch.float32]), losses
+
+
+# --------------------------------------------------------------------------------------
+# N > 1 with the real kernels: ranks share cuda:0, collectives over gloo (host-staged)
+# --------------------------------------------------------------------------------------
+def _run_selftest(world, backend):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29640 + world), os.path.join(ROOT, "tools", "dist_selftest.py")]
+    return subprocess.run(cmd, env=_child_env(SEMIGCN_SELFTEST_BACKEND=backend), capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_partitioned_sgcn_and_mgcn_equal_single_rank_on_device(world):
+    """tools/dist_selftest.py: partitioned SGCN and MGCN (sg_graph_create_rect, sg_gather_rows, sg_bn_finalize_ranks,
+    DistPool) == the plain single-device models: positions <= 1e-5, loss <= 2e-6 (asserted inside the ranks)."""
+    r = _run_selftest(world, "gloo")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "dist_selftest OK" in r.stdout
+    print(r.stdout[-1500:])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for RCCL")
+def test_partitioned_ranks_over_rccl():
+    r = _run_selftest(2, "nccl")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: refuses when fewer devices are visible; with the share-one-GPU
+    self-test switch it starts two ranks itself and rank 0 prints ONE line with n_gpus = 2."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+            "--mesh", "96x64", "--no-cpu-baseline", "--dtype", "fp32"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(base, env=_child_env(), capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()
+    r = subprocess.run(base, env=_child_env(SEMIGCN_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert line["distributed"]["world_size"] == 2 and line["distributed"]["collectives_per_iteration"] > 0

@@ -1,5 +1,7 @@
 """Host logic on CPU: autograd wiring of ChebConv, Sequential semantics, state-dict layout,
 model composition -- with the HIP handles swapped for oracle-backed doubles (conftest)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -390,3 +392,22 @@ def test_weight_cache_invalidation(cpu_kernels):
     conv.load_state_dict(sd)
     assert "_weight_cache" not in conv.__dict__
     assert not torch.allclose(conv(x, ei).detach(), y0)
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`python bench.py --gpus 2` where fewer than 2 HIP devices are visible must exit non-zero before touching a GPU
+    (it used to fall through to a single-rank run that reported n_gpus = 1)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices visible: the refusal path cannot trigger")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEMIGCN_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()
+    # and a launcher whose WORLD_SIZE disagrees with --gpus is an error too, not a silent resize
+    env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "1", "0", "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
