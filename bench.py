@@ -129,8 +129,8 @@ def cpu_baseline(sample: str, full_V: int, budget_s: float = 25.0, full: bool = 
     Default: a BOUNDED sample (a smaller torus whose iterations fit `budget_s` seconds), scaled linearly in V (the
     path is O(V) at fixed valence).  `full=True` (--cpu-full): ONE timed iteration at the full V as BASELINE.md
     section 3 specifies (~2 min and ~50 GB of host memory at V = 1 M), the scaled figure kept beside it.
-    Threads: os.cpu_count() unless a probe shows that fewer are faster (ATen's scatter/index kernels stop scaling
-    early); both probe timings are reported in `sample`."""
+    Threads: the fastest count of a short probe over 8, 16, 32, .. os.cpu_count() threads (ATen's scatter/index
+    kernels stop scaling early); the probe timings are reported in `sample`."""
     from oracle import models as OM            # cpu_baseline leg: the only oracle use in bench.py
     from semigcn_amd import synth
     ncpu = os.cpu_count() or 1
@@ -161,17 +161,25 @@ def cpu_baseline(sample: str, full_V: int, budget_s: float = 25.0, full: bool = 
         return (time.perf_counter() - t0) / n
 
     t_start = time.perf_counter()
-    m, it = make(100, 50)
+    # thread-count probe on a 1.2 K-vertex mesh, counts in increasing order, stopping as soon as more threads are slower
+    # (measured on the 2 x 128-thread GPU host: 0.69 s at 32 threads against 163 s at 256 for the 5 K-vertex probe --
+    # ATen's index/scatter kernels drown in fork-join overhead; an unbounded all-core probe would cost minutes)
+    m, it = make(40, 30)
     probes = {}
-    for c in sorted({min(32, ncpu), ncpu}):
+    for c in sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu}):
         torch.set_num_threads(c)
         it()
         probes[c] = timed(it, 2)
+        if probes[c] > 1.3 * min(probes.values()) or time.perf_counter() - t_start > 10.0:
+            break
     cores = min(probes, key=probes.get)
     torch.set_num_threads(cores)
-    probe_note = ", ".join(f"{probes[c]:.2f} s on {c} threads" for c in sorted(probes))
+    probe_note = ", ".join(f"{probes[c] * 1e3:.0f} ms on {c} threads" for c in sorted(probes))
+    m, it = make(100, 50)
+    it()
+    probes5k = timed(it, 1)
     nu, nv = map(int, sample.split("x"))
-    per_vertex = probes[cores] / m.num_vertices
+    per_vertex = probes5k / m.num_vertices
     while nu * nv * per_vertex * 3 > budget_s and nu * nv > 2 * m.num_vertices:
         nu, nv = max(nu * 3 // 4, 16), max(nv * 3 // 4, 16)
     if nu * nv > m.num_vertices:
@@ -186,7 +194,7 @@ def cpu_baseline(sample: str, full_V: int, budget_s: float = 25.0, full: bool = 
     out = {"value": scaled, "unit": "iter/s", "cores": cores, "kind": "port",
            "sample": f"{n} timed SGCN iterations (fwd+loss+bwd, fp32) of the oracle on a {m.nu}x{m.nv} torus "
                      f"(V={m.num_vertices}, E={m.num_edges}), {dt:.2f} s each on {cores} of {ncpu} logical CPUs "
-                     f"(5K-vertex probe: {probe_note}), scaled linearly in V to V={full_V}",
+                     f"(thread probe, 1.2K vertices, stopped once more threads ran slower: {probe_note}), scaled linearly in V to V={full_V}",
            "edges_aggregated_per_s": AGG_PER_ITER * m.num_edges / dt}
     if full:
         import math

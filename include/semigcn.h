@@ -282,12 +282,12 @@ SG_API int sg_mesh_loss_bwd(const float* pos, const int64_t* faces, const float*
  * B = [W0|W1|W2] ([Cout, K*Cin]); with B = the transposed weights it is their input gradient dT = dOut * Wcat
  * (autograd of the same call sites).  Row strides lda / ldb / ldc are in elements; A, B, C 16-byte aligned,
  * K, N and the strides multiples of 8 (otherwise SG_ERR_UNSUPPORTED: the caller keeps its BLAS call).
- * moments (nullable): float32 [sg_gemm_row_tiles(M), 2, N]; tile t receives the per-column mean and
- * sum (x - mean)^2 of rows [t*R, (t+1)*R) of the ROUNDED result, R = sg_gemm_tile_rows() -- the block moments
+ * moments (nullable): float32 [sg_gemm_row_tiles(M, N), 2, N]; tile t receives the per-column mean and
+ * sum (x - mean)^2 of rows [t*R, (t+1)*R) of the ROUNDED result, R = sg_gemm_tile_rows(N) -- the block moments
  * sg_bn_stats_finalize_tiles merges, so BatchNorm needs no separate pass over C (util/networks.py:43).
  * ------------------------------------------------------------------------- */
-SG_API int64_t sg_gemm_tile_rows(void);
-SG_API int64_t sg_gemm_row_tiles(int64_t M);
+SG_API int64_t sg_gemm_tile_rows(int64_t N);             /* R for an N-column product (128, or 64 for wide outputs) */
+SG_API int64_t sg_gemm_row_tiles(int64_t M, int64_t N);  /* ceil(M / R) */
 SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
                       int64_t M, int64_t N, int64_t K, int dtype, float* moments, void* stream);
 /* sg_bn_stats_finalize for partials cut into uniform tiles of rows_per_tile rows (the last one shorter) */
@@ -304,10 +304,12 @@ enum sg_tune_knob {
                              row length is wave-uniform (A/B switches) */
   SG_TUNE_UNROLL = 2,     /* reserved */
   SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */
-  SG_TUNE_TILED_MIN_ROW_BYTES = 4 /* shared-gather kernel (each distinct source row of a 4-row mini-tile is
+  SG_TUNE_TILED_MIN_ROW_BYTES = 4, /* shared-gather kernel (each distinct source row of a 4-row mini-tile is
                                      gathered once): default 1024 = fp32 rows of >= 1 KiB where it pays;
                                      negative = force it for every row of at least |value| bytes and both
                                      dtypes; 0 = never, and graphs created from now on carry no mini-tiles */
+  SG_TUNE_GEMM_TILE = 5   /* sg_gemm_nt output tile: 0 = by shape (64 x 256 for N > 128, else 128 x min(N,128)),
+                             1 = 128-row tiles always, 2 = 64 x 256 wherever N > 64 (A/B switch) */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

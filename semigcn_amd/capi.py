@@ -60,8 +60,8 @@ _SIGNATURES = {
                                      c_float, c_void_p, c_void_p]),
     "sg_bn_stats_finalize_tiles": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_float, c_float, c_void_p, c_void_p]),
-    "sg_gemm_tile_rows": (c_int64, []),
-    "sg_gemm_row_tiles": (c_int64, [c_int64]),
+    "sg_gemm_tile_rows": (c_int64, [c_int64]),
+    "sg_gemm_row_tiles": (c_int64, [c_int64, c_int64]),
     "sg_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                            c_int, c_void_p, c_void_p]),
     "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -357,7 +357,7 @@ class PoolHandle:
             pass
 
 
-TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB, TUNE_TILED_MIN_ROW_BYTES = 0, 1, 2, 3, 4
+TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB, TUNE_TILED_MIN_ROW_BYTES, TUNE_GEMM_TILE = 0, 1, 2, 3, 4, 5
 
 
 def tuning_set(knob: int, value: int) -> None:
@@ -482,8 +482,9 @@ def bn_stats_finalize_tiles(partial: torch.Tensor, rows_per_tile: int, num_rows:
 
 
 # ---- dense feature x weight product on the matrix cores ------------------------------------------
-def gemm_tile_rows() -> int:
-    return int(load().sg_gemm_tile_rows())
+def gemm_tile_rows(N: int) -> int:
+    """Rows per output tile (and per BatchNorm-moments record) of an N-column sg_gemm_nt product."""
+    return int(load().sg_gemm_tile_rows(int(N)))
 
 
 def gemm_nt_supported(A: torch.Tensor, B: torch.Tensor, ldc: int) -> bool:
@@ -501,7 +502,7 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
             moments: bool = False):
     """``out = A @ B.T (+ bias)`` on the MFMA kernel (csrc/gemm_mfma.hip): A [M, K] and B [N, K] bf16 with unit column
     stride, bias fp32 [N], out bf16 [M, N] (any row stride that is a multiple of 8).  ``moments=True`` also returns
-    the float32 [ceil(M / gemm_tile_rows()), 2, N] per-tile column (mean, M2) of the rounded result."""
+    the float32 [ceil(M / gemm_tile_rows(N)), 2, N] per-tile column (mean, M2) of the rounded result."""
     _require_device(A, "A")
     _require_device(B, "B")
     M, K = A.shape
@@ -514,7 +515,7 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
         _f32vec(bias, N, "bias")
     mom = None
     if moments:
-        mom = torch.empty((int(load().sg_gemm_row_tiles(M)), 2, N), dtype=torch.float32, device=A.device)
+        mom = torch.empty((int(load().sg_gemm_row_tiles(M, N)), 2, N), dtype=torch.float32, device=A.device)
     with _on_device(A.device):
         _check(load().sg_gemm_nt(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), _ptr(bias), _ptr(out),
                                  _rows2d(out, "out"), M, N, K, SG_BF16, _ptr(mom), _stream(A)), "sg_gemm_nt")

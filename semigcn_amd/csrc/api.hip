@@ -305,7 +305,10 @@ SG_API int sg_unpool_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* d
                  1.f, 0.f, 0.f, (hipStream_t)stream);
 }
 
-SG_API int sg_tuning_set(int knob, int value) { return set_tuning(knob, value); }
+SG_API int sg_tuning_set(int knob, int value) {
+  if (knob == SG_TUNE_GEMM_TILE) return set_gemm_tuning(value);
+  return set_tuning(knob, value);
+}
 
 SG_API int64_t sg_mesh_loss_blocks(int64_t V, int64_t F) { return mesh_loss_blocks(V, F); }
 
@@ -410,9 +413,12 @@ SG_API int sg_bn_stats_finalize_tiles(const float* partial, int64_t n_tiles, int
                                         momentum, eps, out, (hipStream_t)stream);
 }
 
-SG_API int64_t sg_gemm_tile_rows(void) { return kGemmTileRows; }
+SG_API int64_t sg_gemm_tile_rows(int64_t N) { return gemm_tile_rows(N); }
 
-SG_API int64_t sg_gemm_row_tiles(int64_t M) { return M <= 0 ? 0 : (M + kGemmTileRows - 1) / kGemmTileRows; }
+SG_API int64_t sg_gemm_row_tiles(int64_t M, int64_t N) {
+  const int64_t r = gemm_tile_rows(N);
+  return M <= 0 ? 0 : (M + r - 1) / r;
+}
 
 SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
                       int64_t M, int64_t N, int64_t K, int dtype, float* moments, void* stream) {

@@ -53,13 +53,13 @@ __device__ __forceinline__ int xcd_run(int b, int nblocks) {   // blocks b, b+8,
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool MOMENTS>
-__global__ __launch_bounds__(kThreads) void gemm_nt_bf16(const GemmArgs g) {
+__global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16(const GemmArgs g) {
   static_assert(WAVES_M * WAVES_N == 4, "four wavefronts per workgroup");
   constexpr int BM = WAVES_M * MT * 16, BN = WAVES_N * NT * 16;
   constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes;
   constexpr int C_PITCH = BN * 2 + 16;                         // padded: the column-per-lane writes spread over banks
   constexpr int C_BYTES = BM * C_PITCH;
-  constexpr int RED_BYTES = MOMENTS ? kThreads * 4 : 0;
+  constexpr int RED_BYTES = MOMENTS ? (WAVES_M * BN * 2 + 4) * 4 : 0;   // per-wavefront column (mean, M2) + row counts
   constexpr int LDS_BYTES = (A_BYTES + B_BYTES > C_BYTES ? A_BYTES + B_BYTES : C_BYTES) + RED_BYTES;
   constexpr int A_CH = BM * 8 / kThreads;                      // 16-B chunks of the A tile per thread (4)
   constexpr int B_CH = (BN * 8 + kThreads - 1) / kThreads;     // of the B tile (4 / 2 / 1 / 1)
@@ -164,25 +164,85 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_bf16(const GemmArgs g) {
   // ---- epilogue: (+ bias) -> bf16 -> LDS image of the C tile [BM][BN] (pitch C_PITCH) ------------------------------
   // accumulator layout of the 16x16 MFMA: column = lane & 15, rows = 4 (lane >> 4) + reg
   uint8_t* const ldsC = lds;
+  int rows_valid = g.M - row0;
+  rows_valid = rows_valid > BM ? BM : rows_valid;
+  // BatchNorm tile moments, taken in REGISTERS from the rounded values: every lane holds 4 MT rows of NT columns;
+  // per lane a two-pass (mean, M2) -- nothing cancels --, then Chan's merge over the 4 lane groups that share a
+  // column (lanes l, l^16, l^32, l^48) and, through a few LDS words, over the WAVES_M wavefronts stacked on it.
+  float cnt = 0.f;                                              // valid rows held by this lane (same for every column)
+  float mom_mean[NT], mom_m2[NT];
+  if (MOMENTS) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cnt += ((wm * MT + i) * 16 + f_c * 4 + q) < rows_valid ? 1.f : 0.f;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int cl = (wn * NT + j) * 16 + f_r;
     const int gc = col0 + cl;
     const float bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
+    float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int rl = (wm * MT + i) * 16 + f_c * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(uint16_t*)(ldsC + (rl + q) * C_PITCH + cl * 2) = __builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][q] + bv));
+      for (int q = 0; q < 4; ++q) {
+        const uint16_t h = __builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][q] + bv));
+        *(uint16_t*)(ldsC + (rl + q) * C_PITCH + cl * 2) = h;
+        if (MOMENTS) {
+          const float v = __uint_as_float((uint32_t)h << 16);
+          acc[i][j][q] = v;                                     // keep the rounded value for the second pass
+          sum += (rl + q) < rows_valid ? v : 0.f;
+        }
+      }
+    }
+    if (MOMENTS) {
+      const float mean = cnt > 0.f ? sum / cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int rl = (wm * MT + i) * 16 + f_c * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float d = (rl + q) < rows_valid ? acc[i][j][q] - mean : 0.f;
+          m2 = fmaf(d, d, m2);
+        }
+      }
+      mom_mean[j] = mean;
+      mom_m2[j] = m2;
+    }
+  }
+  if (MOMENTS) {
+    float* const red = (float*)(lds + LDS_BYTES - RED_BYTES);   // [WAVES_M][BN][2] + [WAVES_M] counts
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float n2 = __shfl_xor(cnt, off, 64);
+      const float tot = cnt + n2;
+      const float w = tot > 0.f ? n2 / tot : 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float mb = __shfl_xor(mom_mean[j], off, 64), qb = __shfl_xor(mom_m2[j], off, 64);
+        const float d = mb - mom_mean[j];
+        mom_mean[j] = fmaf(d, w, mom_mean[j]);
+        mom_m2[j] += qb + d * d * cnt * w;
+      }
+      cnt = tot;
+    }
+    if (f_c == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int cl = (wn * NT + j) * 16 + f_r;
+        red[(wm * BN + cl) * 2 + 0] = mom_mean[j];
+        red[(wm * BN + cl) * 2 + 1] = mom_m2[j];
+      }
+      if (lane == 0 && wn == 0) red[WAVES_M * BN * 2 + wm] = cnt;
     }
   }
   __syncthreads();
 
   // 16-B row segments out: BN / 8 chunks per row
   constexpr int CPR = BN / 8;
-  int rows_valid = g.M - row0;
-  rows_valid = rows_valid > BM ? BM : rows_valid;
 #pragma unroll
   for (int i = 0; i < BM * CPR / kThreads; ++i) {
     const int q = tid + kThreads * i;
@@ -192,45 +252,28 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_bf16(const GemmArgs g) {
       *(u32x4*)(g.C + (int64_t)(row0 + r) * g.ldc + gc) = *(const u32x4*)(ldsC + r * C_PITCH + c * 16);
   }
 
-  if (MOMENTS) {
-    // per-column (mean, M2) of this tile's rows, from the ROUNDED values BatchNorm will read back: kThreads / BN
-    // row groups per column, merged through LDS; two passes (mean first) so nothing cancels
-    constexpr int GROUPS = kThreads / BN;
-    float* const red = (float*)(lds + LDS_BYTES - RED_BYTES);
-    const int c = tid % BN, gsel = tid / BN;
-    const bool con = col0 + c < g.N;
-    float s = 0.f;
-    for (int r = gsel; r < rows_valid; r += GROUPS)
-      s += __uint_as_float((uint32_t)(*(const uint16_t*)(ldsC + r * C_PITCH + c * 2)) << 16);
-    red[tid] = s;
-    __syncthreads();
-    float tot = 0.f;
+  if (MOMENTS && tid < BN && col0 + tid < g.N) {               // merge the WAVES_M partials of column tid, write out
+    const float* red = (const float*)(lds + LDS_BYTES - RED_BYTES);
+    float n = red[WAVES_M * BN * 2], mean = red[tid * 2], m2 = red[tid * 2 + 1];
 #pragma unroll
-    for (int k = 0; k < GROUPS; ++k) tot += red[k * BN + c];
-    const float mean = tot / (float)rows_valid;
-    __syncthreads();
-    float m2 = 0.f;
-    for (int r = gsel; r < rows_valid; r += GROUPS) {
-      const float d = __uint_as_float((uint32_t)(*(const uint16_t*)(ldsC + r * C_PITCH + c * 2)) << 16) - mean;
-      m2 = fmaf(d, d, m2);
+    for (int w = 1; w < WAVES_M; ++w) {
+      const float nb = red[WAVES_M * BN * 2 + w], mb = red[(w * BN + tid) * 2], qb = red[(w * BN + tid) * 2 + 1];
+      const float tot = n + nb;
+      const float wgt = tot > 0.f ? nb / tot : 0.f;
+      const float d = mb - mean;
+      mean = fmaf(d, wgt, mean);
+      m2 += qb + d * d * n * wgt;
+      n = tot;
     }
-    red[tid] = m2;
-    __syncthreads();
-    if (gsel == 0 && con) {
-      float q = 0.f;
-#pragma unroll
-      for (int k = 0; k < GROUPS; ++k) q += red[k * BN + c];
-      float* out = g.moments + (int64_t)(tile / g.n_col_tiles) * 2 * g.N;
-      out[col0 + c] = mean;
-      out[g.N + col0 + c] = q;
-    }
+    float* out = g.moments + (int64_t)(tile / g.n_col_tiles) * 2 * g.N;
+    out[col0 + tid] = mean;
+    out[g.N + col0 + tid] = m2;
   }
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>
 int launch(GemmArgs g, hipStream_t stream) {
   constexpr int BM = WAVES_M * MT * 16, BN = WAVES_N * NT * 16;
-  static_assert(BM == kGemmTileRows, "moments are per kGemmTileRows-row tile");
   g.n_col_tiles = (g.N + BN - 1) / BN;
   const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * g.n_col_tiles;
   SG_REQUIRE(tiles <= INT32_MAX, "sg_gemm_nt: too many tiles");
@@ -243,7 +286,21 @@ int launch(GemmArgs g, hipStream_t stream) {
 
 inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+int g_gemm_tile = 0;   // SG_TUNE_GEMM_TILE: 0 = by shape, 1 = always 128-row tiles, 2 = 64 x 256 wherever N > 64
+
+// 64 x 256 tiles for wide outputs: ONE column tile covers N <= 256, so A leaves HBM exactly once (with 128 x 128 tiles
+// the two or three column tiles of a row tile each pull A through L2: measured 0.42-0.48 of the HBM rate against
+// 0.62 for single-column-tile shapes); B is re-streamed from L2 twice as often, which L2 has the bandwidth for.
+bool wide_tile(int64_t N) { return g_gemm_tile == 2 ? N > 64 : (g_gemm_tile == 0 && N > 128); }
+
 }  // namespace
+
+int gemm_tile_rows(int64_t N) { return wide_tile(N) ? 64 : 128; }
+
+int set_gemm_tuning(int value) {
+  g_gemm_tile = value;
+  return SG_OK;
+}
 
 int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream) {
@@ -266,6 +323,7 @@ int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const
   g.moments = moments;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.n_col_tiles = g.n_tiles = 0;
+  if (wide_tile(N)) return launch<1, 4, 4, 4>(g, stream);  // 64 x 256, wavefront tile 64 x 64
   if (N > 64) return launch<2, 2, 4, 4>(g, stream);     // 128 x 128, wavefront tile 64 x 64
   if (N > 32) return launch<4, 1, 2, 4>(g, stream);     // 128 x 64,  wavefront tile 32 x 64
   if (N > 16) return launch<4, 1, 2, 2>(g, stream);     // 128 x 32

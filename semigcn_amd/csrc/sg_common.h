@@ -124,7 +124,8 @@ int launch_bn_stats_finalize_tiles(const float* partial, int64_t nb, int64_t rpb
                                    float* out, hipStream_t stream);
 
 // gemm_mfma.hip
-constexpr int kGemmTileRows = 128;
+int gemm_tile_rows(int64_t N);      // rows per output tile (= rows per BatchNorm-moments record) for an N-column product
+int set_gemm_tuning(int value);
 int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream);
 

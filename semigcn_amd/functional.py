@@ -156,8 +156,16 @@ def _wcat(weights, dtype):
 USE_MFMA_GEMM = True
 
 
+#: The 128-row-tile kernel streams A and C at 45-75 % of the HBM rate, which is what bounds the products with small
+#: and medium weight matrices; the few compute-bound ones (K*N > ~100 K: the 256/512-channel layers, where a
+#: 256 x 256-tile pipeline reaches 43 % of the MFMA peak against this kernel's 31 %) stay with the BLAS library.
+#: Measured per product at V = 1 M in profiles/r02_mfma_gemm_bench.json (tools/mfma_gemm_bench.py).
+MFMA_MAX_WEIGHT_ELEMS = 100_000
+
+
 def _mfma_ok(a: torch.Tensor, b: torch.Tensor, ldc: int) -> bool:
-    return USE_MFMA_GEMM and a.is_cuda and a.dtype == torch.bfloat16 and capi.gemm_nt_supported(a, b, ldc)
+    return (USE_MFMA_GEMM and a.is_cuda and a.dtype == torch.bfloat16 and b.shape[0] * b.shape[1] <= MFMA_MAX_WEIGHT_ELEMS
+            and capi.gemm_nt_supported(a, b, ldc))
 
 
 def _wcat_pair(weights, dtype):
@@ -177,7 +185,7 @@ def dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = No
         bias32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float()).contiguous()
         if moments is not None:
             res, mom = capi.gemm_nt(a, b, bias32, out=out, moments=True)
-            moments["tiles"], moments["rows"] = mom, capi.gemm_tile_rows()
+            moments["tiles"], moments["rows"] = mom, capi.gemm_tile_rows(b.shape[0])
             return res
         return capi.gemm_nt(a, b, bias32, out=out)
     if bias is not None:

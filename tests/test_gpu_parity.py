@@ -291,13 +291,18 @@ def test_sgcn_error_no_worse_than_fp32_oracle_against_fp64(fixture_meshes):
     """Arbiter: evaluate the oracle in float64; the HIP path's error must be of the size of the
     fp32 oracle's own error -- forward always, gradients whenever the run has the same
     LeakyReLU sign pattern as the fp64 run.  A 40 x 24 torus (960 vertices, ~1.9 M BatchNorm outputs per forward) is
-    large enough that the claim is about the kernels (several workgroups, every lane shape), and at least three of the
-    twelve seeds must run without a single sign flip so that the tight gradient bound is actually exercised."""
+    large enough that the claim is about the kernels (several workgroups, every lane shape); about one run in four has
+    no BatchNorm output within rounding of zero, and seeds are tried (at least 12, at most 40) until three such runs
+    have exercised the tight gradient bound."""
     m = synth.torus_mesh(40, 24)
     z1, xp, ei = torch.from_numpy(m.z1), torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index)
     r = torch.from_numpy(GU.probe("arbiter", (m.num_vertices, 3)))
     tight_runs = 0
-    for seed in range(8, 20):
+    n_seeds = 0
+    for seed in range(8, 48):
+        if n_seeds >= 12 and tight_runs >= 3:
+            break
+        n_seeds += 1
         ora32 = OM.SGCNOracle()
         GU.fill_state(ora32, seed=seed)
         ora64 = OM.SGCNOracle().double()
@@ -331,7 +336,7 @@ def test_sgcn_error_no_worse_than_fp32_oracle_against_fp64(fixture_meshes):
             assert g_hip < max(3 * g_ref, 1e-5), (seed, g_hip, g_ref, flips_ref)
         else:
             assert g_hip < GU.grad_tolerance(flips_hip, 1e-5), (seed, g_hip, flips_hip)
-    assert tight_runs >= 3, f"only {tight_runs} of 12 seeds ran without a LeakyReLU sign flip; cannot assert tight gradient parity"
+    assert tight_runs >= 3, f"only {tight_runs} of {n_seeds} seeds ran without a LeakyReLU sign flip; cannot assert tight gradient parity"
 
 
 def test_sgcn_reordering_is_transparent(fixture_meshes):

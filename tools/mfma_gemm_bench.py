@@ -46,16 +46,24 @@ def main():
     dev = torch.device("cuda:0")
     M = a.V
     res = []
-    tot = {"mfma": 0.0, "mfma+moments": 0.0, "blas": 0.0, "ideal": 0.0}
+    tot = {"mfma": 0.0, "mfma128": 0.0, "mfma64x256": 0.0, "mfma+moments": 0.0, "blas": 0.0, "best": 0.0, "ideal": 0.0}
     for name, N, K in products():
         A = torch.randn(M, K, device=dev).to(torch.bfloat16)
         B = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
         bias = torch.randn(N, device=dev)
         bias16 = bias.to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        def own(tile, moments=False):
+            def run():
+                capi.tuning_set(capi.TUNE_GEMM_TILE, tile)
+                capi.gemm_nt(A, B, bias, out=out, moments=moments)
+                capi.tuning_set(capi.TUNE_GEMM_TILE, 0)
+            return run
         variants = {
-            "mfma": lambda: capi.gemm_nt(A, B, bias, out=out),
-            "mfma+moments": lambda: capi.gemm_nt(A, B, bias, out=out, moments=True),
+            "mfma": own(0),                       # the shipped tile choice
+            "mfma128": own(1),                    # 128-row tiles always
+            "mfma64x256": own(2),                 # 64 x 256 tiles wherever N > 64
+            "mfma+moments": own(0, True),
             "blas": lambda: torch.addmm(bias16, A, B.t(), out=out),
         }
         times = {k: [] for k in variants}
@@ -84,6 +92,7 @@ def main():
             tot[k] += med
             line += f"  {k} {med:7.3f} ms (hbm {rec[k + '_hbm_frac']:.2f} mfma {rec[k + '_mfma_frac']:.2f})"
         tot["ideal"] += ideal
+        tot["best"] += min(rec[k + "_ms"] for k in ("mfma", "blas"))
         res.append(rec)
         print(line + f"  diff {err:.1e}", flush=True)
         del A, B, out
