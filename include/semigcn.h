@@ -302,14 +302,15 @@ enum sg_tune_knob {
                              between the staging phases instead of wavefront-local ones, bit 4: 64-bit gather addressing
                              even where 32-bit offsets would do, bit 5: fixed-size gather batches also where the
                              row length is wave-uniform (A/B switches) */
-  SG_TUNE_UNROLL = 2,     /* reserved */
+  SG_TUNE_UNROLL = 2,     /* gathers a lane group issues back to back in the aggregation kernel: 8, 6 or 4
+                             (fewer = fewer VGPRs = more resident wavefronts); 0 = the shipped choice per shape */
   SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */
   SG_TUNE_TILED_MIN_ROW_BYTES = 4, /* shared-gather kernel (each distinct source row of a 4-row mini-tile is
                                      gathered once): default 1024 = fp32 rows of >= 1 KiB where it pays;
                                      negative = force it for every row of at least |value| bytes and both
                                      dtypes; 0 = never, and graphs created from now on carry no mini-tiles */
-  SG_TUNE_GEMM_TILE = 5   /* sg_gemm_nt output tile: 0 = by shape (64 x 256 for N > 128, else 128 x min(N,128)),
-                             1 = 128-row tiles always, 2 = 64 x 256 wherever N > 64 (A/B switch) */
+  SG_TUNE_GEMM_TILE = 5   /* sg_gemm_nt output tile: 0 / 1 = 128 x min(N,128) (shipped), 2 = 64 x 256 wherever N > 64
+                             (A/B switch; measured slower) */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

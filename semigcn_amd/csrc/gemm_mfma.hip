@@ -286,12 +286,13 @@ int launch(GemmArgs g, hipStream_t stream) {
 
 inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-int g_gemm_tile = 0;   // SG_TUNE_GEMM_TILE: 0 = by shape, 1 = always 128-row tiles, 2 = 64 x 256 wherever N > 64
+int g_gemm_tile = 0;   // SG_TUNE_GEMM_TILE: 0 / 1 = 128-row tiles, 2 = 64 x 256 tiles wherever N > 64
 
-// 64 x 256 tiles for wide outputs: ONE column tile covers N <= 256, so A leaves HBM exactly once (with 128 x 128 tiles
-// the two or three column tiles of a row tile each pull A through L2: measured 0.42-0.48 of the HBM rate against
-// 0.62 for single-column-tile shapes); B is re-streamed from L2 twice as often, which L2 has the bandwidth for.
-bool wide_tile(int64_t N) { return g_gemm_tile == 2 ? N > 64 : (g_gemm_tile == 0 && N > 128); }
+// 64 x 256 tiles (ONE column tile covers N <= 256, so A is fetched by one workgroup only) were measured SLOWER than
+// 128 x 128 tiles on every wide product (e.g. [V,384]x[384,256]: 0.43 ms against 0.33 ms; profiles/
+// r02_mfma_gemm_bench.json): the column tiles of a row tile already share A through L2 (XCD-contiguous tile order),
+// and the narrower row tile re-streams B twice as often.  Kept behind the knob for A/B runs only.
+bool wide_tile(int64_t N) { return g_gemm_tile == 2 && N > 64; }
 
 }  // namespace
 

@@ -170,7 +170,11 @@ __device__ __forceinline__ void gather_batch(const int2* __restrict__ edges, int
   }
 }
 
-template <typename T, int G, int R, int NEPI, bool NARROW>
+// CAP = most gathers a lane group issues back to back (8, 6 or 4): the loaded vectors of a batch are live together, so
+// CAP sets the VGPR budget and with it the wavefronts per SIMD (bf16 C=256: 106 / 84 / 74 VGPRs = 4 / 5 / 6 waves).
+// rocprofv3 PMC (profiles/r02_pmc_issue_spmm.json): wavefronts of this kernel sit in s_waitcnt 70 % of their
+// lifetime at 3.6 resident waves per SIMD -- it is bound by memory latency x resident waves, not by instruction issue.
+template <typename T, int G, int R, int NEPI, bool NARROW, int CAP>
 __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int ch, const int nblocks,
                                                      const int flags) {
   using V = Vt<T>;
@@ -265,15 +269,15 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
       if (uniform && !(flags & kFlagNoExact)) {
         // every lane group of the wavefront has the same row length: it is wave-uniform, so the batches are cut
         // to fit exactly (always the case with one row per wavefront)
-        constexpr int NMAX = R * 8 <= 16 ? 8 : (R * 4 <= 16 ? 4 : 2);
+        constexpr int NMAX = (R * 8 <= 16 && CAP >= 8) ? 8 : (R * 4 <= 16 ? (CAP >= 6 && R * 6 <= 16 ? 6 : 4) : 2);
         int rem = __builtin_amdgcn_readfirstlane(ke - ks);
         while (rem > 0) {
           const int n = rem < NMAX ? rem : NMAX;
           switch (n) {
             case 8: if (NMAX >= 8) gather_batch<T, R, 8, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
             case 7: if (NMAX >= 8) gather_batch<T, R, 7, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
-            case 6: if (NMAX >= 8) gather_batch<T, R, 6, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
-            case 5: if (NMAX >= 8) gather_batch<T, R, 5, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+            case 6: if (NMAX >= 6) gather_batch<T, R, 6, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
+            case 5: if (NMAX >= 6) gather_batch<T, R, 5, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
             case 4: if (NMAX >= 4) gather_batch<T, R, 4, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
             case 3: if (NMAX >= 4) gather_batch<T, R, 3, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
             case 2: gather_batch<T, R, 2, NARROW, true>(edges, k, ke, 0, X, a.ldx, voff, acc); break;
@@ -288,8 +292,8 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
       const int klast = a.C * (int)sizeof(elem_t) <= 256 ? ne : (ke - 1 > ks ? ke - 1 : ks);
       while (__any(k < ke)) {                 // wave-uniform trip count: the longest row decides
         const int rem = ke - k;
-        if (R * 8 <= 16 && __any(rem > 6)) { gather_batch<T, R, 8, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 8; }
-        else if (R * 6 <= 16 && __any(rem > 4)) { gather_batch<T, R, 6, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 6; }
+        if (CAP >= 8 && R * 8 <= 16 && __any(rem > 6)) { gather_batch<T, R, 8, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 8; }
+        else if (CAP >= 6 && R * 6 <= 16 && __any(rem > 4)) { gather_batch<T, R, 6, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 6; }
         else if (R * 4 <= 16 && __any(rem > 2)) { gather_batch<T, R, 4, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 4; }
         else { gather_batch<T, R, 2, NARROW>(edges, k, ke, klast, X, a.ldx, voff, acc); k += 2; }
       }
@@ -620,6 +624,15 @@ struct Tuning {
 };
 Tuning g_tuning;
 
+// Gathers per batch by shape (see spmm_rows, CAP), measured on the 1 M-vertex mesh (tools/agg_bench.py --variants
+// unroll=8|6|4, profiles/r02_agg_cap_sweep.json): 4 gathers per batch (6 resident wavefronts per SIMD) win where a
+// lane group is narrow (C <= 32 fp32 / C <= 64 bf16: -7 .. -19 %) and for bf16 C = 256 (-6 .. -7 %); 8 per batch stays
+// ahead for the shapes in between (fp32 C = 64: 4 is 11 % slower) and for one-row-per-wavefront shapes.
+template <typename T, int G, int R>
+constexpr int default_cap() {
+  return (G <= 8 || (sizeof(typename Vt<T>::elem) == 2 && G == 32 && R == 1)) ? 4 : 8;
+}
+
 template <typename T, int G, int R, int NEPI>
 int launch_rows_epi(const SpmmArgs& a, hipStream_t stream) {
   constexpr int RPW = 64 / G;
@@ -641,8 +654,13 @@ int launch_rows_epi(const SpmmArgs& a, hipStream_t stream) {
   constexpr int64_t esz = sizeof(typename Vt<T>::elem);
   const bool narrow = !(g_tuning.flags & kFlagWideAddr) && a.n_cols > 0 && a.n_cols < (1 << 24) &&
                       a.ldx * esz < (1 << 24) && a.n_cols * a.ldx * esz < ((int64_t)1 << 32);
-  if (narrow) spmm_rows<T, G, R, NEPI, true><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks, g_tuning.flags);
-  else spmm_rows<T, G, R, NEPI, false><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks, g_tuning.flags);
+  const int cap = g_tuning.unroll == 4 || g_tuning.unroll == 6 || g_tuning.unroll == 8 ? g_tuning.unroll : default_cap<T, G, R>();
+#define SG_ROWS(NW, CP) spmm_rows<T, G, R, NEPI, NW, CP><<<nblocks, kBlock, 0, stream>>>(a, ch, nblocks, g_tuning.flags)
+  if (!narrow) SG_ROWS(false, 8);          // > 4 GiB operands / > 16 M rows: rare, one variant
+  else if (cap == 4) SG_ROWS(true, 4);
+  else if (cap == 6) SG_ROWS(true, 6);
+  else SG_ROWS(true, 8);
+#undef SG_ROWS
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
