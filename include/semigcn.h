@@ -88,6 +88,11 @@ typedef struct sg_graph_info {
   int32_t max_degree;   /* longest CSR row */
 } sg_graph_info;
 SG_API int sg_graph_query(const sg_graph* g, sg_graph_info* info);
+/* 1 when sg_graph_create gave the graph a locality view: a symmetric graph whose vertex numbering has no locality (a
+ * raw scan; the operator tier `from torch_geometric.nn import ChebConv`, util/networks.py:4, sees no positions to sort
+ * by) has its ROWS processed in a graph-derived order (two levels of multi-source-BFS cells); column ids, and with them
+ * X, X0, X1 and Y of sg_spmm, stay in the caller's numbering and results are bit-identical.  See SG_TUNE_GRAPH_REORDER. */
+SG_API int sg_graph_is_reordered(const sg_graph* g);
 /* Copies the forward CSR and dis into caller-owned DEVICE buffers on `stream`:
  * rowptr int32 [V_dst+1], colidx int32 [nnz], dis float32 [V_src]; any may be NULL. */
 SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, float* dis, void* stream);
@@ -309,6 +314,9 @@ enum sg_tune_knob {
                                      gathered once): default 1024 = fp32 rows of >= 1 KiB where it pays;
                                      negative = force it for every row of at least |value| bytes and both
                                      dtypes; 0 = never, and graphs created from now on carry no mini-tiles */
+  SG_TUNE_GRAPH_REORDER = 6, /* sg_graph_create: process the rows in a graph-derived locality order (output rows stay
+                                where the caller expects them): 0 = when the vertex numbering has no locality (>= 25 % of
+                                the edges span more than 4096 ids, V >= 65536), 1 = never, 2 = always */
   SG_TUNE_GEMM_TILE = 5   /* sg_gemm_nt output tile: 0 / 1 = 128 x min(N,128) (shipped), 2 = 64 x 256 wherever N > 64
                              (A/B switch; measured slower) */
 };

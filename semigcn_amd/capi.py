@@ -39,6 +39,7 @@ _SIGNATURES = {
                                      POINTER(c_void_p)]),
     "sg_graph_destroy": (c_int, [c_void_p]),
     "sg_graph_query": (c_int, [c_void_p, POINTER(sg_graph_info)]),
+    "sg_graph_is_reordered": (c_int, [c_void_p]),
     "sg_graph_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_spmm": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                         c_void_p, c_int64, c_int64, c_int, c_float, c_float, c_float, c_void_p]),
@@ -213,6 +214,7 @@ class GraphHandle:
         _check(load().sg_graph_query(self._h, byref(info)), "sg_graph_query")
         self.num_rows, self.num_cols, self.nnz = info.V_dst, info.V_src, info.nnz
         self.symmetric, self.max_degree = bool(info.symmetric), info.max_degree
+        self.reordered = load().sg_graph_is_reordered(self._h) == 1     # rows processed in a graph-derived locality order
 
     @classmethod
     def from_edge_index(cls, edge_index: torch.Tensor, num_vertices: int) -> "GraphHandle":
@@ -357,7 +359,7 @@ class PoolHandle:
             pass
 
 
-TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB, TUNE_TILED_MIN_ROW_BYTES, TUNE_GEMM_TILE = 0, 1, 2, 3, 4, 5
+TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB, TUNE_TILED_MIN_ROW_BYTES, TUNE_GEMM_TILE, TUNE_GRAPH_REORDER = 0, 1, 2, 3, 4, 5, 6
 
 
 def tuning_set(knob: int, value: int) -> None:

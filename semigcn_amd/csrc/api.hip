@@ -29,6 +29,9 @@ void destroy_graph(sg_graph* g) {
   if (!g) return;
   g->fwd.release();
   g->bwd.release();
+  g->loc.release();
+  if (g->row_id) (void)hipFree(g->row_id);
+  if (g->dis_dst_loc) (void)hipFree(g->dis_dst_loc);
   if (g->dis_src && g->dis_src != g->dis_dst) (void)hipFree(g->dis_src);
   if (g->dis_dst) (void)hipFree(g->dis_dst);
   delete g;
@@ -50,7 +53,8 @@ int check_dense(const char* what, const void* X, int64_t ld, int64_t C) {
 
 int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64_t ldx,
             const void* X0, int64_t ldx0, const void* X1, int64_t ldx1, void* Y, int64_t ldy,
-            int64_t C, int dtype, float alpha, float beta, float gamma, hipStream_t stream) {
+            int64_t C, int dtype, float alpha, float beta, float gamma, hipStream_t stream,
+            const int32_t* row_id = nullptr) {
   SG_REQUIRE(C >= 0 && C <= INT32_MAX, "C out of range");
   if (c.n_rows == 0 || C == 0) return SG_OK;
   int rc;
@@ -71,6 +75,7 @@ int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64
     a.idx_w = c.idx_w;
     a.tile_uniq_w = c.tile_uniq_w;
   }
+  a.row_id = row_id;
   a.scale_dst = sd;
   a.scale_src = ss;
   a.X = X; a.X0 = X0; a.X1 = X1; a.Y = Y;
@@ -146,6 +151,20 @@ SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void
     }
     if ((rc = pack_source_scale(&g->fwd, g->dis_src, stream)) != SG_OK) break;
     if (!g->symmetric && (rc = pack_source_scale(&g->bwd, g->dis_src, stream)) != SG_OK) break;
+    if (g->symmetric) {      // numbering without locality (a raw scan): process the rows in a graph-derived order
+      if ((rc = locality_order(g->fwd, graph_reorder_mode(), stream, &g->row_id)) != SG_OK) break;
+      if (g->row_id) {
+        if ((rc = permute_rows(g->fwd, g->row_id, stream, &g->loc)) != SG_OK) break;
+        if (hipMalloc((void**)&g->dis_dst_loc, V * sizeof(float)) != hipSuccess) {
+          set_error("hipMalloc of the permuted dis failed");
+          rc = SG_ERR_HIP;
+          break;
+        }
+        if ((rc = gather_floats(g->dis_dst, g->row_id, V, g->dis_dst_loc, stream)) != SG_OK) break;
+        if (tiles_enabled() && (rc = build_tiles(&g->loc, stream)) != SG_OK) break;
+        if ((rc = pack_source_scale(&g->loc, g->dis_src, stream)) != SG_OK) break;
+      }
+    }
     if (hipStreamSynchronize(stream) != hipSuccess) {
       set_error("stream sync failed in sg_graph_create");
       rc = SG_ERR_HIP;
@@ -216,6 +235,14 @@ SG_API int sg_graph_query(const sg_graph* g, sg_graph_info* info) {
   return SG_OK;
 }
 
+SG_API int sg_graph_is_reordered(const sg_graph* g) {
+  if (!g) {
+    set_error("sg_graph_is_reordered: null graph");
+    return SG_ERR_INVALID;
+  }
+  return g->row_id ? 1 : 0;
+}
+
 SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, float* dis, void* stream_) {
   SG_REQUIRE(g != nullptr, "sg_graph_export: null graph");
   hipStream_t stream = (hipStream_t)stream_;
@@ -239,8 +266,11 @@ SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx,
               "apply it owner-computes on exchanged gradient rows");
     return SG_ERR_UNSUPPORTED;
   }
-  const Csr& c = (t && !g->symmetric) ? g->bwd : g->fwd;
   // L^[i,j] = -dis[i] dis[j] (#edges j->i); the transposed CSR carries the same scales
+  if (g->symmetric && g->row_id)      // locality view: rows in processing order, output rows addressed through row_id
+    return run_csr(g->loc, g->dis_dst_loc, g->dis_src, X, ldx, X0, ldx0, X1, ldx1, Y, ldy, C, dtype, -alpha, beta, gamma,
+                   (hipStream_t)stream, g->row_id);
+  const Csr& c = (t && !g->symmetric) ? g->bwd : g->fwd;
   return run_csr(c, g->dis_dst, g->dis_src, X, ldx, X0, ldx0, X1, ldx1, Y, ldy, C, dtype, -alpha,
                  beta, gamma, (hipStream_t)stream);
 }
@@ -307,6 +337,7 @@ SG_API int sg_unpool_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* d
 
 SG_API int sg_tuning_set(int knob, int value) {
   if (knob == SG_TUNE_GEMM_TILE) return set_gemm_tuning(value);
+  if (knob == SG_TUNE_GRAPH_REORDER) return set_graph_reorder_mode(value);
   return set_tuning(knob, value);
 }
 

@@ -66,6 +66,14 @@ int build_csr(const int64_t* dst, const int64_t* src, int64_t n, int64_t n_rows,
 
 // out[i] = (rowptr[i+1]-rowptr[i])^-1/2 (0 where the row is empty); or 1/count when inv_only.
 int degree_scale(const Csr& c, bool inv_sqrt, float* out, hipStream_t stream);
+// Graph-only locality order of a symmetric square CSR.  *order_out (device, [n_rows], caller frees with hipFree) lists the
+// rows in processing order, or stays null when the numbering is already local (mode 0 = decide, 1 = never, 2 = always).
+int locality_order(const Csr& c, int mode, hipStream_t stream, int32_t** order_out);
+// The rows of `base` in the order `order` (order[p] = base row at position p), column ids unchanged.
+int permute_rows(const Csr& base, const int32_t* order, hipStream_t stream, Csr* out);
+int gather_floats(const float* src, const int32_t* order, int64_t n, float* out, hipStream_t stream);
+int graph_reorder_mode();
+int set_graph_reorder_mode(int v);
 // *equal = 1 iff the first n keys of a and b are identical.
 int keys_equal(const uint64_t* a, const uint64_t* b, int64_t n, hipStream_t stream, int* equal);
 
@@ -77,6 +85,8 @@ struct SpmmArgs {
   const uint8_t* tile_eloc = nullptr;
   const int2* idx_w = nullptr;          // non-null: (id, scale bits) pairs replace idx + scale_src lookups
   const int2* tile_uniq_w = nullptr;
+  const int32_t* row_id = nullptr;      // non-null: the CSR is in PROCESSING order; row p is the caller's row row_id[p]
+                                        // (Y / X0 / X1 are addressed by it; scale_dst is indexed by p)
   const float* scale_dst;  // nullable, [n_rows]
   const float* scale_src;  // nullable, [n_cols]
   const void* X;
@@ -158,6 +168,12 @@ struct sg_graph {
   float* dis_src = nullptr;  // [V_src]; == dis_dst for square graphs
   bool symmetric = true;
   bool square = true;
+  // Locality view (symmetric square graphs whose vertex numbering is not local, csr_build.hip::locality_order): the same
+  // operator with its ROWS in a cache-friendly processing order -- column ids stay the caller's, so X / Y need no
+  // permutation; the aggregation kernels address output rows through row_id.  Empty when the numbering is local.
+  sg::Csr loc;
+  int32_t* row_id = nullptr;      // [V] caller's row of processing position p
+  float* dis_dst_loc = nullptr;   // [V] dis_dst[row_id[p]]
 };
 
 struct sg_pool {

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 
   __shared__ int32_t s_rp[kWaves][kChMax + 1];
   __shared__ float s_sd[kWaves][kChMax];
+  __shared__ int32_t s_row[kWaves][kChMax];   // caller's row id of each processed row (Csr::row_id)
   __shared__ int2 s_e[kWaves][kCap + 1];   // + the sentinel slot of gather_batch
 
   const int lane = threadIdx.x & 63;
@@ -194,10 +195,13 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
   int nrows = a.n_rows - r0;
   nrows = nrows < 0 ? 0 : (nrows > ch ? ch : nrows);
 
-  // ---- stage this chunk's row pointers, row scales and neighbour list in LDS (coalesced) ----
+  // ---- stage this chunk's row pointers, row scales, row ids and neighbour list in LDS (coalesced) ----
   if (nrows > 0) {
     for (int l = lane; l <= nrows; l += 64) s_rp[wave][l] = a.rowptr[r0 + l];
-    for (int l = lane; l < nrows; l += 64) s_sd[wave][l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
+    for (int l = lane; l < nrows; l += 64) {
+      s_sd[wave][l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
+      s_row[wave][l] = a.row_id ? a.row_id[r0 + l] : r0 + l;
+    }
   }
   wave_sync(flags);
   int e0 = 0, ne = 0;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
     const int lr = it * RPW + g;
     const bool rvalid = lr < nrows;
     const int lrc = rvalid ? lr : 0;
-    const int row = r0 + lrc;
+    const int row = nrows > 0 ? s_row[wave][lrc] : 0;
     const int ks = s_rp[wave][lrc] - e0;
     const int ke = rvalid ? s_rp[wave][lrc + 1] - e0 : ks;
     const float sdst = a.alpha * s_sd[wave][lrc];
@@ -410,6 +414,7 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
   __shared__ int32_t s_up[kWaves][MT + 1];
   __shared__ int32_t s_rp[kWaves][ROWS + 1];
   __shared__ float s_sd[kWaves][ROWS];
+  __shared__ int32_t s_row[kWaves][ROWS];
   __shared__ int2 s_u[kWaves][CAPW];
   __shared__ uint32_t s_m[kWaves][CAPW];
 
@@ -427,7 +432,10 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
   if (nm > 0) {
     for (int l = lane; l <= nm; l += 64) s_up[wave][l] = a.tile_uptr[m0 + l];
     for (int l = lane; l <= nrows; l += 64) s_rp[wave][l] = a.rowptr[r0 + l];
-    for (int l = lane; l < nrows; l += 64) s_sd[wave][l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
+    for (int l = lane; l < nrows; l += 64) {
+      s_sd[wave][l] = a.scale_dst ? a.scale_dst[r0 + l] : 1.0f;
+      s_row[wave][l] = a.row_id ? a.row_id[r0 + l] : r0 + l;
+    }
   }
   wave_sync(flags);
   int ub = 0, nut = 0, e0 = 0, ne = 0;
@@ -522,8 +530,8 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
     raw_t x0v[kTileRows][R], x1v[kTileRows][R];
 #pragma unroll
     for (int q = 0; q < kTileRows; ++q) {
-      int row = r0 + lr0 + q;
-      row = row < a.n_rows ? row : a.n_rows - 1;
+      const int lq = lr0 + q < nrows ? lr0 + q : (nrows > 0 ? nrows - 1 : 0);
+      const int row = nrows > 0 ? s_row[wave][lq] : 0;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (NEPI >= 1) x0v[q][r] = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff[r]);
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
     for (int q = 0; q < kTileRows; ++q) {
       const int lr = lr0 + q;
       const bool rvalid = tvalid && lr < nrows;
-      const int row = r0 + lr;
+      const int row = rvalid ? s_row[wave][lr] : 0;
       const float sdst = a.alpha * s_sd[wave][rvalid ? lr : 0];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -576,9 +584,10 @@ __global__ __launch_bounds__(kBlock) void spmm_scalar(const SpmmArgs a) {
       acc = fmaf(w, V::load1(a.X, (int64_t)j * a.ldx + c), acc);
     }
     float y = a.alpha * (a.scale_dst ? a.scale_dst[row] : 1.0f) * acc;
-    if (a.X0) y = fmaf(a.beta, V::load1(a.X0, (int64_t)row * a.ldx0 + c), y);
-    if (a.X1) y = fmaf(a.gamma, V::load1(a.X1, (int64_t)row * a.ldx1 + c), y);
-    V::store1(a.Y, (int64_t)row * a.ldy + c, y);
+    const int64_t orow = a.row_id ? a.row_id[row] : row;       // the caller's row of processing position `row`
+    if (a.X0) y = fmaf(a.beta, V::load1(a.X0, orow * a.ldx0 + c), y);
+    if (a.X1) y = fmaf(a.gamma, V::load1(a.X1, orow * a.ldx1 + c), y);
+    V::store1(a.Y, orow * a.ldy + c, y);
   }
 }
 

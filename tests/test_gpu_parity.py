@@ -1149,3 +1149,78 @@ def test_graph_capture_refuses_without_the_runtime_flag(monkeypatch):
     batch = bench.build_mesh_batch(m, torch.device(DEV), n_masks=2)
     with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
         train.SGCNTrainer(SingleScaleGCN(DEV).to(DEV), batch, capture=True)
+
+
+# --------------------------------------------------------------------------------------
+# locality view: a graph whose numbering has no locality gets its rows processed in a graph-derived order
+# --------------------------------------------------------------------------------------
+def test_graph_locality_view_is_transparent_and_bit_identical():
+    """Operator tier on a raw-scan numbering (no positions to sort by): sg_graph_create orders the ROWS by two levels
+    of multi-source-BFS cells.  Nothing the caller sees may change: same CSR export, same rows of Y, bit-identical
+    values (a row's neighbours are still summed in ascending id order) -- against the same graph built with the view
+    switched off, for every kernel family, and against the oracle."""
+    m = synth.torus_mesh(300, 250, permute=True, masks=False)          # 75 000 vertices in random order
+    V = m.num_vertices
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    g_auto = capi.GraphHandle.from_edge_index(ei, V)
+    capi.tuning_set(capi.TUNE_GRAPH_REORDER, 1)
+    try:
+        g_plain = capi.GraphHandle.from_edge_index(ei, V)
+    finally:
+        capi.tuning_set(capi.TUNE_GRAPH_REORDER, 0)
+    assert g_auto.reordered and not g_plain.reordered
+    for a, b in zip(g_auto.arrays(), g_plain.arrays()):
+        assert torch.equal(a, b)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for C, dtype in ((4, torch.float32), (24, torch.float32), (64, torch.float32), (256, torch.float32), (512, torch.float32),
+                     (7, torch.float32), (16, torch.bfloat16), (128, torch.bfloat16), (256, torch.bfloat16)):
+        x = torch.randn(V, C, device=DEV, generator=gen).to(dtype)
+        x0 = torch.randn(V, C, device=DEV, generator=gen).to(dtype)
+        x1 = torch.randn(V, C, device=DEV, generator=gen).to(dtype)
+        for kw in ({}, {"alpha": 2.0, "X0": x0, "beta": -1.0}, {"alpha": 1.0, "X0": x0, "beta": 1.0, "X1": x1, "gamma": -1.0},
+                   {"transpose": True}):
+            ya = g_auto.spmm(x, torch.empty_like(x), **kw)
+            yb = g_plain.spmm(x, torch.empty_like(x), **kw)
+            assert torch.equal(ya, yb), (C, dtype, list(kw))
+        # strided operands: column blocks of a wider buffer, output in place of the epilogue operand
+        wide_a = torch.randn(V, 3 * C, device=DEV, generator=gen).to(dtype)
+        wide_b = wide_a.clone()
+        g_auto.spmm(wide_a[:, :C], wide_a[:, C:2 * C], alpha=2.0, X0=wide_a[:, C:2 * C], beta=1.0)
+        g_plain.spmm(wide_b[:, :C], wide_b[:, C:2 * C], alpha=2.0, X0=wide_b[:, C:2 * C], beta=1.0)
+        assert torch.equal(wide_a, wide_b)
+    x = torch.randn(V, 12, device=DEV, generator=gen)
+    assert rel(g_auto.spmm(x, torch.empty_like(x)), oracle_lhat(torch.from_numpy(m.edge_index), x.cpu())) < 1e-5
+    bits = torch.randint(0, 2 ** 62, (V, 1), device=DEV, generator=gen)
+    assert torch.equal(g_auto.dilate_bits(bits), g_plain.dilate_bits(bits))
+    # numberings WITH locality keep the plain path: grid order, and the Morton order the model tier produces
+    grid = synth.torus_mesh(300, 250, masks=False)
+    assert not capi.GraphHandle.from_edge_index(torch.from_numpy(grid.edge_index).to(DEV), V).reordered
+    from semigcn_amd import reorder
+    _, rank = reorder.morton_order(torch.from_numpy(m.x_pos).to(DEV))
+    assert not capi.GraphHandle.from_edge_index(reorder.permute_edge_index(ei, rank), V).reordered
+
+
+def test_graph_locality_view_forced_on_small_and_degenerate_graphs(fixture_meshes):
+    """SG_TUNE_GRAPH_REORDER = 2 forces the view: tiny meshes, isolated vertices and vertices in components without a
+    seed must come out exactly as without it; an asymmetric graph never gets one."""
+    capi.tuning_set(capi.TUNE_GRAPH_REORDER, 2)
+    try:
+        for name in ("sphere", "torus"):
+            m = fixture_meshes[name]
+            V = m.num_vertices + 5                                         # five isolated vertices at the end
+            ei = torch.from_numpy(m.edge_index).to(DEV)
+            g = capi.GraphHandle.from_edge_index(ei, V)
+            assert g.reordered
+            x = torch.randn(V, 20, device=DEV)
+            y = g.spmm(x, torch.empty_like(x), alpha=2.0, X0=x, beta=-1.0)
+            want = oracle_lhat(torch.from_numpy(m.edge_index), x.cpu(), alpha=2.0, x0=x.cpu(), beta=-1.0)
+            capi.tuning_set(capi.TUNE_GRAPH_REORDER, 1)
+            g0 = capi.GraphHandle.from_edge_index(ei, V)
+            capi.tuning_set(capi.TUNE_GRAPH_REORDER, 2)
+            assert torch.equal(y, g0.spmm(x, torch.empty_like(x), alpha=2.0, X0=x, beta=-1.0))
+            assert torch.equal(y[-5:], -x[-5:])                            # isolated rows: only the epilogue term
+            assert rel(y, want) < 1e-5
+        h = capi.GraphHandle.from_edge_index(nasty_graph().to(DEV), 500)
+        assert not h.symmetric and not h.reordered
+    finally:
+        capi.tuning_set(capi.TUNE_GRAPH_REORDER, 0)
