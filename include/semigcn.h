@@ -79,6 +79,14 @@ SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void
 SG_API int sg_graph_create_rect(const int64_t* dst, const int64_t* src, int64_t n, int64_t V_dst,
                          int64_t V_src, const float* dis_src, void* stream, sg_graph** out);
 
+/* A ROW SUBSET of a partition operator (no reference counterpart; SURVEY 8(e) "overlap with interior-row compute"):
+ * n_rows processed rows, row p writes output row row_id[p] (int32, device) and is scaled by dis_rows[p]; pairs
+ * (dst_pos[i] in [0, n_rows), src[i] in [0, V_src)).  sg_spmm on such a handle touches only the rows row_id names, so
+ * the interior rows of a block can be aggregated while the halo rows are still in flight, and the boundary rows after. */
+SG_API int sg_graph_create_rows(const int64_t* dst_pos, const int64_t* src, int64_t n, int64_t n_rows, int64_t V_src,
+                                const int32_t* row_id, const float* dis_rows, const float* dis_src, void* stream,
+                                sg_graph** out);
+
 SG_API int sg_graph_destroy(sg_graph* g);
 
 typedef struct sg_graph_info {

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "sg_graph_create": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(c_void_p)]),
     "sg_graph_create_rect": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                      POINTER(c_void_p)]),
+    "sg_graph_create_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     POINTER(c_void_p)]),
     "sg_graph_destroy": (c_int, [c_void_p]),
     "sg_graph_query": (c_int, [c_void_p, POINTER(sg_graph_info)]),
     "sg_graph_is_reordered": (c_int, [c_void_p]),
@@ -242,6 +244,26 @@ class GraphHandle:
                                                _ptr(dis_ext), _stream(dst), byref(out)),
                    "sg_graph_create_rect")
         return cls(out.value, dst.device)
+
+    @classmethod
+    def from_rows(cls, dst_pos: torch.Tensor, src: torch.Tensor, row_id: torch.Tensor, out_rows: int, n_ext: int,
+                  dis_rows: torch.Tensor, dis_ext: torch.Tensor) -> "GraphHandle":
+        """Row subset of a partition operator: processed row p (``dst_pos`` values) writes row ``row_id[p]`` of a Y with
+        ``out_rows`` rows; ``src`` indexes the ``n_ext`` rows of X."""
+        for t, n in ((dst_pos, "dst_pos"), (src, "src"), (row_id, "row_id"), (dis_rows, "dis_rows"), (dis_ext, "dis_ext")):
+            _require_device(t, n)
+        dst_pos, src = dst_pos.contiguous().long(), src.contiguous().long()
+        row_id = row_id.contiguous().to(torch.int32)
+        dis_rows, dis_ext = dis_rows.contiguous().float(), dis_ext.contiguous().float()
+        assert dis_rows.numel() == row_id.numel() and dis_ext.numel() == n_ext
+        out = c_void_p()
+        with _on_device(src.device):
+            _check(load().sg_graph_create_rows(_ptr(dst_pos), _ptr(src), dst_pos.numel(), row_id.numel(), int(n_ext),
+                                               _ptr(row_id), _ptr(dis_rows), _ptr(dis_ext), _stream(src), byref(out)),
+                   "sg_graph_create_rows")
+        h = cls(out.value, src.device)
+        h.num_rows = int(out_rows)          # rows of the Y it writes into (it touches only the rows row_id names)
+        return h
 
     def arrays(self):
         """(rowptr int32 [rows+1], colidx int32 [nnz], dis float32 [cols]) as torch tensors."""

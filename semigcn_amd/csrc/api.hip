@@ -220,6 +220,48 @@ SG_API int sg_graph_create_rect(const int64_t* dst, const int64_t* src, int64_t 
   return SG_OK;
 }
 
+SG_API int sg_graph_create_rows(const int64_t* dst_pos, const int64_t* src, int64_t n, int64_t n_rows, int64_t V_src,
+                                const int32_t* row_id, const float* dis_rows, const float* dis_src, void* stream_,
+                                sg_graph** out) {
+  SG_REQUIRE(out != nullptr, "sg_graph_create_rows: out is null");
+  *out = nullptr;
+  SG_REQUIRE(n >= 0 && n_rows >= 0 && V_src >= 0, "sg_graph_create_rows: negative size");
+  SG_REQUIRE((n_rows == 0 || (row_id && dis_rows)) && (V_src == 0 || dis_src), "sg_graph_create_rows: null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  sg_graph* g = new (std::nothrow) sg_graph();
+  SG_REQUIRE(g != nullptr, "out of host memory");
+  int rc = build_csr(dst_pos, src, n, n_rows, V_src, false, stream, &g->fwd, nullptr);
+  if (rc == SG_OK && tiles_enabled()) rc = build_tiles(&g->fwd, stream);
+  if (rc == SG_OK) {
+    const size_t nr = n_rows > 0 ? n_rows : 1, ns = V_src > 0 ? V_src : 1;
+    if (hipMalloc((void**)&g->dis_src, ns * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&g->dis_dst, nr * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&g->row_id, nr * sizeof(int32_t)) != hipSuccess) {
+      set_error("hipMalloc failed in sg_graph_create_rows");
+      rc = SG_ERR_HIP;
+    } else if ((V_src > 0 && hipMemcpyAsync(g->dis_src, dis_src, V_src * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) ||
+               (n_rows > 0 && (hipMemcpyAsync(g->dis_dst, dis_rows, n_rows * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+                               hipMemcpyAsync(g->row_id, row_id, n_rows * sizeof(int32_t), hipMemcpyDeviceToDevice, stream) != hipSuccess)) ||
+               hipStreamSynchronize(stream) != hipSuccess) {
+      set_error("copy failed in sg_graph_create_rows");
+      rc = SG_ERR_HIP;
+    }
+    if (rc == SG_OK) rc = pack_source_scale(&g->fwd, g->dis_src, stream);
+    if (rc == SG_OK && hipStreamSynchronize(stream) != hipSuccess) {
+      set_error("stream sync failed in sg_graph_create_rows");
+      rc = SG_ERR_HIP;
+    }
+  }
+  if (rc != SG_OK) {
+    destroy_graph(g);
+    return rc;
+  }
+  g->symmetric = true;   // applied owner-computes in both directions, like the rectangular operator
+  g->square = false;
+  *out = g;
+  return SG_OK;
+}
+
 SG_API int sg_graph_destroy(sg_graph* g) {
   destroy_graph(g);
   return SG_OK;
@@ -240,7 +282,7 @@ SG_API int sg_graph_is_reordered(const sg_graph* g) {
     set_error("sg_graph_is_reordered: null graph");
     return SG_ERR_INVALID;
   }
-  return g->row_id ? 1 : 0;
+  return (g->square && g->row_id) ? 1 : 0;
 }
 
 SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, float* dis, void* stream_) {
@@ -269,6 +311,9 @@ SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx,
   // L^[i,j] = -dis[i] dis[j] (#edges j->i); the transposed CSR carries the same scales
   if (g->symmetric && g->row_id)      // locality view: rows in processing order, output rows addressed through row_id
     return run_csr(g->loc, g->dis_dst_loc, g->dis_src, X, ldx, X0, ldx0, X1, ldx1, Y, ldy, C, dtype, -alpha, beta, gamma,
+                   (hipStream_t)stream, g->row_id);
+  if (!g->square && g->row_id)         // row subset of a partition operator (sg_graph_create_rows)
+    return run_csr(g->fwd, g->dis_dst, g->dis_src, X, ldx, X0, ldx0, X1, ldx1, Y, ldy, C, dtype, -alpha, beta, gamma,
                    (hipStream_t)stream, g->row_id);
   const Csr& c = (t && !g->symmetric) ? g->bwd : g->fwd;
   return run_csr(c, g->dis_dst, g->dis_src, X, ldx, X0, ldx0, X1, ldx1, Y, ldy, C, dtype, -alpha,

@@ -255,6 +255,12 @@ __global__ void coarse_pairs(int64_t n, const uint64_t* __restrict__ sorted, con
   vals[i] = v;
 }
 
+__global__ void label_keys(int64_t n, const int32_t* __restrict__ seq, const int32_t* __restrict__ lab,
+                           uint32_t* __restrict__ keys) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = (uint32_t)lab[seq[i]];
+}
+
 __global__ void permuted_degrees(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ order, int64_t n,
                                  int32_t* __restrict__ deg) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,11 +296,12 @@ int set_graph_reorder_mode(int v) {
 // Graph-only locality order (the operator tier sees no vertex positions: `from torch_geometric.nn import ChebConv`,
 // util/networks.py:4).  A raw scan numbers its vertices arbitrarily; the aggregation then re-fetches every source row
 // ~deg times from HBM (21-23 % of the roofline).  Cure without touching the caller's X / Y: process
-// the ROWS in an order in which consecutive rows are graph neighbours.  Two multi-source BFS partitions (graph Voronoi
-// cells around pseudo-random seeds, ~256 and ~4096 vertices per cell) give every vertex a (coarse cell, fine cell)
-// pair; sorting by it yields compact patches at both scales -- the working set of the rows in flight on one XCD then
-// fits its L2, like a Morton order from positions (distinct source rows per 8 K-row window: 1.13 x the rows, Morton
-// 1.08 x, random 5.3 x).  Deterministic: double-buffered rounds, smallest label wins, stable sorts.
+// the ROWS in an order in which consecutive rows are graph neighbours.  Three multi-source BFS partitions (graph Voronoi
+// cells around pseudo-random seeds, ~16, ~256 and ~4096 vertices per cell) give every vertex a (large, middle, small
+// cell) triple; sorting by it yields compact patches at every scale -- the working set of the rows in flight on one
+// XCD then fits its L2, like a Morton order from positions (distinct source rows per 8 K-row window: 1.13 x the rows,
+// Morton 1.08 x, random 5.3 x), and the rows of one wavefront's chunk are mostly neighbours.  Deterministic:
+// double-buffered rounds, smallest label wins, stable sorts.
 int locality_order(const Csr& c, int mode, hipStream_t stream, int32_t** order_out) {
   *order_out = nullptr;
   const int64_t n = c.n_rows;
@@ -310,20 +317,22 @@ int locality_order(const Csr& c, int mode, hipStream_t stream, int32_t** order_o
     SG_HIP_TRY(hipStreamSynchronize(stream));
     if ((double)far < 0.25 * (double)c.nnz) return SG_OK;   // grid / Morton / already clustered numbering
   }
-  DeviceBuf lab, keys, keys2, k32a, k32b, vals, temp;
+  DeviceBuf lab, keys, keys2, k32a, k32b, vals, vals2, temp;
   int32_t* order = nullptr;
-  SG_HIP_TRY(hipMalloc(&lab.p, 4 * n * sizeof(int32_t)));     // fine[2][n], coarse[2][n]
+  constexpr int kLevels = 3;                                   // cells of ~16, ~256 and ~4096 vertices
+  SG_HIP_TRY(hipMalloc(&lab.p, 2 * kLevels * n * sizeof(int32_t)));
   int32_t* L = (int32_t*)lab.p;
-  int32_t* final_lab[2] = {nullptr, nullptr};
-  const uint32_t modulus[2] = {256u, 4096u}, residue[2] = {0u, 17u};
+  int32_t* final_lab[kLevels] = {nullptr, nullptr, nullptr};
+  const uint32_t modulus[kLevels] = {16u, 256u, 4096u}, residue[kLevels] = {5u, 0u, 17u};
   int* d_changed = (int*)flag.p;
-  for (int level = 0; level < 2; ++level) {
+  for (int level = 0; level < kLevels; ++level) {
     int32_t* a = L + (2 * level) * n;
     int32_t* b = L + (2 * level + 1) * n;
     seed_labels<<<blocks_for(n), kThreads, 0, stream>>>(n, modulus[level], residue[level], a);
+    const int per_check = level == 0 ? 4 : 8;                  // rounds between host checks
     for (int round = 0; round < 1 << 16;) {
       SG_HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
-      for (int k = 0; k < 8; ++k, ++round) {     // a few rounds per host check
+      for (int k = 0; k < per_check; ++k, ++round) {
         voronoi_round<<<blocks_for(n), kThreads, 0, stream>>>(c.rowptr, c.idx, n, a, b, d_changed);
         int32_t* t = a; a = b; b = t;
       }
@@ -341,7 +350,9 @@ int locality_order(const Csr& c, int mode, hipStream_t stream, int32_t** order_o
   SG_HIP_TRY(hipMalloc(&k32a.p, n * sizeof(uint32_t)));
   SG_HIP_TRY(hipMalloc(&k32b.p, n * sizeof(uint32_t)));
   SG_HIP_TRY(hipMalloc(&vals.p, n * sizeof(int32_t)));
+  SG_HIP_TRY(hipMalloc(&vals2.p, n * sizeof(int32_t)));
   SG_HIP_TRY(hipMalloc((void**)&order, n * sizeof(int32_t)));
+  // sort by (smallest cell, id), then stably by the middle cell, then stably by the largest cell
   fine_keys<<<blocks_for(n), kThreads, 0, stream>>>(n, final_lab[0], (uint64_t*)keys.p);
   size_t tb = 0, tb2 = 0;
   hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tb, (const uint64_t*)keys.p, (uint64_t*)keys2.p, (int)n, 0, 64, stream);
@@ -356,7 +367,12 @@ int locality_order(const Csr& c, int mode, hipStream_t stream, int32_t** order_o
     coarse_pairs<<<blocks_for(n), kThreads, 0, stream>>>(n, (const uint64_t*)keys2.p, final_lab[1], (uint32_t*)k32a.p,
                                                          (int32_t*)vals.p);
     e = hipcub::DeviceRadixSort::SortPairs(temp.p, tb, (const uint32_t*)k32a.p, (uint32_t*)k32b.p, (const int32_t*)vals.p,
-                                           order, (int)n, 0, 32, stream);     // stable: keeps (fine cell, id) inside a coarse cell
+                                           (int32_t*)vals2.p, (int)n, 0, 32, stream);   // stable: keeps (small cell, id)
+  }
+  if (e == hipSuccess) {
+    label_keys<<<blocks_for(n), kThreads, 0, stream>>>(n, (const int32_t*)vals2.p, final_lab[2], (uint32_t*)k32a.p);
+    e = hipcub::DeviceRadixSort::SortPairs(temp.p, tb, (const uint32_t*)k32a.p, (uint32_t*)k32b.p, (const int32_t*)vals2.p,
+                                           order, (int)n, 0, 32, stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e != hipSuccess) {

@@ -105,12 +105,32 @@ class _RowExchange:
     def exchange(self, blk_ext: torch.Tensor) -> None:
         """Fill rows [n_own:] of ``blk_ext`` ([n_ext, C], unit column stride, any row stride) with
         the owners' copies of those rows; rows [:n_own] must be final."""
+        self.exchange_end(self.exchange_begin(blk_ext))
+
+    def exchange_begin(self, blk_ext: torch.Tensor):
+        """Start the exchange and return a token for ``exchange_end``.  Over RCCL the all-to-all is issued asynchronously
+        (it runs on the communicator's stream behind the pack kernel), so kernels launched before ``exchange_end`` --
+        the aggregation of the rows that read no halo row -- overlap with it; under gloo (host-staged) it completes here."""
         if self.world == 1:
-            return                     # (with world > 1 every rank takes part, even with an empty halo: it is a collective)
+            return None                # (with world > 1 every rank takes part, even with an empty halo: it is a collective)
         own = blk_ext[:self.n_own]
         send = capi.gather_rows(self.send_rows, own)
         recv = torch.empty((self.n_halo, blk_ext.shape[1]), dtype=blk_ext.dtype, device=blk_ext.device)
-        self._a2a(recv, send, self.recv_splits, self.send_splits)
+        work = None
+        if send.is_cuda and dist.get_backend(self.group) != "gloo":
+            collective_counts["all_to_all"] += 1
+            work = dist.all_to_all_single(recv, send, list(self.recv_splits), list(self.send_splits), group=self.group,
+                                          async_op=True)
+        else:
+            self._a2a(recv, send, self.recv_splits, self.send_splits)
+        return work, recv, send, blk_ext
+
+    def exchange_end(self, token) -> None:
+        if token is None:
+            return
+        work, recv, _send, blk_ext = token
+        if work is not None:
+            work.wait()                # the CURRENT stream waits for the collective; the host does not block
         blk_ext[self.n_own:].copy_(recv)
 
     def exchange_reverse_add(self, grad_halo: torch.Tensor, grad_own: torch.Tensor) -> None:
@@ -215,6 +235,24 @@ class DistMeshGraph(_RowExchange):
         e_wide = e_own | r1[dst]                                  # ... or in a ring-1 row (complete rows: global degrees)
         self.handle_wide = capi.GraphHandle.from_partition(ext_of[dst[e_wide]], ext_of[src[e_wide]], self.n_ext, self.n_ext,
                                                            dis_ext)
+        # the same wide operator cut in two row sets, for overlap with the exchange: INTERIOR = owned rows none of whose
+        # neighbours is a halo row (they can be aggregated while the halo is in flight), REST = the owned boundary rows
+        # and the ring-1 rows
+        reads_halo = torch.zeros(self.n_ext, dtype=torch.bool, device=dev)
+        reads_halo[ext_of[dst[e_wide & ~own[src]]]] = True
+        is_row = torch.zeros(self.n_ext, dtype=torch.bool, device=dev)
+        is_row[:self.n_own] = True
+        is_row[ext_of[torch.nonzero(r1).flatten()]] = True
+        self._split = []
+        dst_w, src_w = ext_of[dst[e_wide]], ext_of[src[e_wide]]
+        for rows_mask in (is_row & ~reads_halo, is_row & reads_halo):
+            rows = torch.nonzero(rows_mask).flatten()
+            pos = torch.full((self.n_ext,), -1, dtype=torch.long, device=dev)
+            pos[rows] = torch.arange(rows.numel(), device=dev)
+            sel = rows_mask[dst_w]
+            self._split.append(capi.GraphHandle.from_rows(pos[dst_w[sel]], src_w[sel], rows, self.n_ext, self.n_ext,
+                                                          dis_ext[rows], dis_ext))
+        self.n_interior = int((is_row & ~reads_halo).sum())      # rows aggregated while the exchange is in flight
 
         # what I receive from each peer: my halo ids that it owns (contiguous runs of `halo`)
         b = torch.tensor(bounds, device=dev, dtype=torch.long)
@@ -252,6 +290,21 @@ class DistMeshGraph(_RowExchange):
         """L^ on the owned and ring-1 rows: X on ``[owned | halo]`` (both rings valid), Y on all ``n_ext`` rows (its
         ring-2 rows receive only the epilogue terms and are not to be used)."""
         return self.handle_wide.spmm(X_ext, Y_ext, **kw)
+
+    #: aggregate the interior rows while the halo exchange is in flight (False: one launch after the exchange)
+    overlap = True
+
+    def exchange_and_aggregate_wide(self, X_blk: torch.Tensor, X_ext: torch.Tensor, Y_ext: torch.Tensor, **kw):
+        """``exchange(X_blk)`` + ``aggregate_wide(X_ext, Y_ext)`` with the interior rows computed during the exchange.
+        ``X_blk``: the column block(s) to exchange (its owned rows final); ``X_ext``: the block the operator reads
+        (``X_blk`` or a column slice of it).  Epilogue operands in ``kw`` are read on owned / ring-1 rows only."""
+        if not self.overlap or self.world == 1:
+            self.exchange(X_blk)
+            return self.aggregate_wide(X_ext, Y_ext, **kw)
+        token = self.exchange_begin(X_blk)
+        self._split[0].spmm(X_ext, Y_ext, **kw)        # rows that read owned rows only
+        self.exchange_end(token)
+        return self._split[1].spmm(X_ext, Y_ext, **kw)  # boundary rows and ring-1 rows
 
 
 class _HaloExtend(torch.autograd.Function):
@@ -318,8 +371,7 @@ class _DistChebConvFn(torch.autograd.Function):
         if fresh:
             blk[0][:n].copy_(x)
         if K == 3:       # ONE exchange (two rings of x): Tx1 on owned + ring-1 rows, Tx2 on the owned rows
-            g.exchange(blk[0])
-            g.aggregate_wide(blk[0], blk[1], alpha=1.0)
+            g.exchange_and_aggregate_wide(blk[0], blk[0], blk[1], alpha=1.0)
             g.aggregate(blk[1], blk[2][:n], alpha=2.0, X0=blk[0][:n], beta=-1.0)
         else:
             if K > 1:
@@ -360,8 +412,7 @@ class _DistChebConvFn(torch.autograd.Function):
                 gk = [dT[:, k * C:(k + 1) * C] for k in range(K)]
                 dx = torch.empty((n, C), dtype=dout.dtype, device=dout.device)
                 if K == 3:   # ONE exchange of the [g1 | g2] column blocks on both rings; g1 += 2 L g2 on owned + ring 1
-                    g.exchange(dT[:, C:3 * C])
-                    g.aggregate_wide(gk[2], gk[1], alpha=2.0, X0=gk[1], beta=1.0)
+                    g.exchange_and_aggregate_wide(dT[:, C:3 * C], gk[2], gk[1], alpha=2.0, X0=gk[1], beta=1.0)
                     g.aggregate(gk[1], dx, alpha=1.0, X0=gk[0][:n], beta=1.0, X1=gk[2][:n], gamma=-1.0)
                 else:
                     for k in range(K - 2, 0, -1):
@@ -392,8 +443,7 @@ class _DistChebConvPostFn(torch.autograd.Function):
         z = [Z[:, k * Co:(k + 1) * Co] for k in range(K)]
         out = torch.empty((n, Co), dtype=x.dtype, device=x.device)
         if K == 3:       # ONE exchange of [Z1 | Z2] on both rings; b1 = Z1 + 2 L Z2 on owned + ring 1
-            g.exchange(Z[:, Co:3 * Co])
-            g.aggregate_wide(z[2], z[1], alpha=2.0, X0=z[1], beta=1.0)
+            g.exchange_and_aggregate_wide(Z[:, Co:3 * Co], z[2], z[1], alpha=2.0, X0=z[1], beta=1.0)
             g.aggregate(z[1], out, alpha=1.0, X0=z[0][:n], beta=1.0, X1=z[2][:n], gamma=-1.0)
         else:
             for k in range(K - 2, 0, -1):
@@ -417,11 +467,11 @@ class _DistChebConvPostFn(torch.autograd.Function):
         G = torch.empty((g.n_ext, K * Co), dtype=dout.dtype, device=dout.device)
         gk = [G[:, k * Co:(k + 1) * Co] for k in range(K)]
         gk[0][:n].copy_(dout)
-        g.exchange(gk[0])
         if K == 3:       # one exchange (two rings of dOut), as in _DistChebConvFn.forward
-            g.aggregate_wide(gk[0], gk[1], alpha=1.0)
+            g.exchange_and_aggregate_wide(gk[0], gk[0], gk[1], alpha=1.0)
             g.aggregate(gk[1], gk[2][:n], alpha=2.0, X0=gk[0][:n], beta=-1.0)
         else:
+            g.exchange(gk[0])
             g.aggregate(gk[0], gk[1][:n], alpha=1.0)
             for k in range(2, K):
                 g.exchange(gk[k - 1])

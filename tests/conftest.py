@@ -69,6 +69,16 @@ class OracleGraphDouble:
     def from_partition(cls, dst, src, n_owned, n_ext, dis_ext):
         return cls(dst, src, n_owned, n_ext, dis_ext[:n_owned].float(), dis_ext.float(), True, square=False)
 
+    @classmethod
+    def from_rows(cls, dst_pos, src, row_id, out_rows, n_ext, dis_rows, dis_ext):
+        """Row subset (sg_graph_create_rows): processed row p writes row row_id[p] of Y and leaves the others alone."""
+        h = cls(row_id.long()[dst_pos.long()], src, out_rows, n_ext, None, dis_ext.float(), True, square=False)
+        dd = torch.zeros(out_rows)
+        dd[row_id.long()] = dis_rows.float()
+        h.dis_dst = dd
+        h.rows_written = row_id.long()
+        return h
+
     def arrays(self):
         order = torch.argsort(self.dst * self.num_cols + self.src)
         rowptr = torch.zeros(self.num_rows + 1, dtype=torch.int32)
@@ -89,7 +99,11 @@ class OracleGraphDouble:
             out = out + beta * X0.float()
         if X1 is not None:
             out = out + gamma * X1.float()
-        Y.copy_(out.to(Y.dtype))
+        rows = getattr(self, "rows_written", None)
+        if rows is None:
+            Y.copy_(out.to(Y.dtype))
+        else:
+            Y[rows] = out[rows].to(Y.dtype)
         return Y
 
     def close(self):

@@ -191,6 +191,18 @@ def test_partition_plan_is_consistent():
         x_ext = torch.cat([x[g.start:g.end], x[g.halo_ids]])
         y = g.handle.spmm(x_ext, torch.empty(g.n_own, 5))
         assert torch.allclose(y, y_full[g.start:g.end], atol=1e-6)
+        # the wide operator (owned + ring-1 rows) and its interior / rest halves write the same rows with the same values
+        ids_ext = torch.cat([torch.arange(g.start, g.end), g.halo_ids])
+        yw = g.handle_wide.spmm(x_ext, torch.zeros(g.n_ext, 5))
+        ys = torch.full((g.n_ext, 5), float("nan"))
+        g._split[0].spmm(x_ext, ys)
+        assert g.n_interior > 0 and int(torch.isfinite(ys[:, 0]).sum()) == g.n_interior      # interior rows only
+        assert not bool(torch.isfinite(ys[g.n_own:]).any())                                     # ... all of them owned
+        g._split[1].spmm(x_ext, ys)
+        done = torch.isfinite(ys[:, 0])
+        assert int(done.sum()) == g.n_own + g.n_halo1 and bool(done[:g.n_own].all())
+        assert torch.allclose(ys[done], yw[done], atol=1e-6)
+        assert torch.allclose(ys[done], y_full[ids_ext[done]], atol=1e-6)                     # ring-1 rows are complete rows
     with pytest.raises(ValueError, match="symmetric"):
         sgdist.DistMeshGraph(ei[:, :-1], V, 0, 2)
 

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--variants", nargs="*", default=["ch=0,flags=1,unroll=0"])
     ap.add_argument("--json", default=None)
+    ap.add_argument("--reorder", type=int, default=0, help="SG_TUNE_GRAPH_REORDER while the graph is created: 0 auto, 1 never, 2 always")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     nu, nv = map(int, a.mesh.split("x"))
@@ -41,7 +42,14 @@ def main():
         from semigcn_amd import reorder
         order, rank = reorder.morton_order(torch.from_numpy(m.vs).to(dev))
         ei = reorder.permute_edge_index(ei, rank)
+    capi.tuning_set(capi.TUNE_GRAPH_REORDER, a.reorder)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
     g = MeshGraph.from_edge_index(ei, V)
+    torch.cuda.synchronize()
+    print(f"graph created in {(time.perf_counter() - t0) * 1e3:.1f} ms, locality view: {g.handle.reordered}", flush=True)
+    capi.tuning_set(capi.TUNE_GRAPH_REORDER, 0)
     variants = []
     for v in a.variants:
         d = dict(kv.split("=") for kv in v.split(","))
@@ -83,7 +91,8 @@ def main():
                     print(f"{dt:5s} C={C:4d} epi={nepi} {name:28s} median {med:8.4f} ms  min {mn:8.4f} ms  "
                           f"{rec['GBs']:8.1f} GB/s  {100 * rec['frac']:5.1f}% of 8 TB/s", flush=True)
     if a.json:
-        json.dump({"mesh": a.mesh, "permute": a.permute, "V": V, "E": E, "results": out}, open(a.json, "w"), indent=1)
+        json.dump({"mesh": a.mesh, "permute": a.permute, "order": a.order, "reorder_knob": a.reorder,
+                   "locality_view": bool(g.handle.reordered), "V": V, "E": E, "results": out}, open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
