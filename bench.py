@@ -94,14 +94,17 @@ def pmc_traffic(C: int, dtype_name: str, n_epi: int, esize: int):
     while lanes < min(nvec, 64):
         lanes *= 2
     per_lane = 1 if nvec <= 64 else (2 if nvec <= 128 else 4)
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{'fp32' if esize == 4 else 'bf16'}.json")
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{'fp32' if esize == 4 else 'bf16'}.json")))
     kernel = aggregation_kernel_name(C, esize, n_epi)
     try:
+        path = cands[-1]                   # the latest round's table
+        pmc_traffic.source = os.path.relpath(path, ROOT)
         for k in json.load(open(path))["kernels"]:
             if (k.get("kernel", "spmm_rows") == kernel and k["dtype"] == dtype_name and k["lanes_per_row"] == lanes
                     and k["vectors_per_lane"] == per_lane and k["epilogue_operands"] == n_epi):
                 return k["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, IndexError):
         pass
     return None
 
@@ -312,8 +315,9 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
                                           f"{dom['dtype']} (+{dom['epilogue_operands']} epilogue operands)",
                 "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE KiB, separate passes) "
-                                "of this workload, profiles/r01_pmc_traffic_*.json; algorithmic bytes = "
+                "traffic_note": "HBM-side bytes per launch of this kernel variant from the committed rocprofv3 PMC table of this "
+                                "same workload (2*FETCH_SIZE+WRITE_SIZE KiB, separate passes; counters cannot be read from "
+                                f"inside the process): {getattr(pmc_traffic, 'source', None)}; algorithmic bytes = "
                                 f"{round(dom['algorithmic_MB'] * 1e6)}",
                 "all_aggregations_GBs": round(total_B / total_t, 1),
                 "all_aggregations_frac": round(total_B / total_t / HBM_PEAK_GBS, 4),

@@ -309,7 +309,7 @@ SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx,
     return SG_ERR_UNSUPPORTED;
   }
   // L^[i,j] = -dis[i] dis[j] (#edges j->i); the transposed CSR carries the same scales
-  if (g->symmetric && g->row_id)      // locality view: rows in processing order, output rows addressed through row_id
+  if (g->square && g->symmetric && g->row_id && g->loc.rowptr)   // locality view: rows in processing order, output rows addressed through row_id
     return run_csr(g->loc, g->dis_dst_loc, g->dis_src, X, ldx, X0, ldx0, X1, ldx1, Y, ldy, C, dtype, -alpha, beta, gamma,
                    (hipStream_t)stream, g->row_id);
   if (!g->square && g->row_id)         // row subset of a partition operator (sg_graph_create_rows)

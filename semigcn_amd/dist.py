@@ -237,7 +237,8 @@ class DistMeshGraph(_RowExchange):
                                                            dis_ext)
         # the same wide operator cut in two row sets, for overlap with the exchange: INTERIOR = owned rows none of whose
         # neighbours is a halo row (they can be aggregated while the halo is in flight), REST = the owned boundary rows
-        # and the ring-1 rows
+        # and ALL ring-1 rows (a ring-1 row may read owned rows only, but its own epilogue operand / output row is a
+        # halo row that the exchange has yet to fill)
         reads_halo = torch.zeros(self.n_ext, dtype=torch.bool, device=dev)
         reads_halo[ext_of[dst[e_wide & ~own[src]]]] = True
         is_row = torch.zeros(self.n_ext, dtype=torch.bool, device=dev)
@@ -245,14 +246,17 @@ class DistMeshGraph(_RowExchange):
         is_row[ext_of[torch.nonzero(r1).flatten()]] = True
         self._split = []
         dst_w, src_w = ext_of[dst[e_wide]], ext_of[src[e_wide]]
-        for rows_mask in (is_row & ~reads_halo, is_row & reads_halo):
+        owned_row = torch.zeros(self.n_ext, dtype=torch.bool, device=dev)
+        owned_row[:self.n_own] = True
+        interior = owned_row & ~reads_halo
+        for rows_mask in (interior, is_row & ~interior):
             rows = torch.nonzero(rows_mask).flatten()
             pos = torch.full((self.n_ext,), -1, dtype=torch.long, device=dev)
             pos[rows] = torch.arange(rows.numel(), device=dev)
             sel = rows_mask[dst_w]
             self._split.append(capi.GraphHandle.from_rows(pos[dst_w[sel]], src_w[sel], rows, self.n_ext, self.n_ext,
                                                           dis_ext[rows], dis_ext))
-        self.n_interior = int((is_row & ~reads_halo).sum())      # rows aggregated while the exchange is in flight
+        self.n_interior = int(interior.sum())                    # rows aggregated while the exchange is in flight
 
         # what I receive from each peer: my halo ids that it owns (contiguous runs of `halo`)
         b = torch.tensor(bounds, device=dev, dtype=torch.long)

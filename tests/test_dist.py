@@ -169,13 +169,13 @@ def test_partitioned_training_matches_single_rank(world, skip):
 def test_partition_plan_is_consistent():
     _install_doubles()
     from semigcn_amd import dist as sgdist, reorder, synth
-    mesh = synth.torus_mesh(24, 16)
+    mesh = synth.torus_mesh(48, 32, permute=True)     # (rank 0 of 4 has a ring-1 row all of whose neighbours are owned)
     V = mesh.num_vertices
     order, rank_of = reorder.morton_order(torch.from_numpy(mesh.x_pos))
     ei = reorder.permute_edge_index(torch.from_numpy(mesh.edge_index), rank_of)
     world = 4
     gs = [sgdist.DistMeshGraph(ei, V, r, world) for r in range(world)]
-    assert [g.start for g in gs] == [0, 96, 192, 288]
+    assert [g.start for g in gs] == [0, 384, 768, 1152]
     for r, g in enumerate(gs):
         for q, h in enumerate(gs):
             # what r sends to q is exactly what q expects from r, in the same order

@@ -1224,3 +1224,34 @@ def test_graph_locality_view_forced_on_small_and_degenerate_graphs(fixture_meshe
         assert not h.symmetric and not h.reordered
     finally:
         capi.tuning_set(capi.TUNE_GRAPH_REORDER, 0)
+
+
+def test_partition_operators_wide_and_row_subsets_agree():
+    """One rank's operators of a 4-way partition, real kernels, no process group needed: the wide operator (owned +
+    ring-1 rows, sg_graph_create_rect) == its interior / rest halves (sg_graph_create_rows: row subsets that write
+    only their own rows) == the global operator's rows, bit for bit."""
+    from semigcn_amd import dist as sgdist, reorder
+    m = synth.torus_mesh(96, 64, permute=True, masks=False)
+    V = m.num_vertices
+    _, rank_of = reorder.morton_order(torch.from_numpy(m.x_pos).to(DEV))
+    ei = reorder.permute_edge_index(torch.from_numpy(m.edge_index).to(DEV), rank_of)
+    full = capi.GraphHandle.from_edge_index(ei, V)
+    for C, dtype in ((16, torch.float32), (64, torch.bfloat16), (256, torch.float32)):
+        x = torch.randn(V, C, device=DEV).to(dtype)
+        x0 = torch.randn(V, C, device=DEV).to(dtype)
+        y_full = full.spmm(x, torch.empty_like(x), alpha=2.0, X0=x0, beta=-1.0)
+        for r in (0, 3):
+            g = sgdist.DistMeshGraph(ei, V, r, 4)
+            ids = torch.cat([torch.arange(g.start, g.end, device=DEV), g.halo_ids])
+            x_ext, x0_ext = x[ids].contiguous(), x0[ids].contiguous()
+            yw = g.handle_wide.spmm(x_ext, torch.zeros_like(x_ext), alpha=2.0, X0=x0_ext, beta=-1.0)
+            ys = torch.full_like(x_ext, float("nan"))
+            g._split[0].spmm(x_ext, ys, alpha=2.0, X0=x0_ext, beta=-1.0)
+            done = torch.isfinite(ys.float()[:, 0])
+            assert int(done.sum()) == g.n_interior > 0 and not bool(done[g.n_own:].any())
+            g._split[1].spmm(x_ext, ys, alpha=2.0, X0=x0_ext, beta=-1.0)
+            done = torch.isfinite(ys.float()[:, 0])
+            assert int(done.sum()) == g.n_own + g.n_halo1 and bool(done[:g.n_own].all())
+            assert torch.equal(ys[done], yw[done]) and torch.equal(ys[done], y_full[ids[done]])
+            yo = g.handle.spmm(x_ext, torch.empty((g.n_own, C), dtype=dtype, device=DEV), alpha=2.0, X0=x0_ext[:g.n_own], beta=-1.0)
+            assert torch.equal(yo, y_full[g.start:g.end])
