@@ -67,6 +67,9 @@ _SIGNATURES = {
     "sg_gemm_row_tiles": (c_int64, [c_int64, c_int64]),
     "sg_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                            c_int, c_void_p, c_void_p]),
+    "sg_gemm_tn_slabs": (c_int64, [c_int64]),
+    "sg_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
+                           c_void_p]),
     "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_bn_finalize_ranks": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                      c_void_p, c_void_p, c_void_p]),
@@ -544,6 +547,32 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
         _check(load().sg_gemm_nt(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), _ptr(bias), _ptr(out),
                                  _rows2d(out, "out"), M, N, K, SG_BF16, _ptr(mom), _stream(A)), "sg_gemm_nt")
     return (out, mom) if moments else out
+
+
+def gemm_tn_supported(A: torch.Tensor, B: torch.Tensor) -> bool:
+    if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16 or not A.is_cuda or A.dim() != 2 or B.dim() != 2:
+        return False
+    if A.shape[0] != B.shape[0] or A.shape[0] == 0 or A.stride(1) != 1 or B.stride(1) != 1:
+        return False
+    return (A.shape[1] % 8 == 0 and B.shape[1] % 8 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """``A.T @ B`` in float32 for bf16 A [M, N], B [M, Kp] (unit column stride) on the MFMA kernel: the weight gradient
+    ``dOut^T [Tx0|Tx1|Tx2]``; deterministic (slab partials summed in order)."""
+    _require_device(A, "A")
+    _require_device(B, "B")
+    M, N = A.shape
+    Kp = B.shape[1]
+    if B.shape[0] != M:
+        raise SemigcnLibraryError(f"gemm_tn shape mismatch: A {tuple(A.shape)} B {tuple(B.shape)}")
+    out = torch.empty((N, Kp), dtype=torch.float32, device=A.device)
+    ws = torch.empty((int(load().sg_gemm_tn_slabs(M)), N, Kp), dtype=torch.float32, device=A.device)
+    with _on_device(A.device):
+        _check(load().sg_gemm_tn(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), M, N, Kp, SG_BF16, _ptr(ws), _ptr(out),
+                                 Kp, _stream(A)), "sg_gemm_tn")
+    return out
 
 
 def bn_bwd_coeffs(partial: torch.Tensor, count: float, gamma: torch.Tensor, invstd: torch.Tensor) -> torch.Tensor:

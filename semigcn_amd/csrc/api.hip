@@ -505,6 +505,21 @@ SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, co
   return launch_gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, dtype, moments, (hipStream_t)stream);
 }
 
+SG_API int64_t sg_gemm_tn_slabs(int64_t M) { return gemm_tn_slabs(M); }
+
+SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
+                      float* workspace, float* out, int64_t ldo, void* stream) {
+  SG_REQUIRE(M >= 0 && N >= 0 && Kp >= 0, "sg_gemm_tn: negative size");
+  if (N == 0 || Kp == 0) return SG_OK;
+  SG_REQUIRE(out != nullptr && ldo >= Kp, "sg_gemm_tn: bad output");
+  if (M == 0) {
+    SG_HIP_TRY(hipMemset2DAsync(out, ldo * sizeof(float), 0, Kp * sizeof(float), N, (hipStream_t)stream));
+    return SG_OK;
+  }
+  SG_REQUIRE(A && B && workspace && lda >= N && ldb >= Kp, "sg_gemm_tn: null operand or short row stride");
+  return launch_gemm_tn(A, lda, B, ldb, M, N, Kp, dtype, workspace, out, ldo, (hipStream_t)stream);
+}
+
 SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
                             const float* invstd, float* out, void* stream) {
   SG_REQUIRE(nb > 0 && C >= 0 && N > 0 && partial && gamma && invstd && out, "sg_bn_bwd_coeffs: bad argument");

@@ -331,4 +331,192 @@ int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const
   return launch<4, 1, 2, 1>(g, stream);                 // 128 x 16
 }
 
+// =====================================================================================================================
+// Weight gradient:  W[N, Kp] = A[M, N]^T * B[M, Kp]   (bf16 operands, fp32 result)
+//
+// dWcat = dOut^T [Tx0|Tx1|Tx2] of ChebConv's backward (autograd of the `lins[k]` calls, util/networks.py:42,49): the
+// reduction runs over ALL M vertices and the result is tiny.  Both operands are row-major with the reduction index m
+// as the ROW, so the MFMA fragments (8 consecutive m per lane) are columns of the LDS tiles: they are read with
+// ds_read_b64_tr_b16, the gfx950 transposing LDS read (a 16-lane group reads 4 rows x 16 columns and every lane
+// receives one column) -- no transposed copy of dOut or T is ever materialised.
+//  * one workgroup = one 128 x 128 tile of W for one SLAB of kTnSlabRows vertices; it walks its slab in steps of 64
+//    rows: [64 m][128] tiles of A and B through registers into LDS (256-B rows, 32-B segments XOR-swizzled by the row so
+//    that the eight rows a 32-lane half reads hit disjoint banks), 32 MFMAs per wavefront per step;
+//  * the slabs' partial tiles go to an fp32 workspace and are summed in slab order by a second kernel: deterministic,
+//    no atomics;
+//  * workgroups of one slab are neighbours in launch order on one XCD, so the (Kp / 128) x re-read of A's and the
+//    (N / 128) x re-read of B's slab rows are L2 hits.
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+constexpr int kTnSlabRows = 8192;
+constexpr int kTnStep = 64;
+
+struct TnArgs {
+  const uint16_t* A; int64_t lda;
+  const uint16_t* B; int64_t ldb;
+  float* W;                    // [n_slabs][N][Kp]
+  int M, N, Kp;
+  int tiles_n, tiles_k, n_tiles, n_blocks;
+};
+
+__device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(kThreads, 3) void gemm_tn_bf16(const TnArgs g) {
+  constexpr int TILE_BYTES = kTnStep * 256;                       // [64 m][128 columns] bf16
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * TILE_BYTES];
+  uint8_t* const ldsA = lds;
+  uint8_t* const ldsB = lds + TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int blk = xcd_run(blockIdx.x, g.n_blocks);
+  const int slab = blk / g.n_tiles, tile = blk % g.n_tiles;
+  const int n0 = (tile / g.tiles_k) * 128, k0 = (tile % g.tiles_k) * 128;
+  const int m_begin = slab * kTnSlabRows;
+  int m_end = m_begin + kTnSlabRows;
+  m_end = m_end < g.M ? m_end : g.M;
+
+  // staging: chunk q = tid + 256 i -> tile row q / 16, 16-B chunk q % 16 (16 lanes = one 256-B row segment)
+  const int s_c = tid & 15;
+  const bool a_col = n0 + s_c * 8 < g.N, b_col = k0 + s_c * 8 < g.Kp;    // N, Kp % 8 == 0
+  const uint16_t* a_src = g.A + (a_col ? n0 + s_c * 8 : 0);
+  const uint16_t* b_src = g.B + (b_col ? k0 + s_c * 8 : 0);
+  int dst_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (tid >> 4) + 16 * i;
+    dst_off[i] = r * 256 + ((((s_c >> 1) ^ tn_swz(r)) << 5) | ((s_c & 1) << 4));
+  }
+  u32x4 ra[4], rb[4];
+  bool rin[4];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = m0 + (tid >> 4) + 16 * i;
+      rin[i] = m < m_end;
+      m = rin[i] ? m : g.M - 1;                                   // clamped: in bounds, zeroed on the way to LDS
+      ra[i] = *(const u32x4*)(a_src + (int64_t)m * g.lda);
+      rb[i] = *(const u32x4*)(b_src + (int64_t)m * g.ldb);
+    }
+  };
+  auto stash = [&]() {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(u32x4*)(ldsA + dst_off[i]) = (rin[i] && a_col) ? ra[i] : zero;
+      *(u32x4*)(ldsB + dst_off[i]) = (rin[i] && b_col) ? rb[i] : zero;
+    }
+  };
+
+  // transposing fragment reads: lane = 16 g + 4 q + p supplies row (32 ms + 8 g + 4 h + q), columns 4 p .. 4 p + 3 of the
+  // tile's 16-column segment; lane 16 g + i receives column i of those 4 rows (h = 0 / 1: the two halves of the 8 m)
+  const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto frag = [&](const uint8_t* base, int seg, int ms) -> bf16x8 {
+    bf16x4 h[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int row = 32 * ms + 8 * fg + 4 * hh + fq;
+      const uint8_t* p = base + row * 256 + ((seg ^ tn_swz(row)) << 5) + fp * 8;
+      h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
+    }
+    return bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+  };
+
+  if (m_begin < m_end) {
+    fetch(m_begin);
+    stash();
+  }
+  __syncthreads();
+  for (int m0 = m_begin; m0 < m_end; m0 += kTnStep) {
+    const bool more = m0 + kTnStep < m_end;
+    if (more) fetch(m0 + kTnStep);
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag(ldsA, wn * 4 + i, ms);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = frag(ldsB, wk * 4 + j, ms);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      stash();
+      __syncthreads();
+    }
+  }
+
+  // partial tile out: D column = lane & 15 (k'), rows = 4 (lane >> 4) + reg (n)
+  float* const W = g.W + (int64_t)slab * g.N * g.Kp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = k0 + (wk * 4 + j) * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + (wn * 4 + i) * 16 + (lane >> 4) * 4 + q;
+        if (n < g.N && kk < g.Kp) W[(int64_t)n * g.Kp + kk] = acc[i][j][q];
+      }
+    }
+}
+
+// out[n][k] = sum over slabs, in slab order
+__global__ __launch_bounds__(256) void tn_reduce(const float* __restrict__ W, int n_slabs, int64_t elems, int Kp,
+                                                 float* __restrict__ out, int64_t ldo) {
+  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // Kp % 8 == 0: a float4 stays in one row
+  if (e >= elems) return;
+  f32x4 s = *(const f32x4*)(W + e);
+  for (int t = 1; t < n_slabs; ++t) {
+    const f32x4 v = *(const f32x4*)(W + (int64_t)t * elems + e);
+    s += v;
+  }
+  const int64_t n = e / Kp, k = e - n * Kp;
+  *(f32x4*)(out + n * ldo + k) = s;
+}
+
+}  // namespace
+
+int64_t gemm_tn_slabs(int64_t M) { return M <= 0 ? 1 : (M + kTnSlabRows - 1) / kTnSlabRows; }
+
+int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
+                   float* workspace, float* out, int64_t ldo, hipStream_t stream) {
+  if (dtype != SG_BF16) {
+    set_error("sg_gemm_tn: bf16 operands only (dtype %d)", dtype);
+    return SG_ERR_UNSUPPORTED;
+  }
+  if (N % 8 || Kp % 8 || lda % 8 || ldb % 8 || ldo % 4 || !a16(A) || !a16(B) || !a16(out) || !a16(workspace)) {
+    set_error("sg_gemm_tn: needs N, Kp and the operand row strides to be multiples of 8 and 16-byte aligned buffers");
+    return SG_ERR_UNSUPPORTED;
+  }
+  SG_REQUIRE(M > 0 && M <= INT32_MAX && N <= INT32_MAX && Kp <= INT32_MAX, "sg_gemm_tn: size out of range");
+  TnArgs g;
+  g.A = (const uint16_t*)A; g.lda = lda;
+  g.B = (const uint16_t*)B; g.ldb = ldb;
+  g.W = workspace;
+  g.M = (int)M; g.N = (int)N; g.Kp = (int)Kp;
+  g.tiles_n = (int)((N + 127) / 128);
+  g.tiles_k = (int)((Kp + 127) / 128);
+  g.n_tiles = g.tiles_n * g.tiles_k;
+  const int64_t slabs = gemm_tn_slabs(M);
+  SG_REQUIRE(slabs * g.n_tiles <= INT32_MAX, "sg_gemm_tn: too many workgroups");
+  g.n_blocks = (int)(slabs * g.n_tiles);
+  gemm_tn_bf16<<<g.n_blocks, kThreads, 0, stream>>>(g);
+  SG_HIP_TRY(hipGetLastError());
+  const int64_t elems = N * Kp;
+  tn_reduce<<<(int)((elems / 4 + 255) / 256), 256, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
 }  // namespace sg

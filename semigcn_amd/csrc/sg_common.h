@@ -139,6 +139,10 @@ int set_gemm_tuning(int value);
 int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream);
 
+int64_t gemm_tn_slabs(int64_t M);
+int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
+                   float* workspace, float* out, int64_t ldo, hipStream_t stream);
+
 // mesh_loss.hip
 int64_t mesh_loss_blocks(int64_t V, int64_t F);
 int launch_mesh_loss_fwd(const float* pos, const int64_t* faces, const float* tpos, const float* vkeep, const float* tfn,

@@ -140,3 +140,36 @@ def test_chebconv_bf16_layer_same_result_on_mfma_and_blas_paths(cin, cout):
         scale = max(float(pb.norm()), 1e-3 * float(max(q.abs().max() for q in b[2])) * pb.numel() ** 0.5)
         assert float((pa - pb).norm()) <= 3e-2 * scale
     assert GU.rel_l2(a[3].cpu(), b[3].cpu()) < 1e-2 and GU.rel_l2(a[4].cpu(), b[4].cpu()) < 1e-2
+
+
+TN_SHAPES = [  # (M, N, Kp): dW[N, Kp] = A[M, N]^T B[M, Kp]
+    (1, 16, 8), (63, 16, 48), (64, 24, 16), (65, 32, 96), (1000, 48, 32), (8191, 64, 72), (8193, 96, 64),
+    (20000, 128, 192), (16385, 192, 128), (9000, 256, 384), (3000, 384, 256), (2500, 512, 768), (1300, 768, 512),
+]
+
+
+@pytest.mark.parametrize("M,N,Kp", TN_SHAPES)
+def test_gemm_tn_integer_data_is_bit_exact(M, N, Kp):
+    """Weight-gradient product on the transposing-LDS-read kernel, small-integer operands (every partial sum exact in
+    fp32): must EQUAL the fp32 reference bit for bit; both operands asymmetric, several slabs, ragged M / N / Kp."""
+    g = torch.Generator(device=DEV).manual_seed(M + 3 * N + 7 * Kp)
+    a = torch.randint(-2, 3, (M, N), device=DEV, generator=g).to(torch.bfloat16)
+    b = torch.randint(-2, 3, (M, Kp), device=DEV, generator=g).to(torch.bfloat16)
+    a[:, 0] = 1
+    b[:, -1] = torch.arange(M, device=DEV).remainder(3).to(torch.bfloat16)
+    ref = a.float().t() @ b.float()
+    out = capi.gemm_tn(a, b)
+    assert out.dtype == torch.float32 and out.shape == (N, Kp) and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("M,N,Kp", TN_SHAPES[3:])
+def test_gemm_tn_random_data_and_strides(M, N, Kp):
+    g = torch.Generator(device=DEV).manual_seed(N + Kp)
+    wa = torch.randn(M, N + 8, device=DEV, generator=g).to(torch.bfloat16)
+    wb = torch.randn(M, Kp + 16, device=DEV, generator=g).to(torch.bfloat16)
+    a, b = wa[:, 8:], wb[:, :Kp]                                  # column blocks of wider buffers
+    ref = a.double().t() @ b.double()
+    out = capi.gemm_tn(a, b)
+    assert GU.rel_l2(out.double().cpu(), ref.cpu()) < 1e-5          # fp32 accumulation of exact bf16 products
+    assert torch.equal(out, capi.gemm_tn(a, b))                    # deterministic
+    assert GU.rel_l2(F_sg.weight_grad(a.contiguous(), b.contiguous()).double().cpu(), ref.cpu()) < 1e-5

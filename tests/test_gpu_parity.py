@@ -1229,7 +1229,7 @@ def test_graph_locality_view_forced_on_small_and_degenerate_graphs(fixture_meshe
 def test_partition_operators_wide_and_row_subsets_agree():
     """One rank's operators of a 4-way partition, real kernels, no process group needed: the wide operator (owned +
     ring-1 rows, sg_graph_create_rect) == its interior / rest halves (sg_graph_create_rows: row subsets that write
-    only their own rows) == the global operator's rows, bit for bit."""
+    only their own rows) == the owned-rows operator, bit for bit, and == the global operator's rows to rounding."""
     from semigcn_amd import dist as sgdist, reorder
     m = synth.torus_mesh(96, 64, permute=True, masks=False)
     V = m.num_vertices
@@ -1252,6 +1252,9 @@ def test_partition_operators_wide_and_row_subsets_agree():
             g._split[1].spmm(x_ext, ys, alpha=2.0, X0=x0_ext, beta=-1.0)
             done = torch.isfinite(ys.float()[:, 0])
             assert int(done.sum()) == g.n_own + g.n_halo1 and bool(done[:g.n_own].all())
-            assert torch.equal(ys[done], yw[done]) and torch.equal(ys[done], y_full[ids[done]])
+            assert torch.equal(ys[done], yw[done])
+            # against the global operator: same rows, neighbours summed in a different order ([owned | halo] ids)
+            tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+            assert rel(ys[done].float(), y_full[ids[done]].float()) < tol
             yo = g.handle.spmm(x_ext, torch.empty((g.n_own, C), dtype=dtype, device=DEV), alpha=2.0, X0=x0_ext[:g.n_own], beta=-1.0)
-            assert torch.equal(yo, y_full[g.start:g.end])
+            assert torch.equal(yo, ys[:g.n_own])

@@ -98,8 +98,55 @@ def main():
         del A, B, out
     print("totals (one forward + input-gradient pass of every supported layer): " +
           "  ".join(f"{k} {v:.2f} ms" for k, v in tot.items()), flush=True)
+    # ---- weight gradients dW = dOut^T T: own transposing-read kernel against the slab-batched BLAS formulation
+    from semigcn_amd import functional as F_sg
+    tot_dw = {"mfma_tn": 0.0, "blas_slabs": 0.0}
+    dw = []
+    for i in range(13):
+        cin, cout = SGCN[i], SGCN[i + 1]
+        N, Kp = (cout, 3 * cin) if cout >= cin else (3 * cout, cin)
+        if N % 8 or Kp % 8:
+            continue
+        A = torch.randn(M, N, device=dev).to(torch.bfloat16)
+        B = torch.randn(M, Kp, device=dev).to(torch.bfloat16)
+
+        def blas():
+            F_sg.USE_MFMA_GEMM = False
+            try:
+                return F_sg.weight_grad(A, B)
+            finally:
+                F_sg.USE_MFMA_GEMM = True
+        variants = {"mfma_tn": lambda: capi.gemm_tn(A, B), "blas_slabs": blas}
+        times = {k: [] for k in variants}
+        for rnd in range(a.rounds + 1):
+            for k, fn in variants.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    times[k].append(e0.elapsed_time(e1) / a.reps)
+        ref = blas()
+        err = float((capi.gemm_tn(A, B) - ref).abs().max() / ref.abs().max())
+        byts, flops = (M * N + M * Kp) * 2.0, 2.0 * M * N * Kp
+        rec = {"product": f"L{i} dW [{N},V]x[V,{Kp}]", "N": N, "Kp": Kp, "bytes": byts, "flops": flops, "max_rel_diff": err}
+        line = f"{rec['product']:30s}"
+        for k in variants:
+            med = float(np.median(times[k]))
+            rec[k + "_ms"] = round(med, 4)
+            rec[k + "_hbm_frac"] = round(byts / med / 1e-3 / 8e12, 3)
+            rec[k + "_mfma_frac"] = round(flops / med / 1e-3 / 2.5e15, 3)
+            tot_dw[k] += med
+            line += f"  {k} {med:7.3f} ms (hbm {rec[k + '_hbm_frac']:.2f} mfma {rec[k + '_mfma_frac']:.2f})"
+        dw.append(rec)
+        print(line + f"  diff {err:.1e}", flush=True)
+        del A, B
+    print("weight-gradient totals: " + "  ".join(f"{k} {v:.2f} ms" for k, v in tot_dw.items()), flush=True)
     if a.json:
-        json.dump({"V": M, "totals_ms": tot, "products": res}, open(a.json, "w"), indent=1)
+        json.dump({"V": M, "totals_ms": tot, "products": res, "weight_gradient_totals_ms": tot_dw, "weight_gradients": dw},
+                  open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
