@@ -305,9 +305,9 @@ SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, co
                       int64_t M, int64_t N, int64_t K, int dtype, float* moments, void* stream);
 /* Weight gradient on the matrix cores:  out[N, Kp] (float32, row stride ldo) = A[M, N]^T * B[M, Kp], bf16 operands --
  * dWcat = dOut^T [Tx0|Tx1|Tx2], the autograd of the `lins[k]` calls (util/networks.py:42,49), a reduction over all M
- * vertices.  workspace: float32 [sg_gemm_tn_slabs(M), N, Kp] (per-slab partial sums, added in slab order: the result
+ * vertices.  workspace: float32 [sg_gemm_tn_slabs(M, N, Kp), N, Kp] (per-slab partial sums, added in slab order: the result
  * is deterministic).  N, Kp, lda, ldb multiples of 8, 16-byte aligned buffers, else SG_ERR_UNSUPPORTED. */
-SG_API int64_t sg_gemm_tn_slabs(int64_t M);
+SG_API int64_t sg_gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp);
 SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
                       float* workspace, float* out, int64_t ldo, void* stream);
 /* sg_bn_stats_finalize for partials cut into uniform tiles of rows_per_tile rows (the last one shorter) */

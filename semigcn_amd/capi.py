@@ -67,7 +67,7 @@ _SIGNATURES = {
     "sg_gemm_row_tiles": (c_int64, [c_int64, c_int64]),
     "sg_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                            c_int, c_void_p, c_void_p]),
-    "sg_gemm_tn_slabs": (c_int64, [c_int64]),
+    "sg_gemm_tn_slabs": (c_int64, [c_int64, c_int64, c_int64]),
     "sg_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
                            c_void_p]),
     "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -568,7 +568,7 @@ def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     if B.shape[0] != M:
         raise SemigcnLibraryError(f"gemm_tn shape mismatch: A {tuple(A.shape)} B {tuple(B.shape)}")
     out = torch.empty((N, Kp), dtype=torch.float32, device=A.device)
-    ws = torch.empty((int(load().sg_gemm_tn_slabs(M)), N, Kp), dtype=torch.float32, device=A.device)
+    ws = torch.empty((int(load().sg_gemm_tn_slabs(M, N, Kp)), N, Kp), dtype=torch.float32, device=A.device)
     with _on_device(A.device):
         _check(load().sg_gemm_tn(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), M, N, Kp, SG_BF16, _ptr(ws), _ptr(out),
                                  Kp, _stream(A)), "sg_gemm_tn")

@@ -505,7 +505,7 @@ SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, co
   return launch_gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, dtype, moments, (hipStream_t)stream);
 }
 
-SG_API int64_t sg_gemm_tn_slabs(int64_t M) { return gemm_tn_slabs(M); }
+SG_API int64_t sg_gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp) { return gemm_tn_slabs(M, N, Kp); }
 
 SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
                       float* workspace, float* out, int64_t ldo, void* stream) {

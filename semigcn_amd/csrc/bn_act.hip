@@ -354,25 +354,27 @@ __global__ void bn_finalize(const float* __restrict__ stats, double N, int C, co
 // bn_merge + bn_finalize in one launch for the single-device case (N = V), and the per-channel coefficients of the
 // backward pass from the partial sums of col_reduce<MODE 1>: two tiny kernels instead of six launches per
 // BatchNorm (merge, finalize; sum over blocks, /N, gamma*invstd) -- they matter where an iteration is launch-bound.
+// One WORKGROUP per channel (the MFMA product hands over one partial per 128-row tile: 7813 of them at V = 1 M, which a
+// single wavefront per channel took 36 us to walk): every thread merges every 256th block, a shuffle tree merges the
+// lanes of a wavefront, thread 0 merges the four wavefronts -- a fixed order, so the result is deterministic.
 __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ partial, int64_t nb, int64_t V, int C,
                                                          int rpb, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* running_mean,
                                                          float* running_var, float momentum, float eps,
                                                          float* __restrict__ out /*[4][C]*/) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  __shared__ double s_n[4], s_mean[4], s_m2[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x;
   double n = 0.0, mean = 0.0, m2 = 0.0;
-  if (c < C) {
-    for (int64_t b = lane; b < nb; b += 64) {
-      int64_t rows = V - b * rpb;
-      rows = rows > rpb ? rpb : rows;
-      if (rows <= 0) break;
-      const double nbk = (double)rows, mb = partial[(b * 2 + 0) * C + c], qb = partial[(b * 2 + 1) * C + c];
-      const double tot = n + nbk, delta = mb - mean;
-      mean += delta * (nbk / tot);
-      m2 += qb + delta * delta * (n * nbk / tot);
-      n = tot;
-    }
+  for (int64_t b = threadIdx.x; b < nb; b += 256) {
+    int64_t rows = V - b * rpb;
+    rows = rows > rpb ? rpb : rows;
+    if (rows <= 0) break;
+    const double nbk = (double)rows, mb = partial[(b * 2 + 0) * C + c], qb = partial[(b * 2 + 1) * C + c];
+    const double tot = n + nbk, delta = mb - mean;
+    mean += delta * (nbk / tot);
+    m2 += qb + delta * delta * (n * nbk / tot);
+    n = tot;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -385,7 +387,18 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
       n = tot;
     }
   }
-  if (c < C && lane == 0) {
+  if (lane == 0) { s_n[wave] = n; s_mean[wave] = mean; s_m2[wave] = m2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      const double n2 = s_n[w], tot = n + n2;
+      if (tot > 0.0 && n2 > 0.0) {
+        const double delta = s_mean[w] - mean;
+        mean += delta * (n2 / tot);
+        m2 += s_m2[w] + delta * delta * (n * n2 / tot);
+        n = tot;
+      }
+    }
     // through float, exactly as bn_merge hands (mean, M2) to bn_finalize
     const float meanf = (float)mean;
     const double m2d = (double)(float)m2;
@@ -498,7 +511,7 @@ int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_
   if (C == 0) return SG_OK;
   SG_REQUIRE(nb == col_blocks(V), "partial buffer must have sg_col_blocks(V) blocks");
   const int rpb = (int)((V + nb - 1) / nb);
-  bn_stats_finalize<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, gamma, beta, running_mean,
+  bn_stats_finalize<<<(int)C, 256, 0, stream>>>(partial, nb, V, (int)C, rpb, gamma, beta, running_mean,
                                                             running_var, momentum, eps, out);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
@@ -509,7 +522,7 @@ int launch_bn_stats_finalize_tiles(const float* partial, int64_t nb, int64_t rpb
                                    float* out, hipStream_t stream) {
   if (C == 0) return SG_OK;
   SG_REQUIRE(rpb > 0 && rpb <= INT32_MAX && nb == (V + rpb - 1) / rpb, "partial buffer must have ceil(V / rows_per_tile) tiles");
-  bn_stats_finalize<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, V, (int)C, (int)rpb, gamma, beta, running_mean,
+  bn_stats_finalize<<<(int)C, 256, 0, stream>>>(partial, nb, V, (int)C, (int)rpb, gamma, beta, running_mean,
                                                             running_var, momentum, eps, out);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;

@@ -339,7 +339,7 @@ int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const
 // as the ROW, so the MFMA fragments (8 consecutive m per lane) are columns of the LDS tiles: they are read with
 // ds_read_b64_tr_b16, the gfx950 transposing LDS read (a 16-lane group reads 4 rows x 16 columns and every lane
 // receives one column) -- no transposed copy of dOut or T is ever materialised.
-//  * one workgroup = one 128 x 128 tile of W for one SLAB of kTnSlabRows vertices; it walks its slab in steps of 64
+//  * one workgroup = one 128 x 128 tile of W for one SLAB of 512 .. 8192 vertices; it walks its slab in steps of 64
 //    rows: [64 m][128] tiles of A and B through registers into LDS (256-B rows, 32-B segments XOR-swizzled by the row so
 //    that the eight rows a 32-lane half reads hit disjoint banks), 32 MFMAs per wavefront per step;
 //  * the slabs' partial tiles go to an fp32 workspace and are summed in slab order by a second kernel: deterministic,
@@ -349,15 +349,23 @@ int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-constexpr int kTnSlabRows = 8192;
 constexpr int kTnStep = 64;
+constexpr int kTnMaxSlabRows = 8192;
+
+// rows of one slab: enough slabs that (slabs x output tiles) fills the chip several times over even when W is a single
+// tile (N = 32, Kp = 48 at V = 1 M: 1 tile -> ~1000 slabs of 1024 rows), never more than kTnMaxSlabRows
+__host__ __device__ inline int tn_slab_rows(int64_t M, int64_t n_tiles) {
+  int64_t rows = (M * n_tiles / 1024 + kTnStep - 1) / kTnStep * kTnStep;
+  rows = rows < 512 ? 512 : rows;
+  return (int)(rows > kTnMaxSlabRows ? kTnMaxSlabRows : rows);
+}
 
 struct TnArgs {
   const uint16_t* A; int64_t lda;
   const uint16_t* B; int64_t ldb;
   float* W;                    // [n_slabs][N][Kp]
   int M, N, Kp;
-  int tiles_n, tiles_k, n_tiles, n_blocks;
+  int tiles_n, tiles_k, n_tiles, n_blocks, slab_rows;
 };
 
 __device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -372,8 +380,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_tn_bf16(const TnArgs g) {
   const int blk = xcd_run(blockIdx.x, g.n_blocks);
   const int slab = blk / g.n_tiles, tile = blk % g.n_tiles;
   const int n0 = (tile / g.tiles_k) * 128, k0 = (tile % g.tiles_k) * 128;
-  const int m_begin = slab * kTnSlabRows;
-  int m_end = m_begin + kTnSlabRows;
+  const int m_begin = slab * g.slab_rows;
+  int m_end = m_begin + g.slab_rows;
   m_end = m_end < g.M ? m_end : g.M;
 
   // staging: chunk q = tid + 256 i -> tile row q / 16, 16-B chunk q % 16 (16 lanes = one 256-B row segment)
@@ -487,7 +495,11 @@ __global__ __launch_bounds__(256) void tn_reduce(const float* __restrict__ W, in
 
 }  // namespace
 
-int64_t gemm_tn_slabs(int64_t M) { return M <= 0 ? 1 : (M + kTnSlabRows - 1) / kTnSlabRows; }
+int64_t gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
+  if (M <= 0) return 1;
+  const int rows = tn_slab_rows(M, ((N + 127) / 128) * ((Kp + 127) / 128));
+  return (M + rows - 1) / rows;
+}
 
 int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
                    float* workspace, float* out, int64_t ldo, hipStream_t stream) {
@@ -508,7 +520,8 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
   g.tiles_n = (int)((N + 127) / 128);
   g.tiles_k = (int)((Kp + 127) / 128);
   g.n_tiles = g.tiles_n * g.tiles_k;
-  const int64_t slabs = gemm_tn_slabs(M);
+  g.slab_rows = tn_slab_rows(M, g.n_tiles);
+  const int64_t slabs = gemm_tn_slabs(M, N, Kp);
   SG_REQUIRE(slabs * g.n_tiles <= INT32_MAX, "sg_gemm_tn: too many workgroups");
   g.n_blocks = (int)(slabs * g.n_tiles);
   gemm_tn_bf16<<<g.n_blocks, kThreads, 0, stream>>>(g);

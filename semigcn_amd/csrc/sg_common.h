@@ -139,7 +139,7 @@ int set_gemm_tuning(int value);
 int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream);
 
-int64_t gemm_tn_slabs(int64_t M);
+int64_t gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp);
 int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
                    float* workspace, float* out, int64_t ldo, hipStream_t stream);
 

@@ -50,7 +50,8 @@ def weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     batched GEMM over the slabs and a sum over S runs 2-10x faster (2.7 / 0.45 ms) and is
     deterministic (tools/gemm_bench.py).  bf16 features take the library's own kernel (csrc/gemm_mfma.hip, gemm_tn)."""
     V = dout.shape[0]
-    if USE_MFMA_GEMM and dout.is_cuda and dout.dtype == torch.bfloat16 and capi.gemm_tn_supported(dout, T):
+    if (USE_MFMA_GEMM and dout.is_cuda and dout.dtype == torch.bfloat16 and dout.shape[1] * T.shape[1] <= MFMA_MAX_WEIGHT_ELEMS
+            and capi.gemm_tn_supported(dout, T)):
         return capi.gemm_tn(dout, T)       # own MFMA kernel (transposing LDS reads, slab partials summed in order)
     S = min(128 if dout.dtype == torch.float32 else 64, V // 4096)
     if S <= 1 or not (dout.is_contiguous() and T.is_contiguous()):

@@ -172,4 +172,4 @@ def test_gemm_tn_random_data_and_strides(M, N, Kp):
     out = capi.gemm_tn(a, b)
     assert GU.rel_l2(out.double().cpu(), ref.cpu()) < 1e-5          # fp32 accumulation of exact bf16 products
     assert torch.equal(out, capi.gemm_tn(a, b))                    # deterministic
-    assert GU.rel_l2(F_sg.weight_grad(a.contiguous(), b.contiguous()).double().cpu(), ref.cpu()) < 1e-5
+    assert GU.rel_l2(F_sg.weight_grad(a.contiguous(), b.contiguous()).double().cpu(), ref.cpu()) < 1e-5     # own kernel or BLAS slabs, by shape
