@@ -353,9 +353,9 @@ constexpr int kTnStep = 64;
 constexpr int kTnMaxSlabRows = 8192;
 
 // rows of one slab: enough slabs that (slabs x output tiles) fills the chip several times over even when W is a single
-// tile (N = 32, Kp = 48 at V = 1 M: 1 tile -> ~1000 slabs of 1024 rows), never more than kTnMaxSlabRows
+// tile (N = 32, Kp = 48 at V = 1 M: 1 tile -> ~500 slabs of 2048 rows), never more than kTnMaxSlabRows
 __host__ __device__ inline int tn_slab_rows(int64_t M, int64_t n_tiles) {
-  int64_t rows = (M * n_tiles / 1024 + kTnStep - 1) / kTnStep * kTnStep;
+  int64_t rows = (M * n_tiles / 512 + kTnStep - 1) / kTnStep * kTnStep;
   rows = rows < 512 ? 512 : rows;
   return (int)(rows > kTnMaxSlabRows ? kTnMaxSlabRows : rows);
 }
@@ -479,18 +479,25 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_tn_bf16(const TnArgs g) {
     }
 }
 
-// out[n][k] = sum over slabs, in slab order
-__global__ __launch_bounds__(256) void tn_reduce(const float* __restrict__ W, int n_slabs, int64_t elems, int Kp,
-                                                 float* __restrict__ out, int64_t ldo) {
-  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // Kp % 8 == 0: a float4 stays in one row
-  if (e >= elems) return;
-  f32x4 s = *(const f32x4*)(W + e);
-  for (int t = 1; t < n_slabs; ++t) {
-    const f32x4 v = *(const f32x4*)(W + (int64_t)t * elems + e);
-    s += v;
+// out[n][k] = sum over the slabs' partial tiles.  64 x 16 threads: 64 consecutive float4 of the output, 16 slab groups
+// (thread y adds slabs y, y + 16, ..), then the 16 group sums in order -- a fixed summation tree, so the result is
+// deterministic, and a small output with ~500 slabs is not one thread walking 500 dependent loads.
+__global__ __launch_bounds__(1024) void tn_reduce(const float* __restrict__ W, int n_slabs, int64_t elems, int Kp,
+                                                  float* __restrict__ out, int64_t ldo) {
+  __shared__ f32x4 s_part[16][64];
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int64_t e = ((int64_t)blockIdx.x * 64 + x) * 4;      // Kp % 8 == 0: a float4 stays inside one row
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (e < elems)
+    for (int t = y; t < n_slabs; t += 16) acc += *(const f32x4*)(W + (int64_t)t * elems + e);
+  s_part[y][x] = acc;
+  __syncthreads();
+  if (y == 0 && e < elems) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) acc += s_part[k][x];
+    const int64_t n = e / Kp, kk = e - n * Kp;
+    *(f32x4*)(out + n * ldo + kk) = acc;
   }
-  const int64_t n = e / Kp, k = e - n * Kp;
-  *(f32x4*)(out + n * ldo + k) = s;
 }
 
 }  // namespace
@@ -527,7 +534,7 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
   gemm_tn_bf16<<<g.n_blocks, kThreads, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   const int64_t elems = N * Kp;
-  tn_reduce<<<(int)((elems / 4 + 255) / 256), 256, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo);
+  tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
