@@ -200,6 +200,15 @@ SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t
  *                         (kept on the device: no host round trip per BatchNorm)
  * partial is float32 [nb, 2, C].
  * ------------------------------------------------------------------------- */
+/* sg_bn_act_bwd_apply that also leaves colsum[c] = sum over rows of the dH it wrote (as stored) -- the bias gradient of
+ * the ChebConv in front of the BatchNorm (autograd of `out += bias`, [3P] ChebConv.forward): no separate pass over dH.
+ * colsum_partial: float32 [sg_col_apply_blocks(V, C, dtype), C] scratch; that count is 0 for shapes the row-owning
+ * kernel does not serve (then SG_ERR_UNSUPPORTED: use sg_bn_act_bwd_apply and sum the columns separately). */
+SG_API int64_t sg_col_apply_blocks(int64_t V, int64_t C, int dtype);
+SG_API int sg_bn_act_bwd_apply_colsum(const void* dA, int64_t ldda, const void* H, int64_t ldh, const float* scale,
+                                      const float* shift, const float* mean, const float* invstd, const float* k,
+                                      const float* c1, const float* c2, float slope, void* dH, int64_t lddh, int64_t V,
+                                      int64_t C, int dtype, float* colsum_partial, float* colsum, void* stream);
 SG_API int64_t sg_col_blocks(int64_t V);
 SG_API int sg_col_moments(const void* X, int64_t ldx, int64_t V, int64_t C, int dtype, float* partial,
                           int64_t nb, void* stream);

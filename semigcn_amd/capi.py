@@ -82,6 +82,10 @@ _SIGNATURES = {
     "sg_bn_act_bwd_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_int64, c_int,
                                     c_void_p]),
+    "sg_col_apply_blocks": (c_int64, [c_int64, c_int64, c_int]),
+    "sg_bn_act_bwd_apply_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                           c_void_p, c_void_p, c_void_p]),
     "sg_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
                                c_void_p]),
     "sg_mesh_edges": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64), POINTER(c_int),
@@ -626,6 +630,29 @@ def bn_act_bwd_apply(dA, H, scale, shift, mean, invstd, k, c1, c2, slope: float,
                                           float(slope), _ptr(dH), _rows2d(dH, "dH"), V, C, dtype_code(H), _stream(H)),
                "sg_bn_act_bwd_apply")
     return dH
+
+
+def bn_act_bwd_apply_colsum(dA, H, scale, shift, mean, invstd, k, c1, c2, slope: float,
+                            out: Optional[torch.Tensor] = None):
+    """bn_act_bwd_apply that also returns the fp32 column sums of the dH it wrote (the bias gradient of the ChebConv in
+    front of the BatchNorm), or ``(dH, None)`` when the shape is not served by the row-owning kernel."""
+    _require_device(dA, "dA")
+    V, C = H.shape
+    nb = int(load().sg_col_apply_blocks(V, C, dtype_code(H)))
+    dH = torch.empty((V, C), dtype=H.dtype, device=H.device) if out is None else out
+    strides_ok = all(_rows2d(t, "operand") % 4 == 0 for t in (dA, H, dH))
+    if nb == 0 or not strides_ok:
+        return bn_act_bwd_apply(dA, H, scale, shift, mean, invstd, k, c1, c2, slope, out=dH), None
+    part = torch.empty((nb, C), dtype=torch.float32, device=H.device)
+    sums = torch.empty((C,), dtype=torch.float32, device=H.device)
+    with _on_device(H.device):
+        _check(load().sg_bn_act_bwd_apply_colsum(_ptr(dA), _rows2d(dA, "dA"), _ptr(H), _rows2d(H, "H"),
+                                                 _ptr(_f32vec(scale, C, "scale")), _ptr(_f32vec(shift, C, "shift")),
+                                                 _ptr(_f32vec(mean, C, "mean")), _ptr(_f32vec(invstd, C, "invstd")),
+                                                 _ptr(_f32vec(k, C, "k")), _ptr(_f32vec(c1, C, "c1")), _ptr(_f32vec(c2, C, "c2")),
+                                                 float(slope), _ptr(dH), _rows2d(dH, "dH"), V, C, dtype_code(H), _ptr(part),
+                                                 _ptr(sums), _stream(H)), "sg_bn_act_bwd_apply_colsum")
+    return dH, sums
 
 
 # ---- fused loss step ---------------------------------------------------------------------------

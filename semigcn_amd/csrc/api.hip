@@ -577,6 +577,27 @@ SG_API int sg_bn_act_bwd_apply(const void* dA, int64_t ldda, const void* H, int6
                           (hipStream_t)stream);
 }
 
+SG_API int64_t sg_col_apply_blocks(int64_t V, int64_t C, int dtype) { return col_apply_blocks(V, C, dtype); }
+
+SG_API int sg_bn_act_bwd_apply_colsum(const void* dA, int64_t ldda, const void* H, int64_t ldh, const float* scale,
+                                      const float* shift, const float* mean, const float* invstd, const float* k,
+                                      const float* c1, const float* c2, float slope, void* dH, int64_t lddh, int64_t V,
+                                      int64_t C, int dtype, float* colsum_partial, float* colsum, void* stream) {
+  SG_REQUIRE(V > 0 && C > 0, "sg_bn_act_bwd_apply_colsum: empty input");
+  SG_REQUIRE(dA && H && dH && scale && shift && mean && invstd && k && c1 && c2 && colsum_partial && colsum &&
+                 ldda >= C && ldh >= C && lddh >= C,
+             "sg_bn_act_bwd_apply_colsum: bad argument");
+  const int64_t nb = col_apply_blocks(V, C, dtype);
+  if (nb == 0 || ldda % 4 || ldh % 4 || lddh % 4) {
+    set_error("sg_bn_act_bwd_apply_colsum: shape not served (C must fill whole 16-byte vectors, <= 256 of them)");
+    return SG_ERR_UNSUPPORTED;
+  }
+  int rc = launch_col_apply(1, dA, ldda, H, ldh, scale, shift, mean, invstd, k, c1, c2, slope, dH, lddh, V, C, dtype,
+                            (hipStream_t)stream, colsum_partial);
+  if (rc != SG_OK) return rc;
+  return launch_colsum_finalize(colsum_partial, nb, C, colsum, (hipStream_t)stream);
+}
+
 SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y, int64_t ldy,
                    int64_t C, int dtype, void* stream) {
   SG_REQUIRE(n >= 0 && C >= 0, "sg_gather_rows: negative size");

@@ -228,13 +228,16 @@ __global__ __launch_bounds__(kBlock) void col_apply(const void* A_, int64_t lda,
 // Same arithmetic as col_apply, for C / VEC <= 256 column slots: a thread keeps ONE column slot for the
 // whole launch, so the per-channel parameters live in registers (col_apply re-reads 2 (MODE 0) or 7
 // (MODE 1) vectors and does a 64-bit division per element group), and it has U rows in flight.
-template <int DT, int MODE>
+// COLSUM (MODE 1 only): also leave colsum[blockIdx][c] = this workgroup's column sums of the ROUNDED values it wrote --
+// dH is the output gradient of the ChebConv in front of the BatchNorm, and that layer's bias gradient is exactly these
+// column sums: taking them here saves the separate pass over dH (and two launches) per layer.
+template <int DT, int MODE, bool COLSUM = false>
 __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t lda, const void* H_, int64_t ldh,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ kk, const float* __restrict__ c1,
                                                          const float* __restrict__ c2, float slope, void* Y_, int64_t ldy,
-                                                         int64_t V, int C, int tpr_log2) {
+                                                         int64_t V, int C, int tpr_log2, float* __restrict__ colsum = nullptr) {
   using IO = Io<DT>;
   using elem_t = typename IO::elem;
   using raw_t = typename IO::raw;
@@ -246,8 +249,13 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
   const int tc = threadIdx.x & ((1 << tpr_log2) - 1);
   const int tg = threadIdx.x >> tpr_log2;
   const int groups = kBlock >> tpr_log2;
-  if (tc >= C / VEC) return;
-  const int c0 = tc * VEC;
+  __shared__ float s_sum[COLSUM ? kBlock : 1][COLSUM ? VEC : 1];
+  float csum[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) csum[k] = 0.f;
+  const bool col_on = tc < C / VEC;
+  if (!COLSUM && !col_on) return;
+  const int c0 = (col_on ? tc : 0) * VEC;
   float sc[VEC], sh[VEC], mu[VEC], is[VEC], kc[VEC], k1[VEC], k2[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
     }
   }
   const int64_t step = (int64_t)gridDim.x * groups;
-  for (int64_t r = (int64_t)blockIdx.x * groups + tg; r < V; r += step * U) {
+  for (int64_t r = (int64_t)blockIdx.x * groups + tg; col_on && r < V; r += step * U) {
     raw_t xa[U], xh[U];
     bool live[U];
 #pragma unroll
@@ -288,9 +296,44 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
           y[k] = kc[k] * (dz - k1[k] - (h[k] - mu[k]) * k2[k]);
         }
       }
-      if (live[u]) *(raw_t*)(Y + (r + u * step) * ldy + c0) = IO::pack(y);
+      if (live[u]) {
+        const raw_t packed = IO::pack(y);
+        *(raw_t*)(Y + (r + u * step) * ldy + c0) = packed;
+        if (COLSUM) {
+          float yr[VEC];
+          IO::unpack(packed, yr);                      // the values as stored (bf16: rounded)
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) csum[k] += yr[k];
+        }
+      }
     }
   }
+  if (COLSUM) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s_sum[threadIdx.x][k] = csum[k];
+    __syncthreads();
+    if (tg == 0 && col_on) {                         // fixed order over the row groups: deterministic
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float t = 0.f;
+        for (int gq = 0; gq < groups; ++gq) t += s_sum[(gq << tpr_log2) + tc][k];
+        colsum[(int64_t)blockIdx.x * C + c0 + k] = t;
+      }
+    }
+  }
+}
+
+// out[c] = sum over the nb workgroup partials of col_apply_rows<.., COLSUM>, in double, one wavefront per channel
+__global__ __launch_bounds__(256) void colsum_finalize(const float* __restrict__ partial, int64_t nb, int C,
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  double s0 = 0.0;
+  if (c < C)
+    for (int64_t b = lane; b < nb; b += 64) s0 += partial[b * C + c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s0 += __shfl_down(s0, off, 64);
+  if (c < C && lane == 0) out[c] = (float)s0;
 }
 
 // stats[0][c] = mean, stats[1][c] = M2 over all V rows, from the per-block partials (Chan et al.,
@@ -581,10 +624,29 @@ int launch_col_reduce(int mode, const void* A, int64_t lda, const void* H, int64
   return SG_ERR_UNSUPPORTED;
 }
 
+int64_t col_apply_blocks(int64_t V, int64_t C, int dtype) {
+  const int VEC = dtype == SG_F32 ? 4 : 8;
+  if (C % VEC || C / VEC > kBlock || V <= 0) return 0;     // the row-owning kernel does not serve this shape
+  const int ncol = (int)(C / VEC);
+  int lg = 0;
+  while ((1 << lg) < ncol) ++lg;
+  const int groups = kBlock >> lg;
+  int64_t nbr = (V + (int64_t)groups * 4 - 1) / ((int64_t)groups * 4);
+  if (nbr > 256 * 16) nbr = 256 * 16;
+  return nbr < 1 ? 1 : nbr;
+}
+
+int launch_colsum_finalize(const float* partial, int64_t nb, int64_t C, float* out, hipStream_t stream) {
+  if (C == 0) return SG_OK;
+  colsum_finalize<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, (int)C, out);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
 int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_t ldh, const float* scale,
                      const float* shift, const float* mean, const float* invstd, const float* kk, const float* c1,
                      const float* c2, float slope, void* Y, int64_t ldy, int64_t V, int64_t C, int dtype,
-                     hipStream_t stream) {
+                     hipStream_t stream, float* colsum) {
   if (V == 0 || C == 0) return SG_OK;
   auto run = [&](auto dt_tag) -> int {
     constexpr int DT = decltype(dt_tag)::value;
@@ -599,11 +661,14 @@ int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_
       int64_t nbr = (V + (int64_t)groups * 4 - 1) / ((int64_t)groups * 4);
       if (nbr > 256 * 16) nbr = 256 * 16;
       if (nbr < 1) nbr = 1;
+      if (colsum) SG_REQUIRE(mode == 1 && nbr == col_apply_blocks(V, C, dtype), "column sums: wrong partial buffer size");
       if (mode == 0) col_apply_rows<DT, 0><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg);
+      else if (colsum) col_apply_rows<DT, 1, true><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg, colsum);
       else col_apply_rows<DT, 1><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg);
       SG_HIP_TRY(hipGetLastError());
       return SG_OK;
     }
+    SG_REQUIRE(colsum == nullptr, "column sums are only taken by the row-owning kernel (sg_col_apply_blocks() > 0)");
     const int64_t total = V * (vec ? C / VEC : C);
     int64_t nb = (total + kBlock - 1) / kBlock;
     if (nb > 256 * 16) nb = 256 * 16;

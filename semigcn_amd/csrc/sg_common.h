@@ -127,7 +127,9 @@ int launch_bn_finalize(const float* stats, double N, int64_t C, const float* gam
 int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_t ldh, const float* scale,
                      const float* shift, const float* mean, const float* invstd, const float* kk, const float* c1,
                      const float* c2, float slope, void* Y, int64_t ldy, int64_t V, int64_t C, int dtype,
-                     hipStream_t stream);
+                     hipStream_t stream, float* colsum = nullptr);
+int64_t col_apply_blocks(int64_t V, int64_t C, int dtype);
+int launch_colsum_finalize(const float* partial, int64_t nb, int64_t C, float* out, hipStream_t stream);
 
 int launch_bn_stats_finalize_tiles(const float* partial, int64_t nb, int64_t rpb, int64_t V, int64_t C, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,

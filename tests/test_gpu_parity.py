@@ -1258,3 +1258,29 @@ def test_partition_operators_wide_and_row_subsets_agree():
             assert rel(ys[done].float(), y_full[ids[done]].float()) < tol
             yo = g.handle.spmm(x_ext, torch.empty((g.n_own, C), dtype=dtype, device=DEV), alpha=2.0, X0=x0_ext[:g.n_own], beta=-1.0)
             assert torch.equal(yo, ys[:g.n_own])
+
+
+@pytest.mark.parametrize("V,C,dtype", [(5000, 256, torch.float32), (70001, 64, torch.bfloat16), (1200, 8, torch.float32),
+                                       (300000, 16, torch.bfloat16), (999, 512, torch.bfloat16)])
+def test_bn_backward_apply_with_fused_column_sums(V, C, dtype):
+    """sg_bn_act_bwd_apply_colsum == sg_bn_act_bwd_apply bit for bit, and its column sums == the sums of the dH it
+    stored (the bias gradient of the ChebConv in front of the BatchNorm)."""
+    g = torch.Generator(device=DEV).manual_seed(V + C)
+    dA = torch.randn(V, C, device=DEV, generator=g).to(dtype)
+    H = torch.randn(V, C, device=DEV, generator=g).to(dtype)
+    vec = lambda: torch.randn(C, device=DEV, generator=g)
+    scale, shift, mean, k, c1, c2 = vec(), vec(), vec(), vec(), vec() * 0.01, vec() * 0.01
+    invstd = torch.rand(C, device=DEV, generator=g) + 0.5
+    ref = capi.bn_act_bwd_apply(dA, H, scale, shift, mean, invstd, k, c1, c2, 0.01)
+    wide = torch.zeros(V, 3 * C, device=DEV, dtype=dtype)
+    got, sums = capi.bn_act_bwd_apply_colsum(dA, H, scale, shift, mean, invstd, k, c1, c2, 0.01, out=wide[:, :C])
+    assert sums is not None and torch.equal(got, ref) and bool((wide[:, C:] == 0).all())
+    want = ref.double().sum(0)
+    assert float((sums.double() - want).abs().max()) <= 1e-5 * float(ref.double().abs().sum(0).max())
+    _, sums2 = capi.bn_act_bwd_apply_colsum(dA, H, scale, shift, mean, invstd, k, c1, c2, 0.01)
+    assert torch.equal(sums, sums2)                                    # deterministic
+    # a shape the row-owning kernel does not serve falls back (no sums)
+    odd = capi.bn_act_bwd_apply_colsum(dA[:, :7].contiguous(), H[:, :7].contiguous(), scale[:7].contiguous(), shift[:7].contiguous(),
+                                       mean[:7].contiguous(), invstd[:7].contiguous(), k[:7].contiguous(), c1[:7].contiguous(),
+                                       c2[:7].contiguous(), 0.01)
+    assert odd[1] is None and odd[0].shape == (V, 7)
