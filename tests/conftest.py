@@ -41,6 +41,17 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _seed_every_test(request):
+    """Tests that draw inputs without an explicit generator still see the SAME inputs on every run (a seed derived from
+    the test id): a rounding-level kink hit on one box is then reproducible instead of a 1-in-N flake."""
+    import zlib
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF
+    torch.manual_seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    yield
+
+
 class OracleGraphDouble:
     """CPU stand-in for capi.GraphHandle: same methods, oracle arithmetic."""
 

@@ -1075,18 +1075,27 @@ def test_aggregation_code_paths_are_bit_identical(C, dtype):
 
 def test_loss_backward_without_atomics_is_reproducible_and_matches_atomic_kernel():
     """functional.DETERMINISTIC_LOSS_BACKWARD: per-corner gradients + fixed-order CSR sum == the atomic kernel up to
-    fp32 summation order, and identical bits from run to run (with halo rows: V_ext > V)."""
+    fp32 summation order, and identical bits from run to run (with halo rows: V_ext > V).  The normal term is an L1
+    norm: a face with a component of n - n_t within rounding of zero may take either sign in either kernel (they are
+    compiled separately; with unseeded inputs that happened in ~30 % of the runs of the round-1 version of this test),
+    so the vertices of such faces are compared against neither."""
     from semigcn_amd import functional as F_sg, train
     m = synth.torus_mesh(120, 90)
     V = m.num_vertices
     faces = torch.from_numpy(m.faces).to(DEV)
     n_own = V - 700                                            # pretend the last 700 rows are halo rows
     own_faces = faces[(faces[:, 0] < n_own)]
-    pos = (torch.from_numpy(m.vs.astype(np.float32)).to(DEV) + 0.01 * torch.randn(V, 3, device=DEV))
-    tpos = torch.from_numpy(m.vs.astype(np.float32)).to(DEV)[:n_own]
-    tfn = train.face_normals(torch.from_numpy(m.vs.astype(np.float32)).to(DEV), own_faces)
-    vk = (torch.rand(n_own, device=DEV) > 0.1).float()
-    fk = (torch.rand(own_faces.shape[0], device=DEV) > 0.1).float()
+    gen = torch.Generator(device=DEV).manual_seed(1234)
+    vs = torch.from_numpy(m.vs.astype(np.float32)).to(DEV)
+    pos = vs + 0.01 * torch.randn(V, 3, device=DEV, generator=gen)
+    tpos = vs[:n_own]
+    tfn = train.face_normals(vs, own_faces)
+    vk = (torch.rand(n_own, device=DEV, generator=gen) > 0.1).float()
+    fk = (torch.rand(own_faces.shape[0], device=DEV, generator=gen) > 0.1).float()
+    at_kink = ((train.face_normals(pos, own_faces) - tfn).abs() < 1e-5).any(1)
+    safe = torch.ones(V, dtype=torch.bool, device=DEV)
+    safe[own_faces[at_kink].reshape(-1)] = False
+    assert int(safe.sum()) > V - 200
 
     def grad(det):
         F_sg.DETERMINISTIC_LOSS_BACKWARD = det
@@ -1099,7 +1108,13 @@ def test_loss_backward_without_atomics_is_reproducible_and_matches_atomic_kernel
     finally:
         F_sg.DETERMINISTIC_LOSS_BACKWARD = True
     assert torch.equal(a, b)
-    assert rel(a, c) < 2e-6 and bool((a[n_own:] != 0).any())      # halo rows receive face contributions only
+    assert rel(a[safe], c[safe]) < 2e-6 and bool((a[n_own:] != 0).any())      # halo rows receive face contributions only
+    # both against autograd in float64 through the plain formulas
+    p64 = pos.double().requires_grad_(True)
+    d = (tpos.double() - p64[:n_own]) * vk.double().view(-1, 1)
+    s1 = ((train.face_normals(p64, own_faces) - tfn.double()).abs() * fk.double().view(-1, 1)).sum()
+    (0.7 * torch.sqrt((d * d).sum() / 1000.0 + 1e-6) + 4.0 * s1 / 2000.0).backward()
+    assert rel(a[safe], p64.grad[safe]) < 2e-6 and rel(c[safe], p64.grad[safe]) < 2e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
