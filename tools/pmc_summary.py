@@ -32,7 +32,7 @@ def main():
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         agg = collections.defaultdict(list)
         for r in load(f"{root}/pmc_{cname}"):
-            m = re.search(r"spmm_(rows|shared)<(.+?), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", r["Kernel_Name"])
+            m = re.search(r"spmm_(rows|shared)<(.+?), (\d+), (\d+), (\d+)(?:, (?:true|false))?(?:, \d+)?>", r["Kernel_Name"])
             if not m or r["Counter_Name"] != cname:
                 continue
             dt = "bfloat16" if "bf16" in m.group(2) else "float32"
