@@ -15,6 +15,7 @@ otherwise the transposed CSR kept by sg_graph_create is used).
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional, Sequence
 
@@ -488,9 +489,13 @@ class _BNActFn(torch.autograd.Function):
             if ctx.grad_widen > 1:
                 out = _new_wide(x.shape[0], x.shape[0], x.shape[1], ctx.grad_widen, x.dtype, x.device)
             # dx is the output gradient of the ChebConv in front: its bias gradient = the column sums of dx, taken here
-            dx, sums = capi.bn_act_bwd_apply_colsum(dy, x, scale, shift, mean, invstd, co[4], co[2], co[3], ctx.slope, out=out)
-            if sums is not None:
-                _remember_column_sums(dx, sums)
+            if FUSE_BIAS_GRAD:
+                dx, sums = capi.bn_act_bwd_apply_colsum(dy, x, scale, shift, mean, invstd, co[4], co[2], co[3], ctx.slope,
+                                                        out=out)
+                if sums is not None:
+                    _remember_column_sums(dx, sums)
+            else:
+                dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, co[4], co[2], co[3], ctx.slope, out=out)
             return (dx, co[1].to(ctx.param_dtype), co[0].to(ctx.param_dtype), None, None, None, None, None, None, None,
                     None, None, None, None)
         s = part.sum(0)                                                                # [2, C]: sum dz, sum dz*xhat
@@ -514,6 +519,10 @@ class _BNActFn(torch.autograd.Function):
         dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope, out=out)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
+
+#: the fused BatchNorm backward also leaves the column sums of its dH (= the bias gradient of the ChebConv in front);
+#: False: that layer sums the columns of dH in a pass of its own (A/B switch)
+FUSE_BIAS_GRAD = os.environ.get("SEMIGCN_NO_FUSED_BIAS_GRAD") != "1"
 
 #: callables invoked with every fused BN+activation output (sign(y) == sign of the BatchNorm output);
 #: an observability hook, e.g. for recording activation patterns -- empty in normal operation
