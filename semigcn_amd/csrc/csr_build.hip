@@ -18,6 +18,14 @@ void Csr::release() {
   if (tile_eloc) (void)hipFree(tile_eloc);
   if (idx_w) (void)hipFree(idx_w);
   if (tile_uniq_w) (void)hipFree(tile_uniq_w);
+  if (lt_uptr) (void)hipFree(lt_uptr);
+  if (lt_uniq) (void)hipFree(lt_uniq);
+  if (lt_eloc) (void)hipFree(lt_eloc);
+  if (lt_uniq_w) (void)hipFree(lt_uniq_w);
+  lt_uptr = nullptr;
+  lt_uniq = nullptr;
+  lt_eloc = nullptr;
+  lt_uniq_w = nullptr;
   idx_w = nullptr;
   tile_uniq_w = nullptr;
   packed_scale = nullptr;
@@ -113,18 +121,18 @@ struct DeviceBuf {
 // One workgroup per row tile: sort the tile's source ids in LDS (bitonic, padded with INT_MAX),
 // keep the distinct ones.  FILL = false: counts[t] = number of distinct ids, or -1 when the tile has
 // more than kTileEdges edges.  FILL = true: write them to uniq[uptr[t]..] and each edge's slot.
-template <bool FILL>
+template <bool FILL, int MAXE>
 __global__ __launch_bounds__(64) void tile_pass(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
                                                  int64_t n_rows, int tile_rows, int32_t* __restrict__ counts,
                                                  const int32_t* __restrict__ uptr, int32_t* __restrict__ uniq,
                                                  uint8_t* __restrict__ eloc) {
-  __shared__ int32_t s_key[kTileEdges];
+  __shared__ int32_t s_key[MAXE];
   __shared__ int32_t s_cnt;
   const int64_t r0 = (int64_t)blockIdx.x * tile_rows;
   int64_t r1 = r0 + tile_rows;
   if (r1 > n_rows) r1 = n_rows;
   const int e0 = rowptr[r0], ne = rowptr[r1] - e0;
-  if (ne > kTileEdges) {
+  if (ne > MAXE) {
     if (!FILL && threadIdx.x == 0) counts[blockIdx.x] = -1;
     return;
   }
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(64) void tile_pass(const int32_t* __restrict__ rowp
     if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt;
   } else {
     // serial compaction by one wavefront-sized scan is plenty for <= 512 keys
-    __shared__ int32_t s_rank[kTileEdges];
+    __shared__ int32_t s_rank[MAXE];
     if (threadIdx.x == 0) {
       int r = -1;
       for (int i = 0; i < ne; ++i) {
@@ -478,16 +486,23 @@ int build_csr(const int64_t* dst, const int64_t* src, int64_t n, int64_t n_rows,
   return SG_OK;
 }
 
-int build_tiles(Csr* c, hipStream_t stream) {
+// Distinct-source lists of row tiles: tile t = rows [t*tile_rows, (t+1)*tile_rows).  Leaves *uptr / *uniq / *eloc null
+// when some tile has more than max_slots distinct sources, more than MAXE edges, or a duplicate edge inside a row.
+template <int MAXE>
+static int build_tile_set(const Csr* c, int tile_rows, int max_slots, hipStream_t stream, int32_t** uptr_out,
+                          int32_t** uniq_out, uint8_t** eloc_out) {
+  *uptr_out = nullptr;
+  *uniq_out = nullptr;
+  *eloc_out = nullptr;
   if (c->n_rows == 0 || c->nnz == 0) return SG_OK;
-  const int64_t nt = (c->n_rows + kTileRows - 1) / kTileRows;
+  const int64_t nt = (c->n_rows + tile_rows - 1) / tile_rows;
   DeviceBuf counts, temp;
   SG_HIP_TRY(hipMalloc(&counts.p, (nt + 1) * sizeof(int32_t)));
   SG_HIP_TRY(hipMemsetAsync(counts.p, 0, (nt + 1) * sizeof(int32_t), stream));
-  tile_pass<false><<<(int)nt, 64, 0, stream>>>(c->rowptr, c->idx, c->n_rows, kTileRows, (int32_t*)counts.p, nullptr,
-                                               nullptr, nullptr);
+  tile_pass<false, MAXE><<<(int)nt, 64, 0, stream>>>(c->rowptr, c->idx, c->n_rows, tile_rows, (int32_t*)counts.p, nullptr,
+                                                     nullptr, nullptr);
   SG_HIP_TRY(hipGetLastError());
-  // tileable iff every tile has 0 <= distinct <= kTileSlots: min and max over the counts
+  // tileable iff every tile has 0 <= distinct <= max_slots: min and max over the counts
   int32_t* d_minmax = nullptr;
   DeviceBuf mm;
   SG_HIP_TRY(hipMalloc(&mm.p, 2 * sizeof(int32_t)));
@@ -503,20 +518,42 @@ int build_tiles(Csr* c, hipStream_t stream) {
   int32_t h_mm[2] = {0, 0};
   SG_HIP_TRY(hipMemcpyAsync(h_mm, d_minmax, sizeof(h_mm), hipMemcpyDeviceToHost, stream));
   SG_HIP_TRY(hipStreamSynchronize(stream));
-  if (h_mm[0] < 0 || h_mm[1] > kTileSlots) return SG_OK;   // not tileable: the generic kernel serves this graph
-  SG_HIP_TRY(hipMalloc((void**)&c->tile_uptr, (nt + 1) * sizeof(int32_t)));
-  SG_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, tb, (int32_t*)counts.p, c->tile_uptr, (int)nt + 1, stream));
+  if (h_mm[0] < 0 || h_mm[1] > max_slots) return SG_OK;   // not tileable: the generic kernel serves this graph
+  int32_t* uptr = nullptr;
+  int32_t* uniq = nullptr;
+  uint8_t* eloc = nullptr;
+  SG_HIP_TRY(hipMalloc((void**)&uptr, (nt + 1) * sizeof(int32_t)));
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(temp.p, tb, (int32_t*)counts.p, uptr, (int)nt + 1, stream);
   int32_t total = 0;
-  SG_HIP_TRY(hipMemcpyAsync(&total, c->tile_uptr + nt, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  SG_HIP_TRY(hipStreamSynchronize(stream));
-  SG_HIP_TRY(hipMalloc((void**)&c->tile_uniq, (total > 0 ? total : 1) * sizeof(int32_t)));
-  SG_HIP_TRY(hipMalloc((void**)&c->tile_eloc, c->nnz));
-  tile_pass<true><<<(int)nt, 64, 0, stream>>>(c->rowptr, c->idx, c->n_rows, kTileRows, nullptr, c->tile_uptr,
-                                              c->tile_uniq, c->tile_eloc);
-  SG_HIP_TRY(hipGetLastError());
-  SG_HIP_TRY(hipStreamSynchronize(stream));
-  c->tile_rows = kTileRows;
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, uptr + nt, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) e = hipMalloc((void**)&uniq, (total > 0 ? total : 1) * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&eloc, c->nnz);
+  if (e == hipSuccess) {
+    tile_pass<true, MAXE><<<(int)nt, 64, 0, stream>>>(c->rowptr, c->idx, c->n_rows, tile_rows, nullptr, uptr, uniq, eloc);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) {
+    if (uptr) (void)hipFree(uptr);
+    if (uniq) (void)hipFree(uniq);
+    if (eloc) (void)hipFree(eloc);
+    set_error("build_tile_set: %s", hipGetErrorString(e));
+    return SG_ERR_HIP;
+  }
+  *uptr_out = uptr;
+  *uniq_out = uniq;
+  *eloc_out = eloc;
   return SG_OK;
+}
+
+int build_tiles(Csr* c, hipStream_t stream) {
+  int rc = build_tile_set<kTileEdges>(c, kTileRows, kTileSlots, stream, &c->tile_uptr, &c->tile_uniq, &c->tile_eloc);
+  if (rc != SG_OK) return rc;
+  if (c->tile_uptr) c->tile_rows = kTileRows;
+  // LDS tiles of the aggregation kernel that stages source rows in LDS (spmm.hip::spmm_lds): 16 rows, <= kLdsSlots sources
+  rc = build_tile_set<kLdsEdges>(c, kLdsRows, kLdsSlots, stream, &c->lt_uptr, &c->lt_uniq, &c->lt_eloc);
+  return rc;
 }
 
 int pack_source_scale(Csr* c, const float* scale, hipStream_t stream) {
@@ -532,6 +569,17 @@ int pack_source_scale(Csr* c, const float* scale, hipStream_t stream) {
     if (total > 0) {
       SG_HIP_TRY(hipMalloc((void**)&c->tile_uniq_w, (size_t)total * sizeof(int2)));
       pack_scale_kernel<<<blocks_for(total), kThreads, 0, stream>>>(c->tile_uniq, total, scale, c->tile_uniq_w);
+      SG_HIP_TRY(hipGetLastError());
+    }
+  }
+  if (c->lt_uptr) {
+    const int64_t nt = (c->n_rows + kLdsRows - 1) / kLdsRows;
+    int32_t total = 0;
+    SG_HIP_TRY(hipMemcpyAsync(&total, c->lt_uptr + nt, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    SG_HIP_TRY(hipStreamSynchronize(stream));
+    if (total > 0) {
+      SG_HIP_TRY(hipMalloc((void**)&c->lt_uniq_w, (size_t)total * sizeof(int2)));
+      pack_scale_kernel<<<blocks_for(total), kThreads, 0, stream>>>(c->lt_uniq, total, scale, c->lt_uniq_w);
       SG_HIP_TRY(hipGetLastError());
     }
   }

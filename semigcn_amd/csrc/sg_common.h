@@ -47,6 +47,12 @@ struct Csr {
   // adds a full memory latency to every wavefront's chunk).  Valid for the scale vector `packed_scale`.
   int2* idx_w = nullptr;          // [nnz]
   int2* tile_uniq_w = nullptr;    // [tile_uptr[n_tiles]]
+  // LDS tiles (optional, spmm.hip::spmm_lds): kLdsRows rows per tile, its distinct sources lt_uniq[lt_uptr[t] ..) with
+  // the scale packed beside each id in lt_uniq_w, and every edge's slot in its tile's list
+  int32_t* lt_uptr = nullptr;
+  int32_t* lt_uniq = nullptr;
+  uint8_t* lt_eloc = nullptr;
+  int2* lt_uniq_w = nullptr;
   const float* packed_scale = nullptr;
   void release();
 };
@@ -54,6 +60,9 @@ struct Csr {
 constexpr int kTileRows = 4;       // rows per mini-tile (one accumulator set per row in registers)
 constexpr int kTileSlots = 32;     // max distinct source rows per mini-tile
 constexpr int kTileEdges = 128;    // max edges per mini-tile
+constexpr int kLdsRows = 16;       // rows per LDS tile
+constexpr int kLdsSlots = 48;      // max distinct source rows per LDS tile (16 rows + their ring in a locality order: ~36)
+constexpr int kLdsEdges = 256;     // max edges per LDS tile
 int build_tiles(Csr* c, hipStream_t stream);
 // Fills Csr::idx_w (and tile_uniq_w when the CSR carries tiles) for the source scale vector `scale` [n_cols].
 int pack_source_scale(Csr* c, const float* scale, hipStream_t stream);
@@ -85,6 +94,9 @@ struct SpmmArgs {
   const uint8_t* tile_eloc = nullptr;
   const int2* idx_w = nullptr;          // non-null: (id, scale bits) pairs replace idx + scale_src lookups
   const int2* tile_uniq_w = nullptr;
+  const int32_t* lt_uptr = nullptr;     // LDS tiles (see Csr)
+  const uint8_t* lt_eloc = nullptr;
+  const int2* lt_uniq_w = nullptr;
   const int32_t* row_id = nullptr;      // non-null: the CSR is in PROCESSING order; row p is the caller's row row_id[p]
                                         // (Y / X0 / X1 are addressed by it; scale_dst is indexed by p)
   const float* scale_dst;  // nullable, [n_rows]

@@ -35,7 +35,8 @@ struct bf16_tag {};
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32 };
+enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32,
+             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128 };
 
 // Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
 // one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
@@ -254,8 +255,15 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
     raw_t x0v[R], x1v[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (NEPI >= 1) x0v[r] = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff[r]);
-      if (NEPI >= 2) x1v[r] = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + voff[r]);
+      // the epilogue operands and Y are touched once per launch: with kFlagStreamEpilogue they go around the caches'
+      // retention (nontemporal), leaving L2 to the gathered rows, which ARE re-used
+      if (flags & kFlagStreamEpilogue) {
+        if (NEPI >= 1) x0v[r] = __builtin_nontemporal_load((const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff[r]));
+        if (NEPI >= 2) x1v[r] = __builtin_nontemporal_load((const raw_t*)(X1 + (int64_t)row * a.ldx1 + voff[r]));
+      } else {
+        if (NEPI >= 1) x0v[r] = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + voff[r]);
+        if (NEPI >= 2) x1v[r] = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + voff[r]);
+      }
     }
     float acc[R][VEC];
 #pragma unroll
@@ -333,7 +341,10 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const SpmmArgs a, const int 
 #pragma unroll
         for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
       }
-      if (rvalid && vok[r]) *(raw_t*)(Y + (int64_t)row * a.ldy + voff[r]) = V::pack(y);
+      if (rvalid && vok[r]) {
+        if (flags & kFlagStreamEpilogue) __builtin_nontemporal_store(V::pack(y), (raw_t*)(Y + (int64_t)row * a.ldy + voff[r]));
+        else *(raw_t*)(Y + (int64_t)row * a.ldy + voff[r]) = V::pack(y);
+      }
     }
   }
 }
@@ -568,6 +579,157 @@ __global__ __launch_bounds__(kBlock) void spmm_shared(const SpmmArgs a, const in
   }
 }
 
+struct Tuning {
+  int chunk_rows = 0;             // 0 = automatic
+  int flags = kFlagXcdMap;        // kFlag* bits
+  int unroll = 0;                 // 0 = default per shape
+  int slab = 0;                   // channels per column slab; 0 = whole rows
+  int tiled_min_row_bytes = 1024; // shared-gather kernel: see launch_typed_one; 0 = never (and build no mini-tiles)
+};
+Tuning g_tuning;
+
+// ---------------------------------------------------------------------------------------------
+// LDS-tile variant (north_star: "neighbour feature tiles staged in LDS"): one workgroup (2 wavefronts) owns a tile of
+// kLdsRows = 16 consecutive rows.  The tile's DISTINCT source rows (~36 for 16 rows in a locality order, 96 edges)
+// are brought into LDS ONCE with global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip), then every output row sums its
+// neighbours out of LDS in CSR order with the same fma chain as spmm_rows -- bit-identical results, but the
+// L2 -> L1 request stream drops from 6 rows per output row to ~2.2, which is what bounds spmm_rows (a CU's vector L1
+// can keep only so many misses in flight).  ~25 KB of LDS per workgroup at 512-B rows -> 6 tiles in flight per CU:
+// the metadata chain / DMA / compute phases of different tiles overlap through occupancy.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLdsBlock = 128;
+
+template <typename T, int G, int NEPI>
+__global__ __launch_bounds__(kLdsBlock) void spmm_lds(const SpmmArgs a, const int nblocks, const int flags) {
+  using V = Vt<T>;
+  constexpr int VEC = V::VEC;
+  constexpr int RPW = 64 / G;                      // rows (and DMA slots) one wavefront instruction covers
+  constexpr int ROWB = G * 16;                     // bytes of one feature row
+  using raw_t = typename V::raw;
+  using elem_t = typename V::elem;
+
+  __shared__ __attribute__((aligned(16))) uint8_t s_data[kLdsSlots * ROWB];
+  __shared__ int2 s_u[kLdsSlots];
+  __shared__ int32_t s_rp[kLdsRows + 1];
+  __shared__ float s_sd[kLdsRows];
+  __shared__ int32_t s_row[kLdsRows];
+  __shared__ uint8_t s_el[kLdsEdges];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = (flags & kFlagXcdMap) ? xcd_contiguous(blockIdx.x, nblocks) : (int)blockIdx.x;
+  const int r0 = t * kLdsRows;
+  int nrows = a.n_rows - r0;
+  nrows = nrows > kLdsRows ? kLdsRows : nrows;
+
+  // ---- tile metadata: row pointers / scales / row ids, then the distinct-source list and every edge's slot ----
+  if (tid <= nrows) s_rp[tid] = a.rowptr[r0 + tid];
+  if (tid < nrows) {
+    s_sd[tid] = a.scale_dst ? a.scale_dst[r0 + tid] : 1.0f;
+    s_row[tid] = a.row_id ? a.row_id[r0 + tid] : r0 + tid;
+  }
+  const int ub = a.lt_uptr[t];
+  const int nu = a.lt_uptr[t + 1] - ub;
+  if (tid < nu) s_u[tid] = a.lt_uniq_w[ub + tid];
+  __syncthreads();
+  const int e0 = s_rp[0], ne = s_rp[nrows] - e0;
+  for (int k = tid; k < ne; k += kLdsBlock) s_el[k] = a.lt_eloc[e0 + k];
+
+  // ---- LDS-DMA of the source rows: one wavefront instruction = RPW slots of ROWB bytes, 16 B per lane ----
+  const elem_t* __restrict__ X = (const elem_t*)a.X;
+  const int g = lane / G, gl = lane % G;
+  const int n_inst = (nu + RPW - 1) / RPW;
+  for (int i = wave; i < n_inst; i += kLdsBlock / 64) {
+    int slot = i * RPW + g;
+    slot = slot < nu ? slot : nu - 1;               // the tail re-reads the last source row (its LDS slot is unused)
+    const elem_t* src = X + (int64_t)s_u[slot].x * a.ldx + gl * VEC;
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)(s_data + i * (RPW * ROWB)), 16, 0, 0);
+  }
+
+  const elem_t* __restrict__ X0 = (const elem_t*)a.X0;
+  const elem_t* __restrict__ X1 = (const elem_t*)a.X1;
+  elem_t* __restrict__ Y = (elem_t*)a.Y;
+  constexpr int ROWS_PER_IT = RPW * (kLdsBlock / 64);
+  // the epilogue operands of the first row go out together with the DMA
+  raw_t x0v, x1v;
+  {
+    const int lr = wave * RPW + g;
+    const int row = s_row[lr < nrows ? lr : 0];
+    if (NEPI >= 1) x0v = *(const raw_t*)(X0 + (int64_t)row * a.ldx0 + gl * VEC);
+    if (NEPI >= 2) x1v = *(const raw_t*)(X1 + (int64_t)row * a.ldx1 + gl * VEC);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int it = 0; it * ROWS_PER_IT < nrows; ++it) {
+    const int lr = it * ROWS_PER_IT + wave * RPW + g;
+    const bool rvalid = lr < nrows;
+    const int lrc = rvalid ? lr : 0;
+    const int row = s_row[lrc];
+    const int ks = s_rp[lrc] - e0;
+    const int ke = rvalid ? s_rp[lrc + 1] - e0 : ks;
+    raw_t nx0, nx1;                                 // next row's epilogue operands, in flight under this row's sums
+    {
+      const int nl = lr + ROWS_PER_IT;
+      const int nrow = s_row[nl < nrows ? nl : 0];
+      if (NEPI >= 1) nx0 = *(const raw_t*)(X0 + (int64_t)nrow * a.ldx0 + gl * VEC);
+      if (NEPI >= 2) nx1 = *(const raw_t*)(X1 + (int64_t)nrow * a.ldx1 + gl * VEC);
+    }
+    float acc[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+    for (int k = ks; __any(k < ke); k += 4) {       // four neighbours per step out of LDS; dead slots carry weight 0
+      raw_t xv[4];
+      float w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kc = k + u < ke ? k + u : (ke > ks ? ke - 1 : 0);
+        const int slot = ke > ks ? s_el[kc] : 0;
+        w[u] = (k + u < ke) ? __int_as_float(s_u[slot].y) : 0.f;
+        xv[u] = *(const raw_t*)(s_data + slot * ROWB + gl * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[VEC];
+        V::unpack(xv[u], f);
+        axpy<VEC>(w[u], f, acc);
+      }
+    }
+    const float sdst = a.alpha * s_sd[lrc];
+    float y[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) y[c] = sdst * acc[c];
+    if (NEPI >= 1) {
+      float f[VEC];
+      V::unpack(x0v, f);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
+    }
+    if (NEPI >= 2) {
+      float f[VEC];
+      V::unpack(x1v, f);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
+    }
+    if (rvalid) *(raw_t*)(Y + (int64_t)row * a.ldy + gl * VEC) = V::pack(y);
+    if (NEPI >= 1) x0v = nx0;
+    if (NEPI >= 2) x1v = nx1;
+  }
+}
+
+template <typename T, int G>
+int launch_lds(const SpmmArgs& a, hipStream_t stream) {
+  const int64_t nt = ((int64_t)a.n_rows + kLdsRows - 1) / kLdsRows;
+  const int nblocks = (int)nt;
+  SpmmArgs b = a;
+  if (!a.X0 && a.X1) { b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f; }
+  if (b.X0 && b.X1) spmm_lds<T, G, 2><<<nblocks, kLdsBlock, 0, stream>>>(b, nblocks, g_tuning.flags);
+  else if (b.X0) spmm_lds<T, G, 1><<<nblocks, kLdsBlock, 0, stream>>>(b, nblocks, g_tuning.flags);
+  else spmm_lds<T, G, 0><<<nblocks, kLdsBlock, 0, stream>>>(b, nblocks, g_tuning.flags);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
 // Any C, any stride, any alignment: one thread per output element, lanes along the channel.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spmm_scalar(const SpmmArgs a) {
@@ -624,14 +786,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows_scalar(const int32_t* __re
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-struct Tuning {
-  int chunk_rows = 0;             // 0 = automatic
-  int flags = kFlagXcdMap;        // kFlag* bits
-  int unroll = 0;                 // 0 = default per shape
-  int slab = 0;                   // channels per column slab; 0 = whole rows
-  int tiled_min_row_bytes = 1024; // shared-gather kernel: see launch_typed_one; 0 = never (and build no mini-tiles)
-};
-Tuning g_tuning;
+
 
 // Gathers per batch by shape (see spmm_rows, CAP), measured on the 1 M-vertex mesh (tools/agg_bench.py --variants
 // unroll=8|6|4, profiles/r02_agg_cap_sweep.json): 4 gathers per batch (6 resident wavefronts per SIMD) win where a
@@ -733,6 +888,12 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
   const bool forced = tmin < 0 && row_bytes >= -tmin;
   const bool pays = tmin > 0 && sizeof(typename Vt<T>::elem) == 4 && row_bytes >= tmin &&
                     (row_bytes >= 2 * tmin || !(a.X0 || a.X1));
+  // LDS-tile kernel (opt-in while it is being measured: SG_TUNE_FLAGS bit 7): whole-row lane groups of 16 / 32 / 64 lanes
+  if ((g_tuning.flags & kFlagLdsTiles) && a.lt_uptr && a.ldx % VEC == 0 && a.n_cols < ((int64_t)1 << 31)) {
+    if (nvec == 16) return launch_lds<T, 16>(a, stream);
+    if (nvec == 32) return launch_lds<T, 32>(a, stream);
+    if (nvec == 64) return launch_lds<T, 64>(a, stream);
+  }
   if (a.tile_uptr && (forced || pays) && !(g_tuning.flags & kFlagNoTiles)) {
     if (nvec > 16 && nvec <= 32) return launch_shared<T, 32, 1>(a, stream);
     if (nvec > 32 && nvec <= 64) return launch_shared<T, 64, 1>(a, stream);

@@ -1299,3 +1299,31 @@ def test_bn_backward_apply_with_fused_column_sums(V, C, dtype):
                                        mean[:7].contiguous(), invstd[:7].contiguous(), k[:7].contiguous(), c1[:7].contiguous(),
                                        c2[:7].contiguous(), 0.01)
     assert odd[1] is None and odd[0].shape == (V, 7)
+
+
+@pytest.mark.parametrize("C,dtype", [(64, torch.float32), (128, torch.float32), (256, torch.float32), (128, torch.bfloat16),
+                                     (256, torch.bfloat16), (512, torch.bfloat16)])
+def test_lds_tile_kernel_bitwise_equals_generic(C, dtype):
+    """The LDS-staged aggregation kernel (SG_TUNE_FLAGS bit 7: each distinct source row of a 16-row tile is brought into
+    LDS once by LDS-DMA) sums every row's neighbours in the same order with the same fma chain as spmm_rows: identical
+    bits, on a grid-ordered mesh, through the locality view of a permuted one, with every epilogue arity, strided blocks."""
+    for permute in (False, True):
+        m = synth.torus_mesh(320, 250, permute=permute, masks=False)
+        V = m.num_vertices
+        g = capi.GraphHandle.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), V)
+        assert g.reordered == permute
+        gen = torch.Generator(device=DEV).manual_seed(C)
+        wide = torch.randn(V, 3 * C, device=DEV, generator=gen).to(dtype)
+        x, x0, x1 = wide[:, :C], wide[:, C:2 * C], wide[:, 2 * C:]
+        res = {}
+        for flags in (1, 129):
+            capi.tuning_set(capi.TUNE_FLAGS, flags)
+            try:
+                res[flags] = [g.spmm(x, torch.empty((V, C), dtype=dtype, device=DEV)),
+                              g.spmm(x, torch.empty((V, C), dtype=dtype, device=DEV), alpha=2.0, X0=x0, beta=-1.0),
+                              g.spmm(x, torch.empty((V, C), dtype=dtype, device=DEV), alpha=1.0, X0=x0, beta=1.0, X1=x1, gamma=-1.0)]
+            finally:
+                capi.tuning_set(capi.TUNE_FLAGS, 1)
+        for a, b in zip(res[1], res[129]):
+            assert torch.equal(a, b)
+    assert rel(res[129][0].float(), oracle_lhat(torch.from_numpy(m.edge_index), x.float().cpu())) < (1e-5 if dtype == torch.float32 else 2.0 ** -7)

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--variants", nargs="*", default=["ch=0,flags=1,unroll=0"])
     ap.add_argument("--json", default=None)
+    ap.add_argument("--blocks", type=int, default=1, help="operands are column blocks of [V, blocks*C] buffers (the in-model layout: 3)")
     ap.add_argument("--reorder", type=int, default=0, help="SG_TUNE_GRAPH_REORDER while the graph is created: 0 auto, 1 never, 2 always")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -59,9 +60,14 @@ def main():
         dtype = torch.float32 if dt == "fp32" else torch.bfloat16
         es = 4 if dt == "fp32" else 2
         for C in map(int, a.channels.split(",")):
-            x = torch.randn(V, C, device=dev).to(dtype)
-            x0 = torch.randn(V, C, device=dev).to(dtype)
-            y = torch.empty_like(x)
+            if a.blocks > 1:        # [Tx0|Tx1|Tx2]-style: X = block 0, Y = block 1 of one buffer, X0 block 0 of another
+                wide = torch.randn(V, a.blocks * C, device=dev).to(dtype)
+                wide0 = torch.randn(V, a.blocks * C, device=dev).to(dtype)
+                x, y, x0 = wide[:, :C], wide[:, C:2 * C], wide0[:, :C]
+            else:
+                x = torch.randn(V, C, device=dev).to(dtype)
+                x0 = torch.randn(V, C, device=dev).to(dtype)
+                y = torch.empty_like(x)
             for nepi in map(int, a.epilogue.split(",")):
                 times = {v[0]: [] for v in variants}
                 for rnd in range(a.rounds + 1):
