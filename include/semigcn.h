@@ -330,7 +330,9 @@ enum sg_tune_knob {
                              bit 2: ignore the (id, scale) packed neighbour lists, bit 3: workgroup barriers
                              between the staging phases instead of wavefront-local ones, bit 4: 64-bit gather addressing
                              even where 32-bit offsets would do, bit 5: fixed-size gather batches also where the
-                             row length is wave-uniform (A/B switches) */
+                             row length is wave-uniform, bit 6: nontemporal epilogue loads / stores (no effect measured),
+                             bit 7: the experimental LDS-tile kernel (set it when the graph is created AND when it is
+                             applied; measured slower) (A/B switches) */
   SG_TUNE_UNROLL = 2,     /* gathers a lane group issues back to back in the aggregation kernel: 8, 6 or 4
                              (fewer = fewer VGPRs = more resident wavefronts); 0 = the shipped choice per shape */
   SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */

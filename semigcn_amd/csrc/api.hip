@@ -74,7 +74,8 @@ int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64
   if (ss != nullptr && ss == c.packed_scale) {
     a.idx_w = c.idx_w;
     a.tile_uniq_w = c.tile_uniq_w;
-    if (c.lt_uptr && c.lt_uniq_w) {
+    if (c.lt_uptr && c.lt_uniq_w && c.idx_w) {
+      a.lt_idx_w = c.idx_w;
       a.lt_uptr = c.lt_uptr;
       a.lt_eloc = c.lt_eloc;
       a.lt_uniq_w = c.lt_uniq_w;

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(64) void tile_pass(const int32_t* __restrict__ rowp
     if (!FILL && threadIdx.x == 0) counts[blockIdx.x] = -1;
     return;
   }
+  if (FILL && uptr[blockIdx.x + 1] == uptr[blockIdx.x]) return;   // no list for this tile (empty, or clipped: see build_tile_set)
   if (!FILL) {   // a source listed twice in one row (multigraph) cannot be expressed by one slot + one mask bit
     __shared__ int s_dup;
     if (threadIdx.x == 0) s_dup = 0;
@@ -488,8 +489,16 @@ int build_csr(const int64_t* dst, const int64_t* src, int64_t n, int64_t n_rows,
 
 // Distinct-source lists of row tiles: tile t = rows [t*tile_rows, (t+1)*tile_rows).  Leaves *uptr / *uniq / *eloc null
 // when some tile has more than max_slots distinct sources, more than MAXE edges, or a duplicate edge inside a row.
+__global__ void clip_counts(int32_t* __restrict__ counts, int64_t n, int max_slots) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (counts[i] < 0 || counts[i] > max_slots)) counts[i] = 0;
+}
+
+// clip = false: the set exists only if EVERY tile fits (max_slots distinct sources, MAXE edges, no duplicate edge);
+// clip = true: tiles that do not fit get an EMPTY source list (their rows are then gathered from global memory by the
+// kernel's fallback path) -- one awkward tile (a Morton seam, a hub vertex) does not cost the whole graph its tiles.
 template <int MAXE>
-static int build_tile_set(const Csr* c, int tile_rows, int max_slots, hipStream_t stream, int32_t** uptr_out,
+static int build_tile_set(const Csr* c, int tile_rows, int max_slots, bool clip, hipStream_t stream, int32_t** uptr_out,
                           int32_t** uniq_out, uint8_t** eloc_out) {
   *uptr_out = nullptr;
   *uniq_out = nullptr;
@@ -502,6 +511,7 @@ static int build_tile_set(const Csr* c, int tile_rows, int max_slots, hipStream_
   tile_pass<false, MAXE><<<(int)nt, 64, 0, stream>>>(c->rowptr, c->idx, c->n_rows, tile_rows, (int32_t*)counts.p, nullptr,
                                                      nullptr, nullptr);
   SG_HIP_TRY(hipGetLastError());
+  if (clip) clip_counts<<<blocks_for(nt), kThreads, 0, stream>>>((int32_t*)counts.p, nt, max_slots);
   // tileable iff every tile has 0 <= distinct <= max_slots: min and max over the counts
   int32_t* d_minmax = nullptr;
   DeviceBuf mm;
@@ -548,11 +558,12 @@ static int build_tile_set(const Csr* c, int tile_rows, int max_slots, hipStream_
 }
 
 int build_tiles(Csr* c, hipStream_t stream) {
-  int rc = build_tile_set<kTileEdges>(c, kTileRows, kTileSlots, stream, &c->tile_uptr, &c->tile_uniq, &c->tile_eloc);
+  int rc = build_tile_set<kTileEdges>(c, kTileRows, kTileSlots, false, stream, &c->tile_uptr, &c->tile_uniq, &c->tile_eloc);
   if (rc != SG_OK) return rc;
   if (c->tile_uptr) c->tile_rows = kTileRows;
-  // LDS tiles of the aggregation kernel that stages source rows in LDS (spmm.hip::spmm_lds): 16 rows, <= kLdsSlots sources
-  rc = build_tile_set<kLdsEdges>(c, kLdsRows, kLdsSlots, stream, &c->lt_uptr, &c->lt_uniq, &c->lt_eloc);
+  // LDS tiles of the experimental kernel that stages source rows in LDS (spmm.hip::spmm_lds), only on request
+  if (lds_tiles_enabled())
+    rc = build_tile_set<kLdsEdges>(c, kLdsRows, kLdsSlots, true, stream, &c->lt_uptr, &c->lt_uniq, &c->lt_eloc);
   return rc;
 }
 

@@ -97,6 +97,7 @@ struct SpmmArgs {
   const int32_t* lt_uptr = nullptr;     // LDS tiles (see Csr)
   const uint8_t* lt_eloc = nullptr;
   const int2* lt_uniq_w = nullptr;
+  const int2* lt_idx_w = nullptr;       // = idx_w, for the tiles that fall back to global gathers
   const int32_t* row_id = nullptr;      // non-null: the CSR is in PROCESSING order; row p is the caller's row row_id[p]
                                         // (Y / X0 / X1 are addressed by it; scale_dst is indexed by p)
   const float* scale_dst;  // nullable, [n_rows]
@@ -116,6 +117,7 @@ struct SpmmArgs {
 int launch_spmm(const SpmmArgs& a, int dtype, hipStream_t stream);
 int set_tuning(int knob, int value);
 bool tiles_enabled();
+bool lds_tiles_enabled();
 int launch_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t ldx, void* Y,
                        int64_t ldy, int64_t C, int dtype, hipStream_t stream);
 

@@ -589,13 +589,16 @@ struct Tuning {
 Tuning g_tuning;
 
 // ---------------------------------------------------------------------------------------------
-// LDS-tile variant (north_star: "neighbour feature tiles staged in LDS"): one workgroup (2 wavefronts) owns a tile of
-// kLdsRows = 16 consecutive rows.  The tile's DISTINCT source rows (~36 for 16 rows in a locality order, 96 edges)
-// are brought into LDS ONCE with global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip), then every output row sums its
-// neighbours out of LDS in CSR order with the same fma chain as spmm_rows -- bit-identical results, but the
-// L2 -> L1 request stream drops from 6 rows per output row to ~2.2, which is what bounds spmm_rows (a CU's vector L1
-// can keep only so many misses in flight).  ~25 KB of LDS per workgroup at 512-B rows -> 6 tiles in flight per CU:
-// the metadata chain / DMA / compute phases of different tiles overlap through occupancy.
+// LDS-tile variant (north_star: "neighbour feature tiles staged in LDS") -- EXPERIMENTAL, opt-in (SG_TUNE_FLAGS bit 7 when
+// the graph is created and when it is applied), measured SLOWER than spmm_rows: one workgroup (2 wavefronts) owns a tile
+// of kLdsRows = 16 consecutive rows.  The tile's DISTINCT source rows (~36 for 16 rows in Morton order, 96 edges) are
+// brought into LDS ONCE with global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip), then every output row sums its
+// neighbours out of LDS in CSR order with the same fma chain as spmm_rows -- bit-identical results, and the L2 -> L1
+// request stream drops from 6 rows per output row to ~2.2.  ~25 KB of LDS per workgroup at 512-B rows -> 6 tiles in
+// flight per CU.  Measured on the Morton-ordered 1 M-vertex mesh: bf16 C=256 + epilogue 0.56 ms
+// against 0.36 ms, fp32 C=256 1.48 against 0.70 -- every tile pays its metadata chain, the DMA round trip and the
+// reduction one after the other, and 12 wavefronts per CU do not cover that; kept as the measured answer to "why not LDS
+// tiles", and as a working LDS-DMA gather to build a pipelined version on.
 // ---------------------------------------------------------------------------------------------
 constexpr int kLdsBlock = 128;
 
@@ -632,7 +635,11 @@ __global__ __launch_bounds__(kLdsBlock) void spmm_lds(const SpmmArgs a, const in
   if (tid < nu) s_u[tid] = a.lt_uniq_w[ub + tid];
   __syncthreads();
   const int e0 = s_rp[0], ne = s_rp[nrows] - e0;
-  for (int k = tid; k < ne; k += kLdsBlock) s_el[k] = a.lt_eloc[e0 + k];
+  // a tile without a source list although it has edges did not fit the LDS budget (Morton seam, hub vertex, duplicate
+  // edges): its rows gather from global memory, edge by edge, in the same order
+  const bool in_lds = nu > 0;
+  if (in_lds)
+    for (int k = tid; k < ne; k += kLdsBlock) s_el[k] = a.lt_eloc[e0 + k];
 
   // ---- LDS-DMA of the source rows: one wavefront instruction = RPW slots of ROWB bytes, 16 B per lane ----
   const elem_t* __restrict__ X = (const elem_t*)a.X;
@@ -678,21 +685,30 @@ __global__ __launch_bounds__(kLdsBlock) void spmm_lds(const SpmmArgs a, const in
     float acc[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
-    for (int k = ks; __any(k < ke); k += 4) {       // four neighbours per step out of LDS; dead slots carry weight 0
-      raw_t xv[4];
-      float w[4];
+    if (in_lds) {
+      for (int k = ks; __any(k < ke); k += 4) {     // four neighbours per step out of LDS; dead slots carry weight 0
+        raw_t xv[4];
+        float w[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kc = k + u < ke ? k + u : (ke > ks ? ke - 1 : 0);
-        const int slot = ke > ks ? s_el[kc] : 0;
-        w[u] = (k + u < ke) ? __int_as_float(s_u[slot].y) : 0.f;
-        xv[u] = *(const raw_t*)(s_data + slot * ROWB + gl * 16);
+        for (int u = 0; u < 4; ++u) {
+          const int kc = k + u < ke ? k + u : (ke > ks ? ke - 1 : 0);
+          const int slot = ke > ks ? s_el[kc] : 0;
+          w[u] = (k + u < ke) ? __int_as_float(s_u[slot].y) : 0.f;
+          xv[u] = *(const raw_t*)(s_data + slot * ROWB + gl * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float f[VEC];
+          V::unpack(xv[u], f);
+          axpy<VEC>(w[u], f, acc);
+        }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
+    } else {
+      for (int k = ks; k < ke; ++k) {               // rare fallback: straight from global memory
+        const int2 e = a.lt_idx_w[e0 + k];
         float f[VEC];
-        V::unpack(xv[u], f);
-        axpy<VEC>(w[u], f, acc);
+        V::unpack(*(const raw_t*)(X + (int64_t)e.x * a.ldx + gl * VEC), f);
+        axpy<VEC>(__int_as_float(e.y), f, acc);
       }
     }
     const float sdst = a.alpha * s_sd[lrc];
@@ -935,6 +951,7 @@ int launch_typed(const SpmmArgs& a, hipStream_t stream) {
 }  // namespace
 
 bool tiles_enabled() { return g_tuning.tiled_min_row_bytes != 0; }
+bool lds_tiles_enabled() { return (g_tuning.flags & kFlagLdsTiles) != 0; }
 
 int set_tuning(int knob, int value) {
   switch (knob) {

@@ -1304,13 +1304,22 @@ def test_bn_backward_apply_with_fused_column_sums(V, C, dtype):
 @pytest.mark.parametrize("C,dtype", [(64, torch.float32), (128, torch.float32), (256, torch.float32), (128, torch.bfloat16),
                                      (256, torch.bfloat16), (512, torch.bfloat16)])
 def test_lds_tile_kernel_bitwise_equals_generic(C, dtype):
-    """The LDS-staged aggregation kernel (SG_TUNE_FLAGS bit 7: each distinct source row of a 16-row tile is brought into
-    LDS once by LDS-DMA) sums every row's neighbours in the same order with the same fma chain as spmm_rows: identical
-    bits, on a grid-ordered mesh, through the locality view of a permuted one, with every epilogue arity, strided blocks."""
+    """The experimental LDS-staged aggregation kernel (SG_TUNE_FLAGS bit 7: each distinct source row of a 16-row tile is
+    brought into LDS once by LDS-DMA; tiles that do not fit fall back to global gathers) sums every row's neighbours in
+    the same order with the same fma chain as spmm_rows: identical bits, on a Morton-ordered mesh and through the
+    locality view of a randomly numbered one, with every epilogue arity, on strided blocks."""
+    from semigcn_amd import reorder
     for permute in (False, True):
         m = synth.torus_mesh(320, 250, permute=permute, masks=False)
         V = m.num_vertices
-        g = capi.GraphHandle.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), V)
+        ei = torch.from_numpy(m.edge_index).to(DEV)
+        if not permute:      # Morton order: 16 consecutive rows are a compact patch whose sources fit the LDS budget
+            ei = reorder.permute_edge_index(ei, reorder.morton_order(torch.from_numpy(m.x_pos).to(DEV))[1])
+        capi.tuning_set(capi.TUNE_FLAGS, 129)          # the LDS tile lists are only built on request
+        try:
+            g = capi.GraphHandle.from_edge_index(ei, V)
+        finally:
+            capi.tuning_set(capi.TUNE_FLAGS, 1)
         assert g.reordered == permute
         gen = torch.Generator(device=DEV).manual_seed(C)
         wide = torch.randn(V, 3 * C, device=DEV, generator=gen).to(dtype)
@@ -1326,4 +1335,4 @@ def test_lds_tile_kernel_bitwise_equals_generic(C, dtype):
                 capi.tuning_set(capi.TUNE_FLAGS, 1)
         for a, b in zip(res[1], res[129]):
             assert torch.equal(a, b)
-    assert rel(res[129][0].float(), oracle_lhat(torch.from_numpy(m.edge_index), x.float().cpu())) < (1e-5 if dtype == torch.float32 else 2.0 ** -7)
+    assert rel(res[129][0].float(), oracle_lhat(ei.cpu(), x.float().cpu())) < (1e-5 if dtype == torch.float32 else 2.0 ** -7)

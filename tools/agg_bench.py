@@ -44,6 +44,8 @@ def main():
         order, rank = reorder.morton_order(torch.from_numpy(m.vs).to(dev))
         ei = reorder.permute_edge_index(ei, rank)
     capi.tuning_set(capi.TUNE_GRAPH_REORDER, a.reorder)
+    if any("flags=" in v and int(dict(kv.split("=") for kv in v.split(","))["flags"]) & 128 for v in a.variants):
+        capi.tuning_set(capi.TUNE_FLAGS, 129)      # experimental LDS tile lists are only built on request
     torch.cuda.synchronize()
     import time
     t0 = time.perf_counter()
@@ -51,6 +53,7 @@ def main():
     torch.cuda.synchronize()
     print(f"graph created in {(time.perf_counter() - t0) * 1e3:.1f} ms, locality view: {g.handle.reordered}", flush=True)
     capi.tuning_set(capi.TUNE_GRAPH_REORDER, 0)
+    capi.tuning_set(capi.TUNE_FLAGS, 1)
     variants = []
     for v in a.variants:
         d = dict(kv.split("=") for kv in v.split(","))
