@@ -300,7 +300,24 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
     nu, nv = map(int, args.mesh.split("x"))
     kernels, roof = [], None
     if timer is not None:
-        for (C, dt_name, n_epi), times in sorted(timer.results().items(), key=lambda kv: -sum(kv[1])):
+        results = timer.results()
+        # launches that compute a rank's whole block (N > 1 also has row-subset launches for the overlap with the halo
+        # exchange: interior rows / boundary + ring-1 rows; they are left out of the per-kernel roofline)
+        full_rows = max(r for (_, _, _, r) in results) if results else 0
+        if world > 1 and results:
+            g = getattr(getattr(trainer, "part", None), "graph", None)
+            if g is not None:
+                full_rows = g.n_own
+            else:
+                from collections import Counter
+                full_rows = Counter(r for (_, _, _, r), t in results.items() for _ in t).most_common(1)[0][0]
+        merged = {}
+        for (C, dt_name, n_epi, rows), times in results.items():
+            if world == 1 or rows == full_rows:
+                merged.setdefault((C, dt_name, n_epi), []).extend(times)
+        if world > 1:
+            V_local, E_local = full_rows, int(E_total * full_rows / max(V_total, 1))
+        for (C, dt_name, n_epi), times in sorted(merged.items(), key=lambda kv: -sum(kv[1])):
             mean_ms = float(np.mean(times))
             B = algorithmic_bytes(V_local, E_local, C, elem, n_epi)
             kernels.append({"C": C, "dtype": dt_name, "epilogue_operands": n_epi, "launches": len(times),

@@ -223,6 +223,7 @@ class GraphHandle:
         _check(load().sg_graph_query(self._h, byref(info)), "sg_graph_query")
         self.num_rows, self.num_cols, self.nnz = info.V_dst, info.V_src, info.nnz
         self.symmetric, self.max_degree = bool(info.symmetric), info.max_degree
+        self.rows_processed = self.num_rows      # rows one sg_spmm launch computes (a row-subset handle: fewer than num_rows)
         self.reordered = load().sg_graph_is_reordered(self._h) == 1     # rows processed in a graph-derived locality order
 
     @classmethod
@@ -270,7 +271,7 @@ class GraphHandle:
                    "sg_graph_create_rows")
         h = cls(out.value, src.device)
         h.num_rows = int(out_rows)          # rows of the Y it writes into (it touches only the rows row_id names)
-        return h
+        return h                            # (rows_processed stays the subset's size)
 
     def arrays(self):
         """(rowptr int32 [rows+1], colidx int32 [nnz], dis float32 [cols]) as torch tensors."""
@@ -311,7 +312,7 @@ class GraphHandle:
             if timer is not None:
                 ev1.record()
                 n_epi = int(X0 is not None) + int(X1 is not None)
-                timer.records.append(((C, str(X.dtype).replace("torch.", ""), n_epi), ev0, ev1))
+                timer.records.append(((C, str(X.dtype).replace("torch.", ""), n_epi, self.rows_processed), ev0, ev1))
         return Y
 
     def dilate_bits(self, bits: torch.Tensor) -> torch.Tensor:
