@@ -199,6 +199,10 @@ SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t
  *                         all-gather -> out [4,C] as sg_bn_finalize for the whole mesh, out_n[0] = total row count
  *                         (kept on the device: no host round trip per BatchNorm)
  * partial is float32 [nb, 2, C].
+ * batches_tracked (sg_bn_stats_finalize[_tiles], sg_bn_finalize_ranks; may be NULL): nn.BatchNorm1d's int64
+ * num_batches_tracked scalar on the device, incremented by the same launch.
+ * acc_dweight / acc_dbias (sg_bn_bwd_coeffs; may be NULL): float32 [C] gradient accumulators of the BatchNorm weight and
+ * bias (their .grad): += out[1] / += out[0] in the same launch, instead of one autograd add per parameter.
  * ------------------------------------------------------------------------- */
 /* sg_bn_act_bwd_apply that also leaves colsum[c] = sum over rows of the dH it wrote (as stored) -- the bias gradient of
  * the ChebConv in front of the BatchNorm (autograd of `out += bias`, [3P] ChebConv.forward): no separate pass over dH.
@@ -215,12 +219,18 @@ SG_API int sg_col_moments(const void* X, int64_t ldx, int64_t V, int64_t C, int 
 SG_API int sg_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, float* stats, void* stream);
 SG_API int sg_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_t C, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                float* out, void* stream);
+                                float* out, int64_t* batches_tracked, void* stream);
 SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
-                            const float* invstd, float* out, void* stream);
+                            const float* invstd, float* out, float* acc_dweight, float* acc_dbias, void* stream);
 SG_API int sg_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* out,
-                                float* out_n, void* stream);
+                                float* out_n, int64_t* batches_tracked, void* stream);
+/* dst_s[r, c] += src_s[r * src_ld[s] + c] (float32, dst_s contiguous [rows[s], cols[s]]) for n <= 8 small matrices in ONE
+ * launch: a layer's parameter gradients -- the K column (or row) blocks of dWcat = dOut^T [Tx0|Tx1|Tx2] and the bias sums
+ * (autograd of util/networks.py:42,49) -- added into the parameters' .grad accumulators (sgcn.py:123-146 accumulates
+ * five backward passes per optimiser step).  The pointer / size arrays are host arrays. */
+SG_API int sg_multi_add(int64_t n, const float* const* srcs, const int64_t* src_ld, const int64_t* rows, const int64_t* cols,
+                        float* const* dsts, void* stream);
 SG_API int sg_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps, float* out,
                           void* stream);
@@ -322,7 +332,7 @@ SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, in
 /* sg_bn_stats_finalize for partials cut into uniform tiles of rows_per_tile rows (the last one shorter) */
 SG_API int sg_bn_stats_finalize_tiles(const float* partial, int64_t n_tiles, int64_t rows_per_tile, int64_t V, int64_t C,
                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                      float momentum, float eps, float* out, void* stream);
+                                      float momentum, float eps, float* out, int64_t* batches_tracked, void* stream);
 
 enum sg_tune_knob {
   SG_TUNE_CHUNK_ROWS = 0, /* rows per wavefront chunk; 0 = automatic */

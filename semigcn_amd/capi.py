@@ -60,9 +60,9 @@ _SIGNATURES = {
     "sg_col_moments": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "sg_bn_merge": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "sg_bn_stats_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
-                                     c_float, c_void_p, c_void_p]),
+                                     c_float, c_void_p, c_void_p, c_void_p]),
     "sg_bn_stats_finalize_tiles": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_float, c_float, c_void_p, c_void_p]),
+                                           c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "sg_gemm_tile_rows": (c_int64, [c_int64]),
     "sg_gemm_row_tiles": (c_int64, [c_int64, c_int64]),
     "sg_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
@@ -70,9 +70,11 @@ _SIGNATURES = {
     "sg_gemm_tn_slabs": (c_int64, [c_int64, c_int64, c_int64]),
     "sg_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
                            c_void_p]),
-    "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "sg_multi_add": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_bn_finalize_ranks": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
-                                     c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_bn_finalize": (c_int, [c_void_p, ctypes.c_double, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_float, c_void_p, c_void_p]),
     "sg_scale_shift_act": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
@@ -425,6 +427,15 @@ def _f32vec(t: torch.Tensor, n: int, name: str) -> torch.Tensor:
     return t
 
 
+def _counter(t: Optional[torch.Tensor], like: torch.Tensor) -> c_void_p:
+    """Device pointer of nn.BatchNorm1d's ``num_batches_tracked`` (an int64 scalar) -- incremented by the finalize launch."""
+    if t is None:
+        return c_void_p(0)
+    if t.dtype != torch.int64 or t.numel() != 1 or t.device != like.device:
+        raise SemigcnLibraryError("num_batches_tracked must be an int64 scalar on the device of the statistics")
+    return c_void_p(t.data_ptr())
+
+
 def col_moments(X: torch.Tensor) -> torch.Tensor:
     """partial[b] = (mean, sum of squared deviations) per channel over row block b; float32 [nb, 2, C]."""
     _require_device(X, "X")
@@ -464,7 +475,7 @@ def bn_finalize(stats: torch.Tensor, count: float, gamma: torch.Tensor, beta: to
 
 def bn_finalize_ranks(all_stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                       running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], momentum: float,
-                      eps: float):
+                      eps: float, batches_tracked: Optional[torch.Tensor] = None):
     """[world, 2C+1] gathered rows of (mean, M2, count) -> ([4, C] mean/invstd/scale/shift of the whole mesh,
     [1] total row count), everything on the device."""
     world, w = all_stats.shape
@@ -474,15 +485,17 @@ def bn_finalize_ranks(all_stats: torch.Tensor, gamma: torch.Tensor, beta: torch.
     with _on_device(all_stats.device):
         _check(load().sg_bn_finalize_ranks(_ptr(all_stats), world, C, _ptr(_f32vec(gamma, C, "weight")),
                                            _ptr(_f32vec(beta, C, "bias")), _ptr(running_mean), _ptr(running_var),
-                                           float(momentum), float(eps), _ptr(out), _ptr(n), _stream(all_stats)),
+                                           float(momentum), float(eps), _ptr(out), _ptr(n),
+                                           _counter(batches_tracked, all_stats), _stream(all_stats)),
                "sg_bn_finalize_ranks")
     return out, n
 
 
 def bn_stats_finalize(partial: torch.Tensor, num_rows: int, gamma: torch.Tensor, beta: torch.Tensor,
                       running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], momentum: float,
-                      eps: float) -> torch.Tensor:
-    """bn_merge + bn_finalize in one launch (statistics over this device's rows only): [4, C]."""
+                      eps: float, batches_tracked: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bn_merge + bn_finalize in one launch (statistics over this device's rows only): [4, C].  ``batches_tracked``:
+    the module's num_batches_tracked, += 1 by the same launch."""
     nb, _, C = partial.shape
     out = torch.empty((4, C), dtype=torch.float32, device=partial.device)
     for t, n in ((running_mean, "running_mean"), (running_var, "running_var")):
@@ -491,14 +504,14 @@ def bn_stats_finalize(partial: torch.Tensor, num_rows: int, gamma: torch.Tensor,
     with _on_device(partial.device):
         _check(load().sg_bn_stats_finalize(_ptr(partial), nb, int(num_rows), C, _ptr(_f32vec(gamma, C, "weight")),
                                            _ptr(_f32vec(beta, C, "bias")), _ptr(running_mean), _ptr(running_var),
-                                           float(momentum), float(eps), _ptr(out), _stream(partial)),
-               "sg_bn_stats_finalize")
+                                           float(momentum), float(eps), _ptr(out), _counter(batches_tracked, partial),
+                                           _stream(partial)), "sg_bn_stats_finalize")
     return out
 
 
 def bn_stats_finalize_tiles(partial: torch.Tensor, rows_per_tile: int, num_rows: int, gamma: torch.Tensor,
                             beta: torch.Tensor, running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
-                            momentum: float, eps: float) -> torch.Tensor:
+                            momentum: float, eps: float, batches_tracked: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bn_stats_finalize for the per-tile moments the MFMA GEMM emits (uniform tiles of ``rows_per_tile`` rows)."""
     nb, _, C = partial.shape
     out = torch.empty((4, C), dtype=torch.float32, device=partial.device)
@@ -509,7 +522,8 @@ def bn_stats_finalize_tiles(partial: torch.Tensor, rows_per_tile: int, num_rows:
         _check(load().sg_bn_stats_finalize_tiles(_ptr(partial), nb, int(rows_per_tile), int(num_rows), C,
                                                  _ptr(_f32vec(gamma, C, "weight")), _ptr(_f32vec(beta, C, "bias")),
                                                  _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
-                                                 _ptr(out), _stream(partial)), "sg_bn_stats_finalize_tiles")
+                                                 _ptr(out), _counter(batches_tracked, partial), _stream(partial)),
+               "sg_bn_stats_finalize_tiles")
     return out
 
 
@@ -580,15 +594,54 @@ def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def bn_bwd_coeffs(partial: torch.Tensor, count: float, gamma: torch.Tensor, invstd: torch.Tensor) -> torch.Tensor:
-    """[5, C] = (sum dz, sum dz*xhat, c1, c2, k) from the partials of bn_act_bwd_reduce."""
+def bn_bwd_coeffs(partial: torch.Tensor, count: float, gamma: torch.Tensor, invstd: torch.Tensor,
+                  acc_dweight: Optional[torch.Tensor] = None, acc_dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[5, C] = (sum dz, sum dz*xhat, c1, c2, k) from the partials of bn_act_bwd_reduce.  ``acc_dweight`` / ``acc_dbias``:
+    fp32 [C] gradient accumulators (the parameters' .grad), += sum dz*xhat / += sum dz by the same launch."""
     nb, _, C = partial.shape
     out = torch.empty((5, C), dtype=torch.float32, device=partial.device)
+    for t, n in ((acc_dweight, "acc_dweight"), (acc_dbias, "acc_dbias")):
+        if t is not None:
+            _f32vec(t, C, n)
     with _on_device(partial.device):
         _check(load().sg_bn_bwd_coeffs(_ptr(partial), nb, C, float(count), _ptr(_f32vec(gamma, C, "weight")),
-                                       _ptr(_f32vec(invstd, C, "invstd")), _ptr(out), _stream(partial)),
-               "sg_bn_bwd_coeffs")
+                                       _ptr(_f32vec(invstd, C, "invstd")), _ptr(out), _ptr(acc_dweight), _ptr(acc_dbias),
+                                       _stream(partial)), "sg_bn_bwd_coeffs")
     return out
+
+
+MULTI_ADD_MAX = 8
+
+
+def multi_add(srcs, dsts) -> None:
+    """``dsts[i] += srcs[i]`` for small fp32 matrices / vectors in one launch per 8 (sg_multi_add): ``dsts`` contiguous,
+    ``srcs`` of the same shapes with unit inner stride (column or row blocks of a wider matrix are fine)."""
+    if len(srcs) != len(dsts):
+        raise SemigcnLibraryError("multi_add: one destination per source")
+    items = []
+    for s, d in zip(srcs, dsts):
+        _require_device(d, "dst")
+        if s.dtype != torch.float32 or d.dtype != torch.float32 or s.shape != d.shape or s.device != d.device \
+                or not d.is_contiguous() or s.dim() not in (1, 2):
+            raise SemigcnLibraryError(f"multi_add: need float32 pairs of one shape (1-D or 2-D) with a contiguous destination, "
+                                      f"got {s.dtype} {tuple(s.shape)} -> {d.dtype} {tuple(d.shape)}")
+        if s.dim() == 1:
+            if s.numel() > 1 and s.stride(0) != 1:
+                s = s.contiguous()
+            items.append((s, d, 1, s.numel(), s.numel()))
+        else:
+            if s.shape[1] > 1 and s.stride(1) != 1:
+                s = s.contiguous()
+            items.append((s, d, s.shape[0], s.shape[1], _rows2d(s, "src")))
+    lib = load()
+    for at in range(0, len(items), MULTI_ADD_MAX):
+        chunk = items[at:at + MULTI_ADD_MAX]
+        n = len(chunk)
+        vp, i64 = c_void_p * n, c_int64 * n
+        with _on_device(chunk[0][1].device):
+            _check(lib.sg_multi_add(n, vp(*[c[0].data_ptr() for c in chunk]), i64(*[c[4] for c in chunk]),
+                                    i64(*[c[2] for c in chunk]), i64(*[c[3] for c in chunk]),
+                                    vp(*[c[1].data_ptr() for c in chunk]), _stream(chunk[0][1])), "sg_multi_add")
 
 
 def scale_shift_act(X: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, slope: float,

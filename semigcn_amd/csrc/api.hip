@@ -477,22 +477,22 @@ SG_API int sg_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, f
 
 SG_API int sg_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_t C, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                float* out, void* stream) {
+                                float* out, int64_t* batches_tracked, void* stream) {
   SG_REQUIRE(V > 1 && C >= 0 && partial && gamma && beta && out, "sg_bn_stats_finalize: bad argument");
   SG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
              "sg_bn_stats_finalize: give both running buffers or none");
   return launch_bn_stats_finalize(partial, nb, V, C, gamma, beta, running_mean, running_var, momentum, eps, out,
-                                  (hipStream_t)stream);
+                                  batches_tracked, (hipStream_t)stream);
 }
 
 SG_API int sg_bn_stats_finalize_tiles(const float* partial, int64_t n_tiles, int64_t rows_per_tile, int64_t V, int64_t C,
                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                      float momentum, float eps, float* out, void* stream) {
+                                      float momentum, float eps, float* out, int64_t* batches_tracked, void* stream) {
   SG_REQUIRE(V > 1 && C >= 0 && partial && gamma && beta && out, "sg_bn_stats_finalize_tiles: bad argument");
   SG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
              "sg_bn_stats_finalize_tiles: give both running buffers or none");
   return launch_bn_stats_finalize_tiles(partial, n_tiles, rows_per_tile, V, C, gamma, beta, running_mean, running_var,
-                                        momentum, eps, out, (hipStream_t)stream);
+                                        momentum, eps, out, batches_tracked, (hipStream_t)stream);
 }
 
 SG_API int64_t sg_gemm_tile_rows(int64_t N) { return gemm_tile_rows(N); }
@@ -527,19 +527,31 @@ SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, in
 }
 
 SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
-                            const float* invstd, float* out, void* stream) {
+                            const float* invstd, float* out, float* acc_dweight, float* acc_dbias, void* stream) {
   SG_REQUIRE(nb > 0 && C >= 0 && N > 0 && partial && gamma && invstd && out, "sg_bn_bwd_coeffs: bad argument");
-  return launch_bn_bwd_coeffs(partial, nb, C, N, gamma, invstd, out, (hipStream_t)stream);
+  return launch_bn_bwd_coeffs(partial, nb, C, N, gamma, invstd, out, acc_dweight, acc_dbias, (hipStream_t)stream);
+}
+
+SG_API int sg_multi_add(int64_t n, const float* const* srcs, const int64_t* src_ld, const int64_t* rows, const int64_t* cols,
+                        float* const* dsts, void* stream) {
+  SG_REQUIRE(n >= 0 && n <= kMultiAddMax, "sg_multi_add: at most %d matrices per call", kMultiAddMax);
+  SG_REQUIRE(n == 0 || (srcs && src_ld && rows && cols && dsts), "sg_multi_add: bad argument");
+  for (int64_t s = 0; s < n; ++s) {
+    SG_REQUIRE(rows[s] >= 0 && cols[s] >= 0 && cols[s] <= INT32_MAX && (rows[s] * cols[s] == 0 || (srcs[s] && dsts[s])),
+               "sg_multi_add: bad matrix %lld", (long long)s);
+    SG_REQUIRE(rows[s] <= 1 || src_ld[s] >= cols[s], "sg_multi_add: source row stride below the row length");
+  }
+  return launch_multi_add((int)n, srcs, src_ld, rows, cols, dsts, (hipStream_t)stream);
 }
 
 SG_API int sg_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* out,
-                                float* out_n, void* stream) {
+                                float* out_n, int64_t* batches_tracked, void* stream) {
   SG_REQUIRE(world > 0 && C >= 0 && all && gamma && beta && out && out_n, "sg_bn_finalize_ranks: bad argument");
   SG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
              "sg_bn_finalize_ranks: give both running buffers or none");
   return launch_bn_finalize_ranks(all, world, C, gamma, beta, running_mean, running_var, momentum, eps, out, out_n,
-                                  (hipStream_t)stream);
+                                  batches_tracked, (hipStream_t)stream);
 }
 
 SG_API int sg_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,

@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
                                                          int rpb, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* running_mean,
                                                          float* running_var, float momentum, float eps,
-                                                         float* __restrict__ out /*[4][C]*/) {
+                                                         float* __restrict__ out /*[4][C]*/,
+                                                         long long* batches_tracked) {
   __shared__ double s_n[4], s_mean[4], s_m2[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x;
@@ -456,13 +457,16 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2d / (N - 1.0));
     }
+    if (batches_tracked && c == 0) *batches_tracked += 1;      // nn.BatchNorm1d.num_batches_tracked, without a launch of its own
   }
 }
 
-// out[0] = sum dz, out[1] = sum dz*xhat (the bias / weight gradients), out[2] = out[0]/N, out[3] = out[1]/N, out[4] = gamma*invstd
+// out[0] = sum dz, out[1] = sum dz*xhat (the bias / weight gradients), out[2] = out[0]/N, out[3] = out[1]/N, out[4] = gamma*invstd;
+// acc_dweight / acc_dbias (optional): the parameters' gradient accumulators, += out[1] / out[0]
 __global__ __launch_bounds__(256) void bn_bwd_coeffs(const float* __restrict__ partial, int64_t nb, int C, double N,
                                                      const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                     float* __restrict__ out /*[5][C]*/) {
+                                                     float* __restrict__ out /*[5][C]*/, float* acc_dweight,
+                                                     float* acc_dbias) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   double s0 = 0.0, s1 = 0.0;
@@ -484,6 +488,8 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs(const float* __restrict__ p
     out[2 * C + c] = (float)((double)f0 / N);
     out[3 * C + c] = (float)((double)f1 / N);
     out[4 * C + c] = gamma[c] * invstd[c];
+    if (acc_dweight) acc_dweight[c] += f1;
+    if (acc_dbias) acc_dbias[c] += f0;
   }
 }
 
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs(const float* __restrict__ p
 __global__ void bn_finalize_ranks(const float* __restrict__ all, int world, int C, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float* running_mean, float* running_var,
                                   float momentum, float eps, float* __restrict__ out /*[4][C]*/,
-                                  float* __restrict__ out_n) {
+                                  float* __restrict__ out_n, long long* batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double n = 0.0, mean = 0.0, m2 = 0.0;
@@ -519,7 +525,35 @@ __global__ void bn_finalize_ranks(const float* __restrict__ all, int world, int 
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2d / (n - 1.0));
   }
-  if (c == 0) out_n[0] = (float)n;
+  if (c == 0) {
+    out_n[0] = (float)n;
+    if (batches_tracked) *batches_tracked += 1;
+  }
+}
+
+// dst_s[r][c] += src_s[r * ld_s + c] for up to kMultiAddMax small fp32 matrices in one launch: a layer's parameter
+// gradients (column / row blocks of dWcat, the bias sums) added into the parameters' .grad accumulators
+struct MultiAddArgs {
+  const float* src[kMultiAddMax];
+  float* dst[kMultiAddMax];
+  int64_t ld[kMultiAddMax];
+  int cols[kMultiAddMax];
+  int64_t start[kMultiAddMax + 1];   // element offsets of the segments in the flattened index space
+  int n;
+};
+
+__global__ __launch_bounds__(256) void multi_add(MultiAddArgs a) {
+  const int64_t total = a.start[a.n];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < kMultiAddMax; ++k) s += (k < a.n && i >= a.start[k]) ? 1 : 0;
+    const int64_t e = i - a.start[s];
+    const int cols = a.cols[s];
+    const int64_t r = e / cols;
+    const int c = (int)(e - r * cols);
+    a.dst[s][e] += a.src[s][r * a.ld[s] + c];
+  }
 }
 
 inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -532,8 +566,11 @@ int threads_per_row(int ncol) {
 
 }  // namespace
 
+// 128 rows per block up to 2048 blocks: a 125 K-row block of a partitioned mesh still gets ~1000 workgroups (with 512
+// rows per block it got 245 -- less than one per CU -- and the moment passes of a 50 K mesh ran at a seventh of the
+// streaming rate); at V = 1 M the cap decides either way
 int64_t col_blocks(int64_t V) {
-  int64_t nb = (V + 511) / 512;
+  int64_t nb = (V + 127) / 128;
   if (nb < 1) nb = 1;
   if (nb > 2048) nb = 2048;
   return nb;
@@ -550,41 +587,64 @@ int launch_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, floa
 
 int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_t C, const float* gamma,
                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                             float* out, hipStream_t stream) {
+                             float* out, int64_t* batches_tracked, hipStream_t stream) {
   if (C == 0) return SG_OK;
   SG_REQUIRE(nb == col_blocks(V), "partial buffer must have sg_col_blocks(V) blocks");
   const int rpb = (int)((V + nb - 1) / nb);
-  bn_stats_finalize<<<(int)C, 256, 0, stream>>>(partial, nb, V, (int)C, rpb, gamma, beta, running_mean,
-                                                            running_var, momentum, eps, out);
+  bn_stats_finalize<<<(int)C, 256, 0, stream>>>(partial, nb, V, (int)C, rpb, gamma, beta, running_mean, running_var,
+                                                momentum, eps, out, (long long*)batches_tracked);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
 
 int launch_bn_stats_finalize_tiles(const float* partial, int64_t nb, int64_t rpb, int64_t V, int64_t C, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                   float* out, hipStream_t stream) {
+                                   float* out, int64_t* batches_tracked, hipStream_t stream) {
   if (C == 0) return SG_OK;
   SG_REQUIRE(rpb > 0 && rpb <= INT32_MAX && nb == (V + rpb - 1) / rpb, "partial buffer must have ceil(V / rows_per_tile) tiles");
-  bn_stats_finalize<<<(int)C, 256, 0, stream>>>(partial, nb, V, (int)C, (int)rpb, gamma, beta, running_mean,
-                                                            running_var, momentum, eps, out);
+  bn_stats_finalize<<<(int)C, 256, 0, stream>>>(partial, nb, V, (int)C, (int)rpb, gamma, beta, running_mean, running_var,
+                                                momentum, eps, out, (long long*)batches_tracked);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int launch_multi_add(int n, const float* const* srcs, const int64_t* src_ld, const int64_t* rows, const int64_t* cols,
+                     float* const* dsts, hipStream_t stream) {
+  MultiAddArgs a{};
+  a.n = n;
+  int64_t at = 0;
+  for (int s = 0; s < n; ++s) {
+    a.src[s] = srcs[s];
+    a.dst[s] = dsts[s];
+    a.ld[s] = src_ld[s];
+    a.cols[s] = (int)(cols[s] > 0 ? cols[s] : 1);
+    a.start[s] = at;
+    at += rows[s] * cols[s];
+  }
+  a.start[n] = at;
+  if (at == 0) return SG_OK;
+  int64_t blocks = (at + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  multi_add<<<(int)blocks, 256, 0, stream>>>(a);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
 
 int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
-                         const float* invstd, float* out, hipStream_t stream) {
+                         const float* invstd, float* out, float* acc_dweight, float* acc_dbias, hipStream_t stream) {
   if (C == 0) return SG_OK;
-  bn_bwd_coeffs<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out);
+  bn_bwd_coeffs<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out, acc_dweight, acc_dbias);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
 
 int launch_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, float* out,
-                             float* out_n, hipStream_t stream) {
+                             float* out_n, int64_t* batches_tracked, hipStream_t stream) {
   if (C == 0) return SG_OK;
   bn_finalize_ranks<<<(int)((C + 127) / 128), 128, 0, stream>>>(all, (int)world, (int)C, gamma, beta, running_mean,
-                                                               running_var, momentum, eps, out, out_n);
+                                                               running_var, momentum, eps, out, out_n,
+                                                               (long long*)batches_tracked);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

@@ -129,12 +129,12 @@ int launch_col_reduce(int mode, const void* A, int64_t lda, const void* H, int64
 int launch_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, float* stats, hipStream_t stream);
 int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_t C, const float* gamma,
                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                             float* out, hipStream_t stream);
+                             float* out, int64_t* batches_tracked, hipStream_t stream);
 int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
-                         const float* invstd, float* out, hipStream_t stream);
+                         const float* invstd, float* out, float* acc_dweight, float* acc_dbias, hipStream_t stream);
 int launch_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, float* out,
-                             float* out_n, hipStream_t stream);
+                             float* out_n, int64_t* batches_tracked, hipStream_t stream);
 int launch_bn_finalize(const float* stats, double N, int64_t C, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, float* out,
                        hipStream_t stream);
@@ -147,7 +147,10 @@ int launch_colsum_finalize(const float* partial, int64_t nb, int64_t C, float* o
 
 int launch_bn_stats_finalize_tiles(const float* partial, int64_t nb, int64_t rpb, int64_t V, int64_t C, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                   float* out, hipStream_t stream);
+                                   float* out, int64_t* batches_tracked, hipStream_t stream);
+constexpr int kMultiAddMax = 8;
+int launch_multi_add(int n, const float* const* srcs, const int64_t* src_ld, const int64_t* rows, const int64_t* cols,
+                     float* const* dsts, hipStream_t stream);
 
 // gemm_mfma.hip
 int gemm_tile_rows(int64_t N);      // rows per output tile (= rows per BatchNorm-moments record) for an N-column product

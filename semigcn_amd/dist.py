@@ -388,12 +388,13 @@ class _DistChebConvFn(torch.autograd.Function):
         ctx.g, ctx.K, ctx.C = g, K, C
         ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
         ctx.wcat_t = wcat_t
+        ctx.params = (bias, *weights)
         ctx.save_for_backward(T, wcat)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        from .functional import column_sums, dense_nt, weight_grad
+        from .functional import _sink, column_sums, dense_nt, weight_grad
         T, wcat = ctx.saved_tensors
         g, K, C, n = ctx.g, ctx.K, ctx.C, ctx.g.n_own
         dout = dout.contiguous()
@@ -426,6 +427,8 @@ class _DistChebConvFn(torch.autograd.Function):
                     g.exchange(gk[1])
                     x1 = gk[2][:n] if K >= 3 else None
                     g.aggregate(gk[1], dx, alpha=1.0, X0=gk[0][:n], beta=1.0, X1=x1, gamma=-1.0)
+        if dout.is_cuda and _sink(ctx.params, (db, *dws)):      # this rank's partial sums, straight into the .grad accumulators
+            return (None, None, dx) + (None,) * (K + 1)
         return (None, None, dx, db, *dws)
 
 
@@ -459,12 +462,13 @@ class _DistChebConvPostFn(torch.autograd.Function):
         ctx.g, ctx.K, ctx.Co = g, K, Co
         ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
         ctx.wstack_t = wstack_t
+        ctx.params = (bias, *weights)
         ctx.save_for_backward(x, wstack)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        from .functional import column_sums, dense_nt, weight_grad
+        from .functional import _sink, column_sums, dense_nt, weight_grad
         x, wstack = ctx.saved_tensors
         g, K, Co, n = ctx.g, ctx.K, ctx.Co, ctx.g.n_own
         dout = dout.contiguous()
@@ -489,6 +493,8 @@ class _DistChebConvPostFn(torch.autograd.Function):
             dwstack = weight_grad(own, x.contiguous()).to(ctx.param_dtype)
             dws = [dwstack[k * Co:(k + 1) * Co] for k in range(K)]
         db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        if dout.is_cuda and _sink(ctx.params, (db, *dws)):
+            return (None, None, dx) + (None,) * (K + 1)
         return (None, None, dx, db, *dws)
 
 
@@ -572,10 +578,14 @@ def convert_batchnorm(model: nn.Module, group=None) -> nn.Module:
     return model
 
 
-def all_reduce_gradients(params, group=None) -> None:
-    """Sum the per-rank partial parameter gradients: one flat bucket, one all-reduce."""
+def all_reduce_gradients(params, group=None, flat: Optional[torch.Tensor] = None) -> None:
+    """Sum the per-rank partial parameter gradients: one flat bucket, one all-reduce.  ``flat``: the buffer all the
+    ``.grad`` tensors are views of (train.GradBuffer) -- reduced in place, no gather / scatter copies."""
     grads = [p.grad for p in params if p.grad is not None]
     if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    if flat is not None:
+        _all_reduce(flat, dist.ReduceOp.SUM, group)
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     _all_reduce(flat, dist.ReduceOp.SUM, group)
@@ -678,7 +688,8 @@ class DistSGCNTrainer:
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=50, gamma=0.5)
         self.iteration = 0
         self.loss_sum = torch.zeros((), device=part.z1.device)
-        self.opt.zero_grad(set_to_none=True)
+        from .train import GradBuffer
+        self.grads = GradBuffer(self.params)
 
     def loss(self, pos_own: torch.Tensor) -> torch.Tensor:
         from . import train
@@ -703,13 +714,16 @@ class DistSGCNTrainer:
             self.model.train()
         pos = self.model(p, dm)
         loss = self.loss(pos)
-        loss.backward()
+        from .functional import sink_param_grads
+        with sink_param_grads():
+            loss.backward()
         self.loss_sum += loss.detach()
         self.iteration += 1
         if self.iteration % self.accumulate == 0:
-            all_reduce_gradients(self.params, self.group)
+            self.grads.attach()
+            all_reduce_gradients(self.params, self.group, flat=self.grads.whole())
             self.opt.step()
-            self.opt.zero_grad(set_to_none=True)
+            self.grads.zero()
         return loss
 
 
@@ -891,7 +905,8 @@ class DistMGCNTrainer:
         self.target_fn = batch.target_fn[mine]
         self.f_keep = batch.f_keep[mine]
         self.n_f_keep = float(batch.f_keep.sum())
-        self.opt.zero_grad(set_to_none=True)
+        from .train import GradBuffer
+        self.grads = GradBuffer(self.params)
 
     def loss(self, poss) -> torch.Tensor:
         from . import train
@@ -918,11 +933,14 @@ class DistMGCNTrainer:
             self.model.train()
         poss = self.model(b.data, b.v_keep * b.dummy_masks[:, k:k + 1])
         loss = self.loss(poss)
-        loss.backward()
+        from .functional import sink_param_grads
+        with sink_param_grads():
+            loss.backward()
         self.loss_sum += loss.detach()
         self.iteration += 1
         if self.iteration % self.accumulate == 0:
-            all_reduce_gradients(self.params, self.group)
+            self.grads.attach()
+            all_reduce_gradients(self.params, self.group, flat=self.grads.whole())
             self.opt.step()
-            self.opt.zero_grad(set_to_none=True)
+            self.grads.zero()
         return loss

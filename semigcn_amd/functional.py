@@ -15,6 +15,7 @@ otherwise the transposed CSR kept by sg_graph_create is used).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import weakref
 from typing import Optional, Sequence
@@ -122,6 +123,52 @@ def column_sums(x: torch.Tensor) -> torch.Tensor:
     return capi.bn_merge(capi.col_moments(x), x.shape[0])[0] * float(x.shape[0])
 
 
+#: > 0 inside ``sink_param_grads()``
+_sink_depth = 0
+
+#: False (or SEMIGCN_NO_GRAD_SINKS=1): ``sink_param_grads()`` does nothing -- every gradient goes through autograd (A/B switch)
+SINK_PARAM_GRADS = os.environ.get("SEMIGCN_NO_GRAD_SINKS") != "1"
+
+
+@contextlib.contextmanager
+def sink_param_grads():
+    """Inside this context (the trainers wrap ``loss.backward()`` in it) every layer of this package ADDS its parameter
+    gradients into the parameters' existing fp32 ``.grad`` accumulators itself -- one ``sg_multi_add`` launch per ChebConv,
+    none per BatchNorm (its coefficient kernel does it) -- and hands autograd ``None`` for them, instead of one
+    AccumulateGrad add (or copy) launch per parameter: ~85 launches less per SGCN iteration, same sums in the same order.
+    Parameters whose ``.grad`` is missing (or not a contiguous fp32 tensor) get their gradient through autograd as usual.
+    Not for ``torch.autograd.grad`` / parameter hooks: those never see a gradient that was sunk."""
+    global _sink_depth
+    if not SINK_PARAM_GRADS:
+        yield
+        return
+    _sink_depth += 1
+    try:
+        yield
+    finally:
+        _sink_depth -= 1
+
+
+def _sink(params, grads) -> bool:
+    """Add ``grads[i]`` (fp32, or None) into ``params[i].grad`` in one launch if sinking is on and every accumulator
+    involved exists and is a contiguous fp32 tensor; else do nothing and return False (the caller returns the gradients)."""
+    if not _sink_depth:
+        return False
+    srcs, dsts = [], []
+    for p, g in zip(params, grads):
+        if g is None:
+            continue
+        acc = None if p is None else p.grad
+        if acc is None or acc.dtype != torch.float32 or g.dtype != torch.float32 or not acc.is_contiguous() \
+                or acc.device != g.device or acc.shape != g.shape:
+            return False
+        srcs.append(g)
+        dsts.append(acc)
+    if srcs:
+        capi.multi_add(srcs, dsts)
+    return True
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b for the [V, C] vertex features with fp32 parameters; the weight gradient (a
     reduction over all V) uses the slab-batched product and the streaming column sum."""
@@ -130,6 +177,7 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
 
     @staticmethod
@@ -139,6 +187,8 @@ class _LinearFn(torch.autograd.Function):
         dx = dy @ weight if ctx.needs_input_grad[0] else None
         dw = weight_grad(dy, x.contiguous()).to(weight.dtype) if ctx.needs_input_grad[1] else None
         db = column_sums(dy).to(weight.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if dy.is_cuda and _sink(ctx.params, (dw, db)):
+            return dx, None, None
         return dx, dw, db
 
 
@@ -239,6 +289,7 @@ class _ChebConvFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.param_dtype = weights[0].dtype
         ctx.wcat_t = wcat_t
+        ctx.params = (bias, *weights)
         ctx.save_for_backward(T, wcat)
         return out
 
@@ -271,6 +322,8 @@ class _ChebConvFn(torch.autograd.Function):
                 dx = torch.empty((T.shape[0], C), dtype=dout.dtype, device=dout.device)
                 x1 = g[2] if K >= 3 else None
                 graph.aggregate(g[1], dx, alpha=1.0, X0=g[0], beta=1.0, X1=x1, gamma=-1.0, transpose=tr)
+        if dout.is_cuda and _sink(ctx.params, (db, *dws)):
+            return (None, None, None, dx) + (None,) * (K + 1)
         return (None, None, None, dx, db, *dws)
 
 
@@ -315,6 +368,7 @@ class _ChebConvPostFn(torch.autograd.Function):
         ctx.graph, ctx.K, ctx.Co = graph, K, Co
         ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
         ctx.wstack_t = wstack_t
+        ctx.params = (bias, *weights)
         ctx.save_for_backward(x, wstack)
         return out
 
@@ -342,6 +396,8 @@ class _ChebConvPostFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[4:]):
             dwstack = weight_grad(G, x.contiguous()).to(ctx.param_dtype)   # [K*Cout, Cin]
             dws = [dwstack[k * Co:(k + 1) * Co] for k in range(K)]
+        if dout.is_cuda and _sink(ctx.params, (db, *dws)):
+            return (None, None, dx) + (None,) * (K + 1)
         return (None, None, dx, db, *dws)
 
 
@@ -425,7 +481,9 @@ def mesh_unpool(pool: capi.PoolHandle, x: torch.Tensor) -> torch.Tensor:
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, group, widen,
-                grad_widen=1, rows=0, tile_moments=None):
+                grad_widen=1, rows=0, tile_moments=None, batches_tracked=None):
+        """``batches_tracked``: the module's num_batches_tracked when this call is to count (training with running
+        statistics) -- incremented by the statistics kernel itself."""
         V, C = x.shape
         if x.stride(1) != 1 and C > 1:
             x = x.contiguous()
@@ -435,9 +493,10 @@ class _BNActFn(torch.autograd.Function):
         if training and V > 1 and not ctx_group_active(group):
             if tile_moments is not None:       # left behind by the MFMA product that wrote x: no pass over x needed
                 fin = capi.bn_stats_finalize_tiles(tile_moments["tiles"], tile_moments["rows"], V, w32, b32, running_mean,
-                                                   running_var, momentum, eps)
+                                                   running_var, momentum, eps, batches_tracked)
             else:
-                fin = capi.bn_stats_finalize(capi.col_moments(x), V, w32, b32, running_mean, running_var, momentum, eps)
+                fin = capi.bn_stats_finalize(capi.col_moments(x), V, w32, b32, running_mean, running_var, momentum, eps,
+                                             batches_tracked)
             mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
             ctx.N = float(V)
         elif training and ctx_group_active(group):
@@ -451,10 +510,12 @@ class _BNActFn(torch.autograd.Function):
             local[0, 2 * C:].fill_(float(V))
             allst = torch.empty((world, 2 * C + 1), dtype=torch.float32, device=dev)
             _d._all_gather_rows(allst, local, group)
-            fin, n_dev = capi.bn_finalize_ranks(allst, w32, b32, running_mean, running_var, momentum, eps)
+            fin, n_dev = capi.bn_finalize_ranks(allst, w32, b32, running_mean, running_var, momentum, eps, batches_tracked)
             mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
             ctx.N = n_dev
         elif training:      # a single row: nothing to merge
+            if batches_tracked is not None:
+                batches_tracked.add_(1)
             stats = capi.bn_merge(capi.col_moments(x), V)
             fin = capi.bn_finalize(stats, float(V), w32, b32, running_mean, running_var, momentum, eps)
             mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
@@ -475,6 +536,7 @@ class _BNActFn(torch.autograd.Function):
         ctx.save_for_backward(x, scale, shift, mean, invstd, w32)
         ctx.training, ctx.slope, ctx.group, ctx.param_dtype = training, slope, group, weight.dtype
         ctx.grad_widen = grad_widen
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -483,8 +545,14 @@ class _BNActFn(torch.autograd.Function):
         if dy.stride(1) != 1 and dy.shape[1] > 1:
             dy = dy.contiguous()
         part = capi.bn_act_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.slope)
+        nothing = (None,) * 12
         if ctx.training and not ctx_group_active(ctx.group):       # one launch: block sums, /N and gamma*invstd
-            co = capi.bn_bwd_coeffs(part, ctx.N, w32, invstd)
+            weight, bias = ctx.params
+            # sink_param_grads(): the same launch adds the two parameter gradients into their .grad accumulators
+            sunk = bool(_sink_depth) and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and all(
+                p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == x.device
+                for p in (weight, bias))
+            co = capi.bn_bwd_coeffs(part, ctx.N, w32, invstd, weight.grad if sunk else None, bias.grad if sunk else None)
             out = None
             if ctx.grad_widen > 1:
                 out = _new_wide(x.shape[0], x.shape[0], x.shape[1], ctx.grad_widen, x.dtype, x.device)
@@ -496,8 +564,9 @@ class _BNActFn(torch.autograd.Function):
                     _remember_column_sums(dx, sums)
             else:
                 dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, co[4], co[2], co[3], ctx.slope, out=out)
-            return (dx, co[1].to(ctx.param_dtype), co[0].to(ctx.param_dtype), None, None, None, None, None, None, None,
-                    None, None, None, None)
+            if sunk:
+                return (dx, None, None) + nothing
+            return (dx, co[1].to(ctx.param_dtype), co[0].to(ctx.param_dtype)) + nothing
         s = part.sum(0)                                                                # [2, C]: sum dz, sum dz*xhat
         dbeta, dgamma = s[0].to(ctx.param_dtype), s[1].to(ctx.param_dtype)            # this rank's partial sums
         if ctx.training:
@@ -517,7 +586,10 @@ class _BNActFn(torch.autograd.Function):
         if ctx.grad_widen > 1:     # born as block 0 of the conv's [V, K*C] gradient buffer (see _ChebConvPostFn.backward)
             out = _new_wide(x.shape[0], x.shape[0], x.shape[1], ctx.grad_widen, x.dtype, x.device)
         dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope, out=out)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
+        if dy.is_cuda and _sink(ctx.params, (dgamma if ctx.needs_input_grad[1] else None,
+                                             dbeta if ctx.needs_input_grad[2] else None)):
+            return (dx, None, None) + nothing
+        return (dx, dgamma, dbeta) + nothing
 
 
 #: the fused BatchNorm backward also leaves the column sums of its dH (= the bias gradient of the ChebConv in front);
@@ -546,15 +618,23 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int =
     (mean, M2) of x, "rows": rows per tile} when the kernel that produced x already took them (dense_nt)."""
     training = bn.training or not bn.track_running_stats
     momentum = 0.0
+    counter = None
     if bn.training and bn.track_running_stats:
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        if bn.momentum is not None:
+            momentum = bn.momentum
+            if bn.num_batches_tracked is not None and bn.num_batches_tracked.device == x.device:
+                counter = bn.num_batches_tracked       # += 1 inside the statistics kernel: no launch of its own
+            elif bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+        else:      # cumulative moving average: the count is needed on the host
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            momentum = 1.0 / float(bn.num_batches_tracked)
     group = getattr(bn, "group", False) if getattr(bn, "sg_mesh_wide", False) else False
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return _BNActFn.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, float(slope), group, int(widen),
-                          int(grad_widen), int(rows), tile_moments)
+                          int(grad_widen), int(rows), tile_moments, counter)
 
 
 # --------------------------------------------------------------------------------------------

@@ -185,6 +185,49 @@ class _GraphedIteration:
         return self.loss.clone()
 
 
+class GradBuffer:
+    """Every fp32 parameter gradient of a model as a view of ONE flat buffer: ``p.grad`` exists from the start (the layers
+    add into it in place under ``functional.sink_param_grads``; autograd's own AccumulateGrad adds in place too), zeroing
+    all of them is one fill instead of one per parameter, and a partitioned trainer all-reduces the buffer itself."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        main = [p for p in self.params if p.dtype == torch.float32]
+        self.flat = None
+        self.views = {}
+        if main and all(p.device == main[0].device for p in main):
+            self.flat = torch.zeros(sum(p.numel() for p in main), dtype=torch.float32, device=main[0].device)
+            off = 0
+            for p in main:
+                self.views[id(p)] = self.flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        self.attach()
+
+    def attach(self) -> None:
+        """(Re)install the views as ``.grad`` -- also after something set a gradient to None or replaced it."""
+        for p in self.params:
+            v = self.views.get(id(p))
+            if v is None:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            elif p.grad is not v:
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                p.grad = v
+
+    def whole(self):
+        """The flat buffer if EVERY gradient is a view of it (then one collective on it covers them all), else None."""
+        return self.flat if len(self.views) == len(self.params) else None
+
+    def zero(self) -> None:
+        self.attach()
+        if self.flat is not None:
+            self.flat.zero_()
+        for p in self.params:
+            if id(p) not in self.views:
+                p.grad.zero_()
+
+
 class SGCNTrainer:
     """optimizer = Adam(lr), StepLR(50, 0.5) as sgcn.py:79-80; k1 = 4 (sgcn.py:47)."""
 
@@ -200,15 +243,17 @@ class SGCNTrainer:
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=50, gamma=0.5)
         self.iteration = 0
         self.loss_sum = torch.zeros((), device=batch.target_pos.device)
-        self.opt.zero_grad(set_to_none=True)
+        self.grads = GradBuffer(model.parameters())
         self._graphed = _GraphedIteration(model.parameters(), batch.v_keep, self._forward_backward) if capture else None
         self._data = _PrivateData(batch.data) if capture else batch.data
 
     def _forward_backward(self, dm: torch.Tensor) -> torch.Tensor:
+        from .functional import sink_param_grads
         if not self.model.training:      # the recursive mode switch costs ~0.5 ms of host time per call
             self.model.train()
         loss = self.loss(self.model(self._data, dm))
-        loss.backward()
+        with sink_param_grads():         # the layers add their parameter gradients into the GradBuffer views themselves
+            loss.backward()
         return loss.detach()
 
     def loss(self, pos: torch.Tensor) -> torch.Tensor:
@@ -238,7 +283,7 @@ class SGCNTrainer:
         self.iteration += 1
         if self.iteration % self.accumulate == 0:
             self.opt.step()
-            self.opt.zero_grad(set_to_none=self._graphed is None)
+            self.grads.zero()
         return loss
 
 
@@ -256,7 +301,7 @@ class MGCNTrainer:
         self.loss_sum = torch.zeros((), device=batch.target_pos.device)
         self.keeps = [m.to(batch.target_pos.device) for m in model.v_masks_list]
         self.counts = [float(k.sum()) for k in self.keeps]
-        self.opt.zero_grad(set_to_none=True)
+        self.grads = GradBuffer(model.parameters())
         self._graphed = _GraphedIteration(model.parameters(), batch.v_keep, self._forward_backward) if capture else None
         self._data = _PrivateData(batch.data) if capture else batch.data
 
@@ -269,7 +314,7 @@ class MGCNTrainer:
         self.iteration += 1
         if self.iteration % self.accumulate == 0:
             self.opt.step()
-            self.opt.zero_grad(set_to_none=self._graphed is None)
+            self.grads.zero()
         return loss
 
     def _forward_backward(self, dm: torch.Tensor) -> torch.Tensor:
@@ -294,6 +339,8 @@ class MGCNTrainer:
         if self.k2 > 0:
             fn = face_normals(poss[0], b.faces) if fn is None else fn
             loss = loss + self.k2 * bilateral_normal_loss(poss[0], fn, b.faces, b.f2f)[0]
-        loss.backward()
+        from .functional import sink_param_grads
+        with sink_param_grads():
+            loss.backward()
         return loss.detach()
 

@@ -1,0 +1,138 @@
+"""``-m gpu``: the launch-saving plumbing of the training iteration -- parameter gradients added into their ``.grad``
+accumulators by the library's own kernels (functional.sink_param_grads, sg_multi_add, sg_bn_bwd_coeffs' accumulators),
+nn.BatchNorm1d.num_batches_tracked counted inside the statistics kernel -- against the plain autograd route, bit for bit
+(the reference accumulates five backward passes per optimiser step: sgcn.py:123-146)."""
+import copy
+
+import pytest
+import torch
+
+from semigcn_amd import capi, functional as F_sg, nn as sgnn, synth, train
+from semigcn_amd.networks import SingleScaleGCN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class _Data:
+    def __init__(self, m):
+        self.z1 = torch.from_numpy(m.z1).to(DEV).requires_grad_(True)
+        self.x_pos = torch.from_numpy(m.x_pos).to(DEV)
+        self.edge_index = torch.from_numpy(m.edge_index).to(DEV)
+
+
+def test_multi_add_matches_torch_on_blocks_vectors_and_chunks():
+    g = torch.Generator(device=DEV).manual_seed(5)
+    wide = torch.randn(48, 3 * 20, device=DEV, generator=g)
+    tall = torch.randn(3 * 16, 24, device=DEV, generator=g)
+    srcs = [wide[:, k * 20:(k + 1) * 20] for k in range(3)] + [tall[k * 16:(k + 1) * 16] for k in range(3)]
+    srcs += [torch.randn(48, device=DEV, generator=g), torch.randn(1, 7, device=DEV, generator=g),
+             torch.randn(5, 1, device=DEV, generator=g), torch.randn(0, 4, device=DEV), torch.randn(300, 257, device=DEV, generator=g)]
+    dsts = [torch.randn(s.shape, device=DEV, generator=g) for s in srcs]           # 11 pairs: two launches
+    want = [d + s for s, d in zip(srcs, dsts)]
+    capi.multi_add(srcs, dsts)
+    for w, d in zip(want, dsts):
+        assert torch.equal(w, d)
+    with pytest.raises(capi.SemigcnLibraryError, match="one shape"):
+        capi.multi_add([srcs[0]], [torch.zeros(48, 21, device=DEV)])
+    with pytest.raises(capi.SemigcnLibraryError, match="float32"):
+        capi.multi_add([srcs[0].double()], [dsts[0].double()])
+
+
+def test_bn_coefficient_kernel_accumulates_and_statistics_kernel_counts():
+    V, C = 5000, 24
+    x = torch.randn(V, C, device=DEV)
+    dy = torch.randn(V, C, device=DEV)
+    gam, bet = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    count = torch.tensor(41, device=DEV)
+    fin = capi.bn_stats_finalize(capi.col_moments(x), V, gam, bet, None, None, 0.1, 1e-5, count)
+    assert int(count) == 42
+    mom = capi.gemm_nt(x.to(torch.bfloat16), torch.eye(C, device=DEV, dtype=torch.bfloat16), moments=True)[1]
+    capi.bn_stats_finalize_tiles(mom, capi.gemm_tile_rows(C), V, gam, bet, None, None, 0.1, 1e-5, count)
+    assert int(count) == 43
+    with pytest.raises(capi.SemigcnLibraryError, match="int64 scalar"):
+        capi.bn_stats_finalize(capi.col_moments(x), V, gam, bet, None, None, 0.1, 1e-5, torch.zeros(1, device=DEV))
+    part = capi.bn_act_bwd_reduce(dy, x, fin[2], fin[3], fin[0], fin[1], 0.01)
+    plain = capi.bn_bwd_coeffs(part, float(V), gam, fin[1])
+    aw, ab = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+    aw0, ab0 = aw.clone(), ab.clone()
+    co = capi.bn_bwd_coeffs(part, float(V), gam, fin[1], aw, ab)
+    assert torch.equal(co, plain)
+    assert torch.equal(aw, aw0 + plain[1]) and torch.equal(ab, ab0 + plain[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sunk_parameter_gradients_equal_autograd_accumulation(dtype):
+    """Three accumulated forward/backward passes of the SGCN: gradients sunk into preallocated accumulators by the
+    kernels == gradients accumulated by autograd's AccumulateGrad, for every parameter, bit for bit; the BatchNorm
+    counters and running statistics agree as well."""
+    m = synth.torus_mesh(24, 16)
+    D = _Data(m)
+    dm = torch.from_numpy(synth.make_dummy_masks(m.edge_index, m.num_vertices, dm_size=1, k=4, p=0.014, seed=3)).to(DEV)
+    torch.manual_seed(3)
+    net_a = SingleScaleGCN(DEV).to(DEV).train()
+    if dtype != torch.float32:
+        net_a.set_feature_dtype(dtype)
+    net_b = copy.deepcopy(net_a)
+    for p in net_b.parameters():
+        p.grad = torch.zeros_like(p)
+    for it in range(3):
+        (net_a(D, dm) ** 2).mean().backward()
+        with F_sg.sink_param_grads():
+            (net_b(D, dm) ** 2).mean().backward()
+    used = 0
+    for (n, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        if pa.grad is None:          # a parameter the forward pass does not use (the skip blocks of a skip=False net)
+            assert not bool(pb.grad.any()), n
+            continue
+        used += 1
+        assert torch.equal(pa.grad, pb.grad), n
+    assert used >= 13 * 6
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.equal(ba, bb), n
+    assert all(int(b) == 3 for n, b in net_b.named_buffers() if n.endswith("num_batches_tracked"))
+
+
+def test_sinking_is_off_outside_the_context_and_for_missing_accumulators():
+    m = synth.torus_mesh(16, 12)
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    conv = sgnn.ChebConv(8, 16, K=3).to(DEV)
+    x = torch.randn(m.num_vertices, 8, device=DEV)
+    conv(x, ei).sum().backward()
+    ref = [p.grad.clone() for p in conv.parameters()]
+    conv.zero_grad(set_to_none=True)
+    with F_sg.sink_param_grads():                       # no accumulators yet: gradients arrive through autograd
+        conv(x, ei).sum().backward()
+    assert all(torch.equal(p.grad, r) for p, r in zip(conv.parameters(), ref))
+    got = torch.autograd.grad(conv(x, ei).sum(), list(conv.parameters()))          # outside the context: untouched route
+    assert all(torch.equal(g, r) for g, r in zip(got, ref))
+    assert all(torch.equal(p.grad, r) for p, r in zip(conv.parameters(), ref))     # .grad not written by autograd.grad
+
+
+def test_trainer_gradient_buffer_views_and_optimizer_steps():
+    """SGCNTrainer keeps every gradient as a view of one flat buffer; ten iterations (two optimiser steps) give the same
+    parameters as the same loop with per-parameter gradients and autograd accumulation."""
+    m = synth.torus_mesh(24, 16)
+    import bench
+    batch = bench.build_mesh_batch(m, torch.device(DEV), 5)
+    torch.manual_seed(11)
+    net = SingleScaleGCN(DEV).to(DEV)
+    ref = copy.deepcopy(net)
+    tr = train.SGCNTrainer(net, batch)
+    assert tr.grads.whole() is not None and tr.grads.flat.numel() == sum(p.numel() for p in net.parameters())
+    assert all(p.grad.data_ptr() >= tr.grads.flat.data_ptr() for p in net.parameters())
+    opt = torch.optim.Adam(ref.parameters(), lr=0.01)
+    helper = train.SGCNTrainer.__new__(train.SGCNTrainer)
+    helper.mesh, helper.k1, helper.k2 = batch, 4.0, 0.0
+    ref.train()
+    for it in range(10):
+        loss_a = tr.iteration_step()
+        dm = batch.v_keep * batch.dummy_masks[:, it % 5:it % 5 + 1]
+        loss_b = train.SGCNTrainer.loss(helper, ref(batch.data, dm))
+        loss_b.backward()
+        if (it + 1) % 5 == 0:
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        assert torch.equal(loss_a, loss_b.detach()), it
+    for (n, pa), (_, pb) in zip(net.named_parameters(), ref.named_parameters()):
+        assert torch.equal(pa, pb), n

@@ -35,7 +35,7 @@ def main():
     rows = []
     for dt in (torch.float32, torch.bfloat16):
         s = 4 if dt == torch.float32 else 2
-        for C in (16, 64, 256, 512):
+        for C in (16, 32, 64, 128, 256, 512):
             X = torch.randn(V, C, device="cuda").to(dt)
             dA = torch.randn(V, C, device="cuda").to(dt)
             vec = [torch.rand(C, device="cuda") + 0.5 for _ in range(7)]
