@@ -7,6 +7,7 @@ or a tensor is not on a HIP device, the call raises -- it never falls back.
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 from typing import Optional
@@ -166,38 +167,41 @@ def _require_device(t: torch.Tensor, name: str):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_current_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
-def _stream(t: torch.Tensor) -> c_void_p:
+def _stream(t: torch.Tensor) -> int:
     """hipStream_t of torch's CURRENT stream on the tensor's device (looked up on every launch: a
     caller may have switched streams; the raw accessor costs ~0.3 us against ~5 us for the Stream object)."""
     if _raw_stream is not None:
         idx = t.device.index
-        return c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
-    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        return _raw_stream(_current_device() if idx is None else idx)
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
-class _on_device:
-    """``torch.cuda.device(dev)`` only when ``dev`` is not already current (the context manager costs
-    ~10 us of host time per call, which matters at ~700 launches per training iteration)."""
-    __slots__ = ("_ctx",)
-
-    def __init__(self, device: torch.device):
-        idx = device.index
-        self._ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(device)
+class _NoGuard:
+    __slots__ = ()
 
     def __enter__(self):
-        if self._ctx is not None:
-            self._ctx.__enter__()
+        return None
 
     def __exit__(self, *exc):
-        if self._ctx is not None:
-            self._ctx.__exit__(*exc)
         return False
 
 
-def _ptr(t: Optional[torch.Tensor]) -> c_void_p:
-    return c_void_p(0 if t is None else t.data_ptr())
+_NO_GUARD = _NoGuard()
+
+
+def _on_device(device: torch.device):
+    """``torch.cuda.device(dev)`` only when ``dev`` is not already current (the context manager costs
+    ~10 us of host time per call, which matters at ~500 launches per training iteration)."""
+    idx = device.index
+    return _NO_GUARD if (idx is None or idx == _current_device()) else torch.cuda.device(device)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device address for a ``c_void_p`` argument (ctypes takes the int as it is; None = NULL)."""
+    return None if t is None else t.data_ptr()
 
 
 def _rows2d(t: torch.Tensor, name: str) -> int:
@@ -288,6 +292,38 @@ class GraphHandle:
              beta: float = 0.0, X1: Optional[torch.Tensor] = None, gamma: float = 0.0,
              transpose: bool = False) -> torch.Tensor:
         """Y = alpha * op(L^) X + beta * X0 + gamma * X1 (in place into Y)."""
+        # Fast path (~50 calls per training iteration, host-bound on small meshes): the common, well-formed call is
+        # recognised with a handful of attribute reads and handed to the library with plain ints; anything else --
+        # including every malformed call -- goes through _spmm_checked, which raises the precise error.
+        if _timer is None and X.is_cuda and X.dim() == 2 and Y.dim() == 2 and X.device.index == _current_device():
+            dt = X.dtype
+            code = _DTYPES.get(dt)
+            C = X.shape[1]
+            n_in, n_out = (self.num_rows, self.num_cols) if transpose else (self.num_cols, self.num_rows)
+            sx, sy = X.stride(), Y.stride()
+            ok = (code is not None and X.shape[0] == n_in and Y.dtype == dt and Y.device == X.device and Y.shape[0] == n_out
+                  and Y.shape[1] == C and (C <= 1 or (sx[1] == 1 and sy[1] == 1)))
+            p0 = l0 = p1 = l1 = 0
+            if ok and X0 is not None:
+                s0 = X0.stride()
+                ok = (X0.dtype == dt and X0.device == X.device and X0.dim() == 2 and X0.shape[0] == n_out and X0.shape[1] == C
+                      and (C <= 1 or s0[1] == 1))
+                p0, l0 = X0.data_ptr(), (s0[0] if n_out > 1 else max(s0[0], C))
+            if ok and X1 is not None:
+                s1 = X1.stride()
+                ok = (X1.dtype == dt and X1.device == X.device and X1.dim() == 2 and X1.shape[0] == n_out and X1.shape[1] == C
+                      and (C <= 1 or s1[1] == 1))
+                p1, l1 = X1.data_ptr(), (s1[0] if n_out > 1 else max(s1[0], C))
+            if ok and _raw_stream is not None:
+                rc = _lib.sg_spmm(self._h, 1 if transpose else 0, X.data_ptr(), sx[0] if n_in > 1 else max(sx[0], C),
+                                  p0, l0, p1, l1, Y.data_ptr(), sy[0] if n_out > 1 else max(sy[0], C), C, code,
+                                  alpha, beta, gamma, _raw_stream(X.device.index))
+                if rc:
+                    _check(rc, "sg_spmm")
+                return Y
+        return self._spmm_checked(X, Y, alpha, X0, beta, X1, gamma, transpose)
+
+    def _spmm_checked(self, X, Y, alpha, X0, beta, X1, gamma, transpose) -> torch.Tensor:
         for t, n in ((X, "X"), (Y, "Y"), (X0, "X0"), (X1, "X1")):
             if t is not None:
                 _require_device(t, n)
@@ -397,6 +433,15 @@ TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB, TUNE_TILED_MIN_ROW_BYTES, T
 def tuning_set(knob: int, value: int) -> None:
     """Launch tuning of the aggregation kernel (benchmarking aid; results do not depend on it)."""
     _check(load().sg_tuning_set(int(knob), int(value)), "sg_tuning_set")
+    _sizes.cache_clear()          # the GEMM tile knob changes sg_gemm_tile_rows / sg_gemm_row_tiles
+
+
+@functools.lru_cache(maxsize=512)
+def _sizes(fn: str, *args: int) -> int:
+    """The library's buffer-sizing rules (sg_col_blocks, sg_gemm_tn_slabs, ...): pure functions of their integer
+    arguments (and of the tuning knobs: cleared by tuning_set), asked ~100 times per training iteration with the same
+    few arguments -- answered from a cache instead of a foreign call each."""
+    return int(getattr(load(), fn)(*args))
 
 
 def gather_rows(rows: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -417,7 +462,7 @@ def gather_rows(rows: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor]
 
 # ---- BatchNorm(+LeakyReLU) over the vertex axis -------------------------------------------------
 def col_blocks(num_rows: int) -> int:
-    return int(load().sg_col_blocks(int(num_rows)))
+    return _sizes("sg_col_blocks", int(num_rows))
 
 
 def _f32vec(t: torch.Tensor, n: int, name: str) -> torch.Tensor:
@@ -427,13 +472,13 @@ def _f32vec(t: torch.Tensor, n: int, name: str) -> torch.Tensor:
     return t
 
 
-def _counter(t: Optional[torch.Tensor], like: torch.Tensor) -> c_void_p:
+def _counter(t: Optional[torch.Tensor], like: torch.Tensor) -> Optional[int]:
     """Device pointer of nn.BatchNorm1d's ``num_batches_tracked`` (an int64 scalar) -- incremented by the finalize launch."""
     if t is None:
-        return c_void_p(0)
+        return None
     if t.dtype != torch.int64 or t.numel() != 1 or t.device != like.device:
         raise SemigcnLibraryError("num_batches_tracked must be an int64 scalar on the device of the statistics")
-    return c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def col_moments(X: torch.Tensor) -> torch.Tensor:
@@ -530,7 +575,7 @@ def bn_stats_finalize_tiles(partial: torch.Tensor, rows_per_tile: int, num_rows:
 # ---- dense feature x weight product on the matrix cores ------------------------------------------
 def gemm_tile_rows(N: int) -> int:
     """Rows per output tile (and per BatchNorm-moments record) of an N-column sg_gemm_nt product."""
-    return int(load().sg_gemm_tile_rows(int(N)))
+    return _sizes("sg_gemm_tile_rows", int(N))
 
 
 def gemm_nt_supported(A: torch.Tensor, B: torch.Tensor, ldc: int) -> bool:
@@ -561,7 +606,7 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
         _f32vec(bias, N, "bias")
     mom = None
     if moments:
-        mom = torch.empty((int(load().sg_gemm_row_tiles(M, N)), 2, N), dtype=torch.float32, device=A.device)
+        mom = torch.empty((_sizes("sg_gemm_row_tiles", M, N), 2, N), dtype=torch.float32, device=A.device)
     with _on_device(A.device):
         _check(load().sg_gemm_nt(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), _ptr(bias), _ptr(out),
                                  _rows2d(out, "out"), M, N, K, SG_BF16, _ptr(mom), _stream(A)), "sg_gemm_nt")
@@ -587,7 +632,7 @@ def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     if B.shape[0] != M:
         raise SemigcnLibraryError(f"gemm_tn shape mismatch: A {tuple(A.shape)} B {tuple(B.shape)}")
     out = torch.empty((N, Kp), dtype=torch.float32, device=A.device)
-    ws = torch.empty((int(load().sg_gemm_tn_slabs(M, N, Kp)), N, Kp), dtype=torch.float32, device=A.device)
+    ws = torch.empty((_sizes("sg_gemm_tn_slabs", M, N, Kp), N, Kp), dtype=torch.float32, device=A.device)
     with _on_device(A.device):
         _check(load().sg_gemm_tn(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), M, N, Kp, SG_BF16, _ptr(ws), _ptr(out),
                                  Kp, _stream(A)), "sg_gemm_tn")
@@ -692,7 +737,7 @@ def bn_act_bwd_apply_colsum(dA, H, scale, shift, mean, invstd, k, c1, c2, slope:
     front of the BatchNorm), or ``(dH, None)`` when the shape is not served by the row-owning kernel."""
     _require_device(dA, "dA")
     V, C = H.shape
-    nb = int(load().sg_col_apply_blocks(V, C, dtype_code(H)))
+    nb = _sizes("sg_col_apply_blocks", V, C, dtype_code(H))
     dH = torch.empty((V, C), dtype=H.dtype, device=H.device) if out is None else out
     strides_ok = all(_rows2d(t, "operand") % 4 == 0 for t in (dA, H, dH))
     if nb == 0 or not strides_ok:
@@ -722,7 +767,7 @@ def mesh_loss_fwd(pos, faces, target_pos, v_keep, target_fn, f_keep) -> torch.Te
     V, F = target_pos.shape[0], faces.shape[0]
     if faces.dtype != torch.int64 or not faces.is_contiguous():
         raise SemigcnLibraryError("faces must be contiguous int64 [F, 3]")
-    nb = int(load().sg_mesh_loss_blocks(V, F))
+    nb = _sizes("sg_mesh_loss_blocks", V, F)
     part = torch.empty((nb, 2), dtype=torch.float32, device=pos.device)
     with _on_device(pos.device):
         _check(load().sg_mesh_loss_fwd(_ptr(_f32c(pos, "pos")), _ptr(faces), _ptr(_f32c(target_pos, "target_pos")),

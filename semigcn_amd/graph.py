@@ -25,6 +25,8 @@ class MeshGraph:
         self.handle = handle
         self.num_vertices = num_vertices
         self.num_edges = num_edges  # directed, as given (self-loops included)
+        if type(self).aggregate is MeshGraph.aggregate:
+            self.aggregate = handle.spmm       # the bound method itself: one Python frame less per launch
 
     @classmethod
     def from_edge_index(cls, edge_index: torch.Tensor, num_vertices: int) -> "MeshGraph":
