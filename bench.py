@@ -54,6 +54,9 @@ def parse():
                          "`fp32_features` / `bf16_features`")
     ap.add_argument("--single-dtype", action="store_true", help="skip the second run at the other precision")
     ap.add_argument("--permute", action="store_true", help="random vertex order (raw-scan like)")
+    ap.add_argument("--partitioned", action="store_true",
+                    help="diagnostic, --gpus 1 only: run the partitioned code path on ONE rank with every collective issued "
+                         "through RCCL (what a rank of an N-rank job does; not a scaling point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="250x200", help="torus for the CPU baseline sample")
     ap.add_argument("--cpu-full", action="store_true",
@@ -213,12 +216,16 @@ def cpu_baseline(sample: str, full_V: int, budget_s: float = 25.0, full: bool = 
     return out
 
 
+#: the partitioned code path is in use (N > 1 ranks, or --partitioned on one rank)
+DIST_ON = False
+
+
 def build_trainer(args, dtype, device, world, rank, mesh):
     """(trainer, workload string, edge-aggregations per iteration) for one feature dtype."""
     from semigcn_amd import synth, train
     from semigcn_amd.networks import SingleScaleGCN
     nu, nv = map(int, args.mesh.split("x"))
-    if world > 1 and args.model == "sgcn":
+    if DIST_ON and args.model == "sgcn":
         from semigcn_amd import dist as sgdist
         job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh)
         return job.trainer, job.workload, AGG_PER_ITER * mesh.num_edges
@@ -258,7 +265,7 @@ def timed_run(trainer, args, device, world, with_timer: bool):
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if DIST_ON:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize(device)
@@ -270,7 +277,7 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     timer = capi.LaunchTimer() if with_timer else None
     sync()
     capi.set_launch_timer(timer)
-    if world > 1:
+    if DIST_ON:
         from semigcn_amd import dist as sgdist
         c0 = dict(sgdist.collective_counts)
     t0 = time.perf_counter()
@@ -279,9 +286,9 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     sync()
     dt = time.perf_counter() - t0
     capi.set_launch_timer(None)
-    if world > 1:
+    if DIST_ON:
         timed_run.collectives = {k: (v - c0[k]) / args.steps for k, v in sgdist.collective_counts.items()}
-    if world > 1:
+    if DIST_ON:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         if dist.get_backend() == "gloo":
@@ -304,7 +311,7 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
         # launches that compute a rank's whole block (N > 1 also has row-subset launches for the overlap with the halo
         # exchange: interior rows / boundary + ring-1 rows; they are left out of the per-kernel roofline)
         full_rows = max(r for (_, _, _, r) in results) if results else 0
-        if world > 1 and results:
+        if DIST_ON and results:
             g = getattr(getattr(trainer, "part", None), "graph", None)
             if g is not None:
                 full_rows = g.n_own
@@ -313,9 +320,9 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
                 full_rows = Counter(r for (_, _, _, r), t in results.items() for _ in t).most_common(1)[0][0]
         merged = {}
         for (C, dt_name, n_epi, rows), times in results.items():
-            if world == 1 or rows == full_rows:
+            if not DIST_ON or rows == full_rows:
                 merged.setdefault((C, dt_name, n_epi), []).extend(times)
-        if world > 1:
+        if DIST_ON:
             V_local, E_local = full_rows, int(E_total * full_rows / max(V_total, 1))
         for (C, dt_name, n_epi), times in sorted(merged.items(), key=lambda kv: -sum(kv[1])):
             mean_ms = float(np.mean(times))
@@ -327,7 +334,7 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
         total_t = sum(k["total_ms"] for k in kernels)
         dom = kernels[0]
         traffic = pmc_traffic(dom["C"], dom["dtype"], dom["epilogue_operands"], elem) if (
-            world == 1 and (nu, nv) == (1000, 1000) and not args.permute) else None
+            not DIST_ON and (nu, nv) == (1000, 1000) and not args.permute) else None
         roof = {"bound": "hbm", "kernel": f"sg::{aggregation_kernel_name(dom['C'], elem, dom['epilogue_operands'])} C={dom['C']} "
                                           f"{dom['dtype']} (+{dom['epilogue_operands']} epilogue operands)",
                 "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -346,11 +353,17 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
             "roofline": roof, "aggregation_kernels": kernels}
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  Runs BEFORE this process has
     made any HIP call (torch.cuda.device_count() does not initialise the GPU on this image); the ranks are child
     processes of `python -m torch.distributed.run`, nothing is exec'ed over a process that touched the GPU."""
-    import socket
     import subprocess
     shared = os.environ.get("SEMIGCN_BENCH_SHARE_GPU") == "1"
     n_dev = torch.cuda.device_count()
@@ -359,9 +372,7 @@ def spawn_ranks(args) -> int:
               "ranks (SEMIGCN_BENCH_SHARE_GPU=1 runs the N-rank code path on one device over gloo as a self-test)",
               file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -392,12 +403,23 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    global DIST_ON
+    DIST_ON = world > 1 or args.partitioned
+    if args.partitioned and world == 1:
+        # diagnostic: ONE rank runs the partitioned code path -- its own [owned | halo] operators, mesh-wide BatchNorm,
+        # and every collective issued through RCCL although each is the identity (what a rank of an N-rank job does on
+        # the host, measurable on a one-GPU box); its number is not a scaling point
+        from semigcn_amd import dist as sgdist
+        sgdist.FORCE_COLLECTIVES = True
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if DIST_ON:
         import torch.distributed as dist
         if shared:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     from semigcn_amd import capi, synth
     capi.load()
@@ -406,7 +428,7 @@ def main():
     mesh = synth.torus_mesh(nu, nv, permute=args.permute)
     log(f"mesh generated V={mesh.num_vertices} E={mesh.num_edges}")
     dtypes = {"fp32": torch.float32, "bf16": torch.bfloat16}
-    if args.graph and (world > 1 or args.warmup < 4):
+    if args.graph and (DIST_ON or args.warmup < 4):
         raise SystemExit("--graph: single GPU only, and --warmup must be >= 4 (3 eager iterations + the capture)")
     with_timer = not args.no_launch_timer and args.model == "sgcn" and not args.graph   # byte accounting assumes the finest mesh only
 
@@ -417,7 +439,7 @@ def main():
     log(f"timed region done: {main_res['ms_per_step']:.2f} ms/iteration ({args.dtype})")
 
     other = None
-    if world == 1 and args.model == "sgcn" and not args.single_dtype:
+    if not DIST_ON and args.model == "sgcn" and not args.single_dtype:
         # the same workload at the other feature precision, for the record (never `value`)
         del trainer
         torch.cuda.empty_cache()
@@ -454,19 +476,20 @@ def main():
         }
         if other is not None:
             line["fp32_features" if other["dtype"] == "f32" else "bf16_features"] = other
-        if world > 1:
+        if DIST_ON:
             import torch.distributed as dist
             g = trainer.part.graph if hasattr(trainer, "part") and hasattr(trainer.part, "graph") else None
             coll = getattr(timed_run, "collectives", {})
             line["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                                    "devices_visible": torch.cuda.device_count(), "ranks_share_one_gpu": shared,
+                                   "single_rank_diagnostic": bool(args.partitioned and world == 1),
                                    "collectives_per_iteration": round(sum(coll.values()), 1), "collectives_by_kind": coll,
                                    "rank0_owned_rows": None if g is None else g.n_own,
                                    "rank0_halo_rows": None if g is None else g.n_halo}
         line["cpu_baseline"] = cpu_baseline(args.cpu_sample, mesh.num_vertices, full=args.cpu_full) if (
-            world == 1 and not args.no_cpu_baseline) else None
+            not DIST_ON and not args.no_cpu_baseline) else None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if DIST_ON:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

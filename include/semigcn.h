@@ -203,6 +203,10 @@ SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t
  * num_batches_tracked scalar on the device, incremented by the same launch.
  * acc_dweight / acc_dbias (sg_bn_bwd_coeffs; may be NULL): float32 [C] gradient accumulators of the BatchNorm weight and
  * bias (their .grad): += out[1] / += out[0] in the same launch, instead of one autograd add per parameter.
+ * count_dev (sg_bn_bwd_coeffs; may be NULL): the row count N as a float32 scalar ON THE DEVICE (sg_bn_finalize_ranks'
+ * out_n), used instead of the host value N -- a vertex partition calls the kernel once on its partials (nb blocks: the
+ * local sums, out[0..1]) and, after the all-reduce of those sums, once more with them as a single block (nb = 1) for
+ * c1, c2 and k of the whole mesh.
  * ------------------------------------------------------------------------- */
 /* sg_bn_act_bwd_apply that also leaves colsum[c] = sum over rows of the dH it wrote (as stored) -- the bias gradient of
  * the ChebConv in front of the BatchNorm (autograd of `out += bias`, [3P] ChebConv.forward): no separate pass over dH.
@@ -221,7 +225,13 @@ SG_API int sg_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                 float* out, int64_t* batches_tracked, void* stream);
 SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
-                            const float* invstd, float* out, float* acc_dweight, float* acc_dbias, void* stream);
+                            const float* invstd, float* out, float* acc_dweight, float* acc_dbias, const float* count_dev,
+                            void* stream);
+/* sg_bn_merge for partials cut into uniform tiles of rows_per_tile rows (sg_col_moments' blocks: ceil(V / nb); the per-tile
+ * moments of sg_gemm_nt: sg_gemm_tile_rows(N)); count_out (may be NULL): [1] = (float)V -- together with stats [2, C] the
+ * (mean, M2, row count) row a rank contributes to the all-gather of a vertex-partitioned BatchNorm. */
+SG_API int sg_bn_merge_tiles(const float* partial, int64_t n_tiles, int64_t rows_per_tile, int64_t V, int64_t C, float* stats,
+                             float* count_out, void* stream);
 SG_API int sg_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* out,
                                 float* out_n, int64_t* batches_tracked, void* stream);

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+from array import array as _array
 import os
 from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 from typing import Optional
@@ -72,7 +73,8 @@ _SIGNATURES = {
     "sg_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
                            c_void_p]),
     "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p]),
+    "sg_bn_merge_tiles": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sg_multi_add": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_bn_finalize_ranks": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -502,6 +504,21 @@ def bn_merge(partial: torch.Tensor, num_rows: int, out: Optional[torch.Tensor] =
     return stats
 
 
+def bn_local_stats(partial: torch.Tensor, rows_per_tile: int, num_rows: int, out: torch.Tensor) -> torch.Tensor:
+    """``out`` (2C + 1 contiguous floats) = (mean[C], M2[C], row count) of this device's rows from per-tile moments -- the
+    blocks of col_moments (``rows_per_tile = 0``) or the tiles sg_gemm_nt emits: the row a rank contributes to the
+    all-gather of a vertex-partitioned BatchNorm, in one launch."""
+    nb, _, C = partial.shape
+    if out.dtype != torch.float32 or out.numel() != 2 * C + 1 or not out.is_contiguous():
+        raise SemigcnLibraryError(f"bn_local_stats: out must hold 2C + 1 = {2 * C + 1} contiguous floats")
+    rpt = int(rows_per_tile) if rows_per_tile else (int(num_rows) + nb - 1) // nb
+    base = out.data_ptr()
+    with _on_device(partial.device):
+        _check(load().sg_bn_merge_tiles(_ptr(partial), nb, rpt, int(num_rows), C, base, base + 8 * C, _stream(partial)),
+               "sg_bn_merge_tiles")
+    return out
+
+
 def bn_finalize(stats: torch.Tensor, count: float, gamma: torch.Tensor, beta: torch.Tensor,
                 running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], momentum: float,
                 eps: float) -> torch.Tensor:
@@ -639,11 +656,17 @@ def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def bn_bwd_coeffs(partial: torch.Tensor, count: float, gamma: torch.Tensor, invstd: torch.Tensor,
+def bn_bwd_coeffs(partial: torch.Tensor, count, gamma: torch.Tensor, invstd: torch.Tensor,
                   acc_dweight: Optional[torch.Tensor] = None, acc_dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[5, C] = (sum dz, sum dz*xhat, c1, c2, k) from the partials of bn_act_bwd_reduce.  ``acc_dweight`` / ``acc_dbias``:
-    fp32 [C] gradient accumulators (the parameters' .grad), += sum dz*xhat / += sum dz by the same launch."""
+    fp32 [C] gradient accumulators (the parameters' .grad), += sum dz*xhat / += sum dz by the same launch.  ``count``:
+    the row count N, a number -- or a float32 device scalar (a partition's mesh-wide count, bn_finalize_ranks' second result)."""
     nb, _, C = partial.shape
+    count_dev = None
+    if isinstance(count, torch.Tensor):
+        if count.dtype != torch.float32 or count.numel() != 1 or count.device != partial.device:
+            raise SemigcnLibraryError("bn_bwd_coeffs: a device count must be one float32 on the device of the partials")
+        count_dev, count = count, 0.0
     out = torch.empty((5, C), dtype=torch.float32, device=partial.device)
     for t, n in ((acc_dweight, "acc_dweight"), (acc_dbias, "acc_dbias")):
         if t is not None:
@@ -651,7 +674,7 @@ def bn_bwd_coeffs(partial: torch.Tensor, count: float, gamma: torch.Tensor, invs
     with _on_device(partial.device):
         _check(load().sg_bn_bwd_coeffs(_ptr(partial), nb, C, float(count), _ptr(_f32vec(gamma, C, "weight")),
                                        _ptr(_f32vec(invstd, C, "invstd")), _ptr(out), _ptr(acc_dweight), _ptr(acc_dbias),
-                                       _stream(partial)), "sg_bn_bwd_coeffs")
+                                       _ptr(count_dev), _stream(partial)), "sg_bn_bwd_coeffs")
     return out
 
 
@@ -661,32 +684,43 @@ MULTI_ADD_MAX = 8
 def multi_add(srcs, dsts) -> None:
     """``dsts[i] += srcs[i]`` for small fp32 matrices / vectors in one launch per 8 (sg_multi_add): ``dsts`` contiguous,
     ``srcs`` of the same shapes with unit inner stride (column or row blocks of a wider matrix are fine)."""
-    if len(srcs) != len(dsts):
+    n_all = len(srcs)
+    if n_all != len(dsts):
         raise SemigcnLibraryError("multi_add: one destination per source")
-    items = []
+    if n_all == 0:
+        return
+    f32 = torch.float32
+    sp, dp, ld, rows, cols = [], [], [], [], []
+    dev = dsts[0].device
     for s, d in zip(srcs, dsts):
-        _require_device(d, "dst")
-        if s.dtype != torch.float32 or d.dtype != torch.float32 or s.shape != d.shape or s.device != d.device \
-                or not d.is_contiguous() or s.dim() not in (1, 2):
-            raise SemigcnLibraryError(f"multi_add: need float32 pairs of one shape (1-D or 2-D) with a contiguous destination, "
-                                      f"got {s.dtype} {tuple(s.shape)} -> {d.dtype} {tuple(d.shape)}")
-        if s.dim() == 1:
-            if s.numel() > 1 and s.stride(0) != 1:
+        nd = s.dim()
+        if s.dtype != f32 or d.dtype != f32 or s.shape != d.shape or s.device != dev or d.device != dev \
+                or not d.is_cuda or not d.is_contiguous() or nd not in (1, 2):
+            raise SemigcnLibraryError(f"multi_add: need float32 pairs of one shape (1-D or 2-D) on one HIP device with a "
+                                      f"contiguous destination, got {s.dtype} {tuple(s.shape)} -> {d.dtype} {tuple(d.shape)}")
+        st = s.stride()
+        if nd == 1:
+            if st[0] != 1 and s.shape[0] > 1:
                 s = s.contiguous()
-            items.append((s, d, 1, s.numel(), s.numel()))
+            r, c, l = 1, s.shape[0], s.shape[0]
         else:
-            if s.shape[1] > 1 and s.stride(1) != 1:
+            r, c = s.shape
+            if st[1] != 1 and c > 1:
                 s = s.contiguous()
-            items.append((s, d, s.shape[0], s.shape[1], _rows2d(s, "src")))
+                st = s.stride()
+            l = st[0] if r > 1 else max(st[0], c)
+        sp.append(s.data_ptr()); dp.append(d.data_ptr()); ld.append(l); rows.append(r); cols.append(c)
     lib = load()
-    for at in range(0, len(items), MULTI_ADD_MAX):
-        chunk = items[at:at + MULTI_ADD_MAX]
-        n = len(chunk)
-        vp, i64 = c_void_p * n, c_int64 * n
-        with _on_device(chunk[0][1].device):
-            _check(lib.sg_multi_add(n, vp(*[c[0].data_ptr() for c in chunk]), i64(*[c[4] for c in chunk]),
-                                    i64(*[c[2] for c in chunk]), i64(*[c[3] for c in chunk]),
-                                    vp(*[c[1].data_ptr() for c in chunk]), _stream(chunk[0][1])), "sg_multi_add")
+    stream = _stream(dsts[0])
+    with _on_device(dev):
+        for at in range(0, n_all, MULTI_ADD_MAX):
+            n = min(MULTI_ADD_MAX, n_all - at)
+            # one small host array of 5 n 64-bit words: [src pointers | row strides | rows | cols | dst pointers]
+            pack = _array("q", sp[at:at + n] + ld[at:at + n] + rows[at:at + n] + cols[at:at + n] + dp[at:at + n])
+            base = pack.buffer_info()[0]
+            rc = lib.sg_multi_add(n, base, base + 8 * n, base + 16 * n, base + 24 * n, base + 32 * n, stream)
+            if rc:
+                _check(rc, "sg_multi_add")
 
 
 def scale_shift_act(X: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, slope: float,

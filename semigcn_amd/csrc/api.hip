@@ -475,6 +475,12 @@ SG_API int sg_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, f
   return launch_bn_merge(partial, nb, V, C, stats, (hipStream_t)stream);
 }
 
+SG_API int sg_bn_merge_tiles(const float* partial, int64_t n_tiles, int64_t rows_per_tile, int64_t V, int64_t C, float* stats,
+                             float* count_out, void* stream) {
+  SG_REQUIRE(V > 0 && C >= 0 && partial && stats, "sg_bn_merge_tiles: bad argument");
+  return launch_bn_merge_tiles(partial, n_tiles, rows_per_tile, V, C, stats, count_out, (hipStream_t)stream);
+}
+
 SG_API int sg_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_t C, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                 float* out, int64_t* batches_tracked, void* stream) {
@@ -527,9 +533,10 @@ SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, in
 }
 
 SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
-                            const float* invstd, float* out, float* acc_dweight, float* acc_dbias, void* stream) {
-  SG_REQUIRE(nb > 0 && C >= 0 && N > 0 && partial && gamma && invstd && out, "sg_bn_bwd_coeffs: bad argument");
-  return launch_bn_bwd_coeffs(partial, nb, C, N, gamma, invstd, out, acc_dweight, acc_dbias, (hipStream_t)stream);
+                            const float* invstd, float* out, float* acc_dweight, float* acc_dbias, const float* count_dev,
+                            void* stream) {
+  SG_REQUIRE(nb > 0 && C >= 0 && (N > 0 || count_dev) && partial && gamma && invstd && out, "sg_bn_bwd_coeffs: bad argument");
+  return launch_bn_bwd_coeffs(partial, nb, C, N, gamma, invstd, out, acc_dweight, acc_dbias, count_dev, (hipStream_t)stream);
 }
 
 SG_API int sg_multi_add(int64_t n, const float* const* srcs, const int64_t* src_ld, const int64_t* rows, const int64_t* cols,

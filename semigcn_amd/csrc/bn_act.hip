@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void colsum_finalize(const float* __restrict__
 // stats[0][c] = mean, stats[1][c] = M2 over all V rows, from the per-block partials (Chan et al.,
 // in double).  One wavefront per channel: each lane merges every 64th block, then a shuffle tree merges lanes.
 __global__ __launch_bounds__(256) void bn_merge(const float* __restrict__ partial, int64_t nb, int64_t V, int C,
-                                                int rpb, float* __restrict__ stats) {
+                                                int rpb, float* __restrict__ stats, float* count_out) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   double n = 0.0, mean = 0.0, m2 = 0.0;
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void bn_merge(const float* __restrict__ partia
   if (c < C && lane == 0) {
     stats[c] = (float)mean;
     stats[C + c] = (float)m2;
+    if (count_out && c == 0) count_out[0] = (float)V;      // the row count rides along (a partition's all-gather row)
   }
 }
 
@@ -466,7 +467,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
 __global__ __launch_bounds__(256) void bn_bwd_coeffs(const float* __restrict__ partial, int64_t nb, int C, double N,
                                                      const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                      float* __restrict__ out /*[5][C]*/, float* acc_dweight,
-                                                     float* acc_dbias) {
+                                                     float* acc_dbias, const float* __restrict__ count_dev) {
+  if (count_dev) N = (double)count_dev[0];       // the mesh-wide row count of a partition, kept on the device
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   double s0 = 0.0, s1 = 0.0;
@@ -580,7 +582,16 @@ int launch_bn_merge(const float* partial, int64_t nb, int64_t V, int64_t C, floa
   if (C == 0) return SG_OK;
   SG_REQUIRE(nb == col_blocks(V), "partial buffer must have sg_col_blocks(V) blocks");
   const int rpb = (int)((V + nb - 1) / nb);
-  bn_merge<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, stats);
+  bn_merge<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, V, (int)C, rpb, stats, nullptr);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int launch_bn_merge_tiles(const float* partial, int64_t nb, int64_t rpb, int64_t V, int64_t C, float* stats,
+                          float* count_out, hipStream_t stream) {
+  if (C == 0) return SG_OK;
+  SG_REQUIRE(rpb > 0 && rpb <= INT32_MAX && nb == (V + rpb - 1) / rpb, "partial buffer must have ceil(V / rows_per_tile) tiles");
+  bn_merge<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, V, (int)C, (int)rpb, stats, count_out);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
@@ -631,9 +642,11 @@ int launch_multi_add(int n, const float* const* srcs, const int64_t* src_ld, con
 }
 
 int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
-                         const float* invstd, float* out, float* acc_dweight, float* acc_dbias, hipStream_t stream) {
+                         const float* invstd, float* out, float* acc_dweight, float* acc_dbias, const float* count_dev,
+                         hipStream_t stream) {
   if (C == 0) return SG_OK;
-  bn_bwd_coeffs<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out, acc_dweight, acc_dbias);
+  bn_bwd_coeffs<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out, acc_dweight, acc_dbias,
+                                                        count_dev);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

@@ -131,7 +131,10 @@ int launch_bn_stats_finalize(const float* partial, int64_t nb, int64_t V, int64_
                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                              float* out, int64_t* batches_tracked, hipStream_t stream);
 int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, const float* gamma,
-                         const float* invstd, float* out, float* acc_dweight, float* acc_dbias, hipStream_t stream);
+                         const float* invstd, float* out, float* acc_dweight, float* acc_dbias, const float* count_dev,
+                         hipStream_t stream);
+int launch_bn_merge_tiles(const float* partial, int64_t nb, int64_t rpb, int64_t V, int64_t C, float* stats,
+                          float* count_out, hipStream_t stream);
 int launch_bn_finalize_ranks(const float* all, int64_t world, int64_t C, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, float* out,
                              float* out_n, int64_t* batches_tracked, hipStream_t stream);

@@ -25,6 +25,7 @@ New design -- the reference is single-process, single-device and has no counterp
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -45,39 +46,123 @@ from . import reorder as _reorder
 #: collectives issued by this rank since import, by kind (bench.py reports the per-iteration count)
 collective_counts = {"all_reduce": 0, "all_gather": 0, "all_to_all": 0}
 
+#: SEMIGCN_DIST_FORCE_COLLECTIVES=1: a ONE-rank group issues every collective as well (normally skipped: with one rank
+#: they are the identity).  A self-test switch: on a box with a single GPU this is the only way to drive the RCCL code
+#: path -- communicator set-up, the asynchronous all-to-all and its stream wait, the statistics all-gather, the
+#: all-reduces -- through the real library (tests/test_gpu_scale.py).
+FORCE_COLLECTIVES = os.environ.get("SEMIGCN_DIST_FORCE_COLLECTIVES") == "1"
+
+
+def _solo(world: int) -> bool:
+    """True when collectives may be skipped: a single rank (and the self-test switch is off)."""
+    return world == 1 and not FORCE_COLLECTIVES
+
+
+_backend_of: dict = {}
+
+
+def _pg(group):
+    return group if group is not None else dist.distributed_c10d._get_default_group()
+
+
+def _backend(group) -> str:
+    """Backend name of ``group`` (None = WORLD), looked up once per group object."""
+    g = _pg(group)
+    ent = _backend_of.get(id(g))
+    if ent is None or ent[0] is not g:
+        if len(_backend_of) > 16:
+            _backend_of.clear()
+        ent = (g, dist.get_backend(group))
+        _backend_of[id(g)] = ent
+    return ent[1]
+
 
 def _staged(t: torch.Tensor, group) -> bool:
-    return t.is_cuda and dist.get_backend(group) == "gloo"
+    return t.is_cuda and _backend(group) == "gloo"
+
+
+# The collectives go to the ProcessGroup object directly (``allreduce`` / ``_allgather_base`` / ``alltoall_base``: what
+# torch.distributed's module-level functions call after their argument checks, logging wrapper and group lookups --
+# ~10-15 us of host time each, 57 times per partitioned iteration on a rank that is launch-bound).  DIRECT_PG = False
+# (or an older torch without these methods) uses the module-level functions.
+DIRECT_PG = os.environ.get("SEMIGCN_DIST_PUBLIC_API") != "1"
+_opts: dict = {}
+
+
+def _pg_all_reduce(t: torch.Tensor, op, group) -> None:
+    if DIRECT_PG:
+        try:
+            o = _opts.get(("ar", op))
+            if o is None:
+                o = dist.AllreduceOptions()
+                o.reduceOp = op
+                _opts[("ar", op)] = o
+            work = _pg(group).allreduce([t], o)
+        except (AttributeError, TypeError):
+            work = dist.all_reduce(t, op=op, group=group, async_op=True)
+        if work is not None:
+            work.wait()            # device tensors: the CURRENT stream waits for the collective, the host does not block
+        return
+    dist.all_reduce(t, op=op, group=group)
+
+
+def _pg_all_gather(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    if DIRECT_PG:
+        try:
+            work = _pg(group)._allgather_base(out, inp)
+        except (AttributeError, TypeError):
+            work = dist.all_gather_into_tensor(out, inp, group=group, async_op=True)
+        if work is not None:
+            work.wait()
+        return
+    dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _pg_all_to_all(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits, group):
+    """Starts the exchange and returns the Work handle (``.wait()``: the current stream waits)."""
+    if DIRECT_PG:
+        try:
+            o = _opts.get("a2a")
+            if o is None:
+                o = _opts["a2a"] = dist.AllToAllOptions()
+            return _pg(group).alltoall_base(recv, send, recv_splits, send_splits, o)
+        except (AttributeError, TypeError):
+            pass
+    return dist.all_to_all_single(recv, send, recv_splits, send_splits, group=group, async_op=True)
 
 
 def _all_reduce(t: torch.Tensor, op, group) -> None:
     collective_counts["all_reduce"] += 1
     if _staged(t, group):
         h = t.cpu()
-        dist.all_reduce(h, op=op, group=group)
+        _pg_all_reduce(h, op, group)
         t.copy_(h)
     else:
-        dist.all_reduce(t, op=op, group=group)
+        _pg_all_reduce(t, op, group)
 
 
 def _all_gather_rows(out: torch.Tensor, inp: torch.Tensor, group) -> None:
     collective_counts["all_gather"] += 1
     if _staged(inp, group):
         ho, hi = out.cpu(), inp.cpu()
-        dist.all_gather_into_tensor(ho, hi, group=group)
+        _pg_all_gather(ho, hi, group)
         out.copy_(ho)
     else:
-        dist.all_gather_into_tensor(out, inp, group=group)
+        _pg_all_gather(out, inp, group)
 
 
 def _all_to_all_rows(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits, group) -> None:
     collective_counts["all_to_all"] += 1
     if _staged(send, group):
         hr, hs = recv.cpu(), send.cpu()
-        dist.all_to_all_single(hr, hs, list(recv_splits), list(send_splits), group=group)
+        work = _pg_all_to_all(hr, hs, list(recv_splits), list(send_splits), group)
+        if work is not None:
+            work.wait()
         recv.copy_(hr)
     else:
-        dist.all_to_all_single(recv, send, list(recv_splits), list(send_splits), group=group)
+        work = _pg_all_to_all(recv, send, list(recv_splits), list(send_splits), group)
+        if work is not None:
+            work.wait()
 
 
 # --------------------------------------------------------------------------------------
@@ -98,7 +183,7 @@ class _RowExchange:
     ``send_splits, recv_splits`` (rows per peer)."""
 
     def _a2a(self, recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits):
-        if self.world == 1:
+        if _solo(self.world):
             return
         _all_to_all_rows(recv, send, recv_splits, send_splits, self.group)
 
@@ -111,16 +196,15 @@ class _RowExchange:
         """Start the exchange and return a token for ``exchange_end``.  Over RCCL the all-to-all is issued asynchronously
         (it runs on the communicator's stream behind the pack kernel), so kernels launched before ``exchange_end`` --
         the aggregation of the rows that read no halo row -- overlap with it; under gloo (host-staged) it completes here."""
-        if self.world == 1:
+        if _solo(self.world):
             return None                # (with world > 1 every rank takes part, even with an empty halo: it is a collective)
         own = blk_ext[:self.n_own]
         send = capi.gather_rows(self.send_rows, own)
         recv = torch.empty((self.n_halo, blk_ext.shape[1]), dtype=blk_ext.dtype, device=blk_ext.device)
         work = None
-        if send.is_cuda and dist.get_backend(self.group) != "gloo":
+        if send.is_cuda and _backend(self.group) != "gloo":
             collective_counts["all_to_all"] += 1
-            work = dist.all_to_all_single(recv, send, list(self.recv_splits), list(self.send_splits), group=self.group,
-                                          async_op=True)
+            work = _pg_all_to_all(recv, send, self.recv_splits, self.send_splits, self.group)
         else:
             self._a2a(recv, send, self.recv_splits, self.send_splits)
         return work, recv, send, blk_ext
@@ -135,7 +219,7 @@ class _RowExchange:
 
     def exchange_reverse_add(self, grad_halo: torch.Tensor, grad_own: torch.Tensor) -> None:
         """Adjoint of ``exchange``: halo-row gradients travel back to their owners and are added."""
-        if self.world == 1:
+        if _solo(self.world):
             return
         recv = torch.empty((self.n_send, grad_halo.shape[1]), dtype=grad_halo.dtype, device=grad_halo.device)
         self._a2a(recv, grad_halo.contiguous(), self.send_splits, self.recv_splits)
@@ -302,7 +386,7 @@ class DistMeshGraph(_RowExchange):
         """``exchange(X_blk)`` + ``aggregate_wide(X_ext, Y_ext)`` with the interior rows computed during the exchange.
         ``X_blk``: the column block(s) to exchange (its owned rows final); ``X_ext``: the block the operator reads
         (``X_blk`` or a column slice of it).  Epilogue operands in ``kw`` are read on owned / ring-1 rows only."""
-        if not self.overlap or self.world == 1:
+        if not self.overlap or _solo(self.world):
             self.exchange(X_blk)
             return self.aggregate_wide(X_ext, Y_ext, **kw)
         token = self.exchange_begin(X_blk)
@@ -350,7 +434,7 @@ class _AllReduceSum(torch.autograd.Function):
 
 
 def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or _solo(dist.get_world_size(group)):
         return x
     return _AllReduceSum.apply(x, group)
 
@@ -360,7 +444,7 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 class _DistChebConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, g: DistMeshGraph, cache, x, bias, *weights):
+    def forward(ctx, g: DistMeshGraph, cache, moments, x, bias, *weights):
         K, n = len(weights), g.n_own
         C = x.shape[1]
         from .functional import _wcat_pair, dense_nt
@@ -384,7 +468,7 @@ class _DistChebConvFn(torch.autograd.Function):
             for k in range(2, K):
                 g.exchange(blk[k - 1])
                 g.aggregate(blk[k - 1], blk[k][:n], alpha=2.0, X0=blk[k - 2][:n], beta=-1.0)
-        out = dense_nt(T[:n], wcat, bias)
+        out = dense_nt(T[:n], wcat, bias, moments=moments)    # (+ this rank's per-tile BatchNorm moments)
         ctx.g, ctx.K, ctx.C = g, K, C
         ctx.has_bias, ctx.param_dtype = bias is not None, weights[0].dtype
         ctx.wcat_t = wcat_t
@@ -398,9 +482,9 @@ class _DistChebConvFn(torch.autograd.Function):
         T, wcat = ctx.saved_tensors
         g, K, C, n = ctx.g, ctx.K, ctx.C, ctx.g.n_own
         dout = dout.contiguous()
-        need_x, need_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        need_x, need_b = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
         dws = [None] * K
-        if any(ctx.needs_input_grad[4:]):
+        if any(ctx.needs_input_grad[5:]):
             dwcat = weight_grad(dout, T[:n]).to(ctx.param_dtype)       # partial: summed over ranks later
             dws = [dwcat[:, k * C:(k + 1) * C] for k in range(K)]
         db = column_sums(dout).to(ctx.param_dtype) if (ctx.has_bias and need_b) else None
@@ -428,8 +512,8 @@ class _DistChebConvFn(torch.autograd.Function):
                     x1 = gk[2][:n] if K >= 3 else None
                     g.aggregate(gk[1], dx, alpha=1.0, X0=gk[0][:n], beta=1.0, X1=x1, gamma=-1.0)
         if dout.is_cuda and _sink(ctx.params, (db, *dws)):      # this rank's partial sums, straight into the .grad accumulators
-            return (None, None, dx) + (None,) * (K + 1)
-        return (None, None, dx, db, *dws)
+            return (None, None, None, dx) + (None,) * (K + 1)
+        return (None, None, None, dx, db, *dws)
 
 
 class _DistChebConvPostFn(torch.autograd.Function):
@@ -499,14 +583,14 @@ class _DistChebConvPostFn(torch.autograd.Function):
 
 
 def dist_cheb_conv(g: DistMeshGraph, x, weights, bias=None, cache=None, moments=None):
-    """``moments`` is accepted for signature parity with functional.cheb_conv and left empty: mesh-wide BatchNorm
-    statistics are merged across ranks from each rank's own moments pass."""
+    """``moments``: as in functional.cheb_conv -- filled with this rank's per-row-tile moments when the layer's last step
+    is the MFMA product; the mesh-wide BatchNorm behind it merges them with the other ranks' (functional._BNActFn)."""
     from . import functional as F_sg
     if x.shape[0] != g.n_own:
         raise ValueError(f"x has {x.shape[0]} rows but this rank owns {g.n_own} vertices")
     if F_sg.AGGREGATE_AFTER_GEMM_WHEN_NARROWING and len(weights) >= 2 and weights[0].shape[0] < weights[0].shape[1]:
         return _DistChebConvPostFn.apply(g, cache, x, bias, *weights)
-    return _DistChebConvFn.apply(g, cache, x, bias, *weights)
+    return _DistChebConvFn.apply(g, cache, moments, x, bias, *weights)
 
 
 # --------------------------------------------------------------------------------------
@@ -560,7 +644,7 @@ class DistBatchNorm1d(nn.BatchNorm1d):
     sg_mesh_wide = True      # functional.bn_act merges the moments across ranks for these modules
 
     def forward(self, x):
-        if not self.training or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not self.training or not dist.is_initialized() or _solo(dist.get_world_size(self.group)):
             return super().forward(x)
         if self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
@@ -582,7 +666,7 @@ def all_reduce_gradients(params, group=None, flat: Optional[torch.Tensor] = None
     """Sum the per-rank partial parameter gradients: one flat bucket, one all-reduce.  ``flat``: the buffer all the
     ``.grad`` tensors are views of (train.GradBuffer) -- reduced in place, no gather / scatter copies."""
     grads = [p.grad for p in params if p.grad is not None]
-    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not grads or not dist.is_initialized() or _solo(dist.get_world_size(group)):
         return
     if flat is not None:
         _all_reduce(flat, dist.ReduceOp.SUM, group)
@@ -625,7 +709,7 @@ def dist_min_max(z1: torch.Tensor, group=None):
     single-device ``torch.min/max(z1, dim=0)`` (see _GlobalMinMax): dz1 of the partitioned run equals the 1-GPU run's."""
     from .networks import _column_min_max
     lo_l, hi_l = _column_min_max(z1)
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not dist.is_initialized() or _solo(dist.get_world_size(group)):
         return lo_l, hi_l
     return _GlobalMinMax.apply(lo_l, hi_l, group)
 
@@ -866,7 +950,7 @@ def gather_level(x_own: torch.Tensor, part: MGCNPartition, level: int) -> torch.
     pad[:x_own.shape[0]] = x_own.detach()
     ids = torch.full((n_max,), -1, dtype=torch.long, device=x_own.device)
     ids[:x_own.shape[0]] = part.own_ids[level]
-    if part.world == 1:
+    if _solo(part.world):
         allx, alli = pad, ids
     else:
         allx = pad.new_empty((part.world * n_max, x_own.shape[1]))

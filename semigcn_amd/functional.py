@@ -506,8 +506,10 @@ class _BNActFn(torch.autograd.Function):
             import torch.distributed as tdist
             world = tdist.get_world_size(group)
             local = torch.empty((1, 2 * C + 1), dtype=torch.float32, device=dev)
-            capi.bn_merge(capi.col_moments(x), V, out=local[0, :2 * C])
-            local[0, 2 * C:].fill_(float(V))
+            if tile_moments is not None:       # left behind by the MFMA product that wrote x
+                capi.bn_local_stats(tile_moments["tiles"], tile_moments["rows"], V, local)
+            else:
+                capi.bn_local_stats(capi.col_moments(x), 0, V, local)
             allst = torch.empty((world, 2 * C + 1), dtype=torch.float32, device=dev)
             _d._all_gather_rows(allst, local, group)
             fin, n_dev = capi.bn_finalize_ranks(allst, w32, b32, running_mean, running_var, momentum, eps, batches_tracked)
@@ -567,25 +569,41 @@ class _BNActFn(torch.autograd.Function):
             if sunk:
                 return (dx, None, None) + nothing
             return (dx, co[1].to(ctx.param_dtype), co[0].to(ctx.param_dtype)) + nothing
-        s = part.sum(0)                                                                # [2, C]: sum dz, sum dz*xhat
-        dbeta, dgamma = s[0].to(ctx.param_dtype), s[1].to(ctx.param_dtype)            # this rank's partial sums
         if ctx.training:
-            if ctx_group_active(ctx.group):
-                from . import dist as _d
-                import torch.distributed as tdist
-                s = s.clone()
-                _d._all_reduce(s, tdist.ReduceOp.SUM, ctx.group)
-            c = s / ctx.N
-            c1, c2 = c[0], c[1]
-            k = w32 * invstd
+            # vertex partition: this rank's sums (one launch; sunk into the gradient accumulators when those are on) ->
+            # all-reduce -> c1, c2, k of the whole mesh from the reduced sums and the device-resident row count
+            from . import dist as _d
+            import torch.distributed as tdist
+            weight, bias = ctx.params
+            sunk = bool(_sink_depth) and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and all(
+                p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == x.device
+                for p in (weight, bias))
+            loc = capi.bn_bwd_coeffs(part, 1.0, w32, invstd, weight.grad if sunk else None, bias.grad if sunk else None)
+            dgamma = dbeta = None
+            if not sunk:
+                dbeta, dgamma = loc[0].to(ctx.param_dtype).clone(), loc[1].to(ctx.param_dtype).clone()
+            s = loc[:2]                                     # [2, C] contiguous: reduced in place
+            _d._all_reduce(s, tdist.ReduceOp.SUM, ctx.group)
+            co = capi.bn_bwd_coeffs(s.view(1, 2, -1), ctx.N, w32, invstd)
+            k, c1, c2 = co[4], co[2], co[3]
         else:
+            s = part.sum(0)                                                            # [2, C]: sum dz, sum dz*xhat
+            dbeta, dgamma = s[0].to(ctx.param_dtype), s[1].to(ctx.param_dtype)
+            sunk = False
             c1 = torch.zeros_like(scale)
             c2 = c1
             k = scale
         out = None
         if ctx.grad_widen > 1:     # born as block 0 of the conv's [V, K*C] gradient buffer (see _ChebConvPostFn.backward)
             out = _new_wide(x.shape[0], x.shape[0], x.shape[1], ctx.grad_widen, x.dtype, x.device)
-        dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope, out=out)
+        if FUSE_BIAS_GRAD:
+            dx, sums = capi.bn_act_bwd_apply_colsum(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope, out=out)
+            if sums is not None:
+                _remember_column_sums(dx, sums)
+        else:
+            dx = capi.bn_act_bwd_apply(dy, x, scale, shift, mean, invstd, k, c1, c2, ctx.slope, out=out)
+        if sunk:
+            return (dx, None, None) + nothing
         if dy.is_cuda and _sink(ctx.params, (dgamma if ctx.needs_input_grad[1] else None,
                                              dbeta if ctx.needs_input_grad[2] else None)):
             return (dx, None, None) + nothing
@@ -606,7 +624,10 @@ def ctx_group_active(group) -> bool:
     if group is False:
         return False
     import torch.distributed as tdist
-    return tdist.is_initialized() and tdist.get_world_size(group) > 1
+    if not tdist.is_initialized():
+        return False
+    from .dist import _solo
+    return not _solo(tdist.get_world_size(group))
 
 
 def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int = 1,

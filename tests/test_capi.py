@@ -56,7 +56,8 @@ def test_argument_validation_without_gpu():
     g2 = (ctypes.c_float * 2)(1.0, 1.0)
     assert lib.sg_mesh_loss_bwd_det(None, None, None, None, None, None, g2, 0, 0, 0, None, None, None, None) == -1
     assert b"incidence" in lib.sg_last_error()
-    assert lib.sg_bn_bwd_coeffs(None, 0, 4, 1.0, None, None, None, None, None, None) == -1
+    assert lib.sg_bn_bwd_coeffs(None, 0, 4, 1.0, None, None, None, None, None, None, None) == -1
+    assert lib.sg_bn_merge_tiles(None, 1, 1, 0, 4, None, None, None) == -1
     assert lib.sg_bn_stats_finalize(None, 1, 1, 4, None, None, None, None, 0.1, 1e-5, None, None, None) == -1
     assert lib.sg_multi_add(9, None, None, None, None, None, None) == -1
     assert b"at most 8" in lib.sg_last_error()

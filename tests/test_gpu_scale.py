@@ -193,10 +193,11 @@ def test_c5_mesh_aggregation_properties_and_training_step():
 # --------------------------------------------------------------------------------------
 # N > 1 with the real kernels: ranks share cuda:0, collectives over gloo (host-staged)
 # --------------------------------------------------------------------------------------
-def _run_selftest(world, backend):
+def _run_selftest(world, backend, **env):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29640 + world), os.path.join(ROOT, "tools", "dist_selftest.py")]
-    return subprocess.run(cmd, env=_child_env(SEMIGCN_SELFTEST_BACKEND=backend), capture_output=True, text=True, timeout=900)
+    return subprocess.run(cmd, env=_child_env(SEMIGCN_SELFTEST_BACKEND=backend, **env), capture_output=True, text=True,
+                          timeout=900)
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -207,6 +208,19 @@ def test_partitioned_sgcn_and_mgcn_equal_single_rank_on_device(world):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "dist_selftest OK" in r.stdout
     print(r.stdout[-1500:])
+
+
+def test_one_rank_over_rccl_with_every_collective_issued():
+    """The RCCL code path on a one-GPU box: ONE rank, backend "nccl", and SEMIGCN_DIST_FORCE_COLLECTIVES=1 so that the
+    rank issues every collective of the partitioned iteration through the real library (communicator set-up, asynchronous
+    all-to-all + stream wait, statistics all-gather, min/max / loss / gradient all-reduces) although each is the identity
+    for a single rank; results must still equal the plain single-device model (asserted inside the rank)."""
+    r = _run_selftest(1, "nccl", SEMIGCN_DIST_FORCE_COLLECTIVES="1")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "dist_selftest OK" in r.stdout
+    counts = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("collectives ")][-1].split(" ", 1)[1])
+    assert counts["backend"] == "nccl" and counts["all_to_all"] >= 28 and counts["all_gather"] >= 13 and counts["all_reduce"] >= 10
+    print(r.stdout[-800:])
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for RCCL")

@@ -76,6 +76,8 @@ def main():
     mgcn_selftest(rank, world, dev)
     dist.barrier()
     if rank == 0:
+        import json
+        print("collectives " + json.dumps({"backend": dist.get_backend(), "world_size": world, **sgdist.collective_counts}))
         print("dist_selftest OK")
     dist.destroy_process_group()
 

@@ -3,7 +3,10 @@
 of the 1 M mesh is in): wall time per iteration, time until the last launch is enqueued, and a cProfile with the
 backward pass pulled onto the calling thread (autograd multithreading off) so that its Python frames are visible.
 
-    python tools/host_profile.py [250x200] [bf16|fp32] [N lines]
+    python tools/host_profile.py [250x200] [bf16|fp32] [N lines] [partitioned]
+
+``partitioned``: ONE rank runs the partitioned code path with every collective issued through RCCL (dist.FORCE_COLLECTIVES):
+the host work of a rank of an N-rank job.
 """
 import cProfile, os, pstats, sys, io, time
 import torch
@@ -11,17 +14,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 MESH = sys.argv[1] if len(sys.argv) > 1 else "250x200"
 DT = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 NL = int(sys.argv[3]) if len(sys.argv) > 3 else 45
+PART = len(sys.argv) > 4 and sys.argv[4] == "partitioned"
 sys.argv = ["bench.py", "--mesh", MESH]
 import bench
 from semigcn_amd import synth, train
 from semigcn_amd.networks import SingleScaleGCN
 dev = torch.device("cuda:0")
 mesh = synth.torus_mesh(*map(int, MESH.split("x")))
-batch = bench.build_mesh_batch(mesh, dev, 5)
-model = SingleScaleGCN(dev).to(dev)
-if DT == "bf16":
-    model.set_feature_dtype(torch.bfloat16)
-tr = train.SGCNTrainer(model, batch)
+if PART:
+    import torch.distributed as dist
+    from semigcn_amd import dist as sgdist
+    sgdist.FORCE_COLLECTIVES = True
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(bench.free_port()))
+    dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+    nu, nv = map(int, MESH.split("x"))
+    tr = sgdist.build_partitioned_job(nu, nv, 1, 0, dev, dtype=torch.bfloat16 if DT == "bf16" else torch.float32, mesh=mesh).trainer
+else:
+    batch = bench.build_mesh_batch(mesh, dev, 5)
+    model = SingleScaleGCN(dev).to(dev)
+    if DT == "bf16":
+        model.set_feature_dtype(torch.bfloat16)
+    tr = train.SGCNTrainer(model, batch)
 
 
 def run(n):
