@@ -323,17 +323,27 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
   }
 }
 
-// out[c] = sum over the nb workgroup partials of col_apply_rows<.., COLSUM>, in double, one wavefront per channel
+// Sum of per-block partial values of ONE channel over nb blocks by a whole workgroup (256 threads), in double and in a
+// fixed order (thread t takes blocks t, t + 256, ..; a shuffle tree per wavefront; thread 0 adds the four wavefront
+// sums): valid in thread 0.  One wavefront per channel walked up to 4096 strided partials in 64 dependent steps -- 17-28 us
+// per launch, 26 launches per training iteration.
+__device__ inline double block_sum_256(double v, double* s_w /*[4]*/) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// out[c] = sum over the nb workgroup partials of col_apply_rows<.., COLSUM>; one workgroup per channel
 __global__ __launch_bounds__(256) void colsum_finalize(const float* __restrict__ partial, int64_t nb, int C,
                                                        float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  __shared__ double s_w[4];
+  const int c = blockIdx.x;
   double s0 = 0.0;
-  if (c < C)
-    for (int64_t b = lane; b < nb; b += 64) s0 += partial[b * C + c];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s0 += __shfl_down(s0, off, 64);
-  if (c < C && lane == 0) out[c] = (float)s0;
+  for (int64_t b = threadIdx.x; b < nb; b += 256) s0 += partial[b * C + c];
+  s0 = block_sum_256(s0, s_w);
+  if (threadIdx.x == 0) out[c] = (float)s0;
 }
 
 // stats[0][c] = mean, stats[1][c] = M2 over all V rows, from the per-block partials (Chan et al.,
@@ -468,22 +478,17 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs(const float* __restrict__ p
                                                      const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                      float* __restrict__ out /*[5][C]*/, float* acc_dweight,
                                                      float* acc_dbias, const float* __restrict__ count_dev) {
+  __shared__ double s_w0[4], s_w1[4];
   if (count_dev) N = (double)count_dev[0];       // the mesh-wide row count of a partition, kept on the device
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int c = blockIdx.x;                      // one workgroup per channel
   double s0 = 0.0, s1 = 0.0;
-  if (c < C) {
-    for (int64_t b = lane; b < nb; b += 64) {
-      s0 += partial[(b * 2 + 0) * C + c];
-      s1 += partial[(b * 2 + 1) * C + c];
-    }
+  for (int64_t b = threadIdx.x; b < nb; b += 256) {
+    s0 += partial[(b * 2 + 0) * C + c];
+    s1 += partial[(b * 2 + 1) * C + c];
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    s0 += __shfl_down(s0, off, 64);
-    s1 += __shfl_down(s1, off, 64);
-  }
-  if (c < C && lane == 0) {
+  s0 = block_sum_256(s0, s_w0);
+  s1 = block_sum_256(s1, s_w1);
+  if (threadIdx.x == 0) {
     const float f0 = (float)s0, f1 = (float)s1;
     out[c] = f0;
     out[C + c] = f1;
@@ -645,7 +650,7 @@ int launch_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double N, 
                          const float* invstd, float* out, float* acc_dweight, float* acc_dbias, const float* count_dev,
                          hipStream_t stream) {
   if (C == 0) return SG_OK;
-  bn_bwd_coeffs<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out, acc_dweight, acc_dbias,
+  bn_bwd_coeffs<<<(int)C, 256, 0, stream>>>(partial, nb, (int)C, N, gamma, invstd, out, acc_dweight, acc_dbias,
                                                         count_dev);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
@@ -711,7 +716,7 @@ int64_t col_apply_blocks(int64_t V, int64_t C, int dtype) {
 
 int launch_colsum_finalize(const float* partial, int64_t nb, int64_t C, float* out, hipStream_t stream) {
   if (C == 0) return SG_OK;
-  colsum_finalize<<<(int)((C + 3) / 4), 256, 0, stream>>>(partial, nb, (int)C, out);
+  colsum_finalize<<<(int)C, 256, 0, stream>>>(partial, nb, (int)C, out);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
