@@ -286,6 +286,19 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     sync()
     dt = time.perf_counter() - t0
     capi.set_launch_timer(None)
+    # the dense products get their own short pass AFTER the timed region (an event pair per product inside it would cost
+    # the headline ~0.7 % for ~65 more pairs per iteration; the aggregation kernel's pairs stay inside, as the contract asks)
+    timed_run.gemm_timer, timed_run.gemm_steps = None, 0
+    if with_timer:
+        from semigcn_amd import functional as F_sg
+        timed_run.gemm_timer, timed_run.gemm_steps = capi.LaunchTimer(), max(1, min(args.steps, 5))
+        F_sg.set_gemm_timer(timed_run.gemm_timer)
+        t1 = time.perf_counter()
+        for _ in range(timed_run.gemm_steps):
+            trainer.iteration_step()
+        sync()
+        timed_run.gemm_dt = time.perf_counter() - t1
+        F_sg.set_gemm_timer(None)
     if DIST_ON:
         timed_run.collectives = {k: (v - c0[k]) / args.steps for k, v in sgdist.collective_counts.items()}
     if DIST_ON:
@@ -346,11 +359,53 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
                 "all_aggregations_GBs": round(total_B / total_t, 1),
                 "all_aggregations_frac": round(total_B / total_t / HBM_PEAK_GBS, 4),
                 "aggregation_share_of_step": round(total_t / (dt * 1e3), 4)}
-    return {"value": value, "ms_per_step": dt / args.steps * 1e3,
+    dense = dense_products(getattr(timed_run, "gemm_timer", None), getattr(timed_run, "gemm_steps", 0),
+                           getattr(timed_run, "gemm_dt", 0.0))
+    return {"value": value, "ms_per_step": dt / args.steps * 1e3, "dense_products": dense,
             "dtype": "f32" if dtype == torch.float32 else "bf16 storage / f32 accumulate",
             "edges_aggregated_per_s": agg_edges * value, "optimizer_steps_per_s": value / 5.0,
             "mean_loss": float(trainer.loss_sum.item()) / max(trainer.iteration, 1),
             "roofline": roof, "aggregation_kernels": kernels}
+
+
+MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3}     # MI355X_MICROARCH.md, dense peaks (bf16 MFMA; f32-input MFMA)
+
+
+def dense_products(timer, steps: int, dt: float):
+    """The dense per-vertex feature x weight products (ChebConv's `lins`, util/networks.py:42,49, and their autograd) of
+    the timed region, each launch timed with HIP events on its stream: per shape the MFMA roofline fraction
+    (flops = 2 M N K against the dense peak of the operand type) next to the HBM one (operand + result bytes, the weight
+    matrix L2-resident), and the totals -- which engine ran it: "mfma" = csrc/gemm_mfma.hip, "blas" = hipBLASLt.
+    Measured over `steps` extra iterations right after the timed region (see timed_run)."""
+    if timer is None or not timer.records or steps < 1:
+        return None
+    shapes, by_engine = [], {}
+    tot_ms = tot_flops = 0.0
+    for (kind, M, N, K, dt_name, engine), times in sorted(timer.results().items(), key=lambda kv: -sum(kv[1])):
+        elem = 4 if dt_name == "float32" else 2
+        mean_ms = float(np.mean(times))
+        flops = 2.0 * M * N * K
+        # "nt": A [M,K] read, C [M,N] written;  "tn" (weight gradient): both [M,N] and [M,K] operands read, result tiny
+        byts = (M * K + M * N) * elem
+        peak = MFMA_PEAK_TFLOPS[dt_name]
+        shapes.append({"kind": kind, "M": M, "N": N, "K": K, "dtype": dt_name, "engine": engine, "launches": len(times),
+                       "mean_ms": round(mean_ms, 4), "TFLOPs": round(flops / mean_ms / 1e9, 1),
+                       "mfma_frac": round(flops / mean_ms / 1e9 / peak, 4),
+                       "hbm_frac": round(byts / mean_ms / 1e6 / HBM_PEAK_GBS, 4)})
+        e = by_engine.setdefault(engine, {"ms_per_iteration": 0.0, "TFLOP_per_iteration": 0.0})
+        e["ms_per_iteration"] += sum(times) / steps
+        e["TFLOP_per_iteration"] += flops * len(times) / steps / 1e12
+        tot_ms += sum(times)
+        tot_flops += flops * len(times)
+    for e in by_engine.values():
+        e["TFLOPs"] = round(e["TFLOP_per_iteration"] / e["ms_per_iteration"] * 1e3, 1)
+        e["ms_per_iteration"], e["TFLOP_per_iteration"] = round(e["ms_per_iteration"], 3), round(e["TFLOP_per_iteration"], 3)
+    dt_name = shapes[0]["dtype"]
+    return {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS[dt_name], "unit": "TFLOP/s",
+            "achieved": round(tot_flops / tot_ms / 1e9, 1), "frac": round(tot_flops / tot_ms / 1e9 / MFMA_PEAK_TFLOPS[dt_name], 4),
+            "ms_per_iteration": round(tot_ms / steps, 3), "share_of_step": round(tot_ms / (dt * 1e3), 4),
+            "measured_over": f"{steps} iterations after the timed region (HIP events on the launching stream)",
+            "by_engine": by_engine, "shapes": shapes[:12]}
 
 
 def free_port() -> int:
@@ -448,6 +503,8 @@ def main():
         dt2, timer2 = timed_run(tr2, args, device, world, with_timer)
         other = summarize(dt2, timer2, args, dtypes[od], mesh, world, agg2, tr2)
         other.pop("aggregation_kernels")
+        if other.get("dense_products"):
+            other["dense_products"].pop("shapes")
         log(f"second precision done: {other['ms_per_step']:.2f} ms/iteration ({od})")
         del tr2
         torch.cuda.empty_cache()
@@ -473,6 +530,7 @@ def main():
             "edges_aggregated_per_s": main_res["edges_aggregated_per_s"],
             "optimizer_steps_per_s": main_res["optimizer_steps_per_s"], "mean_loss": main_res["mean_loss"],
             "roofline": main_res["roofline"], "aggregation_kernels": main_res["aggregation_kernels"],
+            "dense_products": main_res["dense_products"],
         }
         if other is not None:
             line["fp32_features" if other["dtype"] == "f32" else "bf16_features"] = other

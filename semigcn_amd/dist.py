@@ -478,7 +478,7 @@ class _DistChebConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        from .functional import _sink, column_sums, dense_nt, weight_grad
+        from .functional import _sink, column_sums, dense_nn, dense_nt, weight_grad
         T, wcat = ctx.saved_tensors
         g, K, C, n = ctx.g, ctx.K, ctx.C, ctx.g.n_own
         dout = dout.contiguous()
@@ -494,7 +494,7 @@ class _DistChebConvFn(torch.autograd.Function):
             if ctx.wcat_t is not None:
                 dense_nt(dout, ctx.wcat_t, out=dT[:n])
             else:
-                torch.mm(dout, wcat, out=dT[:n])
+                dense_nn(dout, wcat, out=dT[:n])
             if K == 1:
                 dx = dT
             else:
@@ -552,7 +552,7 @@ class _DistChebConvPostFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        from .functional import _sink, column_sums, dense_nt, weight_grad
+        from .functional import _sink, column_sums, dense_nn, dense_nt, weight_grad
         x, wstack = ctx.saved_tensors
         g, K, Co, n = ctx.g, ctx.K, ctx.Co, ctx.g.n_own
         dout = dout.contiguous()
@@ -571,7 +571,7 @@ class _DistChebConvPostFn(torch.autograd.Function):
         own = G[:n]
         dx = None
         if ctx.needs_input_grad[2]:
-            dx = dense_nt(own, ctx.wstack_t) if ctx.wstack_t is not None else own @ wstack
+            dx = dense_nt(own, ctx.wstack_t) if ctx.wstack_t is not None else dense_nn(own, wstack)
         dws = [None] * K
         if any(ctx.needs_input_grad[4:]):
             dwstack = weight_grad(own, x.contiguous()).to(ctx.param_dtype)

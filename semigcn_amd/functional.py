@@ -45,7 +45,47 @@ def _bmm_f32_out(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         return torch.bmm(a, b).float()
 
 
+#: optional per-call timing of the dense products (capi.LaunchTimer: HIP events on the launching stream); bench.py installs
+#: one over its timed region.  Keys: (kind, M, N, K, dtype name, engine) with kind "nt" (features x weights: forward and
+#: input gradient) or "tn" (weight gradient), engine "mfma" (csrc/gemm_mfma.hip) or "blas" (hipBLASLt through torch)
+_gemm_timer = None
+
+
+def set_gemm_timer(timer) -> None:
+    global _gemm_timer
+    _gemm_timer = timer
+
+
+class _timed:
+    """``with _timed(key):`` -- records an event pair around the product when a timer is installed, nothing otherwise."""
+    __slots__ = ("key", "ev")
+
+    def __init__(self, key):
+        self.key, self.ev = key, None
+
+    def __enter__(self):
+        if _gemm_timer is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            self.ev[1].record()
+            _gemm_timer.records.append((self.key, self.ev[0], self.ev[1]))
+        return False
+
+
 def weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
+    if _gemm_timer is None or not dout.is_cuda:
+        return _weight_grad(dout, T)
+    own = (USE_MFMA_GEMM and dout.dtype == torch.bfloat16 and dout.shape[1] * T.shape[1] <= MFMA_MAX_WEIGHT_ELEMS
+           and capi.gemm_tn_supported(dout, T))
+    with _timed(("tn", dout.shape[0], dout.shape[1], T.shape[1], str(dout.dtype).replace("torch.", ""), "mfma" if own else "blas")):
+        return _weight_grad(dout, T)
+
+
+def _weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     """dW = dOut^T T in fp32: a [Cout x V] x [V x K*Cin] product whose reduction runs over ALL
     vertices and whose output is tiny.  hipBLASLt's own choice for that shape leaves most CUs idle
     (measured at V = 1 M: 5.5 ms fp32 / 2.3 ms bf16 for 256x768); cutting V into S slabs, one
@@ -247,6 +287,17 @@ def _wcat_pair(weights, dtype):
 
 def dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
              moments: Optional[dict] = None) -> torch.Tensor:
+    """``_dense_nt`` (below), timed per call when a timer is installed (``set_gemm_timer``)."""
+    if _gemm_timer is None or not a.is_cuda:
+        return _dense_nt(a, b, bias, out, moments)
+    ldc = b.shape[0] if out is None else out.stride(0)
+    own = _mfma_ok(a, b, ldc) and (out is None or (out.stride(1) == 1 and out.data_ptr() % 16 == 0))
+    with _timed(("nt", a.shape[0], b.shape[0], a.shape[1], str(a.dtype).replace("torch.", ""), "mfma" if own else "blas")):
+        return _dense_nt(a, b, bias, out, moments)
+
+
+def _dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              moments: Optional[dict] = None) -> torch.Tensor:
     """``a @ b.T (+ bias)`` for the [V, C] vertex features: the MFMA kernel for bf16 operands it accepts, else the BLAS
     library.  ``bias`` is the fp32 parameter.  ``moments`` (a dict): on the MFMA path it receives ``"tiles"`` = the
     per-row-tile column (mean, M2) of the result and ``"rows"`` = rows per tile, for the BatchNorm that follows."""
@@ -261,6 +312,14 @@ def dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = No
     if bias is not None:
         return torch.addmm(bias.to(a.dtype), a, b.t()) if out is None else torch.addmm(bias.to(a.dtype), a, b.t(), out=out)
     return a @ b.t() if out is None else torch.mm(a, b.t(), out=out)
+
+
+def dense_nn(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``a @ w`` on the BLAS library (the input-gradient product where no transposed weight copy is kept: fp32 features)."""
+    if _gemm_timer is None or not a.is_cuda:
+        return a @ w if out is None else torch.mm(a, w, out=out)
+    with _timed(("nt", a.shape[0], w.shape[1], a.shape[1], str(a.dtype).replace("torch.", ""), "blas")):
+        return a @ w if out is None else torch.mm(a, w, out=out)
 
 
 class _ChebConvFn(torch.autograd.Function):
@@ -308,7 +367,7 @@ class _ChebConvFn(torch.autograd.Function):
         dx = None
         if need_x:
             # [V, K*C]; block k = dL/dTx_k before the recurrence is unwound
-            dT = dense_nt(dout, ctx.wcat_t) if ctx.wcat_t is not None else dout @ wcat
+            dT = dense_nt(dout, ctx.wcat_t) if ctx.wcat_t is not None else dense_nn(dout, wcat)
             if K == 1:
                 dx = dT
             else:
@@ -391,7 +450,7 @@ class _ChebConvPostFn(torch.autograd.Function):
             graph.aggregate(g[k - 1], g[k], alpha=2.0, X0=g[k - 2], beta=-1.0, transpose=tr)
         dx = None
         if ctx.needs_input_grad[2]:
-            dx = dense_nt(G, ctx.wstack_t) if ctx.wstack_t is not None else G @ wstack
+            dx = dense_nt(G, ctx.wstack_t) if ctx.wstack_t is not None else dense_nn(G, wstack)
         dws = [None] * K
         if any(ctx.needs_input_grad[4:]):
             dwstack = weight_grad(G, x.contiguous()).to(ctx.param_dtype)   # [K*Cout, Cin]
