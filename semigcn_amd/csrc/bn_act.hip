@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda
   using elem_t = typename IO::elem;
   using raw_t = typename IO::raw;
   constexpr int VEC = VECW;  // IO::VEC (vector path) or 1 (scalar path)
+  constexpr bool LEAN = DT == SG_BF16 && VECW > 1;
   __shared__ float s_red[2][kBlock][VECW];
   const elem_t* A = (const elem_t*)A_;
   const elem_t* H = (const elem_t*)H_;
@@ -136,6 +137,13 @@ __global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda
               const float d = (x[u][k] - kshift[k]) * on;
               a0[k] += d;
               a1[k] = fmaf(d, d, a1[k]);
+            } else if (LEAN) {
+              // bf16 rows carry twice the values per byte and this loop is VALU-bound there: the row mask is folded into
+              // the operand (a dead row's dA is 0), invstd is applied once at the end
+              const float xm = live[u] ? x[u][k] : 0.f;
+              const float dz = fmaf(sc[k], h[u][k], sh[k]) > 0.f ? xm : xm * slope;
+              a0[k] += dz;
+              a1[k] = fmaf(dz, h[u][k] - mu[k], a1[k]);
             } else {
               const float dz = x[u][k] * act_slope(fmaf(sc[k], h[u][k], sh[k]), slope) * on;
               a0[k] += dz;
@@ -144,6 +152,10 @@ __global__ __launch_bounds__(kBlock) void col_reduce(const void* A_, int64_t lda
           }
         }
       }
+    }
+    if (MODE == 1 && LEAN) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) a1[k] *= is[k];
     }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { s_red[0][threadIdx.x][k] = a0[k]; s_red[1][threadIdx.x][k] = a1[k]; }
@@ -256,6 +268,10 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
   const bool col_on = tc < C / VEC;
   if (!COLSUM && !col_on) return;
   const int c0 = (col_on ? tc : 0) * VEC;
+  // bf16 (LEAN): dH = k (dz - c1 - xhat c2) regrouped per channel as  x t - A - B h  with t = k or k slope by the sign of
+  // the BatchNorm output, B = k c2 invstd, A = k c1 - B mean: 5 VALU operations per value instead of 8 (this pass is close
+  // to VALU-bound with 8 values per 16-byte vector); the result is rounded to bf16 (2^-9) right after
+  constexpr bool LEAN = MODE == 1 && DT == SG_BF16;
   float sc[VEC], sh[VEC], mu[VEC], is[VEC], kc[VEC], k1[VEC], k2[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
@@ -267,6 +283,12 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
       kc[k] = kk[c0 + k];
       k1[k] = c1[c0 + k];
       k2[k] = c2[c0 + k] * is[k];
+      if (LEAN) {
+        const float B = kc[k] * k2[k];
+        k2[k] = -B;                          // -B
+        k1[k] = fmaf(B, mu[k], -kc[k] * k1[k]);   // -A = B mean - k c1
+        is[k] = kc[k] * slope;               // t for a negative BatchNorm output
+      }
     }
   }
   const int64_t step = (int64_t)gridDim.x * groups;
@@ -291,6 +313,9 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
         if (MODE == 0) {
           const float z = fmaf(sc[k], x[k], sh[k]);
           y[k] = z > 0.f ? z : z * slope;
+        } else if (LEAN) {
+          const float t = fmaf(sc[k], h[k], sh[k]) > 0.f ? kc[k] : is[k];
+          y[k] = fmaf(x[k], t, fmaf(k2[k], h[k], k1[k]));
         } else {
           const float dz = x[k] * act_slope(fmaf(sc[k], h[k], sh[k]), slope);
           y[k] = kc[k] * (dz - k1[k] - (h[k] - mu[k]) * k2[k]);
