@@ -344,6 +344,24 @@ SG_API int sg_bn_stats_finalize_tiles(const float* partial, int64_t n_tiles, int
                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                                       float momentum, float eps, float* out, int64_t* batches_tracked, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * The network's input step, fused (SingleScaleGCN.forward, util/networks.py:65-79: bounding-box normalisation with one
+ * scale and a per-axis centre, masking, the mask appended as 4th channel) and its autograd.
+ *   mid = (lo + hi) / 2, extent = max_k (hi[k] - lo[k]);   v = order ? order[p] : p
+ *   X[p] = ( dm[v] (z1[v] - mid) / extent, dm[v] )          X: [V, >= 4] of `dtype`, row stride ldx (elements)
+ * z1 float32 [V, 3]; dm float32 [V] or NULL (all ones); order / rank int64 [V] or NULL (inverse permutations of each other:
+ * processing row p holds vertex order[p], vertex v sits in processing row rank[v]); lo, hi float32 [3] ON THE DEVICE.
+ * sg_input_prep_bwd: gX = dL/dX (rows in processing order) -> dz1 [V, 3] (caller order; may be NULL), d_lo / d_hi [3]
+ * (the gradients of the bounds, which the caller's autograd routes to the arg-extreme vertices); partial: float32
+ * [sg_input_prep_blocks(V), 4] scratch (block sums in a fixed order: deterministic).
+ * ------------------------------------------------------------------------- */
+SG_API int64_t sg_input_prep_blocks(int64_t V);
+SG_API int sg_input_prep(const float* z1, const float* dm, const int64_t* order, const float* lo, const float* hi, void* X,
+                         int64_t ldx, int64_t V, int dtype, void* stream);
+SG_API int sg_input_prep_bwd(const void* gX, int64_t ldg, const float* z1, const float* dm, const int64_t* rank,
+                             const float* lo, const float* hi, float* dz1, float* partial, float* d_lo, float* d_hi, int64_t V,
+                             int dtype, void* stream);
+
 enum sg_tune_knob {
   SG_TUNE_CHUNK_ROWS = 0, /* rows per wavefront chunk; 0 = automatic */
   SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map, bit 1: never use the shared-gather kernel,

@@ -76,6 +76,10 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "sg_bn_merge_tiles": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sg_multi_add": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sg_input_prep_blocks": (c_int64, [c_int64]),
+    "sg_input_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "sg_input_prep_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sg_bn_finalize_ranks": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_bn_finalize": (c_int, [c_void_p, ctypes.c_double, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
@@ -786,6 +790,51 @@ def bn_act_bwd_apply_colsum(dA, H, scale, shift, mean, invstd, k, c1, c2, slope:
                                                  float(slope), _ptr(dH), _rows2d(dH, "dH"), V, C, dtype_code(H), _ptr(part),
                                                  _ptr(sums), _stream(H)), "sg_bn_act_bwd_apply_colsum")
     return dH, sums
+
+
+# ---- the network's input step ------------------------------------------------------------------
+def _prep_args(z1, dm, perm, lo, hi):
+    _require_device(z1, "z1")
+    V = z1.shape[0]
+    if z1.dtype != torch.float32 or z1.dim() != 2 or z1.shape[1] != 3 or not z1.is_contiguous():
+        raise SemigcnLibraryError(f"z1 must be contiguous float32 [V, 3], got {z1.dtype} {tuple(z1.shape)}")
+    if dm is not None and (dm.dtype != torch.float32 or dm.numel() != V or not dm.is_contiguous() or dm.device != z1.device):
+        raise SemigcnLibraryError("dm must be V contiguous float32 values on the device of z1")
+    if perm is not None and (perm.dtype != torch.int64 or perm.numel() != V or not perm.is_contiguous()
+                             or perm.device != z1.device):
+        raise SemigcnLibraryError("order / rank must be V contiguous int64 values on the device of z1")
+    for t, n in ((lo, "lo"), (hi, "hi")):
+        if t.dtype != torch.float32 or t.numel() != 3 or not t.is_contiguous() or t.device != z1.device:
+            raise SemigcnLibraryError(f"{n} must be 3 contiguous float32 values on the device of z1")
+    return V
+
+
+def input_prep(z1: torch.Tensor, dm: Optional[torch.Tensor], order: Optional[torch.Tensor], lo: torch.Tensor,
+               hi: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[V, 4] network input in processing order and feature dtype (sg_input_prep): ``(dm (z1 - mid) / extent, dm)``."""
+    V = _prep_args(z1, dm, order, lo, hi)
+    X = torch.empty((V, 4), dtype=dtype, device=z1.device)
+    with _on_device(z1.device):
+        _check(load().sg_input_prep(_ptr(z1), _ptr(dm), _ptr(order), _ptr(lo), _ptr(hi), _ptr(X), 4, V, dtype_code(X),
+                                    _stream(z1)), "sg_input_prep")
+    return X
+
+
+def input_prep_bwd(gX: torch.Tensor, z1: torch.Tensor, dm: Optional[torch.Tensor], rank: Optional[torch.Tensor],
+                   lo: torch.Tensor, hi: torch.Tensor, need_dz1: bool = True):
+    """(dz1 [V, 3] or None, d_lo [3], d_hi [3]) from gX = dL/dX [V, >= 3 columns] (sg_input_prep_bwd)."""
+    V = _prep_args(z1, dm, rank, lo, hi)
+    if gX.shape[0] != V or gX.device != z1.device:
+        raise SemigcnLibraryError("gX must have one row per vertex on the device of z1")
+    ldg = _rows2d(gX, "gX")
+    dz1 = torch.empty((V, 3), dtype=torch.float32, device=z1.device) if need_dz1 else None
+    part = torch.empty((_sizes("sg_input_prep_blocks", V), 4), dtype=torch.float32, device=z1.device)
+    dlh = torch.empty((2, 3), dtype=torch.float32, device=z1.device)
+    with _on_device(z1.device):
+        _check(load().sg_input_prep_bwd(_ptr(gX), ldg, _ptr(z1), _ptr(dm), _ptr(rank), _ptr(lo), _ptr(hi), _ptr(dz1),
+                                        _ptr(part), dlh.data_ptr(), dlh.data_ptr() + 12, V, dtype_code(gX), _stream(z1)),
+               "sg_input_prep_bwd")
+    return dz1, dlh[0], dlh[1]
 
 
 # ---- fused loss step ---------------------------------------------------------------------------

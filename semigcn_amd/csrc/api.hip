@@ -539,6 +539,23 @@ SG_API int sg_bn_bwd_coeffs(const float* partial, int64_t nb, int64_t C, double 
   return launch_bn_bwd_coeffs(partial, nb, C, N, gamma, invstd, out, acc_dweight, acc_dbias, count_dev, (hipStream_t)stream);
 }
 
+SG_API int64_t sg_input_prep_blocks(int64_t V) { return input_prep_blocks(V); }
+
+SG_API int sg_input_prep(const float* z1, const float* dm, const int64_t* order, const float* lo, const float* hi, void* X,
+                         int64_t ldx, int64_t V, int dtype, void* stream) {
+  SG_REQUIRE(V >= 0 && ldx >= 4 && (V == 0 || (z1 && lo && hi && X)), "sg_input_prep: bad argument");
+  SG_REQUIRE(dtype == SG_F32 || dtype == SG_BF16, "sg_input_prep: unknown dtype %d", dtype);
+  return launch_input_prep(z1, dm, order, lo, hi, X, ldx, V, dtype, (hipStream_t)stream);
+}
+
+SG_API int sg_input_prep_bwd(const void* gX, int64_t ldg, const float* z1, const float* dm, const int64_t* rank,
+                             const float* lo, const float* hi, float* dz1, float* partial, float* d_lo, float* d_hi, int64_t V,
+                             int dtype, void* stream) {
+  SG_REQUIRE(V >= 0 && ldg >= 3 && (V == 0 || (gX && z1 && lo && hi && partial && d_lo && d_hi)), "sg_input_prep_bwd: bad argument");
+  SG_REQUIRE(dtype == SG_F32 || dtype == SG_BF16, "sg_input_prep_bwd: unknown dtype %d", dtype);
+  return launch_input_prep_bwd(gX, ldg, z1, dm, rank, lo, hi, dz1, partial, d_lo, d_hi, V, dtype, (hipStream_t)stream);
+}
+
 SG_API int sg_multi_add(int64_t n, const float* const* srcs, const int64_t* src_ld, const int64_t* rows, const int64_t* cols,
                         float* const* dsts, void* stream) {
   SG_REQUIRE(n >= 0 && n <= kMultiAddMax, "sg_multi_add: at most %d matrices per call", kMultiAddMax);

@@ -155,6 +155,14 @@ constexpr int kMultiAddMax = 8;
 int launch_multi_add(int n, const float* const* srcs, const int64_t* src_ld, const int64_t* rows, const int64_t* cols,
                      float* const* dsts, hipStream_t stream);
 
+// input_prep.hip
+int64_t input_prep_blocks(int64_t V);
+int launch_input_prep(const float* z1, const float* dm, const int64_t* order, const float* lo, const float* hi, void* X,
+                      int64_t ldx, int64_t V, int dtype, hipStream_t stream);
+int launch_input_prep_bwd(const void* gX, int64_t ldg, const float* z1, const float* dm, const int64_t* rank, const float* lo,
+                          const float* hi, float* dz1, float* partial, float* d_lo, float* d_hi, int64_t V, int dtype,
+                          hipStream_t stream);
+
 // gemm_mfma.hip
 int gemm_tile_rows(int64_t N);      // rows per output tile (= rows per BatchNorm-moments record) for an N-column product
 int set_gemm_tuning(int value);

@@ -718,6 +718,59 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, slope: float, widen: int =
 
 
 # --------------------------------------------------------------------------------------------
+# the network's input / output steps (csrc/input_prep.hip)
+# --------------------------------------------------------------------------------------------
+class _InputPrepFn(torch.autograd.Function):
+    """``cat([dm (z1 - mid) / extent, dm], 1)[order].to(dtype)`` of SingleScaleGCN.forward (util/networks.py:67-79) in one
+    launch; backward in two (dz1 in caller order + the gradients of the bounds ``lo`` / ``hi``, which autograd then routes
+    to the arg-extreme vertices through the min / max that produced them)."""
+
+    @staticmethod
+    def forward(ctx, z1, lo, hi, dm, order, rank, dtype):
+        z1c = z1.contiguous()
+        dmc = None if dm is None else dm.reshape(-1).contiguous()
+        lo_c, hi_c = lo.reshape(-1).contiguous(), hi.reshape(-1).contiguous()
+        ctx.save_for_backward(z1c, lo_c, hi_c)
+        ctx.dm, ctx.rank, ctx.lo_shape = dmc, rank, lo.shape
+        return capi.input_prep(z1c, dmc, order, lo_c, hi_c, dtype)
+
+    @staticmethod
+    def backward(ctx, gX):
+        z1, lo, hi = ctx.saved_tensors
+        if gX.stride(1) != 1:
+            gX = gX.contiguous()
+        dz1, d_lo, d_hi = capi.input_prep_bwd(gX, z1, ctx.dm, ctx.rank, lo, hi, need_dz1=ctx.needs_input_grad[0])
+        return (dz1, d_lo.view(ctx.lo_shape) if ctx.needs_input_grad[1] else None,
+                d_hi.view(ctx.lo_shape) if ctx.needs_input_grad[2] else None, None, None, None, None)
+
+
+def input_prep(z1: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, dm: Optional[torch.Tensor],
+               order: Optional[torch.Tensor], rank: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+    """The [V, 4] network input in processing order (``order`` / ``rank``: the inverse permutations, or None) and
+    feature dtype, from z1 [V, 3] fp32, the bounds ``lo`` / ``hi`` [1, 3] and the mask ``dm`` [V, 1] (or None)."""
+    return _InputPrepFn.apply(z1, lo, hi, dm, order, rank, dtype)
+
+
+class _OutputFn(torch.autograd.Function):
+    """``base + x[rank]`` (rows back in caller order); backward is the gather by the inverse permutation instead of the
+    zero-fill + atomic index_add that autograd derives for index_select."""
+
+    @staticmethod
+    def forward(ctx, x, base, rank, order):
+        ctx.order = order
+        return base + x.index_select(0, rank)
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = g.index_select(0, ctx.order) if ctx.needs_input_grad[0] else None
+        return gx, (g if ctx.needs_input_grad[1] else None), None, None
+
+
+def output_in_caller_order(x: torch.Tensor, base: torch.Tensor, rank: torch.Tensor, order: torch.Tensor) -> torch.Tensor:
+    return _OutputFn.apply(x, base, rank, order)
+
+
+# --------------------------------------------------------------------------------------------
 # fused loss step (csrc/mesh_loss.hip)
 # --------------------------------------------------------------------------------------------
 _incidence_cache: dict = {}

@@ -168,10 +168,18 @@ class SingleScaleGCN(nn.Module):
         if getattr(graph, "sg_partitioned", False):
             from .dist import dist_min_max
             lo, hi = dist_min_max(z1, graph.group)
-        x = prepare_input(z1, self._mask(dm, z1.shape[0], z1.dtype), lo, hi)
-        if order is not None:
-            x = x.index_select(0, order)
-        x = x.to(self.feature_dtype)
+        mask = self._mask(dm, z1.shape[0], z1.dtype)
+        if z1.is_cuda and z1.dtype == torch.float32 and mask.dtype == torch.float32 and mask.numel() == z1.shape[0]:
+            # one launch: normalise, mask, append the mask, rows into processing order, feature dtype (csrc/input_prep.hip)
+            from .functional import input_prep
+            if lo is None:
+                lo, hi = _column_min_max(z1)
+            x = input_prep(z1, lo, hi, mask, order, rank, self.feature_dtype)
+        else:
+            x = prepare_input(z1, mask, lo, hi)
+            if order is not None:
+                x = x.index_select(0, order)
+            x = x.to(self.feature_dtype)
 
         enc: List[torch.Tensor] = []
         for i, block in enumerate(self.blocks):
@@ -182,5 +190,8 @@ class SingleScaleGCN(nn.Module):
             if i < N_ENCODER:
                 enc.append(x)
         if rank is not None:
+            if x.is_cuda:
+                from .functional import output_in_caller_order
+                return output_in_caller_order(x, x_pos, rank, order)
             x = x.index_select(0, rank)
         return x_pos + x

@@ -62,6 +62,9 @@ def test_argument_validation_without_gpu():
     assert lib.sg_multi_add(9, None, None, None, None, None, None) == -1
     assert b"at most 8" in lib.sg_last_error()
     assert lib.sg_multi_add(0, None, None, None, None, None, None) == 0
+    assert lib.sg_input_prep(None, None, None, None, None, None, 4, 5, 0, None) == -1
+    assert lib.sg_input_prep_bwd(None, 4, None, None, None, None, None, None, None, None, None, 5, 0, None) == -1
+    assert lib.sg_input_prep_blocks(0) == 0 and lib.sg_input_prep_blocks(1025) == 2
 
 
 def test_no_cpu_fallback():

@@ -136,3 +136,64 @@ def test_trainer_gradient_buffer_views_and_optimizer_steps():
         assert torch.equal(loss_a, loss_b.detach()), it
     for (n, pa), (_, pb) in zip(net.named_parameters(), ref.named_parameters()):
         assert torch.equal(pa, pb), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("permuted", [False, True])
+def test_fused_input_step_equals_the_reference_composition(dtype, permuted):
+    """sg_input_prep / sg_input_prep_bwd against the op-by-op composition of util/networks.py:67-79 (prepare_input ->
+    rows into processing order -> feature dtype): forward bit for bit, dz1 (direct part + the part routed through the
+    bounding box's arg-extreme vertices) to fp32 rounding."""
+    from semigcn_amd.networks import _column_min_max, prepare_input
+    g = torch.Generator(device=DEV).manual_seed(12)
+    V = 20000
+    z = (torch.randn(V, 3, device=DEV, generator=g) * torch.tensor([1.0, 2.5, 0.7], device=DEV)).contiguous()
+    dm = (torch.rand(V, 1, device=DEV, generator=g) > 0.1).float()
+    order = torch.randperm(V, device=DEV, generator=g) if permuted else None
+    rank = torch.empty_like(order) if permuted else None
+    if permuted:
+        rank[order] = torch.arange(V, device=DEV)
+    w = torch.randn(V, 4, device=DEV, generator=g)
+
+    za = z.clone().requires_grad_(True)
+    xa = prepare_input(za, dm)
+    if permuted:
+        xa = xa.index_select(0, order)
+    xa = xa.to(dtype)
+    (xa.float() * w).sum().backward()
+
+    zb = z.clone().requires_grad_(True)
+    lo, hi = _column_min_max(zb)
+    xb = F_sg.input_prep(zb, lo, hi, dm, order, rank, dtype)
+    assert xb.dtype == dtype and torch.equal(xa.detach(), xb.detach())
+    (xb.float() * w).sum().backward()
+    scale = float(za.grad.abs().max())
+    assert float((za.grad - zb.grad).abs().max()) <= 2e-6 * scale, float((za.grad - zb.grad).abs().max()) / scale
+    # the bounding-box gradient is really there: with detached bounds only the (at most six) arg-extreme rows differ
+    zd = z.clone().requires_grad_(True)
+    lo_d, hi_d = _column_min_max(zd.detach())
+    (F_sg.input_prep(zd, lo_d, hi_d, dm, order, rank, dtype).float() * w).sum().backward()
+    moved = int(((zd.grad - zb.grad).abs().sum(1) > 0).sum())
+    assert 1 <= moved <= 6, moved
+
+    # no mask, no order: dm = None means all ones
+    zc = z.clone().requires_grad_(True)
+    xc = F_sg.input_prep(zc, *_column_min_max(zc), None, None, None, torch.float32)
+    assert torch.equal(xc.detach(), prepare_input(z, torch.ones(V, 1, device=DEV)))
+
+
+def test_output_step_gathers_both_ways():
+    g = torch.Generator(device=DEV).manual_seed(2)
+    V = 5000
+    x = torch.randn(V, 3, device=DEV, generator=g, requires_grad=True)
+    base = torch.randn(V, 3, device=DEV, generator=g)
+    order = torch.randperm(V, device=DEV, generator=g)
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(V, device=DEV)
+    w = torch.randn(V, 3, device=DEV, generator=g)
+    y = F_sg.output_in_caller_order(x, base, rank, order)
+    assert torch.equal(y.detach(), base + x.detach()[rank])
+    (y * w).sum().backward()
+    ref = torch.zeros_like(w)
+    ref[rank] = w                                      # adjoint of the gather by rank
+    assert torch.equal(x.grad, ref)
