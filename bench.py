@@ -23,8 +23,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-if "--graph" in sys.argv:      # must be in the environment before the first HIP call (semigcn_amd.train.GRAPH_ENV)
-    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# hipGraph replays (--graph; the default for partitioned SGCN runs) are exact only with the runtime's graph "packet capture"
+# off, and the runtime reads the flag once, at its initialisation: it has to be in the environment before the first HIP call
+# (semigcn_amd.train.GRAPH_ENV).  It changes nothing for eager execution.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import numpy as np
 import torch
@@ -63,10 +65,12 @@ def parse():
                     help="CPU baseline: additionally time ONE oracle iteration at the full mesh size (BASELINE.md section 3; "
                          "~2 min and ~50 GB of host memory at V = 1 M)")
     ap.add_argument("--no-launch-timer", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay each iteration from a hipGraph (1 GPU; pays off on launch-bound meshes <= ~200 K "
-                         "vertices and MGCN; sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, see DESIGN.md section 8); "
-                         "per-launch kernel timing is off in this mode")
+    ap.add_argument("--graph", action="store_true", default=None,
+                    help="replay each iteration from hipGraphs: one graph on 1 GPU (pays off on launch-bound meshes <= ~200 K "
+                         "vertices and MGCN), a tape of graph segments with the collectives between them on a partition "
+                         "(segments.py; the DEFAULT for --gpus N > 1 / --partitioned with the SGCN, where a rank is host-bound); "
+                         "needs --warmup >= 4")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager execution also on a partition")
     ap.add_argument("--model", default="sgcn", choices=["sgcn", "mgcn"],
                     help="mgcn: BASELINE config c3 (3 pool levels, hierarchy from meshprep.DeviceMesh); not the headline metric")
     return ap.parse_args()
@@ -227,7 +231,8 @@ def build_trainer(args, dtype, device, world, rank, mesh):
     nu, nv = map(int, args.mesh.split("x"))
     if DIST_ON and args.model == "sgcn":
         from semigcn_amd import dist as sgdist
-        job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh)
+        job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh,
+                                           capture=args.graph)
         return job.trainer, job.workload, AGG_PER_ITER * mesh.num_edges
     batch = build_mesh_batch(mesh, device, n_masks=5)
     torch.manual_seed(314)                               # sgcn.py:19-25,76
@@ -274,7 +279,10 @@ def timed_run(trainer, args, device, world, with_timer: bool):
         trainer.iteration_step()
         torch.cuda.synchronize(device)
         log(f"warm-up iteration {i} done")
-    timer = capi.LaunchTimer() if with_timer else None
+    # a rank that replays hipGraph segments issues its kernels from the graphs: per-launch event pairs are impossible inside
+    # them, so its launches are timed in a short EAGER pass after the timed region (same kernels, same buffers)
+    replays = getattr(trainer, "_segmented", None) is not None
+    timer = capi.LaunchTimer() if (with_timer and not replays) else None
     sync()
     capi.set_launch_timer(timer)
     if DIST_ON:
@@ -286,11 +294,19 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     sync()
     dt = time.perf_counter() - t0
     capi.set_launch_timer(None)
-    # the dense products get their own short pass AFTER the timed region (an event pair per product inside it would cost
-    # the headline ~0.7 % for ~65 more pairs per iteration; the aggregation kernel's pairs stay inside, as the contract asks)
+    timed_run.timer_dt, timed_run.timer_steps = dt, args.steps
+    if DIST_ON:
+        timed_run.collectives = {k: (v - c0[k]) / args.steps for k, v in sgdist.collective_counts.items()}
     timed_run.gemm_timer, timed_run.gemm_steps = None, 0
     if with_timer:
         from semigcn_amd import functional as F_sg
+        seg = getattr(trainer, "_segmented", None)
+        if replays:
+            trainer._segmented = None                      # eager iterations of the same trainer
+            timer = capi.LaunchTimer()
+            capi.set_launch_timer(timer)
+        # the dense products get their own short pass AFTER the timed region (an event pair per product inside it would
+        # cost the headline ~0.7 %; the aggregation kernel's pairs stay inside it on one GPU, as the contract asks)
         timed_run.gemm_timer, timed_run.gemm_steps = capi.LaunchTimer(), max(1, min(args.steps, 5))
         F_sg.set_gemm_timer(timed_run.gemm_timer)
         t1 = time.perf_counter()
@@ -299,8 +315,10 @@ def timed_run(trainer, args, device, world, with_timer: bool):
         sync()
         timed_run.gemm_dt = time.perf_counter() - t1
         F_sg.set_gemm_timer(None)
-    if DIST_ON:
-        timed_run.collectives = {k: (v - c0[k]) / args.steps for k, v in sgdist.collective_counts.items()}
+        if replays:
+            capi.set_launch_timer(None)
+            trainer._segmented = seg
+            timed_run.timer_dt, timed_run.timer_steps = timed_run.gemm_dt, timed_run.gemm_steps
     if DIST_ON:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -358,7 +376,10 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
                                 f"{round(dom['algorithmic_MB'] * 1e6)}",
                 "all_aggregations_GBs": round(total_B / total_t, 1),
                 "all_aggregations_frac": round(total_B / total_t / HBM_PEAK_GBS, 4),
-                "aggregation_share_of_step": round(total_t / (dt * 1e3), 4)}
+                "aggregation_share_of_step": round(total_t / (getattr(timed_run, "timer_dt", dt) * 1e3), 4),
+                "measured_over": ("the timed region" if getattr(timed_run, "timer_steps", args.steps) == args.steps and not getattr(
+                    trainer, "_segmented", None) else f"{timed_run.timer_steps} eager iterations after the timed region "
+                    "(the timed iterations replay hipGraph segments)")}
     dense = dense_products(getattr(timed_run, "gemm_timer", None), getattr(timed_run, "gemm_steps", 0),
                            getattr(timed_run, "gemm_dt", 0.0))
     return {"value": value, "ms_per_step": dt / args.steps * 1e3, "dense_products": dense,
@@ -437,12 +458,22 @@ def spawn_ranks(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+#: file descriptor of the process's real standard output (see main)
+REAL_STDOUT = 1
+
+
 def main():
+    global REAL_STDOUT
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
+    # ONE JSON line on standard output, nothing else: RCCL prints a version banner and gloo its connection notes to fd 1 from
+    # C code, so fd 1 is pointed at standard error for the run and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -483,9 +514,15 @@ def main():
     mesh = synth.torus_mesh(nu, nv, permute=args.permute)
     log(f"mesh generated V={mesh.num_vertices} E={mesh.num_edges}")
     dtypes = {"fp32": torch.float32, "bf16": torch.bfloat16}
-    if args.graph and (DIST_ON or args.warmup < 4):
-        raise SystemExit("--graph: single GPU only, and --warmup must be >= 4 (3 eager iterations + the capture)")
-    with_timer = not args.no_launch_timer and args.model == "sgcn" and not args.graph   # byte accounting assumes the finest mesh only
+    if args.graph is None:          # default: segment replay on a partition (SGCN, enough warm-up), eager on one GPU
+        args.graph = bool(DIST_ON and args.model == "sgcn" and args.warmup >= 4)
+        if DIST_ON and not args.graph:
+            log("partitioned run without hipGraph segments (needs the SGCN and --warmup >= 4): eager")
+    if args.graph and (args.warmup < 4 or (DIST_ON and args.model != "sgcn")):
+        raise SystemExit("--graph: --warmup must be >= 4 (3 eager iterations + the capture); partitioned runs: SGCN only")
+    # byte accounting assumes the finest mesh only; inside a whole-iteration hipGraph launches cannot be timed, a partitioned
+    # rank that replays segments times them in a short EAGER pass after the timed region (timed_run)
+    with_timer = not args.no_launch_timer and args.model == "sgcn" and (not args.graph or DIST_ON)
 
     trainer, workload, agg_edges = build_trainer(args, dtypes[args.dtype], device, world, rank, mesh)
     log("model built; warm-up")
@@ -541,12 +578,16 @@ def main():
             line["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                                    "devices_visible": torch.cuda.device_count(), "ranks_share_one_gpu": shared,
                                    "single_rank_diagnostic": bool(args.partitioned and world == 1),
+                                   "hip_graph_segments": (lambda sg_: None if sg_ is None or sg_.segments is None else
+                                                          {"graphs": sg_.segments[0], "eager_actions": sg_.segments[1]})(
+                                       getattr(trainer, "_segmented", None)),
                                    "collectives_per_iteration": round(sum(coll.values()), 1), "collectives_by_kind": coll,
                                    "rank0_owned_rows": None if g is None else g.n_own,
                                    "rank0_halo_rows": None if g is None else g.n_halo}
         line["cpu_baseline"] = cpu_baseline(args.cpu_sample, mesh.num_vertices, full=args.cpu_full) if (
             not DIST_ON and not args.no_cpu_baseline) else None
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(REAL_STDOUT, (json.dumps(line) + "\n").encode())
     if DIST_ON:
         import torch.distributed as dist
         dist.barrier()

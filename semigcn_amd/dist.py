@@ -36,6 +36,7 @@ import torch.nn as nn
 
 from . import capi
 from . import reorder as _reorder
+from . import segments as _seg
 
 
 # --------------------------------------------------------------------------------------
@@ -131,38 +132,48 @@ def _pg_all_to_all(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_spl
     return dist.all_to_all_single(recv, send, recv_splits, send_splits, group=group, async_op=True)
 
 
+# Every collective is an EAGER action in the sense of segments.py: issued through ``_seg.eager`` so that an iteration that
+# is being recorded cuts its hipGraph segment around it and replays the same call on the same (static) tensors.
 def _all_reduce(t: torch.Tensor, op, group) -> None:
-    collective_counts["all_reduce"] += 1
-    if _staged(t, group):
-        h = t.cpu()
-        _pg_all_reduce(h, op, group)
-        t.copy_(h)
-    else:
-        _pg_all_reduce(t, op, group)
+    def run():
+        collective_counts["all_reduce"] += 1
+        if _staged(t, group):
+            h = t.cpu()
+            _pg_all_reduce(h, op, group)
+            t.copy_(h)
+        else:
+            _pg_all_reduce(t, op, group)
+    _seg.eager(run)
 
 
 def _all_gather_rows(out: torch.Tensor, inp: torch.Tensor, group) -> None:
-    collective_counts["all_gather"] += 1
-    if _staged(inp, group):
-        ho, hi = out.cpu(), inp.cpu()
-        _pg_all_gather(ho, hi, group)
-        out.copy_(ho)
-    else:
-        _pg_all_gather(out, inp, group)
+    def run():
+        collective_counts["all_gather"] += 1
+        if _staged(inp, group):
+            ho, hi = out.cpu(), inp.cpu()
+            _pg_all_gather(ho, hi, group)
+            out.copy_(ho)
+        else:
+            _pg_all_gather(out, inp, group)
+    _seg.eager(run)
 
 
 def _all_to_all_rows(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits, group) -> None:
-    collective_counts["all_to_all"] += 1
-    if _staged(send, group):
-        hr, hs = recv.cpu(), send.cpu()
-        work = _pg_all_to_all(hr, hs, list(recv_splits), list(send_splits), group)
-        if work is not None:
-            work.wait()
-        recv.copy_(hr)
-    else:
-        work = _pg_all_to_all(recv, send, list(recv_splits), list(send_splits), group)
-        if work is not None:
-            work.wait()
+    recv_splits, send_splits = list(recv_splits), list(send_splits)
+
+    def run():
+        collective_counts["all_to_all"] += 1
+        if _staged(send, group):
+            hr, hs = recv.cpu(), send.cpu()
+            work = _pg_all_to_all(hr, hs, recv_splits, send_splits, group)
+            if work is not None:
+                work.wait()
+            recv.copy_(hr)
+        else:
+            work = _pg_all_to_all(recv, send, recv_splits, send_splits, group)
+            if work is not None:
+                work.wait()
+    _seg.eager(run)
 
 
 # --------------------------------------------------------------------------------------
@@ -203,8 +214,12 @@ class _RowExchange:
         recv = torch.empty((self.n_halo, blk_ext.shape[1]), dtype=blk_ext.dtype, device=blk_ext.device)
         work = None
         if send.is_cuda and _backend(self.group) != "gloo":
-            collective_counts["all_to_all"] += 1
-            work = _pg_all_to_all(recv, send, self.recv_splits, self.send_splits, self.group)
+            work = {}                  # filled by the (eager, replayable) start action, drained by the wait action
+
+            def start():
+                collective_counts["all_to_all"] += 1
+                work["w"] = _pg_all_to_all(recv, send, self.recv_splits, self.send_splits, self.group)
+            _seg.eager(start)
         else:
             self._a2a(recv, send, self.recv_splits, self.send_splits)
         return work, recv, send, blk_ext
@@ -214,7 +229,11 @@ class _RowExchange:
             return
         work, recv, _send, blk_ext = token
         if work is not None:
-            work.wait()                # the CURRENT stream waits for the collective; the host does not block
+            def wait():
+                w = work.pop("w", None)
+                if w is not None:
+                    w.wait()           # the CURRENT stream waits for the collective; the host does not block
+            _seg.eager(wait)
         blk_ext[self.n_own:].copy_(recv)
 
     def exchange_reverse_add(self, grad_halo: torch.Tensor, grad_own: torch.Tensor) -> None:
@@ -764,7 +783,10 @@ class DistSGCNTrainer:
     """SGCNTrainer (semigcn_amd.train, the loop of sgcn.py:118-147) on a vertex partition."""
 
     def __init__(self, model: nn.Module, part: PartitionedMesh, group=None, lr: float = 0.01, k1: float = 4.0,
-                 accumulate: int = 5):
+                 accumulate: int = 5, capture: bool = False):
+        """``capture=True``: after three eager iterations the iteration is recorded as hipGraph segments with the
+        collectives between them and replayed from that tape (segments.py, train._SegmentedIteration): the host work of a
+        rank drops from ~450 launches with their Python / autograd glue to ~60 graph launches + the 57 collectives."""
         self.model, self.part, self.group, self.k1, self.accumulate = model, part, group, k1, accumulate
         convert_batchnorm(model, group)
         self.params = [p for p in model.parameters()]
@@ -772,8 +794,21 @@ class DistSGCNTrainer:
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=50, gamma=0.5)
         self.iteration = 0
         self.loss_sum = torch.zeros((), device=part.z1.device)
-        from .train import GradBuffer
+        from .train import GradBuffer, _SegmentedIteration
         self.grads = GradBuffer(self.params)
+        self._segmented = None
+        if capture:
+            leaves = [part.z1] if isinstance(part.z1, torch.Tensor) and part.z1.requires_grad else []
+            self._segmented = _SegmentedIteration(self.params, part.v_keep, self._forward_backward, leaves)
+
+    def _forward_backward(self, dm: torch.Tensor) -> torch.Tensor:
+        from .functional import sink_param_grads
+        if not self.model.training:
+            self.model.train()
+        loss = self.loss(self.model(self.part, dm))
+        with sink_param_grads():
+            loss.backward()
+        return loss.detach()
 
     def loss(self, pos_own: torch.Tensor) -> torch.Tensor:
         from . import train
@@ -794,14 +829,8 @@ class DistSGCNTrainer:
         p = self.part
         k = self.iteration % p.dummy_masks.shape[1] if mask_index is None else mask_index
         dm = p.v_keep * p.dummy_masks[:, k:k + 1]
-        if not self.model.training:
-            self.model.train()
-        pos = self.model(p, dm)
-        loss = self.loss(pos)
-        from .functional import sink_param_grads
-        with sink_param_grads():
-            loss.backward()
-        self.loss_sum += loss.detach()
+        loss = self._segmented(dm) if self._segmented is not None else self._forward_backward(dm)
+        self.loss_sum += loss
         self.iteration += 1
         if self.iteration % self.accumulate == 0:
             self.grads.attach()
@@ -820,7 +849,7 @@ class _Job:
 
 
 def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permute: bool = False,
-                          dtype=torch.float32, group=None, mesh=None) -> _Job:
+                          dtype=torch.float32, group=None, mesh=None, capture: bool = False) -> _Job:
     """bench.py's N > 1 leg: the SAME nu x nv mesh as the 1-GPU run, cut into ``world`` blocks
     (strong scaling)."""
     from . import synth
@@ -832,14 +861,15 @@ def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permu
     model = SingleScaleGCN(device).to(device)
     if dtype != torch.float32:
         model.set_feature_dtype(dtype)
-    trainer = DistSGCNTrainer(model, part, group)
+    trainer = DistSGCNTrainer(model, part, group, capture=capture)
     halo = torch.tensor([part.graph.n_halo], device=device)
     if world > 1:
         _all_reduce(halo, dist.ReduceOp.MAX, group)
     workload = (f"SGCN train iteration on a closed torus mesh {nu}x{nv} (V={mesh.num_vertices} E={mesh.num_edges}), "
                 f"{'fp32' if dtype == torch.float32 else 'bf16'} features, Morton-ordered and vertex-partitioned into "
                 f"{world} blocks (<= {int(halo)} halo rows per rank), "
-                f"halo exchange + mesh-wide BatchNorm + gradient all-reduce over RCCL")
+                f"halo exchange + mesh-wide BatchNorm + gradient all-reduce over RCCL"
+                + (", iteration replayed from hipGraph segments between the collectives" if capture else ""))
     return _Job(trainer, mesh.num_vertices, mesh.num_edges, workload)
 
 

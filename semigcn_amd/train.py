@@ -185,6 +185,61 @@ class _GraphedIteration:
         return self.loss.clone()
 
 
+class _SegmentedIteration:
+    """One training iteration of a PARTITIONED model recorded as a tape of hipGraph segments with the collectives between
+    them and replayed from it (semigcn_amd/segments.py).  Same contract as _GraphedIteration for ``body(mask)``; in
+    addition every collective / wait inside it must go through ``segments.eager`` (dist.py's do).  The backward pass runs
+    on the calling thread while recording (segments are begun and ended on one thread)."""
+
+    WARMUP = 3
+
+    def __init__(self, params, mask_like: torch.Tensor, body, leaves=()):
+        if not graphs_usable():
+            raise RuntimeError(f"hipGraph replay needs {GRAPH_ENV[0]}={GRAPH_ENV[1]} in the environment BEFORE the process first touches "
+                               "the GPU (see _GraphedIteration)")
+        self.params, self.leaves, self.body = [p for p in params], [t for t in leaves], body
+        self.mask = torch.zeros_like(mask_like)
+        self.rec = None
+        self.loss = None
+        self.calls = 0
+        self.stream = torch.cuda.Stream(mask_like.device)
+
+    def __call__(self, mask: torch.Tensor) -> torch.Tensor:
+        from . import segments
+        cur = torch.cuda.current_stream()
+        self.mask.copy_(mask)
+        if self.rec is not None:
+            self.stream.wait_stream(cur)
+            self.rec.replay()
+            cur.wait_stream(self.stream)
+            return self.loss.clone()
+        self.calls += 1
+        if self.calls <= self.WARMUP:
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream), torch.autograd.set_multithreading_enabled(False):
+                loss = self.body(self.mask)
+            cur.wait_stream(self.stream)
+            return loss
+        for t in list(self.params) + list(self.leaves):      # gradients must accumulate in place inside the segments
+            if t.requires_grad and t.grad is None:
+                t.grad = torch.zeros_like(t)
+        import gc
+        gc.collect()
+        rec = segments.SegmentRecorder(self.stream)
+        self.stream.wait_stream(cur)
+        with torch.autograd.set_multithreading_enabled(False):
+            self.loss = rec.record(lambda: self.body(self.mask))
+        self.rec = rec
+        rec.replay()                                           # the recording pass executed no captured kernel
+        cur.wait_stream(self.stream)
+        return self.loss.clone()
+
+    @property
+    def segments(self):
+        """(graph segments, eager actions) of the recorded tape, or None before the recording."""
+        return None if self.rec is None else self.rec.counts()
+
+
 class GradBuffer:
     """Every fp32 parameter gradient of a model as a view of ONE flat buffer: ``p.grad`` exists from the start (the layers
     add into it in place under ``functional.sink_param_grads``; autograd's own AccumulateGrad adds in place too), zeroing

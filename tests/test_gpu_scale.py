@@ -223,6 +223,31 @@ def test_one_rank_over_rccl_with_every_collective_issued():
     print(r.stdout[-800:])
 
 
+def _run_segment_replay(world, backend, **env):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29700 + world + (7 if backend == "nccl" else 0)),
+           os.path.join(ROOT, "tests", "segment_replay_script.py")]
+    return subprocess.run(cmd, env=_child_env(SEMIGCN_SELFTEST_BACKEND=backend, DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", **env),
+                          capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_segmented_replay_of_the_partitioned_iteration_one_rank_over_rccl(dtype):
+    """The partitioned iteration recorded as hipGraph segments with the RCCL collectives between them (segments.py) ==
+    the eager partitioned iteration, bit for bit over nine iterations (tests/segment_replay_script.py)."""
+    r = _run_segment_replay(1, "nccl", SEMIGCN_DIST_FORCE_COLLECTIVES="1", SEMIGCN_SELFTEST_DTYPE=dtype)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "SEGMENT_REPLAY_OK" in r.stdout
+    print(r.stdout[-600:])
+
+
+def test_segmented_replay_two_ranks_sharing_the_gpu():
+    """Same, two ranks on one device with the collectives staged through the host (gloo): real halos, real peers."""
+    r = _run_segment_replay(2, "gloo")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "SEGMENT_REPLAY_OK" in r.stdout
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for RCCL")
 def test_partitioned_ranks_over_rccl():
     r = _run_selftest(2, "nccl")
@@ -239,8 +264,16 @@ def test_bench_gpus_2_starts_its_own_ranks():
         assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()
     r = subprocess.run(base, env=_child_env(SEMIGCN_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # ONE JSON line, nothing else on stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert line["distributed"]["world_size"] == 2 and line["distributed"]["collectives_per_iteration"] > 0
+    # with enough warm-up the ranks replay hipGraph segments between their collectives (the default on a partition)
+    r = subprocess.run(base[:5] + ["6", "--warmup", "5"] + base[8:], env=_child_env(SEMIGCN_BENCH_SHARE_GPU="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip())
+    seg = line["distributed"]["hip_graph_segments"]
+    assert seg is not None and seg["graphs"] > 50 and seg["eager_actions"] >= 57 and line["roofline"] is not None
+    assert "eager iterations after the timed region" in line["roofline"]["measured_over"]
