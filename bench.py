@@ -71,6 +71,10 @@ def parse():
                          "(segments.py; the DEFAULT for --gpus N > 1 / --partitioned with the SGCN, where a rank is host-bound); "
                          "needs --warmup >= 4")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager execution also on a partition")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="experimental, partitioned SGCN over RCCL only: ONE hipGraph per iteration with the RCCL calls "
+                         "captured inside it instead of graph segments between eager collectives (exercised on a one-rank "
+                         "communicator only; never the default)")
     ap.add_argument("--model", default="sgcn", choices=["sgcn", "mgcn"],
                     help="mgcn: BASELINE config c3 (3 pool levels, hierarchy from meshprep.DeviceMesh); not the headline metric")
     return ap.parse_args()
@@ -232,7 +236,7 @@ def build_trainer(args, dtype, device, world, rank, mesh):
     if DIST_ON and args.model == "sgcn":
         from semigcn_amd import dist as sgdist
         job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh,
-                                           capture=args.graph)
+                                           capture=("whole" if args.graph and args.graph_collectives else args.graph))
         return job.trainer, job.workload, AGG_PER_ITER * mesh.num_edges
     batch = build_mesh_batch(mesh, device, n_masks=5)
     torch.manual_seed(314)                               # sgcn.py:19-25,76

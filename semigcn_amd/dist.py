@@ -797,7 +797,15 @@ class DistSGCNTrainer:
         from .train import GradBuffer, _SegmentedIteration
         self.grads = GradBuffer(self.params)
         self._segmented = None
-        if capture:
+        if capture == "whole":
+            # experimental: ONE hipGraph for the whole iteration with the RCCL calls captured inside it (no segment
+            # boundaries at all).  Exercised on a one-rank communicator only -- not the default anywhere.
+            from .train import _GraphedIteration
+            if _backend(group) == "gloo":
+                raise ValueError('capture="whole" needs the nccl backend (gloo collectives are staged through the host)')
+            self._segmented = _GraphedIteration(self.params, part.v_keep, self._forward_backward)
+            self._segmented.segments = None
+        elif capture:
             leaves = [part.z1] if isinstance(part.z1, torch.Tensor) and part.z1.requires_grad else []
             self._segmented = _SegmentedIteration(self.params, part.v_keep, self._forward_backward, leaves)
 

@@ -46,21 +46,23 @@ def main():
             _ = part.v_keep * 2.0                  # an unrelated eager kernel between iterations ...
             losses.append(float(tr.iteration_step()))
             torch.cuda.synchronize()               # ... and an idle GPU before the next replay
-        if capture:
+        if capture is True:
             assert tr._segmented.rec is not None
             print(f"[rank {rank}] tape: %d graph segments, %d eager actions" % tr._segmented.rec.counts(), flush=True)
         return losses, {k: v.clone() for k, v in model.state_dict().items()}
 
+    mode = os.environ.get("SEMIGCN_SELFTEST_CAPTURE", "segments")
     le, se = run(False)
     c0 = dict(sgdist.collective_counts)
-    lg, sg = run(True)
+    lg, sg = run(True if mode == "segments" else mode)
     c1 = dict(sgdist.collective_counts)
     assert lg == le, (lg, le)
     for k in se:
         assert torch.equal(se[k], sg[k]), k
     # the replays issued the same collectives as the eager iterations
     per_run = {k: c1[k] - c0[k] for k in c0}
-    assert per_run == {k: c0[k] - 0 for k in c0} or all(per_run[k] >= 9 * n for k, n in (("all_to_all", 28), ("all_gather", 13))), per_run
+    if mode == "segments":
+        assert all(per_run[k] >= 9 * n for k, n in (("all_to_all", 28), ("all_gather", 13))), per_run
     dist.barrier()
     if rank == 0:
         print("SEGMENT_REPLAY_OK", backend, world, str(dtype), le[-1], per_run)

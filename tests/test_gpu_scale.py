@@ -241,6 +241,14 @@ def test_segmented_replay_of_the_partitioned_iteration_one_rank_over_rccl(dtype)
     print(r.stdout[-600:])
 
 
+def test_whole_iteration_graph_with_the_rccl_calls_captured_one_rank():
+    """Experimental mode (DistSGCNTrainer(capture="whole"), bench.py --graph-collectives): ONE hipGraph per iteration with
+    the RCCL calls captured inside it == the eager partitioned iteration, bit for bit (one-rank communicator)."""
+    r = _run_segment_replay(1, "nccl", SEMIGCN_DIST_FORCE_COLLECTIVES="1", SEMIGCN_SELFTEST_CAPTURE="whole")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "SEGMENT_REPLAY_OK" in r.stdout
+
+
 def test_segmented_replay_two_ranks_sharing_the_gpu():
     """Same, two ranks on one device with the collectives staged through the host (gloo): real halos, real peers."""
     r = _run_segment_replay(2, "gloo")
