@@ -227,8 +227,19 @@ class _SegmentedIteration:
         gc.collect()
         rec = segments.SegmentRecorder(self.stream)
         self.stream.wait_stream(cur)
-        with torch.autograd.set_multithreading_enabled(False):
-            self.loss = rec.record(lambda: self.body(self.mask))
+        try:
+            with torch.autograd.set_multithreading_enabled(False):
+                self.loss = rec.record(lambda: self.body(self.mask))
+        except Exception as e:      # best effort: a rank that cannot record keeps running eagerly (every rank must take the
+            import sys              # same branch -- the collectives inside body() pair up either way)
+            print(f"semigcn_amd: recording the iteration as hipGraph segments failed ({type(e).__name__}: {e}); "
+                  "continuing eagerly", file=sys.stderr, flush=True)
+            self.calls = -(1 << 60)                            # stay on the eager branch from now on
+            torch.cuda.synchronize()
+            with torch.cuda.stream(self.stream), torch.autograd.set_multithreading_enabled(False):
+                loss = self.body(self.mask)
+            cur.wait_stream(self.stream)
+            return loss
         self.rec = rec
         rec.replay()                                           # the recording pass executed no captured kernel
         cur.wait_stream(self.stream)
