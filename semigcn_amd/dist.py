@@ -242,7 +242,17 @@ class _RowExchange:
             return
         recv = torch.empty((self.n_send, grad_halo.shape[1]), dtype=grad_halo.dtype, device=grad_halo.device)
         self._a2a(recv, grad_halo.contiguous(), self.send_splits, self.recv_splits)
-        grad_own.index_add_(0, self.send_rows.long(), recv)
+        if recv.is_cuda and self.n_send > 0:
+            # a boundary row can sit in the halo of SEVERAL peers (3+ ranks): its returning contributions are summed in a
+            # fixed order by the segment kernel (sg_unpool_bwd over the send list), not by index_add_'s atomics -- the
+            # partitioned iteration stays bit-reproducible run to run
+            rev = getattr(self, "_reverse_sum", None)
+            if rev is None:
+                rev = self._reverse_sum = capi.PoolHandle(torch.arange(self.n_send, device=recv.device),
+                                                          self.send_rows.long(), self.n_send, self.n_own)
+            grad_own.add_(rev.unpool_bwd(recv))
+        else:
+            grad_own.index_add_(0, self.send_rows.long(), recv)
 
 
 class HaloPlan(_RowExchange):

@@ -210,6 +210,17 @@ def test_partitioned_sgcn_and_mgcn_equal_single_rank_on_device(world):
     print(r.stdout[-1500:])
 
 
+def test_eight_ranks_on_a_200k_vertex_mesh_equal_single_rank():
+    """The 8-way partition the scaling run uses (Morton blocks, two-ring halos, 7 peers per rank), on a 500x400 mesh with
+    the eight ranks sharing the one GPU over gloo: partitioned SGCN forward / loss / reduced gradients == the single-device
+    model (asserted inside the ranks: positions <= 1e-5, loss <= 2e-6)."""
+    r = _run_selftest(8, "gloo", SEMIGCN_SELFTEST_MESH="500x400", SEMIGCN_SELFTEST_SKIP_MGCN="1")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "dist_selftest OK" in r.stdout
+    assert sum("pos rel-L2" in ln for ln in r.stdout.splitlines()) == 8
+    print(r.stdout[-1800:])
+
+
 def test_one_rank_over_rccl_with_every_collective_issued():
     """The RCCL code path on a one-GPU box: ONE rank, backend "nccl", and SEMIGCN_DIST_FORCE_COLLECTIVES=1 so that the
     rank issues every collective of the partitioned iteration through the real library (communicator set-up, asynchronous
@@ -249,9 +260,10 @@ def test_whole_iteration_graph_with_the_rccl_calls_captured_one_rank():
     assert "SEGMENT_REPLAY_OK" in r.stdout
 
 
-def test_segmented_replay_two_ranks_sharing_the_gpu():
-    """Same, two ranks on one device with the collectives staged through the host (gloo): real halos, real peers."""
-    r = _run_segment_replay(2, "gloo")
+@pytest.mark.parametrize("world", [2, 8])
+def test_segmented_replay_ranks_sharing_the_gpu(world):
+    """Same, 2 and 8 ranks on one device with the collectives staged through the host (gloo): real halos, real peers."""
+    r = _run_segment_replay(world, "gloo")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "SEGMENT_REPLAY_OK" in r.stdout
 

@@ -34,7 +34,8 @@ def main():
     from semigcn_amd.networks import SingleScaleGCN
     import bench
 
-    mesh = synth.torus_mesh(96, 64, permute=True)
+    nu, nv = map(int, os.environ.get("SEMIGCN_SELFTEST_MESH", "96x64").split("x"))
+    mesh = synth.torus_mesh(nu, nv, permute=True)
     part = sgdist.partition_mesh(mesh, rank, world, dev, n_masks=2)
     model = SingleScaleGCN(dev)
     GU.fill_state(model, seed=77)
@@ -73,7 +74,8 @@ def main():
     print(f"[rank {rank}/{world}] own={g.n_own} halo={g.n_halo} send={g.n_send}  pos rel-L2 {e_pos:.2e}  "
           f"loss rel {e_loss:.2e}  worst param-grad rel-L2 {worst:.2e}", flush=True)
     assert e_pos < 1e-5 and e_loss < 2e-6 and worst < 3e-2
-    mgcn_selftest(rank, world, dev)
+    if os.environ.get("SEMIGCN_SELFTEST_SKIP_MGCN") != "1":
+        mgcn_selftest(rank, world, dev)
     dist.barrier()
     if rank == 0:
         import json
