@@ -10,8 +10,9 @@ bash tools/config_table.sh $O/configs_n1.jsonl > $O/config_table.log 2>&1
 bash tools/launch_census.sh $T --mesh 250x200 --dtype bf16 > $O/launch_census.log 2>&1
 cp $O/launch_census.txt $O/launch_census_c2_bf16.txt
 for i in 1 2; do
-  python bench.py --mesh 354x354 --dtype bf16 --single-dtype --no-cpu-baseline --no-launch-timer --steps 60 --warmup 10 2>/dev/null | grep "^{" >> $O/rank_proxy_125k.jsonl
-  python bench.py --mesh 354x354 --dtype bf16 --single-dtype --no-cpu-baseline --no-launch-timer --steps 60 --warmup 10 --partitioned 2>/dev/null | grep "^{" >> $O/rank_proxy_125k.jsonl
+  for m in "" "--partitioned --no-graph" "--partitioned" "--graph"; do
+    python bench.py --mesh 354x354 --dtype bf16 --single-dtype --no-cpu-baseline --no-launch-timer --steps 60 --warmup 10 $m 2>/dev/null >> $O/rank_proxy_125k.jsonl
+  done
 done
 python tools/overlap_probe.py 2>/dev/null | grep "^C=" > $O/overlap_probe.txt
 python tools/overlap_probe.py --N 512 --Kp 768 2>/dev/null | grep "^C=" >> $O/overlap_probe.txt
