@@ -518,10 +518,16 @@ def main():
     mesh = synth.torus_mesh(nu, nv, permute=args.permute)
     log(f"mesh generated V={mesh.num_vertices} E={mesh.num_edges}")
     dtypes = {"fp32": torch.float32, "bf16": torch.bfloat16}
-    if args.graph is None:          # default: segment replay on a partition (SGCN, enough warm-up), eager on one GPU
-        args.graph = bool(DIST_ON and args.model == "sgcn" and args.warmup >= 4)
+    if args.graph is None:
+        # default: eager on one GPU; on a partition segment replay where a rank is host-bound -- up to ~300 K rows per rank
+        # (measured on the one-rank proxy: 125 K rows 7.2 ms replayed against 8.9-11.3 eager, 250 K rows 11.0 against
+        # 10.7-13.4, 500 K rows 18.3 against 17.8: above that the GPU is the bound and the graph launches only add bubbles)
+        rows_per_rank = mesh.num_vertices // max(world, 1)
+        args.graph = bool(DIST_ON and args.model == "sgcn" and args.warmup >= 4 and rows_per_rank <= 300_000
+                          and args.dtype == "bf16")          # (fp32 features: GPU-bound on the fp32 products at any size)
         if DIST_ON and not args.graph:
-            log("partitioned run without hipGraph segments (needs the SGCN and --warmup >= 4): eager")
+            log(f"partitioned run without hipGraph segments ({rows_per_rank} rows per rank, {args.dtype}; the default needs the SGCN, "
+                "bf16 features, --warmup >= 4 and <= 300000 rows per rank): eager")
     if args.graph and (args.warmup < 4 or (DIST_ON and args.model != "sgcn")):
         raise SystemExit("--graph: --warmup must be >= 4 (3 eager iterations + the capture); partitioned runs: SGCN only")
     # byte accounting assumes the finest mesh only; inside a whole-iteration hipGraph launches cannot be timed, a partitioned

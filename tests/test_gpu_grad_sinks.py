@@ -61,6 +61,20 @@ def test_bn_coefficient_kernel_accumulates_and_statistics_kernel_counts():
     assert torch.equal(aw, aw0 + plain[1]) and torch.equal(ab, ab0 + plain[0])
 
 
+def test_partition_statistics_row_also_where_the_block_count_is_capped():
+    """bn_local_stats on col_moments' partials at row counts where sg_col_blocks caps the block count (V > 262 144: a few
+    empty blocks at the end) -- the row a rank of a 2-way partition of the 1 M mesh contributes to the statistics all-gather."""
+    for V in (300_000, 501_264, 5_000):
+        C = 8
+        x = torch.randn(V, C, device=DEV) * 2 + 1
+        local = torch.empty(1, 2 * C + 1, device=DEV)
+        capi.bn_local_stats(capi.col_moments(x), 0, V, local)
+        var, mean = torch.var_mean(x.double(), dim=0, unbiased=False)
+        assert float((local[0, :C].double() - mean).abs().max()) < 1e-5
+        assert float((local[0, C:2 * C].double() / V - var).abs().max() / var.max()) < 1e-5
+        assert float(local[0, 2 * C]) == float(V)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_sunk_parameter_gradients_equal_autograd_accumulation(dtype):
     """Three accumulated forward/backward passes of the SGCN: gradients sunk into preallocated accumulators by the

@@ -289,8 +289,9 @@ def test_bench_gpus_2_starts_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert line["distributed"]["world_size"] == 2 and line["distributed"]["collectives_per_iteration"] > 0
-    # with enough warm-up the ranks replay hipGraph segments between their collectives (the default on a partition)
-    r = subprocess.run(base[:5] + ["6", "--warmup", "5"] + base[8:], env=_child_env(SEMIGCN_BENCH_SHARE_GPU="1"),
+    # with enough warm-up and bf16 features the ranks replay hipGraph segments between their collectives (the default for
+    # host-bound ranks: <= 300 K rows each)
+    r = subprocess.run(base[:5] + ["6", "--warmup", "5"] + base[8:-1] + ["bf16"], env=_child_env(SEMIGCN_BENCH_SHARE_GPU="1"),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads(r.stdout.strip())
