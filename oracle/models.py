@@ -41,11 +41,13 @@ class SGCNOracle(nn.Module):
     """13 x [ChebConv(K=3), BatchNorm1d, LeakyReLU]; last block + Linear(16,3);
     six skip Linears always constructed (util/networks.py:40-61)."""
 
-    def __init__(self, skip: bool = False):
+    def __init__(self, skip: bool = False, act: Optional[nn.Module] = None):
+        """``act``: stands in for the ONE shared ``nn.LeakyReLU()`` instance of util/networks.py:17-18 (the tests inject
+        a module that applies a prescribed sign pattern, tests/golden_util.py::PrescribedLeakyReLU)."""
         super().__init__()
         h = SGCN_WIDTHS
         self.skip = skip
-        act = nn.LeakyReLU()
+        act = nn.LeakyReLU() if act is None else act
         blocks = []
         for i in range(13):
             mods = [(ChebConv(h[i], h[i + 1], K=3), "x, edge_index -> x"), nn.BatchNorm1d(h[i + 1]), act]
@@ -213,3 +215,32 @@ def mask_norm_rec_loss(pred: torch.Tensor, real: torch.Tensor, mask) -> torch.Te
     m = torch.as_tensor(mask, dtype=torch.bool)
     d = (pred[m] - real[m]).abs().sum(1)
     return d.sum() / d.shape[0]
+
+
+def sgcn_training_loop(net: nn.Module, z1, x_pos, edge_index, faces, target_pos, target_fn, v_mask, f_mask,
+                       dummy_masks: torch.Tensor, mask_order: Sequence[int], batch: int = 5, lr: float = 0.01,
+                       k1: float = 4.0, on_iteration=None):
+    """The inner loop of sgcn.py:118-147 on the oracle: for every group of ``batch`` masks -- ``zero_grad``, then per
+    mask ``dm = v_mask * dummy`` (:126-128), forward, ``loss_p + k1 * loss_n`` (:130-131,138), ``backward`` -- then ONE
+    ``Adam.step`` (:146); ``Adam(lr=pos_lr)`` and ``k1 = 4`` are the script's defaults (:79, :47).  ``mask_order`` stands
+    in for the script's ``torch.randperm`` (:119).  ``net(z1, x_pos, edge_index, dm)`` is an oracle model in train
+    mode.  Returns the list of per-iteration loss values (Python floats, the ``loss.item()`` of :144).
+    ``on_iteration(i)`` (optional) is called before iteration i's forward."""
+    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    vm = torch.as_tensor(v_mask)
+    rm = vm.reshape(-1, 1).float()
+    losses = []
+    order = list(mask_order)
+    for start in range(0, len(order), batch):
+        net.train()
+        opt.zero_grad()
+        for i, k in enumerate(order[start:start + batch]):
+            if on_iteration is not None:
+                on_iteration(start + i)
+            dm = rm * dummy_masks[:, k].reshape(-1, 1)
+            pos = net(z1, x_pos, edge_index, dm)
+            loss = mask_pos_rec_loss(pos, target_pos, vm) + k1 * mask_norm_rec_loss(compute_fn(pos, faces), target_fn, f_mask)
+            loss.backward()
+            losses.append(float(loss.item()))
+        opt.step()
+    return losses

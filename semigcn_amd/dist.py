@@ -710,9 +710,12 @@ def all_reduce_gradients(params, group=None, flat: Optional[torch.Tensor] = None
 
 class _GlobalMinMax(torch.autograd.Function):
     """(lo_local, hi_local) [1, n] -> mesh-wide (lo, hi): ONE all-reduce (max of [-lo | hi]).  Every rank goes on with
-    the replicated bounds, so d loss / d bound is the SUM over ranks of the local terms (one all-reduce of 2n floats
-    in backward); it is then handed to the rank(s) whose local extreme IS the global one, where ``_column_min_max``'s
-    own backward routes it to the arg-extreme vertex -- as torch.min/max(z1, dim=0) does on a single device."""
+    the replicated bounds, so d loss / d bound is the SUM over ranks of the local terms (one all-reduce in backward); it
+    is then handed to ONE rank whose local extreme IS the global one -- the lowest such rank when several ranks hold
+    the same extreme value (grid-like meshes do) -- where ``_column_min_max``'s own backward routes it to the arg-extreme
+    vertex: one vertex per bound, as torch.min/max(z1, dim=0) does on a single device.  The tie is broken inside the
+    backward's all-reduce: every holder adds 2^rank to a per-bound word, the sum is the set of holders (exact in fp32 up
+    to 24 ranks), its lowest bit the winner."""
 
     @staticmethod
     def forward(ctx, lo_l, hi_l, group):
@@ -721,16 +724,21 @@ class _GlobalMinMax(torch.autograd.Function):
         _all_reduce(both, dist.ReduceOp.MAX, group)
         lo_g, hi_g = -both[:, :n], both[:, n:].clone()
         ctx.group = group
-        ctx.save_for_backward(lo_l == lo_g, hi_l == hi_g)
+        ctx.save_for_backward(torch.cat([lo_l == lo_g, hi_l == hi_g], dim=1))
         return lo_g, hi_g
 
     @staticmethod
     def backward(ctx, g_lo, g_hi):
-        own_lo, own_hi = ctx.saved_tensors
-        g = torch.cat([g_lo, g_hi], dim=1).contiguous()
-        _all_reduce(g, dist.ReduceOp.SUM, ctx.group)
+        (own,) = ctx.saved_tensors
         n = g_lo.shape[1]
-        return g[:, :n] * own_lo.to(g.dtype), g[:, n:] * own_hi.to(g.dtype), None
+        rank = dist.get_rank(ctx.group)
+        if dist.get_world_size(ctx.group) > 24:
+            raise RuntimeError("the holder word of _GlobalMinMax is exact up to 24 ranks")
+        g = torch.cat([g_lo, g_hi, own.to(g_lo.dtype) * float(1 << rank)], dim=1).contiguous()
+        _all_reduce(g, dist.ReduceOp.SUM, ctx.group)
+        holders = g[:, 2 * n:].to(torch.int64)
+        mine = ((holders & -holders) == (1 << rank)).to(g.dtype)          # lowest set bit = the lowest holding rank
+        return g[:, :n] * mine[:, :n], g[:, n:2 * n] * mine[:, n:], None
 
 
 def dist_min_max(z1: torch.Tensor, group=None):

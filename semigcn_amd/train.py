@@ -112,7 +112,12 @@ else:
 
 def graphs_usable() -> bool:
     """True only if DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was in the environment when the HIP runtime initialised (setting
-    it afterwards has no effect on the runtime and would let a corrupting replay through)."""
+    it afterwards has no effect on the runtime and would let a corrupting replay through).  BEST EFFORT: the value is
+    sampled at torch's lazy CUDA initialisation (or at import, if torch was initialised already); the HIP runtime itself
+    can have been brought up earlier (a profiler's preloaded library, ``torch.cuda.device_count()`` on some builds) and
+    would then not have seen a flag set in between.  That is why the replaying trainers do not rely on this guard alone:
+    the first replay is compared with an eager pass over the same inputs before it is trusted
+    (``replay_matches_eager``)."""
     if not _flag_at_gpu_init["known"]:
         if torch.cuda.is_initialized():
             _record_flag_at_init()
@@ -203,6 +208,10 @@ class _SegmentedIteration:
         self.loss = None
         self.calls = 0
         self.stream = torch.cuda.Stream(mask_like.device)
+        _SegmentedIteration._instances += 1
+        self._uid = _SegmentedIteration._instances      # the same on every rank (the ranks build the same trainers)
+
+    _instances = 0
 
     def __call__(self, mask: torch.Tensor) -> torch.Tensor:
         from . import segments
@@ -230,16 +239,20 @@ class _SegmentedIteration:
         try:
             with torch.autograd.set_multithreading_enabled(False):
                 self.loss = rec.record(lambda: self.body(self.mask))
-        except Exception as e:      # best effort: a rank that cannot record keeps running eagerly (every rank must take the
-            import sys              # same branch -- the collectives inside body() pair up either way)
-            print(f"semigcn_amd: recording the iteration as hipGraph segments failed ({type(e).__name__}: {e}); "
-                  "continuing eagerly", file=sys.stderr, flush=True)
-            self.calls = -(1 << 60)                            # stay on the eager branch from now on
-            torch.cuda.synchronize()
-            with torch.cuda.stream(self.stream), torch.autograd.set_multithreading_enabled(False):
-                loss = self.body(self.mask)
-            cur.wait_stream(self.stream)
-            return loss
+        except Exception as e:
+            # body() may have issued k of its ~57 collectives before failing; re-running it eagerly here would put k + N
+            # collectives on this rank's communicator against 2 N on a rank that recorded -- the sequences no longer pair
+            # up and the job hangs until a watchdog fires.  So: tell the other ranks (through the rendezvous STORE, not
+            # through a collective) and fail; the launcher starts a fresh set of ranks without replay (bench.py).
+            _publish_record_outcome(self._uid, ok=False)
+            raise RuntimeError(f"recording the iteration as hipGraph segments failed on this rank ({type(e).__name__}: {e}); "
+                               "a partially recorded iteration cannot be continued eagerly (its collectives would no longer "
+                               "pair up across ranks) -- restart without capture") from e
+        _publish_record_outcome(self._uid, ok=True)
+        failed = _ranks_that_failed_to_record(self._uid)
+        if failed:
+            raise RuntimeError(f"rank(s) {failed} could not record the iteration as hipGraph segments; every rank drops its "
+                               "tape -- restart without capture")
         self.rec = rec
         rec.replay()                                           # the recording pass executed no captured kernel
         cur.wait_stream(self.stream)
@@ -249,6 +262,79 @@ class _SegmentedIteration:
     def segments(self):
         """(graph segments, eager actions) of the recorded tape, or None before the recording."""
         return None if self.rec is None else self.rec.counts()
+
+
+def _default_store():
+    import torch.distributed as tdist
+    if not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size() <= 1:
+        return None
+    try:
+        return tdist.distributed_c10d._get_default_store()
+    except Exception:
+        return None
+
+
+def _publish_record_outcome(uid: int, ok: bool) -> None:
+    """One key per (recorder, rank) in the job's rendezvous store: a side channel that does not depend on the order of the
+    collectives a failing rank may have left half issued."""
+    store = _default_store()
+    if store is None:
+        return
+    import torch.distributed as tdist
+    try:
+        store.set(f"semigcn/segrec/{uid}/{tdist.get_rank()}", "ok" if ok else "fail")
+    except Exception:
+        pass
+
+
+def _ranks_that_failed_to_record(uid: int, timeout_s: float = 300.0):
+    """Ranks whose recording failed (or that did not report within ``timeout_s``); [] when every rank recorded."""
+    store = _default_store()
+    if store is None:
+        return []
+    import datetime
+    import torch.distributed as tdist
+    bad = []
+    for r in range(tdist.get_world_size()):
+        key = f"semigcn/segrec/{uid}/{r}"
+        try:
+            store.wait([key], datetime.timedelta(seconds=timeout_s))
+            if store.get(key) != b"ok":
+                bad.append(r)
+        except Exception:
+            bad.append(r)
+    return bad
+
+
+def replay_matches_eager(trainer, mask_index: int = 0, rtol: float = 1e-6) -> bool:
+    """Trust a replaying trainer only after ONE replayed iteration has reproduced an eager one: both run on the same mask
+    with the same parameters (no optimiser step lies between them; BatchNorm normalises with batch statistics in training
+    mode, so the running averages moving in between do not matter), and their loss values -- on a partition the mesh-wide,
+    all-reduced value, hence the same number on every rank -- must agree to ``rtol`` (the replay tests find them
+    bit-identical).  Costs two iterations.  Not for models with active Dropout (MGCN: two passes draw different
+    masks).  Returns False (and leaves the trainer on its EAGER path) otherwise; every
+    rank reaches the same verdict without further communication."""
+    rep = getattr(trainer, "_segmented", None) or getattr(trainer, "_graphed", None)
+    if rep is None:
+        return True
+    attr = "_segmented" if getattr(trainer, "_segmented", None) is not None else "_graphed"
+    while getattr(rep, "rec", None) is None and getattr(rep, "graph", None) is None:
+        trainer.iteration_step(mask_index)              # still warming up / recording
+    while (trainer.iteration + 1) % trainer.accumulate == 0:
+        trainer.iteration_step(mask_index)              # keep the pair clear of the optimiser step
+    setattr(trainer, attr, None)
+    try:
+        eager = float(trainer.iteration_step(mask_index))
+    finally:
+        setattr(trainer, attr, rep)
+    replayed = float(trainer.iteration_step(mask_index))
+    ok = abs(replayed - eager) <= rtol * max(abs(eager), 1e-30)
+    if not ok:
+        import sys
+        print(f"semigcn_amd: replayed iteration loss {replayed!r} != eager {eager!r}; hipGraph replay switched off for this "
+              "trainer", file=sys.stderr, flush=True)
+        setattr(trainer, attr, None)
+    return ok
 
 
 class GradBuffer:
@@ -267,17 +353,23 @@ class GradBuffer:
             for p in main:
                 self.views[id(p)] = self.flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
-        self.attach()
+        # a NEW buffer starts from zero: whatever a backward pass made before the trainer existed left in ``.grad`` (a
+        # parity check, a smoke run) must not reach the first optimiser step -- the reference zeroes the gradients at the
+        # head of every accumulation cycle (sgcn.py:121)
+        self.attach(keep=False)
 
-    def attach(self) -> None:
-        """(Re)install the views as ``.grad`` -- also after something set a gradient to None or replaced it."""
+    def attach(self, keep: bool = True) -> None:
+        """(Re)install the views as ``.grad`` -- also after something set a gradient to None or replaced it in the middle
+        of an accumulation cycle (``keep``: what that gradient holds is carried over into the view)."""
         for p in self.params:
             v = self.views.get(id(p))
             if v is None:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
+                elif not keep:
+                    p.grad.zero_()
             elif p.grad is not v:
-                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                if keep and p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                     v.copy_(p.grad)
                 p.grad = v
 

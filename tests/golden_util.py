@@ -141,3 +141,63 @@ class ActivationMasks:
 
 def grad_tolerance(flips: int, tight: float, per_flip: float = 2e-2) -> float:
     return tight if flips == 0 else tight + per_flip * flips
+
+
+class PrescribedLeakyReLU(torch.nn.Module):
+    """LeakyReLU that applies a PRESCRIBED sign pattern: call i uses ``masks[i]`` (bool, the input's shape) instead of
+    ``z > 0``.  Gives two implementations of one network the same piecewise-linear branch, so that their gradients can
+    be compared with a flat bound: where a BatchNorm output sits within rounding of zero, one implementation's
+    ``z > 0`` and the other's differ, and that one slope (1 vs 0.01) moves every upstream gradient.  The forward value
+    changes only where the prescribed sign differs from the module's own, by 0.99 |z| with |z| at rounding level; the
+    module counts those elements (``flips``) and keeps their largest |z| / rms(z) (``max_flip_z``) so a test can
+    assert that nothing but rounding-level kink crossings was overridden."""
+
+    def __init__(self, masks=None, negative_slope: float = 0.01):
+        super().__init__()
+        self.negative_slope = negative_slope
+        self.masks = masks
+        self.reset()
+
+    def reset(self, masks=None):
+        if masks is not None:
+            self.masks = masks
+        self.calls, self.flips, self.elements, self.max_flip_z = 0, 0, 0, 0.0
+
+    def forward(self, z):
+        m = self.masks[self.calls % len(self.masks)]
+        self.calls += 1
+        with torch.no_grad():
+            own = z > 0
+            diff = own != m
+            n = int(diff.sum())
+            self.elements += z.numel()
+            if n:
+                self.flips += n
+                rms = float(z.pow(2).mean().sqrt())
+                self.max_flip_z = max(self.max_flip_z, float(z[diff].abs().max()) / max(rms, 1e-30))
+        return torch.where(m, z, self.negative_slope * z)
+
+
+class FusedActivationMasks:
+    """The sign pattern of every fused BatchNorm+activation output of ``semigcn_amd`` during the forward passes inside the
+    ``with`` block, rows brought into the caller's vertex order by ``rank`` (the model's processing-order map, or None);
+    kept on the device until ``cpu()``."""
+
+    def __init__(self, rank=None):
+        self.rank = rank
+        self.masks = []
+
+    def __enter__(self):
+        from semigcn_amd import functional as F_sg
+        self._obs = lambda y: self.masks.append((y.detach() > 0) if self.rank is None
+                                                else (y.detach() > 0).index_select(0, self.rank))
+        F_sg.bn_act_observers.append(self._obs)
+        return self
+
+    def __exit__(self, *exc):
+        from semigcn_amd import functional as F_sg
+        F_sg.bn_act_observers.remove(self._obs)
+        return False
+
+    def cpu(self):
+        return [m.cpu() for m in self.masks]

@@ -67,7 +67,11 @@ def _run_rank(rank, world, port, out_dir, skip):
     zz = part.z1.detach().clone().requires_grad_(True)             # bounding box: gradient reaches the arg-extreme's owner
     lo_mm, hi_mm = sgdist.dist_min_max(zz)
     ((2.0 * lo_mm.sum() + 3.0 * hi_mm.sum()) / world).backward()      # each rank holds 1/world of the replicated term
-    lin = {"mm_lo": lo_mm.detach().clone(), "mm_hi": hi_mm.detach().clone(), "mm_dz": zz.grad.clone(),
+    # the same extreme value on EVERY rank: the bound's gradient must still reach exactly one vertex of the mesh
+    zt = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], [0.0, 0.5, -0.5]], requires_grad=True)
+    lo_t, hi_t = sgdist.dist_min_max(zt)
+    ((2.0 * lo_t.sum() + 3.0 * hi_t.sum()) / world).backward()
+    lin = {"tie_dz": zt.grad.clone(), "mm_lo": lo_mm.detach().clone(), "mm_hi": hi_mm.detach().clone(), "mm_dz": zz.grad.clone(),
            "conv_y": y.detach().clone(), "conv_dx": x.grad.clone(), "conv_dw": conv.lins[2].weight.grad.clone(),
            "conv_db": conv.bias.grad.clone(), "conv2_y": y2.detach().clone(), "conv2_dx": x2.grad.clone(),
            "conv2_dw": conv2.lins[1].weight.grad.clone(), "conv2_db": conv2.bias.grad.clone(), "bn_y": yb.detach().clone(), "bn_dx": xb.grad.clone(),
@@ -127,6 +131,9 @@ def test_partitioned_training_matches_single_rank(world, skip):
         parts = _launch(world, d, skip, 29600 + world)
     assert sum(p["range"][1] - p["range"][0] for p in parts) == 384
     assert all(p["n_halo"] > 0 for p in parts)
+    tie = [p["lin"]["tie_dz"] for p in parts]
+    assert torch.equal(tie[0], torch.tensor([[2.0] * 3, [3.0] * 3, [0.0] * 3])) and all(float(t.abs().max()) == 0.0 for t in tie[1:])
+    assert torch.equal(ref["lin"]["tie_dz"], tie[0])
     # exact pieces: partitioned ChebConv and mesh-wide BatchNorm == their single-rank results
     for key in ("conv_y", "conv_dx", "conv2_y", "conv2_dx", "bn_y", "bn_dx"):
         assert rel_l2(torch.cat([p["lin"][key] for p in parts], dim=0), ref["lin"][key]) < 2e-6, key

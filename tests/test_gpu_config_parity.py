@@ -1,0 +1,264 @@
+"""Model-level parity AT CONFIGURATION SIZE and for the headline storage type.
+
+The fixtures of test_gpu_parity.py pin the path on 240-960 vertices.  Here the reference's forward
+(util/networks.py:63-103: batch-statistics BatchNorm over ALL V vertices), its loss (sgcn.py:129-138) and the whole
+backward are compared with the oracle where BASELINE.json's configurations live:
+
+  c2  SGCN, 250 x 200 torus (V = 50 K), fp32, train mode             test_c2_*
+  c4  SGCN, 1000 x 1000 (V = 1 M): one full-size oracle iteration     test_c4_*   (~3 min of host time)
+  c4's storage type: bf16 features against the bf16-STORAGE oracle    test_bf16_*
+  the training loop of sgcn.py:118-147 as a 10-iteration trajectory   test_training_trajectory_*
+
+Gradient bounds are FLAT: the oracle runs with the LeakyReLU sign pattern the HIP forward produced
+(golden_util.PrescribedLeakyReLU), so both sides differentiate the same piecewise-linear branch; the test asserts that
+the pattern was overridden only at rounding-level kink crossings (a handful of elements with |z| < 1e-4 rms).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as GU
+from oracle import bf16 as OB, models as OM
+from semigcn_amd import functional as F_sg, synth, train
+from semigcn_amd.networks import CHANNELS, SingleScaleGCN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+# --------------------------------------------------------------------------------------
+def _batch(m, n_masks, device=DEV):
+    V = m.num_vertices
+    faces = torch.from_numpy(m.faces).to(device)
+    target = torch.from_numpy(m.vs.astype(np.float32)).to(device)
+    v_keep = torch.from_numpy(m.v_mask.astype(np.float32)).view(-1, 1).to(device)
+    f_keep = v_keep[faces[:, 0]] * v_keep[faces[:, 1]] * v_keep[faces[:, 2]]
+    dms = torch.from_numpy(synth.make_dummy_masks(m.edge_index, V, dm_size=n_masks, k=4, p=0.014, seed=317)).to(device)
+
+    class Data:
+        z1 = torch.from_numpy(m.z1).to(device).requires_grad_(True)
+        x_pos = torch.from_numpy(m.x_pos).to(device)
+        edge_index = torch.from_numpy(m.edge_index).to(device)
+
+    return train.MeshBatch(Data, faces, target, train.face_normals(target, faces), v_keep, f_keep, dms)
+
+
+class _OracleSide:
+    """The oracle's inputs and loss for one mesh (sgcn.py:126-138), on the host."""
+
+    def __init__(self, m, batch):
+        self.z1 = torch.from_numpy(m.z1).requires_grad_(True)
+        self.x_pos, self.ei = torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index)
+        self.faces = torch.from_numpy(m.faces)
+        self.tgt = torch.from_numpy(m.vs.astype(np.float32))
+        self.tfn = OM.compute_fn(self.tgt, self.faces)
+        self.v_mask = m.v_mask
+        self.f_mask = m.v_mask[m.faces].all(1)
+        self.dms = batch.dummy_masks.cpu()
+        self.rm = torch.from_numpy(m.v_mask.astype(np.float32)).view(-1, 1)
+
+    def dm(self, k):
+        return self.rm * self.dms[:, k:k + 1]
+
+    def loss(self, pos):
+        return OM.mask_pos_rec_loss(pos, self.tgt, self.v_mask) + 4.0 * OM.mask_norm_rec_loss(
+            OM.compute_fn(pos, self.faces), self.tfn, self.f_mask)
+
+
+def _worst_param_grad_error(net, ora, floor_frac=1e-2):
+    """max over parameters of |g_hip - g_ora|_2 / max(|g_ora|_2, floor sqrt(n)), floor = floor_frac x the largest
+    gradient entry of the model (the ChebConv biases in front of a BatchNorm have a true gradient of exactly zero:
+    what either side returns there is rounding noise)."""
+    og = {n: p.grad for n, p in ora.named_parameters() if p.grad is not None}
+    floor = floor_frac * max(float(g.abs().max()) for g in og.values())
+    worst, where = 0.0, None
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            assert n not in og or float(og[n].abs().max()) == 0.0, n
+            continue
+        a, b = p.grad.detach().cpu().double(), og[n].double()
+        e = float((a - b).norm()) / max(float(b.norm()), floor * np.sqrt(b.numel()))
+        if e > worst:
+            worst, where = e, n
+    return worst, where
+
+
+def _bn_state_error(net, ora):
+    so, worst = ora.state_dict(), 0.0
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            a, b = v.detach().cpu().double(), so[k].double()
+            worst = max(worst, float((a - b).abs().max() / max(float(b.abs().max()), 1e-30)))
+        elif k.endswith("num_batches_tracked"):
+            assert int(v) == int(so[k]), k
+    return worst
+
+
+def _one_iteration_both_sides(m, *, feature_dtype, seed, skip=False, post=True, threads=None):
+    """One training iteration (forward, loss, backward) on the HIP path and on the oracle run with the HIP forward's
+    LeakyReLU sign pattern.  Returns a dict of error figures."""
+    batch = _batch(m, n_masks=1)
+    net = SingleScaleGCN(DEV, skip=skip)
+    GU.fill_state(net, seed=seed)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(DEV).train()
+    if feature_dtype == torch.bfloat16:
+        net.set_feature_dtype(torch.bfloat16)
+    tr = train.SGCNTrainer(net, batch)
+    data = batch.data
+    dm = batch.v_keep * batch.dummy_masks[:, :1]
+    rank = net._layout(data)[2]
+    with GU.FusedActivationMasks(rank) as rec:
+        pos = net(data, dm)
+    loss = tr.loss(pos)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    act = GU.PrescribedLeakyReLU(rec.cpu())
+    rec.masks = []
+    if feature_dtype == torch.bfloat16:
+        V = m.num_vertices
+        blas = []
+        for i in range(13):
+            cin, cout = CHANNELS[i], CHANNELS[i + 1]
+            narrowing = post and cout < cin
+            wshape = (3 * cout, cin) if narrowing else (cout, 3 * cin)
+            a = torch.empty((V, wshape[1]), dtype=torch.bfloat16, device=DEV)
+            if not F_sg._mfma_ok(a, torch.empty(wshape, dtype=torch.bfloat16, device=DEV), wshape[0]):
+                blas.append(i)
+        ora = OB.SGCNOracleBf16(skip=skip, post_when_narrowing=post, act=act, bias_bf16_layers=blas)
+    else:
+        ora = OM.SGCNOracle(skip=skip, act=act)
+    ora.load_state_dict(state0)
+    ora.train()
+    side = _OracleSide(m, batch)
+    old_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    try:
+        ref = ora(side.z1, side.x_pos, side.ei, side.dm(0))
+        ref_loss = side.loss(ref)
+        ref_loss.backward()
+    finally:
+        torch.set_num_threads(old_threads)
+    xp = side.x_pos
+    g_err, g_where = _worst_param_grad_error(net, ora)
+    res = {
+        "pos": GU.rel_l2(pos.detach().cpu(), ref.detach()),
+        "offset": GU.rel_l2(pos.detach().cpu() - xp, ref.detach() - xp),
+        "loss": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
+        "dz1": GU.rel_l2(data.z1.grad.cpu(), side.z1.grad),
+        "param_grad": g_err, "param_grad_where": g_where,
+        "bn": _bn_state_error(net, ora),
+        "flip_frac": act.flips / max(act.elements, 1), "flips": act.flips, "max_flip_z": act.max_flip_z,
+        "loss_value": float(ref_loss),
+    }
+    print({k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
+    return res
+
+
+def _assert_pattern_only_overridden_at_kinks(res, frac=2e-5, z=1e-3):
+    assert res["flip_frac"] <= frac, res
+    assert res["max_flip_z"] <= z, res
+
+
+# --------------------------------------------------------------------------------------
+# c2: SGCN on the 50 K-vertex mesh, fp32, train mode (BASELINE configs[1])
+# --------------------------------------------------------------------------------------
+def test_c2_sgcn_train_iteration_vs_oracle():
+    res = _one_iteration_both_sides(synth.torus_mesh(250, 200), feature_dtype=torch.float32, seed=50)
+    _assert_pattern_only_overridden_at_kinks(res)
+    assert res["pos"] < 1e-5 and res["offset"] < 1e-5, res           # north_star: 1e-5 relative fp32
+    assert res["loss"] < 1e-5, res
+    assert res["bn"] < 1e-5, res
+    assert res["dz1"] < 2e-4 and res["param_grad"] < 2e-4, res        # flat: same activation pattern on both sides
+
+
+def test_c2_sgcn_with_skip_connections_vs_oracle():
+    res = _one_iteration_both_sides(synth.torus_mesh(100, 50), feature_dtype=torch.float32, seed=51, skip=True)
+    _assert_pattern_only_overridden_at_kinks(res, frac=1e-4)
+    assert res["pos"] < 1e-5 and res["offset"] < 1e-5 and res["loss"] < 1e-5 and res["bn"] < 1e-5, res
+    assert res["dz1"] < 2e-4 and res["param_grad"] < 2e-4, res
+
+
+# --------------------------------------------------------------------------------------
+# c4: ONE full-size oracle iteration at V = 1 M (BASELINE.md section 3's CPU run) against the HIP fp32 iteration
+# --------------------------------------------------------------------------------------
+@pytest.mark.skipif(os.environ.get("SEMIGCN_SKIP_FULL_SIZE_ORACLE") == "1", reason="switched off by the environment")
+def test_c4_full_size_train_iteration_vs_oracle():
+    import psutil
+    if psutil.virtual_memory().available < 90e9:
+        pytest.skip("the full-size oracle iteration needs ~60 GB of host memory")
+    threads = min(16, os.cpu_count() or 1)       # ATen's index/scatter kernels stop scaling there (bench.py's probe)
+    res = _one_iteration_both_sides(synth.torus_mesh(1000, 1000), feature_dtype=torch.float32, seed=52, threads=threads)
+    _assert_pattern_only_overridden_at_kinks(res)
+    assert res["pos"] < 1e-5 and res["offset"] < 1e-5, res
+    assert res["loss"] < 1e-5 and res["bn"] < 1e-5, res
+    assert res["dz1"] < 2e-4 and res["param_grad"] < 2e-4, res
+
+
+# --------------------------------------------------------------------------------------
+# bf16 feature storage (BASELINE configs[3]) against the oracle that rounds at the same storage points
+# --------------------------------------------------------------------------------------
+BF16_TOL = 5e-3
+
+
+@pytest.mark.parametrize("name", ["sphere", "torus", "c2"])
+@pytest.mark.parametrize("post", [True, False])
+def test_bf16_features_vs_bf16_storage_oracle(name, post, fixture_meshes, monkeypatch):
+    if name == "c2" and not post:
+        pytest.skip("the reference's evaluation order at 50 K is covered by the fixtures")
+    monkeypatch.setattr(F_sg, "AGGREGATE_AFTER_GEMM_WHEN_NARROWING", post)
+    m = synth.torus_mesh(250, 200) if name == "c2" else fixture_meshes[name]
+    res = _one_iteration_both_sides(m, feature_dtype=torch.bfloat16, seed=60, post=post)
+    # a bf16 rounding that falls the other way (fp32 summation order) moves that row by one bf16 ulp: a sign change it
+    # causes downstream is a consequence, not a kink crossing -- bound the fraction only
+    assert res["flip_frac"] <= 1e-3, res
+    assert res["offset"] < BF16_TOL and res["loss"] < BF16_TOL, res
+    assert res["dz1"] < 4 * BF16_TOL and res["param_grad"] < 4 * BF16_TOL, res
+    assert res["bn"] < BF16_TOL, res
+
+
+def test_bf16_oracle_is_not_the_fp32_oracle(fixture_meshes):
+    """The bound above means something only if bf16 storage moves the result by much more than the bound: the bf16
+    oracle against the fp32 oracle on the same inputs (host only; here because it sizes BF16_TOL)."""
+    m = fixture_meshes["torus"]
+    a, b = OM.SGCNOracle(), OB.SGCNOracleBf16()
+    GU.fill_state(a, seed=60)
+    b.load_state_dict(a.state_dict())
+    a.train(), b.train()
+    z1, xp, ei = torch.from_numpy(m.z1), torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index)
+    pa, pb = a(z1, xp, ei, None), b(z1, xp, ei, None)
+    assert GU.rel_l2((pb - xp).detach(), (pa - xp).detach()) > 4 * BF16_TOL
+
+
+# --------------------------------------------------------------------------------------
+# the training loop of sgcn.py:118-147 as a trajectory: 10 iterations, 2 Adam steps
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size", ["c1", "c2"])
+def test_training_trajectory_vs_oracle_loop(size):
+    m = synth.torus_mesh(100, 50) if size == "c1" else synth.torus_mesh(250, 200)
+    n_iter = 10
+    batch = _batch(m, n_masks=n_iter)
+    torch.manual_seed(314)
+    net = SingleScaleGCN(DEV)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(DEV)
+    tr = train.SGCNTrainer(net, batch, lr=0.01, k1=4.0, accumulate=5)
+    hip = [float(tr.iteration_step(mask_index=k)) for k in range(n_iter)]
+    ora = OM.SGCNOracle()
+    ora.load_state_dict(state0)
+    side = _OracleSide(m, batch)
+    ref = OM.sgcn_training_loop(ora, side.z1, side.x_pos, side.ei, side.faces, side.tgt, side.tfn, side.v_mask,
+                                side.f_mask, side.dms, range(n_iter), batch=5, lr=0.01, k1=4.0)
+    err = [abs(a - b) / abs(b) for a, b in zip(hip, ref)]
+    print("trajectory", size, [f"{b:.6f}" for b in ref], [f"{e:.1e}" for e in err])
+    assert max(err[:5]) < 1e-5, err                  # before the first Adam step: one forward each
+    assert max(err) < 1e-4, err                      # after one and two Adam steps
+    # the parameters after two Adam steps (where the gradient is above rounding noise the first steps are +-lr exactly)
+    so = ora.state_dict()
+    worst = max(float((v.detach().cpu() - so[k]).abs().max()) for k, v in net.state_dict().items()
+                if v.is_floating_point() and "running" not in k and not k.endswith(".bias"))
+    print("max parameter difference after 2 Adam steps", worst)

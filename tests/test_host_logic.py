@@ -461,3 +461,35 @@ def test_segment_tape_orders_graphs_and_eager_actions(monkeypatch):
     with pytest.raises(ZeroDivisionError):
         segments.SegmentRecorder(stream=None).record(lambda: 1 / 0)
     assert not segments.recording()
+
+
+def test_trainer_trajectory_equals_the_oracle_loop(cpu_kernels, fixture_meshes):
+    """train.SGCNTrainer (5 accumulated forward + loss + backward passes, Adam, in-place gradient buffer) against the
+    oracle's restatement of sgcn.py:118-147 over 10 iterations / 2 Adam steps -- the host logic of the trajectory test
+    that runs on the device in tests/test_gpu_config_parity.py."""
+    from semigcn_amd import synth, train
+    m = fixture_meshes["torus"]
+    V = m.num_vertices
+    faces = torch.from_numpy(m.faces)
+    target = torch.from_numpy(m.vs.astype(np.float32))
+    v_keep = torch.from_numpy(m.v_mask.astype(np.float32)).view(-1, 1)
+    f_keep = v_keep[faces[:, 0]] * v_keep[faces[:, 1]] * v_keep[faces[:, 2]]
+    dms = torch.from_numpy(synth.make_dummy_masks(m.edge_index, V, dm_size=10, k=1, p=0.05))
+    data = _Data(m)
+    batch = train.MeshBatch(data, faces, target, train.face_normals(target, faces), v_keep, f_keep, dms)
+    torch.manual_seed(5)
+    net = SingleScaleGCN("cpu", reorder=False)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    # a stale gradient from a pass made BEFORE the trainer exists must not reach the first Adam step (sgcn.py:121)
+    (net(data, None) ** 2).mean().backward()
+    tr = train.SGCNTrainer(net, batch, lr=0.01, k1=4.0, accumulate=5)
+    net.load_state_dict(state0)
+    mine = [float(tr.iteration_step(mask_index=k)) for k in range(10)]
+    ora = OM.SGCNOracle()
+    ora.load_state_dict(state0)
+    tfn = OM.compute_fn(target, faces)
+    ref = OM.sgcn_training_loop(ora, torch.from_numpy(m.z1).requires_grad_(True), torch.from_numpy(m.x_pos),
+                                torch.from_numpy(m.edge_index), faces, target, tfn, m.v_mask, m.v_mask[m.faces].all(1),
+                                dms, range(10), batch=5, lr=0.01, k1=4.0)
+    err = [abs(a - b) / abs(b) for a, b in zip(mine, ref)]
+    assert max(err[:5]) < 1e-5 and max(err) < 2e-3, err     # a 240-vertex mesh: one LeakyReLU flip moves a gradient by ~0.5 %

@@ -209,3 +209,80 @@ def test_refine_oracle_vs_reference_golden(name):
         ref = g[f"{name}/{tag}/ref_pos"]
         assert np.abs(x - ref).max() / np.abs(ref).max() < 1e-5      # the reference's fp32 dense solve: ~1e-6..4e-6
         assert np.abs(ref - g[f"{name}/new_pos"]).max() > 1e-2      # the solve moves vertices (not a trivial fixture)
+
+
+# ---- bf16-storage oracle and the prescribed-pattern activation (the checkers of tests/test_gpu_config_parity.py) ----
+@pytest.mark.parametrize("skip", [False, True])
+@pytest.mark.parametrize("post", [False, True])
+def test_bf16_oracle_without_rounding_is_the_fp32_oracle(skip, post, fixture_meshes, monkeypatch):
+    """With its rounding switched off, the bf16-storage oracle -- a hand-written backward of the ChebConv recurrence in
+    either evaluation order -- must BE the fp32 oracle: same forward, same autograd gradients."""
+    from oracle import bf16 as OB
+    monkeypatch.setattr(OB, "rb", lambda t: t)
+    m = fixture_meshes["torus"]
+    a, b = OM.SGCNOracle(skip=skip), OB.SGCNOracleBf16(skip=skip, post_when_narrowing=post)
+    GU.fill_state(a, seed=11)
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    b.load_state_dict(a.state_dict())
+    a.train(), b.train()
+    ei, xp = torch.from_numpy(m.edge_index), torch.from_numpy(m.x_pos)
+    za, zb = (torch.from_numpy(m.z1).requires_grad_(True) for _ in range(2))
+    r = torch.from_numpy(GU.probe("bf16-oracle", (m.num_vertices, 3)))
+    ra, rb_ = GU.ActivationMasks(a), GU.ActivationMasks(b)
+    pa, pb = a(za, xp, ei, None), b(zb, xp, ei, None)
+    ra.close(), rb_.close()
+    flips = ra.flips_against(rb_)
+    (pa * r).sum().backward()
+    (pb * r).sum().backward()
+    assert GU.rel_l2(pb.detach(), pa.detach()) < 1e-5
+    tol = GU.grad_tolerance(flips, 2e-4)
+    assert GU.rel_l2(zb.grad, za.grad) < tol
+    ga = dict(a.named_parameters())
+    floor = 1e-2 * max(float(p.grad.abs().max()) for p in ga.values() if p.grad is not None)
+    for n, p in b.named_parameters():
+        if p.grad is None:
+            continue
+        ref = ga[n].grad
+        assert float((p.grad - ref).norm()) <= tol * max(float(ref.norm()), floor * np.sqrt(ref.numel())), n
+
+
+def test_bf16_oracle_stores_bf16_values(fixture_meshes):
+    from oracle import bf16 as OB
+    m = fixture_meshes["sphere"]
+    net = OB.SGCNOracleBf16().train()
+    GU.fill_state(net, seed=12)
+    seen = []
+    hooks = [blk.module_0.register_forward_hook(lambda mod, i, o: seen.append((i[0], o))) for blk in net.blocks]
+    z = torch.from_numpy(m.z1).requires_grad_(True)
+    out = net(z, torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index), None)
+    for h in hooks:
+        h.remove()
+    assert len(seen) == 13
+    for x_in, y in seen:            # what a conv reads and what it writes are bf16-representable
+        assert torch.equal(x_in, OB.rb(x_in)) and torch.equal(y, OB.rb(y))
+    assert out.dtype == torch.float32
+    (out ** 2).mean().backward()
+    assert bool(torch.isfinite(z.grad).all())
+
+
+def test_prescribed_leaky_relu_with_its_own_pattern_is_leaky_relu(fixture_meshes):
+    m = fixture_meshes["torus"]
+    ref = OM.SGCNOracle()
+    GU.fill_state(ref, seed=13)
+    ref.train()
+    rec = GU.ActivationMasks(ref)
+    z1, xp, ei = torch.from_numpy(m.z1), torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index)
+    p0 = ref(z1, xp, ei, None)
+    rec.close()
+    act = GU.PrescribedLeakyReLU(rec.masks)
+    net = OM.SGCNOracle(act=act)
+    GU.fill_state(net, seed=13)
+    net.train()
+    p1 = net(z1, xp, ei, None)
+    assert torch.equal(p0, p1) and act.flips == 0 and act.calls == 13
+    # an overridden element is counted (and those it moves across their kinks downstream) and changes the output
+    masks = [mk.clone() for mk in rec.masks]
+    masks[5][7, 3] = ~masks[5][7, 3]
+    act.reset(masks)
+    p2 = net(z1, xp, ei, None)
+    assert act.flips >= 1 and act.max_flip_z > 0 and not torch.equal(p0, p2)
