@@ -74,6 +74,45 @@ class SGCNOracle(nn.Module):
         return x_pos + x
 
 
+class SGCNComposition(nn.Module):
+    """util/networks.py:9-103 restated over an INJECTED operator namespace: ``ops.ChebConv`` / ``ops.Sequential`` stand
+    where the reference has ``from torch_geometric.nn import ChebConv, Sequential`` (util/networks.py:4).  With
+    ``ops = oracle.pyg_restatement`` this is SGCNOracle; with ``ops = semigcn_amd.nn`` it is what the reference's own
+    class becomes after ``compat.install()`` -- the zero-line integration -- including the reference's habit of moving
+    ``z1``, ``x_pos``, ``edge_index`` and ``dm`` to the device on EVERY forward (:65,77).  Needed because the reference
+    itself does not travel to the GPU box."""
+
+    def __init__(self, device, ops, skip: bool = False):
+        super().__init__()
+        self.device, self.skip = device, skip
+        h = SGCN_WIDTHS
+        act = nn.LeakyReLU()
+        blocks = []
+        for i in range(13):
+            mods = [(ops.ChebConv(h[i], h[i + 1], K=3), "x, edge_index -> x"), nn.BatchNorm1d(h[i + 1]), act]
+            if i == 12:
+                mods.append((nn.Linear(h[13], h[14]), "x -> x"))
+            blocks.append(ops.Sequential("x, edge_index", mods))
+        self.blocks = nn.ModuleList(blocks)
+        self.skip_blocks = nn.ModuleList([nn.Linear(2 * h[j + 1], h[j + 1]) for j in range(6)])
+
+    def forward(self, data, dm=None):
+        z1, x_pos, edge_index = data.z1.to(self.device), data.x_pos.to(self.device), data.edge_index.to(self.device)
+        if type(dm) == np.ndarray:
+            dm = torch.from_numpy(dm)
+        elif type(dm) != torch.Tensor:
+            dm = torch.ones([z1.shape[0], 1])
+        x = normalise_input(z1, dm.to(self.device))
+        kept = []
+        for i, blk in enumerate(self.blocks):
+            if i >= 8 and self.skip:
+                x = self.skip_blocks[13 - i](torch.cat([kept[13 - i], x], dim=1))
+            x = blk(x, edge_index)
+            if i <= 5:
+                kept.append(x)
+        return x_pos + x
+
+
 def pool_mean(pool_hash: np.ndarray, x: torch.Tensor, n_coarse: Optional[int] = None) -> torch.Tensor:
     """out[s] = mean_{o: hash[o]=s} x[o]   (util/meshnet.py:14-17, builder :331-335)."""
     fine = torch.as_tensor(pool_hash[:, 0]).long()

@@ -65,6 +65,65 @@ def _torus_faces(nu: int, nv: int, flip_frac: float, rng: np.random.Generator) -
     return faces
 
 
+def random_edge_flips(faces: np.ndarray, vs: Optional[np.ndarray], n_flips: int, rng: np.random.Generator,
+                      vmin: int = 4, vmax: int = 9, max_rounds: int = 60) -> np.ndarray:
+    """``n_flips`` random VALID edge flips on a closed manifold triangle mesh ("0.15 * E_und
+    random valid edge flips; keeps V, E; valence 4..9").  A flip replaces the edge a-b shared by the triangles (a,b,c)
+    and (b,a,d) by c-d: triangles (a,d,c), (d,b,c).  Valid: a and b keep valence >= ``vmin``, c and d stay <= ``vmax``,
+    c-d is not an edge yet, and (with positions ``vs``) neither new triangle folds over (its normal keeps the side of
+    the two old ones).  Vectorised in rounds: a random subset of the edges is drawn, every drawn edge claims its four
+    vertices with a random priority, and the edges that hold all four of their claims (no other flip of the round
+    touches those vertices) are flipped together; rounds repeat until ``n_flips`` flips are done."""
+    faces = np.ascontiguousarray(faces, dtype=np.int64).copy()
+    V = int(faces.max()) + 1
+    done = 0
+    for _ in range(max_rounds):
+        need = n_flips - done
+        if need <= 0:
+            break
+        F = faces.shape[0]
+        src, dst, opp = faces.ravel(), faces[:, [1, 2, 0]].ravel(), faces[:, [2, 0, 1]].ravel()
+        he_face = np.repeat(np.arange(F), 3)
+        key = np.minimum(src, dst) * np.int64(V) + np.maximum(src, dst)
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        if not (ks.shape[0] % 2 == 0 and np.array_equal(ks[0::2], ks[1::2]) and (ks.shape[0] < 4 or np.all(ks[2::2] > ks[0:-2:2]))):
+            raise ValueError("random_edge_flips needs a closed manifold mesh (every edge in exactly two triangles)")
+        h1, h2 = order[0::2], order[1::2]
+        ekeys = ks[0::2]                                   # sorted unique undirected edge keys
+        val = np.bincount(src, minlength=V)
+        n_e = h1.shape[0]
+        cand = rng.permutation(n_e)[: min(n_e, max(4 * need, 1024))]
+        a, b, c, d = src[h1[cand]], dst[h1[cand]], opp[h1[cand]], opp[h2[cand]]
+        ok = (val[a] - 1 >= vmin) & (val[b] - 1 >= vmin) & (val[c] + 1 <= vmax) & (val[d] + 1 <= vmax) & (c != d)
+        nk = np.minimum(c, d) * np.int64(V) + np.maximum(c, d)
+        pos = np.searchsorted(ekeys, nk)
+        ok &= ~((pos < n_e) & (ekeys[np.minimum(pos, n_e - 1)] == nk))
+        if vs is not None:
+            pa, pb, pc, pd = vs[a], vs[b], vs[c], vs[d]
+            n_old = np.cross(pb - pa, pc - pa) + np.cross(pa - pb, pd - pb)
+            n1, n2 = np.cross(pd - pa, pc - pa), np.cross(pb - pd, pc - pd)
+            ok &= ((n1 * n_old).sum(1) > 0) & ((n2 * n_old).sum(1) > 0)
+        cand, a, b, c, d = cand[ok], a[ok], b[ok], c[ok], d[ok]
+        if cand.shape[0] == 0:
+            continue
+        prio = rng.permutation(cand.shape[0]).astype(np.int64) + 1
+        claim = np.zeros(V, np.int64)
+        for v in (a, b, c, d):
+            np.maximum.at(claim, v, prio)
+        win = (claim[a] == prio) & (claim[b] == prio) & (claim[c] == prio) & (claim[d] == prio)
+        w = np.flatnonzero(win)[:need]
+        if w.shape[0] == 0:
+            continue
+        f1, f2 = he_face[h1[cand[w]]], he_face[h2[cand[w]]]
+        faces[f1] = np.stack([a[w], d[w], c[w]], 1)
+        faces[f2] = np.stack([d[w], b[w], c[w]], 1)
+        done += w.shape[0]
+    if done < n_flips:
+        raise RuntimeError(f"only {done} of {n_flips} valid edge flips found")
+    return faces
+
+
 def edges_from_faces(faces: np.ndarray, num_vertices: int) -> np.ndarray:
     """Unique undirected edges (lo, hi) in the order a face-by-face scan first
     meets them -- the order util/mesh.py:60-100 (``build_gemm``) produces."""
@@ -119,11 +178,14 @@ def make_v_mask(edge_index: np.ndarray, num_vertices: int, n_holes: int = 5,
 
 
 def torus_mesh(nu: int, nv: int, *, flip_frac: float = 0.45, jitter: float = 0.05,
-               permute: bool = False, seed: int = 314, masks: bool = True) -> SynthMesh:
-    """Closed torus triangulation with V = nu*nv vertices (nu, nv >= 4)."""
+               permute: bool = False, seed: int = 314, masks: bool = True, edge_flips: Optional[float] = None) -> SynthMesh:
+    """Closed torus triangulation with V = nu*nv vertices (nu, nv >= 4).  Irregularity: by default every quad's
+    diagonal is flipped independently with probability ``flip_frac`` (valence 4..8); ``edge_flips = 0.15`` is SURVEY.md
+    section 8(d)'s recipe instead -- the regular triangulation followed by ``edge_flips * E_und`` random valid edge
+    flips (``random_edge_flips``: valence 4..9), which bench.py uses."""
     assert nu >= 4 and nv >= 4
     rng = np.random.default_rng(seed)
-    faces = _torus_faces(nu, nv, flip_frac, rng)
+    faces = _torus_faces(nu, nv, 0.0 if edge_flips is not None else flip_frac, rng)
     V = nu * nv
     u, v = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
     th = 2 * np.pi * u.ravel() / nu
@@ -132,6 +194,8 @@ def torus_mesh(nu: int, nv: int, *, flip_frac: float = 0.45, jitter: float = 0.0
     r = nv / (2 * np.pi)
     vs = np.stack([(R + r * np.cos(ph)) * np.cos(th), (R + r * np.cos(ph)) * np.sin(th), r * np.sin(ph)], 1)
     vs = vs + rng.normal(0.0, jitter, vs.shape)
+    if edge_flips is not None:
+        faces = random_edge_flips(faces, vs, int(round(edge_flips * 3 * V)), rng)
     perm = None
     if permute:
         perm = np.random.default_rng(seed + 4).permutation(V)

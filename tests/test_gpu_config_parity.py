@@ -237,28 +237,108 @@ def test_bf16_oracle_is_not_the_fp32_oracle(fixture_meshes):
 # --------------------------------------------------------------------------------------
 # the training loop of sgcn.py:118-147 as a trajectory: 10 iterations, 2 Adam steps
 # --------------------------------------------------------------------------------------
-@pytest.mark.parametrize("size", ["c1", "c2"])
-def test_training_trajectory_vs_oracle_loop(size):
+def _trajectory_setup(size):
     m = synth.torus_mesh(100, 50) if size == "c1" else synth.torus_mesh(250, 200)
-    n_iter = 10
-    batch = _batch(m, n_masks=n_iter)
-    torch.manual_seed(314)
+    batch = _batch(m, n_masks=10)
+    torch.manual_seed(314)                               # sgcn.py:19-25,76: the reference's seed
     net = SingleScaleGCN(DEV)
     state0 = {k: v.clone() for k, v in net.state_dict().items()}
     net.to(DEV)
+    return m, batch, net, state0, _OracleSide(m, batch)
+
+
+@pytest.mark.parametrize("size", ["c1", "c2"])
+def test_training_trajectory_resynchronised_at_the_optimiser_steps(size):
+    """Every one of the 10 losses at 1e-5, both Adam steps entry by entry (golden_util.synchronised_trajectory)."""
+    m, batch, net, state0, side = _trajectory_setup(size)
     tr = train.SGCNTrainer(net, batch, lr=0.01, k1=4.0, accumulate=5)
-    hip = [float(tr.iteration_step(mask_index=k)) for k in range(n_iter)]
     ora = OM.SGCNOracle()
     ora.load_state_dict(state0)
-    side = _OracleSide(m, batch)
-    ref = OM.sgcn_training_loop(ora, side.z1, side.x_pos, side.ei, side.faces, side.tgt, side.tfn, side.v_mask,
-                                side.f_mask, side.dms, range(n_iter), batch=5, lr=0.01, k1=4.0)
+
+    def oracle_iteration(k):
+        loss = side.loss(ora(side.z1, side.x_pos, side.ei, side.dm(k)))
+        loss.backward()
+        return float(loss.detach())
+    errs, dev = GU.synchronised_trajectory(tr, net, ora, oracle_iteration, batch.dummy_masks)
+    print("trajectory (re-synchronised)", size, [f"{e:.1e}" for e in errs], dev)
+    assert len(errs) == 10 and max(errs) < 1e-5
+
+
+def test_training_trajectory_free_running_vs_the_oracles_own_spread():
+    """The same loop free-running (train.SGCNTrainer.iteration_step against oracle.models.sgcn_training_loop, no
+    re-synchronisation).  Before the first Adam step the losses agree at 1e-5.  After it Adam's sign-like first step has
+    moved every noise-level gradient entry by +-lr, differently on every run of ANY implementation: the yardstick is the
+    oracle against ITSELF at two thread counts (1e-3 .. 9e-3 on the 240- and 5 000-vertex meshes), and the HIP path has
+    to stay within 3 x that spread."""
+    m, batch, net, state0, side = _trajectory_setup("c1")
+    tr = train.SGCNTrainer(net, batch, lr=0.01, k1=4.0, accumulate=5)
+    hip = [float(tr.iteration_step(mask_index=k)) for k in range(10)]
+    runs = []
+    old = torch.get_num_threads()
+    try:
+        for threads in (max(1, old // 2), old):
+            torch.set_num_threads(threads)
+            ora = OM.SGCNOracle()
+            ora.load_state_dict(state0)
+            z1 = side.z1.detach().clone().requires_grad_(True)
+            runs.append(OM.sgcn_training_loop(ora, z1, side.x_pos, side.ei, side.faces, side.tgt, side.tfn, side.v_mask,
+                                              side.f_mask, side.dms, range(10), batch=5, lr=0.01, k1=4.0))
+    finally:
+        torch.set_num_threads(old)
+    ref = runs[1]
     err = [abs(a - b) / abs(b) for a, b in zip(hip, ref)]
-    print("trajectory", size, [f"{b:.6f}" for b in ref], [f"{e:.1e}" for e in err])
-    assert max(err[:5]) < 1e-5, err                  # before the first Adam step: one forward each
-    assert max(err) < 1e-4, err                      # after one and two Adam steps
-    # the parameters after two Adam steps (where the gradient is above rounding noise the first steps are +-lr exactly)
-    so = ora.state_dict()
-    worst = max(float((v.detach().cpu() - so[k]).abs().max()) for k, v in net.state_dict().items()
-                if v.is_floating_point() and "running" not in k and not k.endswith(".bias"))
-    print("max parameter difference after 2 Adam steps", worst)
+    own = [abs(a - b) / abs(b) for a, b in zip(runs[0], ref)]
+    print("trajectory (free-running) hip vs oracle", [f"{e:.1e}" for e in err], "oracle vs itself", [f"{e:.1e}" for e in own])
+    assert max(err[:5]) < 1e-5, err
+    assert max(err[5:]) < max(3.0 * max(own[5:]), 1e-2), (err, own)
+
+
+# --------------------------------------------------------------------------------------
+# the ZERO-LINE integration on hardware (INTEGRATION.md section 1): the reference's model composition over the operator
+# tier (what `from torch_geometric.nn import ChebConv, Sequential` resolves to after compat.install()), host-resident
+# data moved to the device on every forward as util/networks.py:65 does
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("container", ["compat.Data", "plain tensors"])
+@pytest.mark.parametrize("name,skip", [("sphere", False), ("torus", True)])
+def test_reference_composition_on_the_operator_tier(name, skip, container, fixture_meshes, monkeypatch):
+    from semigcn_amd import capi, compat, graph, nn as sgnn
+    g2 = GU.load("g2_sgcn.npz")
+    m = fixture_meshes[name]
+    tag = f"{name}/skip{int(skip)}"
+    net = OM.SGCNComposition(torch.device(DEV), sgnn, skip=skip)
+    assert list(net.state_dict().keys()) == list(g2[f"{name}/state_dict_keys"])
+    GU.fill_state(net, seed=314)
+    net.to(DEV)
+    z1 = torch.from_numpy(m.z1).requires_grad_(True)
+    if container == "compat.Data":      # what util/datamaker.py:105 builds once compat.install() is in effect
+        data = compat.Data(x=z1, z1=z1, x_pos=torch.from_numpy(m.x_pos), edge_index=torch.from_numpy(m.edge_index))
+    else:                               # any other holder of plain host tensors
+
+        class data:
+            pass
+        data.z1, data.x_pos, data.edge_index = z1, torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index)
+    graph.clear_graph_cache()
+    builds, syncs = [], []
+    real_build, real_fp = capi.GraphHandle.from_edge_index, graph._fingerprint
+    monkeypatch.setattr(capi.GraphHandle, "from_edge_index", classmethod(lambda cls, e, n: (builds.append(1), real_build(e, n))[1]))
+    monkeypatch.setattr(graph, "_fingerprint", lambda e: (syncs.append(1), real_fp(e))[1])
+    dm = g2[f"{name}/dm"]
+    net.eval()
+    with torch.no_grad():
+        assert GU.rel_l2(net(data, dm).cpu(), g2[tag + "/eval_dm_ndarray"]) < 1e-5
+        assert GU.rel_l2(net(data, torch.from_numpy(dm)).cpu(), g2[tag + "/eval_dm_tensor"]) < 1e-5
+        assert GU.rel_l2(net(data, None).cpu(), g2[tag + "/eval_dm_none"]) < 1e-5
+        for _ in range(7):
+            net(data, dm)
+    assert len(builds) == 1, builds                      # ten forwards, ONE sg_graph_create
+    if container == "compat.Data":
+        assert len(syncs) == 1                           # the same device tensor comes back from every .to(device)
+        assert data.edge_index.to(DEV) is data.edge_index.to(DEV) and data.edge_index.to(DEV).is_cuda
+    else:
+        assert len(syncs) == 10                          # a fresh device tensor per forward: found by content each time
+    net.train()
+    pos = net(data, torch.from_numpy(dm))
+    assert GU.rel_l2(pos.detach().cpu(), g2[tag + "/train_out"]) < 1e-5
+    (pos * torch.from_numpy(GU.probe(tag + "/r", (m.num_vertices, 3))).to(DEV)).sum().backward()
+    assert GU.rel_l2(z1.grad, g2[tag + "/dz1"]) < GU.grad_tolerance(3, 2e-3)     # (flip-aware bound: test_sgcn_vs_reference_golden)
+    assert len(builds) == 1

@@ -298,3 +298,21 @@ def test_bench_gpus_2_starts_its_own_ranks():
     seg = line["distributed"]["hip_graph_segments"]
     assert seg is not None and seg["graphs"] > 50 and seg["eager_actions"] >= 57 and line["roofline"] is not None
     assert "eager iterations after the timed region" in line["roofline"]["measured_over"]
+
+
+def test_bench_supervisor_retries_without_replay_after_a_stall():
+    """an N > 1 run whose hipGraph-replay attempt hangs (injected: the last rank sleeps after its
+    warm-up) is killed at the attempt's wall-clock limit and re-run ONCE from fresh worker processes with --no-graph;
+    the line says so.  A run that stalls in both attempts exits non-zero with the reason."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "5",
+            "--mesh", "96x64", "--no-cpu-baseline", "--dtype", "bf16"]
+    env = _child_env(SEMIGCN_BENCH_SHARE_GPU="1", SEMIGCN_BENCH_ATTEMPT_TIMEOUT="75")
+    r = subprocess.run(base + ["--stall-after-warmup", "600"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])["distributed"]
+    assert d["attempt"] == 2 and "within 75 s" in d["first_attempt_failure"] and d["hip_graph_segments"] is None
+    assert "starting a fresh worker without hipGraph replay" in r.stderr
+    r = subprocess.run(base + ["--stall-after-warmup", "-600"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "both attempts failed" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

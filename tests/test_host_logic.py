@@ -145,9 +145,38 @@ def test_graph_cache_reuses_and_invalidates(cpu_kernels, fixture_meshes):
     ei = torch.from_numpy(fixture_meshes["torus"].edge_index).clone()
     g1 = graph_for(ei, 240)
     assert graph_for(ei, 240) is g1                 # level 1: same tensor object
-    assert graph_for(ei.clone(), 240) is not g1     # different storage -> rebuilt
-    ei[0, 0] = (ei[0, 0] + 1) % 240                 # in-place edit bumps the version counter
-    assert graph_for(ei, 240) is not g1
+    builds = []
+    from semigcn_amd import capi
+    real = capi.GraphHandle.from_edge_index
+    capi.GraphHandle.from_edge_index = classmethod(lambda cls, e, n: (builds.append(1), real(e, n))[1])
+    try:
+        # level 2: ANOTHER tensor object with the same edges (what `data.edge_index.to(device)` per forward produces,
+        # util/networks.py:65) finds the graph by content, wherever the allocator put it; so does a column permutation
+        assert graph_for(ei.clone(), 240) is g1
+        assert graph_for(ei[:, torch.randperm(ei.shape[1])].contiguous(), 240) is g1
+        assert not builds
+        assert graph_for(ei, 241) is not g1             # same edges, another vertex count: a different operator
+        ei[0, 0] = (ei[0, 0] + 1) % 240                 # in-place edit bumps the version counter
+        assert graph_for(ei, 240) is not g1
+        assert len(builds) == 2
+    finally:
+        capi.GraphHandle.from_edge_index = real
+
+
+def test_resident_tensor_of_compat_data():
+    """compat.Data keeps ``edge_index`` as a tensor whose ``.to(device)`` returns one cached device copy (a CPU target
+    and every other operation see a plain tensor; the CUDA branch is exercised in tests/test_gpu_config_parity.py)."""
+    import copy
+    import pickle
+    ei = torch.randint(0, 10, (2, 30))
+    d = compat.Data(x=torch.randn(10, 3), edge_index=ei)
+    r = d["edge_index"]
+    assert isinstance(r, compat.ResidentTensor) and d.edge_index is r and d.num_edges == 30
+    assert type(r.to("cpu")) is torch.Tensor and type(r + 1) is torch.Tensor and type(r[0]) is torch.Tensor
+    assert torch.equal(torch.cat([r, r[[1, 0], :]], dim=1)[:, 30:], ei[[1, 0], :])
+    for c in (copy.deepcopy(d)["edge_index"], pickle.loads(pickle.dumps(r))):
+        assert isinstance(c, compat.ResidentTensor) and torch.equal(c, ei) and c.data_ptr() != r.data_ptr()
+    assert type(r.to(torch.int32)) is torch.Tensor and r.to(torch.int32).dtype == torch.int32
 
 
 def _mgcn_from_golden(device, g3, skip=False):
@@ -465,8 +494,9 @@ def test_segment_tape_orders_graphs_and_eager_actions(monkeypatch):
 
 def test_trainer_trajectory_equals_the_oracle_loop(cpu_kernels, fixture_meshes):
     """train.SGCNTrainer (5 accumulated forward + loss + backward passes, Adam, in-place gradient buffer) against the
-    oracle's restatement of sgcn.py:118-147 over 10 iterations / 2 Adam steps -- the host logic of the trajectory test
-    that runs on the device in tests/test_gpu_config_parity.py."""
+    oracle's restatement of sgcn.py:118-147 over 10 iterations / 2 Adam steps -- the host logic of the trajectory tests
+    that run on the device in tests/test_gpu_config_parity.py (see golden_util.synchronised_trajectory for why the two
+    sides are re-synchronised at the optimiser steps)."""
     from semigcn_amd import synth, train
     m = fixture_meshes["torus"]
     V = m.num_vertices
@@ -483,13 +513,30 @@ def test_trainer_trajectory_equals_the_oracle_loop(cpu_kernels, fixture_meshes):
     # a stale gradient from a pass made BEFORE the trainer exists must not reach the first Adam step (sgcn.py:121)
     (net(data, None) ** 2).mean().backward()
     tr = train.SGCNTrainer(net, batch, lr=0.01, k1=4.0, accumulate=5)
+    assert all(float(p.grad.abs().max()) == 0.0 for p in net.parameters() if p.grad is not None)
     net.load_state_dict(state0)
+    # (a) the trainer's own stepping against the oracle's loop, free-running: exact agreement before the first step
     mine = [float(tr.iteration_step(mask_index=k)) for k in range(10)]
     ora = OM.SGCNOracle()
     ora.load_state_dict(state0)
-    tfn = OM.compute_fn(target, faces)
-    ref = OM.sgcn_training_loop(ora, torch.from_numpy(m.z1).requires_grad_(True), torch.from_numpy(m.x_pos),
-                                torch.from_numpy(m.edge_index), faces, target, tfn, m.v_mask, m.v_mask[m.faces].all(1),
-                                dms, range(10), batch=5, lr=0.01, k1=4.0)
+    tfn, f_mask = OM.compute_fn(target, faces), m.v_mask[m.faces].all(1)
+    z1o, xpo, eio = torch.from_numpy(m.z1).requires_grad_(True), torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index)
+    ref = OM.sgcn_training_loop(ora, z1o, xpo, eio, faces, target, tfn, m.v_mask, f_mask, dms, range(10), batch=5, lr=0.01, k1=4.0)
     err = [abs(a - b) / abs(b) for a, b in zip(mine, ref)]
-    assert max(err[:5]) < 1e-5 and max(err) < 2e-3, err     # a 240-vertex mesh: one LeakyReLU flip moves a gradient by ~0.5 %
+    assert max(err[:5]) < 1e-5 and max(err) < 5e-2, err     # after a step: Adam's sign-step on noise-level entries
+    # (b) re-synchronised at the optimiser steps: every loss tight, every above-noise parameter takes the same step
+    net.load_state_dict(state0)
+    ora.load_state_dict(state0)
+    tr = train.SGCNTrainer(net, batch, lr=0.01, k1=4.0, accumulate=5)
+
+    def oracle_iteration(k):
+        dm = v_keep * dms[:, k:k + 1]
+        pos = ora(z1o, xpo, eio, dm)
+        loss = OM.mask_pos_rec_loss(pos, target, m.v_mask) + 4.0 * OM.mask_norm_rec_loss(OM.compute_fn(pos, faces), tfn, f_mask)
+        loss.backward()
+        return float(loss)
+    # (240 vertices: ONE LeakyReLU sign that differs moves a gradient by ~0.5 % of its rms, hence the noise floor here)
+    # and one sign that differs in the five passes after the first step moves the second step by a sizeable part of lr:
+    # the second step is asserted at configuration size on the device only)
+    errs, dev = GU.synchronised_trajectory(tr, net, ora, oracle_iteration, dms, noise=5e-2, step_tol=(0.02, 2.0))
+    assert len(errs) == 10
