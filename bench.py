@@ -657,10 +657,21 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if DIST_ON:
         import torch.distributed as dist
+        store = None
+        attempt = int(os.environ.get("SEMIGCN_BENCH_ATTEMPT", "1"))
+        if attempt > 1:
+            # a supervisor's second set of workers (supervise_rank): the launcher's store still holds the first set's
+            # rendezvous keys (this torch adds no per-attempt prefix), so the second set meets under a prefix of its own
+            import datetime
+            agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+            base = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world,
+                                 is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=300),
+                                 wait_for_workers=False)
+            store = dist.PrefixStore(f"semigcn/attempt{attempt}", base)
         if shared:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+            dist.init_process_group("nccl", store=store, device_id=device, rank=rank, world_size=world)
 
     from semigcn_amd import capi, synth
     capi.load()

@@ -327,7 +327,12 @@ SG_API int sg_mesh_loss_bwd(const float* pos, const int64_t* faces, const float*
  * moments (nullable): float32 [sg_gemm_row_tiles(M, N), 2, N]; tile t receives the per-column mean and
  * sum (x - mean)^2 of rows [t*R, (t+1)*R) of the ROUNDED result, R = sg_gemm_tile_rows(N) -- the block moments
  * sg_bn_stats_finalize_tiles merges, so BatchNorm needs no separate pass over C (util/networks.py:43).
+ * Two kernels serve it: a 128-row tile that streams A and C (the HBM-bound layers) and, for the compute-bound products
+ * (K * N > 100 K weight elements, K % 64 == 0, N % 256 == 0, M >= 16 K: the 256- and 512-channel layers), a persistent
+ * 256 x 256 tile with eight wavefronts (csrc/gemm_mfma256.hip).  The latter does not emit `moments`: a call that passes
+ * moments != NULL is served by the 128-row kernel; sg_gemm_nt_takes_big_tile tells which kernel a moments-free call gets.
  * ------------------------------------------------------------------------- */
+SG_API int sg_gemm_nt_takes_big_tile(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc);
 SG_API int64_t sg_gemm_tile_rows(int64_t N);             /* R for an N-column product (128, or 64 for wide outputs) */
 SG_API int64_t sg_gemm_row_tiles(int64_t M, int64_t N);  /* ceil(M / R) */
 SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
@@ -381,8 +386,9 @@ enum sg_tune_knob {
   SG_TUNE_GRAPH_REORDER = 6, /* sg_graph_create: process the rows in a graph-derived locality order (output rows stay
                                 where the caller expects them): 0 = when the vertex numbering has no locality (>= 25 % of
                                 the edges span more than 4096 ids, V >= 65536), 1 = never, 2 = always */
-  SG_TUNE_GEMM_TILE = 5   /* sg_gemm_nt output tile: 0 / 1 = 128 x min(N,128) (shipped), 2 = 64 x 256 wherever N > 64
-                             (A/B switch; measured slower) */
+  SG_TUNE_GEMM_TILE = 5   /* sg_gemm_nt kernel: 0 = automatic (shipped: 128 x min(N,128) tiles, the persistent 256 x 256 kernel
+                             for the compute-bound products), 1 = 128-row tiles only, 2 = 64 x 256 wherever N > 64 (A/B
+                             switch; measured slower), 3 = the 256 x 256 kernel wherever it takes the shape */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

@@ -65,6 +65,7 @@ _SIGNATURES = {
                                      c_float, c_void_p, c_void_p, c_void_p]),
     "sg_bn_stats_finalize_tiles": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "sg_gemm_nt_takes_big_tile": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, c_int64]),
     "sg_gemm_tile_rows": (c_int64, [c_int64]),
     "sg_gemm_row_tiles": (c_int64, [c_int64, c_int64]),
     "sg_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
@@ -608,6 +609,12 @@ def gemm_nt_supported(A: torch.Tensor, B: torch.Tensor, ldc: int) -> bool:
     K, N = A.shape[1], B.shape[0]
     return (K % 8 == 0 and N % 8 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and ldc % 8 == 0
             and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_nt_takes_big_tile(M: int, N: int, K: int, lda: int, ldb: int, ldc: int) -> bool:
+    """True when a moments-free sg_gemm_nt call of this shape is served by the persistent 256 x 256 kernel
+    (csrc/gemm_mfma256.hip: the compute-bound products) rather than by the 128-row-tile kernel."""
+    return bool(_sizes("sg_gemm_nt_takes_big_tile", int(M), int(N), int(K), int(lda), int(ldb), int(ldc)))
 
 
 def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,

@@ -501,6 +501,10 @@ SG_API int sg_bn_stats_finalize_tiles(const float* partial, int64_t n_tiles, int
                                         momentum, eps, out, batches_tracked, (hipStream_t)stream);
 }
 
+SG_API int sg_gemm_nt_takes_big_tile(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc) {
+  return gemm_nt_takes_big_tile(M, N, K, lda, ldb, ldc) ? 1 : 0;
+}
+
 SG_API int64_t sg_gemm_tile_rows(int64_t N) { return gemm_tile_rows(N); }
 
 SG_API int64_t sg_gemm_row_tiles(int64_t M, int64_t N) {

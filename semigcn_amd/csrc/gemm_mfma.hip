@@ -286,7 +286,13 @@ int launch(GemmArgs g, hipStream_t stream) {
 
 inline bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-int g_gemm_tile = 0;   // SG_TUNE_GEMM_TILE: 0 / 1 = 128-row tiles, 2 = 64 x 256 tiles wherever N > 64
+int g_gemm_tile = 0;   // SG_TUNE_GEMM_TILE: 0 = automatic, 1 = 128-row tiles only, 2 = 64 x 256 tiles wherever N > 64,
+                       // 3 = the 256 x 256 eight-wavefront kernel (gemm_mfma256.hip) wherever it takes the shape
+
+// automatic choice: the persistent 256 x 256 kernel serves the compute-bound products (K x N above ~100 K elements: the
+// 256- and 512-channel layers), the 128-row-tile kernel below the HBM-bound ones
+constexpr int64_t kBigMinWeightElems = 100000;
+constexpr int64_t kBigMinRows = 16384;
 
 // 64 x 256 tiles (ONE column tile covers N <= 256, so A is fetched by one workgroup only) were measured SLOWER than
 // 128 x 128 tiles on every wide product (e.g. [V,384]x[384,256]: 0.43 ms against 0.33 ms; profiles/
@@ -297,6 +303,11 @@ bool wide_tile(int64_t N) { return g_gemm_tile == 2 && N > 64; }
 }  // namespace
 
 int gemm_tile_rows(int64_t N) { return wide_tile(N) ? 64 : 128; }
+
+bool gemm_nt_takes_big_tile(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc) {
+  if (g_gemm_tile == 1 || g_gemm_tile == 2 || !gemm_nt_256_supported(M, N, K, lda, ldb, ldc)) return false;
+  return g_gemm_tile == 3 || (K * N > kBigMinWeightElems && M >= kBigMinRows);
+}
 
 int set_gemm_tuning(int value) {
   g_gemm_tile = value;
@@ -316,6 +327,8 @@ int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const
     return SG_ERR_UNSUPPORTED;
   }
   SG_REQUIRE(M <= INT32_MAX && N <= INT32_MAX && K <= INT32_MAX, "sg_gemm_nt: size out of range");
+  if (moments == nullptr && gemm_nt_takes_big_tile(M, N, K, lda, ldb, ldc))
+    return launch_gemm_nt_256(A, lda, B, ldb, bias, C, ldc, M, N, K, stream);
   GemmArgs g;
   g.A = (const uint16_t*)A; g.lda = lda;
   g.B = (const uint16_t*)B; g.ldb = ldb;

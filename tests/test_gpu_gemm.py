@@ -173,3 +173,97 @@ def test_gemm_tn_random_data_and_strides(M, N, Kp):
     assert GU.rel_l2(out.double().cpu(), ref.cpu()) < 1e-5          # fp32 accumulation of exact bf16 products
     assert torch.equal(out, capi.gemm_tn(a, b))                    # deterministic
     assert GU.rel_l2(F_sg.weight_grad(a.contiguous(), b.contiguous()).double().cpu(), ref.cpu()) < 1e-5     # own kernel or BLAS slabs, by shape
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the persistent 256 x 256-tile kernel (csrc/gemm_mfma256.hip): the compute-bound products
+# ---------------------------------------------------------------------------------------------------------------------
+BIG_SHAPES = [  # (M, N, K): one partial tile .. many tiles per workgroup stream, 2 .. 12 K steps, 1 .. 3 column tiles
+    (256, 256, 128), (300, 256, 256), (1000, 512, 128), (4097, 256, 768), (70001, 512, 768), (70001, 768, 256),
+    (131072, 256, 384), (200003, 768, 512), (1_000_000, 512, 768),
+]
+
+
+def _with_tile(tile, fn):
+    capi.tuning_set(capi.TUNE_GEMM_TILE, tile)
+    try:
+        return fn()
+    finally:
+        capi.tuning_set(capi.TUNE_GEMM_TILE, 0)
+
+
+@pytest.mark.parametrize("M,N,K", BIG_SHAPES)
+def test_big_tile_gemm_integer_data_is_bit_exact(M, N, K):
+    """Exact integers (see test_gemm_nt_integer_data_is_bit_exact): every LDS-DMA chunk, swizzled fragment read, swapped
+    MFMA operand and 8-byte store lands where it must, on every workgroup stream, across tile boundaries of the persistent
+    loop, with rows past M clamped on the way in and masked on the way out.  Repeated: the counted-vmcnt / raw-barrier
+    pipeline is a race screen as much as a layout check (guide 5: "screen it for races over many runs at several sizes")."""
+    assert capi.gemm_nt_takes_big_tile(M, N, K, K, K, N) == (K * N > 100_000 and M >= 16384)
+    g = torch.Generator(device=DEV).manual_seed(M + 3 * N + K)
+    lim = 2 if K > 64 else 3
+    a = torch.randint(-lim, lim + 1, (M, K), device=DEV, generator=g).to(torch.bfloat16)
+    b = torch.randint(-1, 2, (N, K), device=DEV, generator=g).to(torch.bfloat16)
+    b[:, 0] = torch.arange(N, device=DEV).remainder(5).to(torch.bfloat16) - 2
+    a[:, 1] = torch.arange(M, device=DEV).remainder(3).to(torch.bfloat16) - 1          # rows differ: a shifted tile shows
+    ref = _with_tile(1, lambda: capi.gemm_nt(a, b))            # the 128-row kernel (itself pinned to fp32 matmul above)
+    if M <= 300_000:
+        assert torch.equal(ref, _ref(a, b).to(torch.bfloat16))
+    for rep in range(4 if M <= 300_000 else 2):
+        out = torch.full((M + 3, N), 9.0, device=DEV, dtype=torch.bfloat16)
+        _with_tile(3, lambda: capi.gemm_nt(a, b, out=out[:M]))
+        assert torch.equal(out[:M], ref), (rep, int((out[:M] != ref).sum()))
+        assert bool((out[M:] == 9).all())                      # nothing written past row M
+
+
+@pytest.mark.parametrize("M,N,K", [(4097, 256, 768), (70001, 512, 768), (200003, 768, 512)])
+def test_big_tile_gemm_random_data_bias_and_strides(M, N, K):
+    g = torch.Generator(device=DEV).manual_seed(N + K + 1)
+    wide = torch.randn(M, K + 24, device=DEV, generator=g).to(torch.bfloat16)
+    a = wide[:, 8:8 + K]
+    b = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = _ref(a, b, bias)
+    outw = torch.full((M, N + 16), 7.0, device=DEV, dtype=torch.bfloat16)
+    out = _with_tile(3, lambda: capi.gemm_nt(a, b, bias, out=outw[:, 8:8 + N]))
+    assert float((out.float() - ref).abs().max() / ref.abs().max()) < 2.0 ** -8
+    assert bool((outw[:, :8] == 7).all()) and bool((outw[:, 8 + N:] == 7).all())
+    # the same values as the 128-row kernel up to fp32 summation order (same bf16 rounding of nearly the same sums)
+    out128 = _with_tile(1, lambda: capi.gemm_nt(a, b, bias))
+    assert float((out.float() - out128.float()).abs().max() / ref.abs().max()) < 2.0 ** -7
+    assert float((out != out128).float().mean()) < 0.01
+
+
+def test_big_tile_kernel_serves_the_wide_layers_of_the_model():
+    """functional.dense_nt hands the K x N > 100 K products to the 256 x 256 kernel and nothing goes to the BLAS library:
+    a 256 -> 512 ChebConv layer (forward [V,768] x [768,512], input gradient [V,512] x [512,768]) on 70 K vertices against the
+    same layer with the kernel switched off."""
+    m = synth.torus_mesh(280, 250, masks=False)
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    conv = sgnn.ChebConv(256, 512, K=3)
+    GU.fill_state(conv, seed=8)
+    conv.to(DEV)
+    x = torch.randn(m.num_vertices, 256, device=DEV).bfloat16().requires_grad_(True)
+    r = torch.randn(m.num_vertices, 512, device=DEV).bfloat16()
+    timer = capi.LaunchTimer()
+    F_sg.set_gemm_timer(timer)
+    try:
+        y = conv(x, ei)
+        (y * r).sum().backward()
+    finally:
+        F_sg.set_gemm_timer(None)
+    torch.cuda.synchronize()
+    engines = {(k[0], k[2], k[3]): k[5] for k in timer.results()}
+    assert engines[("nt", 512, 768)] == "mfma" and engines[("nt", 768, 512)] == "mfma", engines
+    gx, gw = x.grad.clone(), conv.lins[1].weight.grad.clone()
+    x.grad = None
+    conv.zero_grad()
+    old = F_sg.USE_MFMA_BIG_TILE
+    F_sg.USE_MFMA_BIG_TILE = False
+    try:
+        y2 = conv(x, ei)
+        (y2 * r).sum().backward()
+    finally:
+        F_sg.USE_MFMA_BIG_TILE = old
+    assert GU.rel_l2(y.detach().float().cpu(), y2.detach().float().cpu()) < 2.0 ** -8
+    assert GU.rel_l2(gx.float().cpu(), x.grad.float().cpu()) < 2.0 ** -7
+    assert GU.rel_l2(gw.cpu(), conv.lins[1].weight.grad.cpu()) < 2.0 ** -7
