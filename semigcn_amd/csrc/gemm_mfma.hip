@@ -290,8 +290,8 @@ int g_gemm_tile = 0;   // SG_TUNE_GEMM_TILE: 0 = automatic, 1 = 128-row tiles on
                        // 3 = the 256 x 256 eight-wavefront kernel (gemm_mfma256.hip) wherever it takes the shape
 
 // automatic choice: the persistent 256 x 256 kernel serves the compute-bound products (K x N above ~100 K elements: the
-// 256- and 512-channel layers), the 128-row-tile kernel below the HBM-bound ones
-constexpr int64_t kBigMinWeightElems = 100000;
+// 256- and 512-channel layers and [V,384] x [384,256]), the 128-row-tile kernel below the HBM-bound ones
+constexpr int64_t kBigMinWeightElems = 90000;
 constexpr int64_t kBigMinRows = 16384;
 
 // 64 x 256 tiles (ONE column tile covers N <= 256, so A is fetched by one workgroup only) were measured SLOWER than

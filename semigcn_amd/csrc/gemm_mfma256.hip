@@ -24,9 +24,10 @@
 //    first K steps of the workgroup's NEXT row tile are already arriving, so the pipeline is filled once per launch, not
 //    once per tile (K is only 4 .. 12 steps long: a per-tile prologue would cost 15 .. 40 % of the tile);
 //  * the MFMA operands are swapped (D = B-fragment x A-fragment = a tile of C^T), so a lane holds FOUR CONSECUTIVE
-//    COLUMNS of one row of C: the tile leaves the registers as 8-byte stores with no LDS transpose and no barrier.  The
+//    COLUMNS of one row of C, eight after one v_permlane16_swap with its neighbour: the tile leaves the registers as
+//    16-byte stores (64 contiguous bytes per row and instruction) with no LDS transpose and no barrier.  The
 //    stores sit in the same in-order VMEM queue as the DMA, so the four phases after an epilogue wait for
-//    vmcnt(8 + 32) instead of vmcnt(8): exactly 32 stores are issued per wavefront per full tile (a partial tile is the
+//    vmcnt(8 + 16) instead of vmcnt(8): exactly 16 stores are issued per wavefront per full tile (a partial tile is the
 //    last of its stream: nothing follows it).
 //
 // Column tiles of one row tile are walked by sibling workgroups on ONE XCD (block ids b, b + 8, ..) in step, so A leaves
@@ -40,6 +41,9 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads256 = 512;
 constexpr int kHalf = 16384;            // one half-tile: 128 rows x 64 bf16
@@ -53,18 +57,75 @@ struct Big {
   uint16_t* C; int64_t ldc;
   int M, N, K;
   int n_col_tiles, n_row_tiles, streams;
+#ifdef SG_GEMM256_STAMPS
+  unsigned long long* stamps;           // tools/gemm256_stamps.hip: [2 wavefronts][K steps][4 phases][6] shader-clock stamps
+#endif
 };
+
+#if defined(SG_GEMM256_STAMPS) && !defined(SG_G256_NOSTAMP)
+// (kept in LDS behind the staging buffers and flushed at the end: a global store per stamp would sit in the VMEM queue
+//  that the counted vmcnt waits watch)
+#define SG_STAMP(ph, k)                                                                                         \
+  if (blockIdx.x == 8 && (wave == 0 || wave == 4) && lane == 0 && s >= 16 && s < 32)                              \
+    ((unsigned long long*)(lds + 2 * kBuf))[(((wave >> 2) * 16 + (s - 16)) * 4 + (ph)) * 6 + (k)] = __builtin_readcyclecounter();
+#else
+#define SG_STAMP(ph, k)
+#endif
 
 #define SG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define SG_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifdef SG_G256_NOBARRIER
+#define SG_BARRIER()
+#else
+#define SG_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+#ifdef SG_G256_NTSTORE
+#define SG_STORE16(p, v) __builtin_nontemporal_store(v, (u32x4*)(p))
+#else
+#define SG_STORE16(p, v) (*(u32x4*)(p) = (v))
+#endif
+#ifdef SG_G256_ONEBAR
+#define SG_BARRIER2()
+#else
+#define SG_BARRIER2() SG_BARRIER()
+#endif
+#ifdef SG_G256_NOREAD
+#define SG_LDS_FRAG(ptr) sg_fake_frag(ptr)
+#else
+#define SG_LDS_FRAG(ptr) (*(const bf16x8*)(ptr))
+#endif
+#ifdef SG_G256_NOMFMA
+#define SG_MFMA(a, b, c, x, y, z) ((c) + f32x4{(float)(a)[0], (float)(b)[1], 0.f, 0.f})
+#else
+#define SG_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#endif
+#ifdef SG_G256_NOPRIO
+#define SG_PRIO(p)
+#else
+#define SG_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
+__device__ __forceinline__ bf16x8 sg_fake_frag(const uint8_t* p) {
+  bf16x8 v;
+  asm volatile("" : "=v"(v) : "v"(p));
+  return v;
+}
 
 __device__ __forceinline__ void glds16(const void* src, uint8_t* lds_dst) {
+#ifdef SG_G256_NOLOAD
+  asm volatile("" ::"v"(src), "s"(lds_dst));
+  return;
+#endif
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                    (void __attribute__((address_space(3)))*)lds_dst, 16, 0, 0);
 }
 
 __global__ __launch_bounds__(kThreads256, 1) void gemm_nt_256(const Big g) {
+#ifdef SG_GEMM256_STAMPS
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * kBuf + 2 * 16 * 4 * 6 * 8];
+#else
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * kBuf];      // the ONLY LDS object (guide 5, trap 4a)
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,8 +190,9 @@ __global__ __launch_bounds__(kThreads256, 1) void gemm_nt_256(const Big g) {
   };
   auto load_b = [&](int h, int buf) {
     uint8_t* dst = lds + buf * kBuf + (2 + h) * kHalf + wave * 2048;
+    const char* const b_base = Bw + lk * 128;        // (a scalar base + a 32-bit lane offset: the saddr form of the DMA)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(Bw + lk * 128 + offB[h][i], dst + i * 1024);
+    for (int i = 0; i < 2; ++i) glds16(b_base + offB[h][i], dst + i * 1024);
   };
 
   // ---- fragment read addresses -------------------------------------------------------------------------------------
@@ -156,11 +218,14 @@ __global__ __launch_bounds__(kThreads256, 1) void gemm_nt_256(const Big g) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bias_r[j][q]));
 
-  f32x4 acc[8][4];
+  f32x4 bias_v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias_v[j] = f32x4{bias_r[j][0], bias_r[j][1], bias_r[j][2], bias_r[j][3]};
+  f32x4 acc[8][4];                                      // start from the bias: the epilogue is convert + store only
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) acc[i][j] = bias_v[j];
 
   // ---- prologue: K step 0 whole, A-h0 / B-h0 of K step 1 --------------------------------------------------------------
   set_tile(0);
@@ -173,129 +238,181 @@ __global__ __launch_bounds__(kThreads256, 1) void gemm_nt_256(const Big g) {
   load_b(0, 1);
   // cursor convention from here on: at the top of K step s the cursor is at step s + 1; after phase 1 it moves to s + 2
   SG_WAIT_VM(8);                                        // A-h0, B-h0 of step 0 have landed (this wavefront's share)
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();            // wavefronts 4-7 run half a phase behind
+  SG_BARRIER();
+  if (wr == 1) SG_BARRIER2();            // wavefronts 4-7 run half a phase behind
+
+  // ---- epilogue, one quadrant of the wavefront's tile at a time -------------------------------------------------------------
+  // Lane (row fr, group fq) holds columns 4 fq .. + 3 of each 16-column fragment; v_permlane16_swap trades the odd 16-lane
+  // rows of one register with the even rows of another, so fragments j and j + 1 swap halves between lane groups (0, 1)
+  // and (2, 3) and a lane owns EIGHT consecutive columns: 16-byte stores, 64 contiguous bytes per row and instruction.  The
+  // stores are request-bound (8-byte stores -- twice the write requests -- cost 10-20 % of the whole product).  Tried and
+  // not kept: spreading the four quadrants over the four phases of the next K step (the stores then sit between the DMA
+  // loads in the in-order VMEM queue and hold them up: +8 .. +20 % time), non-temporal stores (+5 .. +20 %).
+  int since = 2;                                        // K steps since a tile was stored (0: the step right after), capped at 2
+  int pend_row0 = 0;                                    // first row of the tile being stored
+  auto store_quadrant = [&](int q) {
+    const int i0 = q >= 2 ? 4 : 0, jp = (q == 1 || q == 2) ? 1 : 0;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = i0 + ii;
+      const int row = pend_row0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fr;
+      uint16_t* const cptr = g.C + (int64_t)row * g.ldc + col0 + wc * 32 + (fq & 1) * 16 + (fq >> 1) * 8 + jp * 128;
+      uint32_t lo[2], hi[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * jp + jj;
+        lo[jj] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[i][j][0], acc[i][j][1]}, bf16x2));
+        hi[jj] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[i][j][2], acc[i][j][3]}, bf16x2));
+        acc[i][j] = bias_v[j];
+      }
+      const auto ra = __builtin_amdgcn_permlane16_swap(lo[0], lo[1], false, false);
+      const auto rb = __builtin_amdgcn_permlane16_swap(hi[0], hi[1], false, false);
+      if (row < g.M) SG_STORE16(cptr, (u32x4{ra[0], rb[0], ra[1], rb[1]}));
+    }
+  };
+  // counted waits: 8 = four half-tiles of DMA younger than the one needed next; the 16 stores of a tile sit in the same
+  // in-order queue, which raises the count to 24 for the four phases of the K step after them
+#define SG_PHASE_WAIT(n0, n1)                 \
+  if (since == 0) SG_WAIT_VM(n0);             \
+  else SG_WAIT_VM(n1);
 
   bf16x8 af[4][2], bf0[2][2], bf1[2][2];
   int ct_k = 0, ct_t = 0;                               // compute position: K step ct_k of tile ct_t
   for (int s = 0; s < total; ++s) {
     const int buf = s & 1;
     const uint8_t* const base = lds + buf * kBuf;
-    const bool after_store = (ct_k == 0) && (s > 0);    // the stores of the previous tile sit in the VMEM queue
     // ---------------- phase 0: A0 x B0 ----------------------------------------------------------------------------------
+    SG_STAMP(0, 0)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) bf0[j][ks] = *(const bf16x8*)(base + BH0 * kHalf + b_rd[ks] + j * 2048);
+      for (int ks = 0; ks < 2; ++ks) bf0[j][ks] = SG_LDS_FRAG(base + BH0 * kHalf + b_rd[ks] + j * 2048);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(base + AH0 * kHalf + a_rd[ks] + i * 2048);
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = SG_LDS_FRAG(base + AH0 * kHalf + a_rd[ks] + i * 2048);
     load_b(1, buf ^ 1);                                 // B-h1 of step s + 1
-    if (after_store) SG_WAIT_VM(40); else SG_WAIT_VM(8);
-    __builtin_amdgcn_s_barrier();
+    SG_STAMP(0, 1)
+    SG_PHASE_WAIT(24, 8)
+    SG_STAMP(0, 2)
+    SG_BARRIER();
+    SG_STAMP(0, 3)
     SG_WAIT_LGKM0();
-    __builtin_amdgcn_s_setprio(1);
+    SG_PRIO(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
+          acc[i][j] = SG_MFMA(bf0[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+    SG_PRIO(0);
+    SG_STAMP(0, 4)
+    SG_BARRIER2();
+    SG_STAMP(0, 5)
     // ---------------- phase 1: A0 x B1 ----------------------------------------------------------------------------------
+    SG_STAMP(1, 0)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) bf1[j][ks] = *(const bf16x8*)(base + BH1 * kHalf + b_rd[ks] + j * 2048);
+      for (int ks = 0; ks < 2; ++ks) bf1[j][ks] = SG_LDS_FRAG(base + BH1 * kHalf + b_rd[ks] + j * 2048);
     load_a(1, buf ^ 1);                                 // A-h1 of step s + 1
     advance();                                          // cursor = step s + 2
-    if (after_store) SG_WAIT_VM(40); else SG_WAIT_VM(8);
-    __builtin_amdgcn_s_barrier();
+    SG_STAMP(1, 1)
+    SG_PHASE_WAIT(24, 8)
+    SG_STAMP(1, 2)
+    SG_BARRIER();
+    SG_STAMP(1, 3)
     SG_WAIT_LGKM0();
-    __builtin_amdgcn_s_setprio(1);
+    SG_PRIO(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j][ks], af[i][ks], acc[i][2 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
+          acc[i][2 + j] = SG_MFMA(bf1[j][ks], af[i][ks], acc[i][2 + j], 0, 0, 0);
+    SG_PRIO(0);
+    SG_STAMP(1, 4)
+    SG_BARRIER2();
+    SG_STAMP(1, 5)
     // ---------------- phase 2: A1 x B1 ----------------------------------------------------------------------------------
+    SG_STAMP(2, 0)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(base + AH1 * kHalf + a_rd[ks] + i * 2048);
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = SG_LDS_FRAG(base + AH1 * kHalf + a_rd[ks] + i * 2048);
     load_a(0, buf);                                     // A-h0 of step s + 2 (this buffer's A-h0 was last read in phase 0)
-    if (after_store) SG_WAIT_VM(40); else SG_WAIT_VM(8);
-    __builtin_amdgcn_s_barrier();
+    SG_STAMP(2, 1)
+    SG_PHASE_WAIT(24, 8)
+    SG_STAMP(2, 2)
+    SG_BARRIER();
+    SG_STAMP(2, 3)
     SG_WAIT_LGKM0();
-    __builtin_amdgcn_s_setprio(1);
+    SG_PRIO(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j][ks], af[i][ks], acc[4 + i][2 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
+          acc[4 + i][2 + j] = SG_MFMA(bf1[j][ks], af[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+    SG_PRIO(0);
+    SG_STAMP(2, 4)
+    SG_BARRIER2();
+    SG_STAMP(2, 5)
     // ---------------- phase 3: A1 x B0 (both still in registers) --------------------------------------------------------
+    SG_STAMP(3, 0)
     load_b(0, buf);                                     // B-h0 of step s + 2
-    if (after_store) SG_WAIT_VM(40); else SG_WAIT_VM(8);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
+    SG_STAMP(3, 1)
+    SG_PHASE_WAIT(24, 8)
+    SG_STAMP(3, 2)
+    SG_BARRIER();
+    SG_STAMP(3, 3)
+    SG_PRIO(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j][ks], af[i][ks], acc[4 + i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
+          acc[4 + i][j] = SG_MFMA(bf0[j][ks], af[i][ks], acc[4 + i][j], 0, 0, 0);
+    SG_PRIO(0);
+    SG_STAMP(3, 4)
+    SG_BARRIER2();
+    SG_STAMP(3, 5)
 
-    // ---------------- end of a tile: (+ bias) -> bf16 -> 8-byte stores, accumulators cleared -----------------------------
+    // ---------------- end of a tile: convert, store (16 stores per wavefront), restart the sums from the bias ---------------
+    since = since < 2 ? since + 1 : 2;
     if (++ct_k == nk) {
-      const int row0 = (stream + ct_t * g.streams) * 256;
+      pend_row0 = (stream + ct_t * g.streams) * 256;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = row0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fr;
-        uint16_t* const crow = g.C + (int64_t)row * g.ldc + col0 + wc * 32 + fq * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          u32x2 pk;
-          pk.x = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][0] + bias_r[j][0])) |
-                 ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][1] + bias_r[j][1])) << 16);
-          pk.y = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][2] + bias_r[j][2])) |
-                 ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][3] + bias_r[j][3])) << 16);
-          if (row < g.M) *(u32x2*)(crow + (j >> 1) * 128 + (j & 1) * 16) = pk;
-          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
+      for (int q = 0; q < 4; ++q) store_quadrant(q);
+      since = 0;
       ct_k = 0;
       ++ct_t;
     }
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();            // pairs with the extra barrier of wavefronts 4-7
+  if (wr == 0) SG_BARRIER2();            // pairs with the extra barrier of wavefronts 4-7
   SG_WAIT_VM(0);                                        // no LDS-DMA may be in flight when the workgroup ends
+#ifdef SG_GEMM256_STAMPS
+  __syncthreads();
+  if (blockIdx.x == 8)
+    for (int i = tid; i < 2 * 16 * 4 * 6; i += kThreads256) g.stamps[i] = ((unsigned long long*)(lds + 2 * kBuf))[i];
+#endif
 }
 
 }  // namespace
 
 bool gemm_nt_256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc) {
-  return K >= 128 && K % 64 == 0 && N >= 256 && N % 256 == 0 && M >= 256 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
+  return K >= 128 && K % 64 == 0 && N >= 256 && N % 256 == 0 && M >= 256 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
          256 * lda * 2 < (int64_t)1 << 31 && 256 * ldb * 2 < (int64_t)1 << 31;
 }
 
 int launch_gemm_nt_256(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
                        int64_t M, int64_t N, int64_t K, hipStream_t stream) {
   SG_REQUIRE(gemm_nt_256_supported(M, N, K, lda, ldb, ldc), "sg_gemm_nt (256-tile kernel): unsupported shape");
-  SG_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((uintptr_t)C & 7) == 0, "sg_gemm_nt (256-tile kernel): misaligned operand");
+  SG_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((uintptr_t)C & 15) == 0, "sg_gemm_nt (256-tile kernel): misaligned operand");
   Big g;
   g.A = (const uint16_t*)A; g.lda = lda;
   g.B = (const uint16_t*)B; g.ldb = ldb;

@@ -279,8 +279,7 @@ USE_MFMA_BIG_TILE = os.environ.get("SEMIGCN_NO_BIG_TILE_GEMM") != "1"
 
 
 def _mfma_big(a: torch.Tensor, b: torch.Tensor, ldc: int) -> bool:
-    return (USE_MFMA_BIG_TILE and b.shape[0] * b.shape[1] > MFMA_MAX_WEIGHT_ELEMS
-            and capi.gemm_nt_takes_big_tile(a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), ldc))
+    return USE_MFMA_BIG_TILE and capi.gemm_nt_takes_big_tile(a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), ldc)
 
 
 def _mfma_ok(a: torch.Tensor, b: torch.Tensor, ldc: int) -> bool:

@@ -44,13 +44,21 @@ ora = OB.SGCNOracleBf16(post_when_narrowing=post, bias_bf16_layers=blas)
 ora.load_state_dict(state0)
 ora.train()
 hc, hb, oc, ob, hin, oin = [], [], [], [], [], []
+def keep(into_in, into_out, unpermute):
+    def hook(mod, i, o):
+        f = (lambda t: t.detach().float().index_select(0, rank).cpu()) if unpermute else (lambda t: t.detach())
+        if into_in is not None:
+            into_in.append(f(i[0]))
+        into_out.append(f(o))
+    return hook
+
+
 for b in net.blocks:
-    b.module_0.register_forward_hook(lambda mod, i, o: (hin.append(i[0].detach().float().index_select(0, rank).cpu()),
-                                                         hc.append(o.detach().float().index_select(0, rank).cpu())))
-    b.register_forward_hook(lambda mod, i, o: hb.append(o.detach().float().index_select(0, rank).cpu()))
+    b.module_0.register_forward_hook(keep(hin, hc, True))
+    b.register_forward_hook(keep(None, hb, True))
 for b in ora.blocks:
-    b.module_0.register_forward_hook(lambda mod, i, o: (oin.append(i[0].detach()), oc.append(o.detach())))
-    b.register_forward_hook(lambda mod, i, o: ob.append(o.detach()))
+    b.module_0.register_forward_hook(keep(oin, oc, False))
+    b.register_forward_hook(keep(None, ob, False))
 with torch.no_grad():
     ph = net(D, None)
     po = ora(torch.from_numpy(m.z1), torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index), None)
