@@ -375,7 +375,8 @@ enum sg_tune_knob {
                              even where 32-bit offsets would do, bit 5: fixed-size gather batches also where the
                              row length is wave-uniform, bit 6: nontemporal epilogue loads / stores (no effect measured),
                              bit 7: the experimental LDS-tile kernel (set it when the graph is created AND when it is
-                             applied; measured slower) (A/B switches) */
+                             applied; measured slower), bit 8: 4-channel bf16 rows on the one-thread-per-element kernel instead of the
+                             one-thread-per-row kernel (A/B switches) */
   SG_TUNE_UNROLL = 2,     /* gathers a lane group issues back to back in the aggregation kernel: 8, 6 or 4
                              (fewer = fewer VGPRs = more resident wavefronts); 0 = the shipped choice per shape */
   SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */

@@ -105,7 +105,7 @@ struct Big {
 #define SG_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #endif
 
-__device__ __forceinline__ bf16x8 sg_fake_frag(const uint8_t* p) {
+[[maybe_unused]] __device__ __forceinline__ bf16x8 sg_fake_frag(const uint8_t* p) {
   bf16x8 v;
   asm volatile("" : "=v"(v) : "v"(p));
   return v;

@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32,
-             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128 };
+             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256 };
 
 // Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
 // one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
@@ -769,6 +769,77 @@ __global__ __launch_bounds__(kBlock) void spmm_scalar(const SpmmArgs a) {
   }
 }
 
+// bf16 rows of FOUR channels (8 bytes: the network's input layer, util/networks.py:15 h[0] = 4) -- too short for the
+// 16-byte vectors of spmm_rows, and one thread per ELEMENT (spmm_scalar) spends four threads' worth of row-pointer and
+// index loads per row.  One thread per ROW: 8-byte gathers, up to four in flight (slots past the end of the row re-read
+// its last neighbour with weight zero, like spmm_rows' batches), the same fma chain in CSR order as spmm_scalar, so the
+// result is bit-identical to it.
+__global__ __launch_bounds__(kBlock) void spmm_quad_bf16(const SpmmArgs a) {
+  const uint16_t* __restrict__ X = (const uint16_t*)a.X;
+  const uint16_t* __restrict__ X0 = (const uint16_t*)a.X0;
+  const uint16_t* __restrict__ X1 = (const uint16_t*)a.X1;
+  uint16_t* __restrict__ Y = (uint16_t*)a.Y;
+  auto widen = [](uint2 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  };
+  for (int row = blockIdx.x * kBlock + threadIdx.x; row < a.n_rows; row += gridDim.x * kBlock) {
+    const int k0 = a.rowptr[row], k1 = a.rowptr[row + 1];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = k0; k < k1; k += 4) {
+      uint2 v[4];
+      float w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool on = k + u < k1;
+        const int kk = on ? k + u : k1 - 1;
+        int j;
+        float ws;
+        if (a.idx_w) {
+          const int2 e = a.idx_w[kk];
+          j = e.x;
+          ws = __int_as_float(e.y);
+        } else {
+          j = a.idx[kk];
+          ws = a.scale_src ? a.scale_src[j] : 1.0f;
+        }
+        w[u] = on ? ws : 0.f;
+        v[u] = *(const uint2*)(X + (int64_t)j * a.ldx);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float x[4];
+        widen(v[u], x);
+        if (k + u < k1) {                     // (a skipped slot must not touch the sum: 0 * inf would)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = fmaf(w[u], x[c], acc[c]);
+        }
+      }
+    }
+    const float sd = a.alpha * (a.scale_dst ? a.scale_dst[row] : 1.0f);
+    const int64_t orow = a.row_id ? a.row_id[row] : row;
+    float y[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) y[c] = sd * acc[c];
+    if (X0) {
+      float x[4];
+      widen(*(const uint2*)(X0 + orow * a.ldx0), x);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y[c] = fmaf(a.beta, x[c], y[c]);
+    }
+    if (X1) {
+      float x[4];
+      widen(*(const uint2*)(X1 + orow * a.ldx1), x);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y[c] = fmaf(a.gamma, x[c], y[c]);
+    }
+    uint2 out;
+    out.x = Vt<bf16_tag>::cvt2(y[0], y[1]);
+    out.y = Vt<bf16_tag>::cvt2(y[2], y[3]);
+    *(uint2*)(Y + orow * a.ldy) = out;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void gather_rows_vec(const int32_t* __restrict__ rows, int64_t n,
                                                           const void* X, int64_t ldx, void* Y,
@@ -884,6 +955,15 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
                       aligned16(a.Y) && (!a.X0 || (a.ldx0 % VEC == 0 && aligned16(a.X0))) &&
                       (!a.X1 || (a.ldx1 % VEC == 0 && aligned16(a.X1))) && a.C / VEC <= 256;
   (void)esz;
+  if (esz == 2 && a.C == 4 && a.ldx % 4 == 0 && a.ldy % 4 == 0 && ((uintptr_t)a.X & 7) == 0 && ((uintptr_t)a.Y & 7) == 0 &&
+      (!a.X0 || (a.ldx0 % 4 == 0 && ((uintptr_t)a.X0 & 7) == 0)) && (!a.X1 || (a.ldx1 % 4 == 0 && ((uintptr_t)a.X1 & 7) == 0)) &&
+      !(g_tuning.flags & kFlagNoQuad)) {
+    int nb = (a.n_rows + kBlock - 1) / kBlock;
+    nb = nb > 256 * 64 ? 256 * 64 : nb;
+    spmm_quad_bf16<<<nb, kBlock, 0, stream>>>(a);
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
+  }
   if (!vec_ok) {
     const int64_t total = (int64_t)a.n_rows * a.C;
     int64_t nb = (total + kBlock - 1) / kBlock;

@@ -257,7 +257,8 @@ class MGCN(nn.Module):
         self.decoder2 = UpConv(128, 32, e[2], e[1], u[1], K=K, drop_rate=0.2)
         self.decoder1 = nn.Sequential(UpConv(32, 16, e[1], e[0], u[0], K=K, drop_rate=0.0), _Fp32Linear(16, 3))
         self.mcnn3, self.mcnn2, self.mcnn1 = _head(256, K), _head(128, K), _head(32, K)
-        self.skip2, self.skip1 = nn.Linear(256, 128), nn.Linear(64, 32)
+        self.skip2, self.skip1 = _Fp32Linear(256, 128), _Fp32Linear(64, 32)     # (nn.Linear: fp32 parameters, any input dtype)
+        self.feature_dtype = torch.float32
 
         # target / smooth positions per level (util/meshnet.py:251-276)
         self.smposs_list = [s.to(device) for s in smposs]
@@ -309,6 +310,14 @@ class MGCN(nn.Module):
                 color[self.f_masks_list[l + 1].numpy()] = np.array([0.332, 0.664, 1.0])
             simp.save_as_ply("{}/pooled/ini_{}_vs.ply".format(root, len(simp.vs)), color)
 
+    def set_feature_dtype(self, dtype: torch.dtype) -> "MGCN":
+        """Store the per-vertex features between kernels in ``dtype`` (float32 or bfloat16) on every level, as
+        SingleScaleGCN.set_feature_dtype does: fp32 accumulation, fp32 parameters, fp32 heads and outputs."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("feature dtype must be float32 or bfloat16")
+        self.feature_dtype = dtype
+        return self
+
     # ------------------------------------------------------------------------------------
     def forward(self, data, dm=None):
         z1 = data.z1.to(self.device)
@@ -329,6 +338,8 @@ class MGCN(nn.Module):
         elif self._orders is not None:
             x = x.index_select(0, self._orders[0][0])
             heads = self._graphs
+        fd = getattr(self, "feature_dtype", torch.float32)
+        x = x.to(fd)
 
         res1_enc = self.encoder1(x)
         res2_enc = self.encoder2(res1_enc)
@@ -337,12 +348,12 @@ class MGCN(nn.Module):
 
         res2_dec = self.decoder3(res3_bot)
         if self.skip:
-            res2_dec = self.skip2(torch.cat([res2_dec, res2_enc], dim=1))
+            res2_dec = self.skip2(torch.cat([res2_dec, res2_enc], dim=1)).to(fd)
         out2 = self.mcnn2(res2_dec, heads[2])
 
         res1_dec = self.decoder2(res2_dec)
         if self.skip:
-            res1_dec = self.skip1(torch.cat([res1_dec, res1_enc], dim=1))
+            res1_dec = self.skip1(torch.cat([res1_dec, res1_enc], dim=1)).to(fd)
         out1 = self.mcnn1(res1_dec, heads[1])
 
         out0 = self.decoder1(res1_dec)

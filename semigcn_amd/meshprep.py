@@ -169,15 +169,117 @@ def contract_matching(edges: torch.Tensor, priority: torch.Tensor, num_vertices:
     return root_id[parent], int(is_root.sum())
 
 
+#: util/mesh.py:10-11
+OPTIM_VALENCE, VALENCE_WEIGHT = 6, 1
+
+
+def _vertex_quadrics(vs: torch.Tensor, faces: torch.Tensor) -> torch.Tensor:
+    """Q_v = sum over the faces around v of [n | d]^T [n | d] (unit normal n, d = -n . centroid): util/mesh.py:397-406,
+    as [V, 4, 4] float64 on the device (an index_add over the 3 F face corners instead of a Python loop over V)."""
+    p = vs.double()
+    a, b, c = p[faces[:, 0]], p[faces[:, 1]], p[faces[:, 2]]
+    n = torch.linalg.cross(b - a, c - a, dim=1)
+    n = n / n.norm(dim=1, keepdim=True).clamp_min(1e-30)
+    d = -(n * ((a + b + c) / 3.0)).sum(1, keepdim=True)
+    abcd = torch.cat([n, d], dim=1)                                   # [F, 4]
+    q = abcd.unsqueeze(2) * abcd.unsqueeze(1)                         # [F, 4, 4]
+    Q = torch.zeros((vs.shape[0], 4, 4), dtype=torch.float64, device=vs.device)
+    for k in range(3):
+        Q.index_add_(0, faces[:, k], q)
+    return Q
+
+
+def qem_contract(vs: torch.Tensor, faces: torch.Tensor, target_v: int, max_cluster: int = 5, rounds: int = 6):
+    """The reference's simplification criterion (util/mesh.py:394-482: quadric error of the edge MIDPOINT under the sum of
+    the two end vertices' quadrics, times the valence penalty |valence_new - 6| + 1, x 1e5 for a valence of 3), applied
+    in parallel: instead of one heap-ordered collapse at a time, ``rounds`` rounds of a locally-dominant matching on the
+    CURRENT (already contracted) mesh -- an edge is collapsed when it is the cheapest remaining edge at both of its ends
+    -- each round taking its share of the vertices still to remove.  Like the reference, the surviving vertex (the
+    lower id) moves to the midpoint and KEEPS its own quadric (util/mesh.py:564-571), a vertex that has been merged
+    into can be merged again in a later round (clusters of 1 .. ``max_cluster``; the reference's reach 5), and an edge
+    whose ends share other than two neighbours is not collapsed (util/mesh.py:460-464: it would fold the surface).
+    Returns ``coarse_of`` int64 [V] (ids ascend with the cluster's smallest member) and V_coarse."""
+    dev = vs.device
+    V = vs.shape[0]
+    need = V - int(target_v)
+    Q = _vertex_quadrics(vs, faces)
+    pos = vs.double().clone()
+    rep = torch.arange(V, device=dev)                 # representative (surviving vertex) of every original vertex
+    size = torch.ones(V, dtype=torch.int64, device=dev)
+    f = faces.clone()
+    big = torch.iinfo(torch.int64).max
+    for r in range(rounds):
+        if need <= 0:
+            break
+        # current mesh: faces over representatives, degenerate ones dropped
+        f = rep[f]
+        f = f[(f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 2] != f[:, 0])]
+        he = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], dim=0)
+        lo, hi = torch.minimum(he[:, 0], he[:, 1]), torch.maximum(he[:, 0], he[:, 1])
+        key, cnt = torch.unique(lo * V + hi, return_counts=True)
+        ea, eb = key // V, key % V                      # undirected edges, ea < eb
+        nf = torch.bincount(f.reshape(-1), minlength=V)                     # faces around a vertex (= its valence)
+        # shared neighbours of the two ends = faces on the edge for a manifold interior edge: exactly two, else skip
+        ok = (cnt == 2) & (size[ea] + size[eb] <= max_cluster)
+        val_new = nf[ea] + nf[eb] - 4
+        pen = (val_new - OPTIM_VALENCE).abs().double() * VALENCE_WEIGHT + 1.0
+        pen = torch.where(val_new == 3, pen * 100000.0, pen)
+        mid = 0.5 * (pos[ea] + pos[eb])
+        v4 = torch.cat([mid, torch.ones((mid.shape[0], 1), dtype=torch.float64, device=dev)], dim=1)
+        Qs = Q[ea] + Q[eb]
+        err = torch.einsum("ei,eij,ej->e", v4, Qs, v4) * pen
+        err = torch.where(ok, err, torch.full_like(err, float("inf")))
+        # a round's quota: its share of what is left (the last round takes whatever it can)
+        quota = need if r == rounds - 1 else -(-need // (rounds - r))
+        rank = torch.empty_like(key)
+        rank[torch.argsort(err, stable=True)] = torch.arange(key.numel(), device=dev)
+        cand = torch.nonzero(ok, as_tuple=False).reshape(-1)
+        used = torch.zeros(V, dtype=torch.bool, device=dev)
+        taken = 0
+        while taken < quota and cand.numel():
+            a, b, rk = ea[cand], eb[cand], rank[cand]
+            best = torch.full((V,), big, dtype=torch.int64, device=dev)
+            best.scatter_reduce_(0, a, rk, "amin")
+            best.scatter_reduce_(0, b, rk, "amin")
+            win = (best[a] == rk) & (best[b] == rk)
+            w = cand[win]
+            if w.numel() == 0:
+                break
+            if w.numel() > quota - taken:
+                w = w[torch.argsort(rank[w])[: quota - taken]]
+            a, b = ea[w], eb[w]
+            # the two triangles on a collapsing edge vanish; their third vertices must not collapse in the same round
+            # towards each other through this pair -- vertex-disjointness of the matching already guarantees a, b are fresh
+            pos[a] = 0.5 * (pos[a] + pos[b])
+            size[a] = size[a] + size[b]
+            rep_b = torch.arange(V, device=dev)
+            rep_b[b] = a
+            rep = rep_b[rep]
+            used[a] = True
+            used[b] = True
+            taken += int(w.numel())
+            cand = cand[~win]
+            cand = cand[~(used[ea[cand]] | used[eb[cand]])]
+        need -= taken
+        if taken == 0:
+            break
+    is_root = rep == torch.arange(V, device=dev)
+    root_id = torch.cumsum(is_root.to(torch.int64), 0) - 1
+    return root_id[rep], int(is_root.sum()), pos[is_root].float()
+
+
 class DeviceMesh:
     """What ``MGCN(device, smo_mesh, ini_mesh, v_mask)`` reads from the reference's ``Mesh``
     (util/meshnet.py:170-199: ``.vs .faces .edge_index .path .simplification(target_v)`` and, on
     the result, ``.pool_hash``), held on the device so that a 1 M-vertex hierarchy is built in
-    milliseconds.  ``simplification`` is NOT the reference's QEM edge collapse
-    (util/mesh.py:394-482: Python heap loop, minutes at 50 K vertices): it contracts a
-    shortest-edge-first matching, which yields the same artefacts -- ``pool_hash`` rows
-    (fine_i, coarse_i) covering every fine vertex with clusters of one or two, positions at the
-    cluster mean, the surviving triangles, and the quotient graph as ``edge_index``."""
+    a fraction of a second.  ``simplification`` applies the reference's criterion -- quadric error of the edge midpoint
+    with its valence penalty (util/mesh.py:394-482) -- as rounds of a parallel matching instead of one heap-ordered
+    collapse at a time (``qem_contract``; ``criterion="length"`` is the shortest-edge matching of rounds 1-2: clusters of
+    one or two).  The artefacts are the reference's: ``pool_hash`` rows (fine_i, coarse_i) covering every fine vertex
+    (clusters of 1 .. 5), positions (midpoints of the collapses, as util/mesh.py:564), the surviving triangles, and the
+    quotient graph as ``edge_index``.  The collapse ORDER differs from a sequential heap, so the clusters are not the
+    reference's clusters; tests/test_gpu_parity.py compares the two hierarchies by what they are for: geometric error of
+    the coarse meshes, and the loss an MGCN trained on either reaches."""
 
     def __init__(self, vs, faces, device="cuda", path: str = "./mesh.obj", pool_hash=None, edge_index=None):
         device = torch.device(device)
@@ -188,15 +290,19 @@ class DeviceMesh:
         self.pool_hash = pool_hash
         self.path = path
 
-    def simplification(self, target_v: int) -> "DeviceMesh":
+    def simplification(self, target_v: int, criterion: str = "qem") -> "DeviceMesh":
         V = self.vs.shape[0]
         half = self.edge_index.shape[1] // 2
         und = self.edge_index[:, :half].t().contiguous()
-        d = self.vs[und[:, 0]] - self.vs[und[:, 1]]
-        coarse_of, Vc = contract_matching(und, (d * d).sum(1), V, target_v)
         fine = torch.arange(V, device=self.vs.device)
-        pool = capi.PoolHandle(fine, coarse_of, V, Vc)
-        cvs = pool.pool_mean(self.vs.contiguous())
+        if criterion == "qem":
+            coarse_of, Vc, cvs = qem_contract(self.vs, self.faces, target_v)
+        elif criterion == "length":
+            d = self.vs[und[:, 0]] - self.vs[und[:, 1]]
+            coarse_of, Vc = contract_matching(und, (d * d).sum(1), V, target_v)
+            cvs = capi.PoolHandle(fine, coarse_of, V, Vc).pool_mean(self.vs.contiguous())
+        else:
+            raise ValueError("criterion must be 'qem' or 'length'")
         cf = coarse_of[self.faces]
         alive = (cf[:, 0] != cf[:, 1]) & (cf[:, 1] != cf[:, 2]) & (cf[:, 2] != cf[:, 0])
         ce = coarse_of[und]

@@ -6,7 +6,8 @@ backward are compared with the oracle where BASELINE.json's configurations live:
 
   c2  SGCN, 250 x 200 torus (V = 50 K), fp32, train mode             test_c2_*
   c4  SGCN, 1000 x 1000 (V = 1 M): one full-size oracle iteration     test_c4_*   (~3 min of host time)
-  c4's storage type: bf16 features against the bf16-STORAGE oracle    test_bf16_*
+  c4's storage type: bf16 features against the bf16-STORAGE oracle    test_bf16_*  (block by block, and end to end
+                                                                      relative to what bf16 storage itself costs)
   the training loop of sgcn.py:118-147 as a 10-iteration trajectory   test_training_trajectory_*
 
 Gradient bounds are FLAT: the oracle runs with the LeakyReLU sign pattern the HIP forward produced
@@ -236,11 +237,13 @@ def test_c2_sgcn_with_skip_connections_vs_oracle():
 # --------------------------------------------------------------------------------------
 @pytest.mark.skipif(os.environ.get("SEMIGCN_SKIP_FULL_SIZE_ORACLE") == "1", reason="switched off by the environment")
 def test_c4_full_size_train_iteration_vs_oracle():
-    """V = 1 M.  At this size the fp32 ORACLE is the noisier side (ATen's CPU BatchNorm and scatter_add sum a million rows
-    in fp32 chunk by chunk: its running statistics are 1e-4, its offsets 8e-4 from the float64 evaluation -- measured,
-    profiles/r03_c4_parity_fp32_fp64.json), so the comparison that means something is against the oracle in float64: one
-    full-size float64 iteration (~4 min, ~110 GB of host memory).  SEMIGCN_C4_BOTH_ORACLES=1 runs the fp32 oracle as
-    well and applies the relative criterion of the c2 test."""
+    """V = 1 M.  At this size the fp32 ORACLE is the noisier side by two orders of magnitude (ATen's CPU BatchNorm and
+    scatter_add sum a million rows in fp32 chunk by chunk).  Measured with both oracles, profiles/
+    r03_c4_parity_fp32_fp64.json -- distance from the float64 evaluation, HIP fp32 path / fp32 oracle: network offsets
+    8.1e-6 / 7.6e-4, loss 7e-9 / 1.0e-5, BatchNorm running statistics 1.6e-7 / 1.0e-4, dz1 3.5e-4 / 1.8e-2, parameter
+    gradients 7.5e-4 / 2.7e-2.  So the comparison that means something is against the oracle in float64: one full-size
+    float64 iteration (~4 min, ~110 GB of host memory), with flat bounds a factor 2-3 above the measured HIP figures.
+    SEMIGCN_C4_BOTH_ORACLES=1 runs the fp32 oracle as well and applies the relative criterion of the c2 test."""
     import psutil
     both = os.environ.get("SEMIGCN_C4_BOTH_ORACLES") == "1"
     if psutil.virtual_memory().available < (200e9 if both else 140e9):
@@ -256,44 +259,148 @@ def test_c4_full_size_train_iteration_vs_oracle():
     assert h["pos"] < 1e-5 and h["loss"] < 1e-5 and h["bn"] < 1e-5, res
     if both:
         _assert_fp32_parity(res)
-    else:       # what the fp32 oracle itself reaches at this size (see the docstring), as flat bounds
-        assert h["offset"] < 8e-4 and h["dz1"] < 2e-2 and h["param_grad"] < 3e-2, res
+    else:
+        assert h["offset"] < 2e-5 and h["dz1"] < 1.5e-3 and h["param_grad"] < 2.5e-3, res
 
 
 # --------------------------------------------------------------------------------------
 # bf16 feature storage (BASELINE configs[3]) against the oracle that rounds at the same storage points
 # --------------------------------------------------------------------------------------
-BF16_TOL = 5e-3
+# Two bf16 evaluations of this network that differ ONLY in the order of their fp32 additions do not stay together end to
+# end: an fp32 sum that lands on the other side of a bf16 rounding boundary moves one stored value by 2^-8, the next
+# layer's products spread that over ~19 rows x Cout outputs of which one in sqrt(3 Cin) crosses a boundary of its own,
+# and BatchNorm's mean carries it to every row -- after three layers every element is an independent draw of the same
+# rounding noise (measured: 2 % of the elements differ after the first conv, 25 % after the second block, 79 % after the
+# fifth; tools/bf16_probe.py).  So "HIP bf16 == bf16 oracle to 5e-3 end to end" is not a property ANY pair of
+# implementations has.  What the storage oracle can and does pin:
+#   (a) every block on its own, fed the oracle's input and the oracle's output gradient (teacher forcing): forward,
+#       input gradient and parameter gradients of the HIP block against the oracle block -- same storage points or not;
+#   (b) end to end, the HIP bf16 path is no further from the fp32 oracle than the bf16-storage oracle is (outputs, loss,
+#       direction of the gradients): bf16 storage costs what it must and nothing more.
+BF16_BLOCK_TOL = {"out": 1e-3, "dx": 2e-2, "dw": 2.5e-2}     # measured: 2.0e-4, 8.3e-3, 1.1e-2 (block 9, aggregation after the product)
 
 
-@pytest.mark.parametrize("name", ["sphere", "torus", "c2"])
+def _blas_layers(V, post):
+    blas = []
+    for i in range(13):
+        cin, cout = CHANNELS[i], CHANNELS[i + 1]
+        wshape = (3 * cout, cin) if (post and cout < cin) else (cout, 3 * cin)
+        a = torch.empty((V, wshape[1]), dtype=torch.bfloat16, device=DEV)
+        if not F_sg._mfma_ok(a, torch.empty(wshape, dtype=torch.bfloat16, device=DEV), wshape[0]):
+            blas.append(i)
+    return blas
+
+
 @pytest.mark.parametrize("post", [True, False])
-def test_bf16_features_vs_bf16_storage_oracle(name, post, fixture_meshes, monkeypatch):
-    if name == "c2" and not post:
-        pytest.skip("the reference's evaluation order at 50 K is covered by the fixtures")
+def test_bf16_blocks_teacher_forced_vs_bf16_storage_oracle(post, monkeypatch):
     monkeypatch.setattr(F_sg, "AGGREGATE_AFTER_GEMM_WHEN_NARROWING", post)
-    m = synth.torus_mesh(250, 200) if name == "c2" else fixture_meshes[name]
-    res = _one_iteration_both_sides(m, feature_dtype=torch.bfloat16, seed=60, post=post)
-    # a bf16 rounding that falls the other way (fp32 summation order) moves that row by one bf16 ulp: a sign change it
-    # causes downstream is a consequence, not a kink crossing -- bound the fraction only
-    assert res["flip_frac"] <= 1e-3, res
-    h = res["hip_vs_oracle"]
-    assert h["offset"] < BF16_TOL and h["loss"] < BF16_TOL, res
-    assert h["dz1"] < 4 * BF16_TOL and h["param_grad"] < 4 * BF16_TOL, res
-    assert h["bn"] < BF16_TOL, res
+    m = synth.torus_mesh(100, 50)
+    V = m.num_vertices
+    net = SingleScaleGCN(DEV, reorder=False)
+    GU.fill_state(net, seed=61)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(DEV).train()
+    net.set_feature_dtype(torch.bfloat16)
+    ora = OB.SGCNOracleBf16(post_when_narrowing=post, bias_bf16_layers=_blas_layers(V, post))
+    ora.load_state_dict(state0)
+    ora.train()
+    # the oracle end to end, every block's input / output and their gradients kept
+    xs, ys, dys, dxs = [None] * 13, [None] * 13, [None] * 13, [None] * 13
 
+    def pre(i):
+        def hook(mod, args):
+            x = args[0]
+            if not x.requires_grad:                 # block 0's input: the rounded network input
+                x = x.detach().requires_grad_(True)
+            xs[i] = x
+            x.register_hook(lambda g: dxs.__setitem__(i, g.detach().clone()))
+            return (x,) + tuple(args[1:])
+        return hook
 
-def test_bf16_oracle_is_not_the_fp32_oracle(fixture_meshes):
-    """The bound above means something only if bf16 storage moves the result by much more than the bound: the bf16
-    oracle against the fp32 oracle on the same inputs (host only; here because it sizes BF16_TOL)."""
-    m = fixture_meshes["torus"]
-    a, b = OM.SGCNOracle(), OB.SGCNOracleBf16()
-    GU.fill_state(a, seed=60)
-    b.load_state_dict(a.state_dict())
-    a.train(), b.train()
+    def post_hook(i):
+        def hook(mod, args, out):
+            ys[i] = out
+            out.register_hook(lambda g: dys.__setitem__(i, g.detach().clone()))
+        return hook
+    for i, blk in enumerate(ora.blocks):
+        blk.register_forward_pre_hook(pre(i))
+        blk.register_forward_hook(post_hook(i))
     z1, xp, ei = torch.from_numpy(m.z1), torch.from_numpy(m.x_pos), torch.from_numpy(m.edge_index)
-    pa, pb = a(z1, xp, ei, None), b(z1, xp, ei, None)
-    assert GU.rel_l2((pb - xp).detach(), (pa - xp).detach()) > 4 * BF16_TOL
+    r = torch.from_numpy(GU.probe("bf16-blocks", (V, 3)))
+    (ora(z1, xp, ei, None) * r).sum().backward()
+    og = {n: p.grad for n, p in ora.named_parameters() if p.grad is not None}
+
+    class D:
+        z1 = torch.from_numpy(m.z1).to(DEV)
+        x_pos = torch.from_numpy(m.x_pos).to(DEV)
+        edge_index = torch.from_numpy(m.edge_index).to(DEV)
+    graph = net.graph(D)
+    worst = {"out": (0.0, None), "dx": (0.0, None), "dw": (0.0, None)}
+    for i, blk in enumerate(net.blocks):
+        net.zero_grad(set_to_none=True)
+        x = xs[i].detach().to(DEV).to(torch.bfloat16).requires_grad_(True)
+        y = blk(x, graph)
+        assert y.dtype == (torch.float32 if i == 12 else torch.bfloat16)
+        e_out = GU.rel_l2(y.detach().float().cpu(), ys[i].detach())
+        y.backward(dys[i].to(DEV).to(y.dtype))
+        e_dx = GU.rel_l2(x.grad.float().cpu(), dxs[i])
+        e_dw = 0.0
+        for n, p in blk.named_parameters():
+            ref = og[f"blocks.{i}.{n}"]
+            if n == "module_0.bias":                # in front of a BatchNorm: exactly zero in exact arithmetic
+                continue
+            e_dw = max(e_dw, GU.rel_l2(p.grad.float().cpu(), ref))
+        print(f"block {i:2d} {CHANNELS[i]:3d}->{CHANNELS[i + 1]:3d}  out {e_out:.2e}  dx {e_dx:.2e}  dw {e_dw:.2e}")
+        for k, e in (("out", e_out), ("dx", e_dx), ("dw", e_dw)):
+            if e > worst[k][0]:
+                worst[k] = (e, i)
+    print("worst", worst)
+    for k, (e, i) in worst.items():
+        assert e < BF16_BLOCK_TOL[k], (k, i, e)
+
+
+def _cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("name", ["torus", "c1", "c2"])
+def test_bf16_end_to_end_no_further_from_fp32_than_the_storage_oracle(name, fixture_meshes):
+    m = {"torus": lambda: fixture_meshes["torus"], "c1": lambda: synth.torus_mesh(100, 50),
+         "c2": lambda: synth.torus_mesh(250, 200)}[name]()
+    V = m.num_vertices
+    batch = _batch(m, n_masks=1)
+    net = SingleScaleGCN(DEV)
+    GU.fill_state(net, seed=62)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(DEV).train()
+    net.set_feature_dtype(torch.bfloat16)
+    tr = train.SGCNTrainer(net, batch)
+    pos = net(batch.data, batch.v_keep * batch.dummy_masks[:, :1])
+    loss = tr.loss(pos)
+    loss.backward()
+    side = _OracleSide(m, batch)
+    xp = side.x_pos.double()
+    hip = (pos.detach().cpu().double() - xp, float(loss.detach()), batch.data.z1.grad.cpu().double(),
+           {n: p.grad.detach().cpu().double() for n, p in net.named_parameters() if p.grad is not None})
+    runs = {}
+    for key, ora in (("fp32", OM.SGCNOracle()), ("bf16", OB.SGCNOracleBf16(bias_bf16_layers=_blas_layers(V, True)))):
+        ora.load_state_dict(state0)
+        o = _oracle_run(ora, side, m, torch.float32, None)
+        runs[key] = (o[0] - xp, o[1], o[2], o[3])
+    ref = runs["fp32"]
+    names = [n for n in ref[3] if not n.endswith("module_0.bias")]
+
+    def dist(a):
+        flat = lambda g: torch.cat([g[n].reshape(-1) for n in names])
+        return {"offset": GU.rel_l2(a[0], ref[0]), "loss": abs(a[1] - ref[1]) / abs(ref[1]),
+                "cos_dz1": _cos(a[2], ref[2]), "cos_params": _cos(flat(a[3]), flat(ref[3]))}
+    d_hip, d_ora = dist(hip), dist(runs["bf16"])
+    print(name, "HIP bf16 vs fp32 oracle", {k: f"{v:.3e}" for k, v in d_hip.items()})
+    print(name, "bf16-storage oracle vs fp32 oracle", {k: f"{v:.3e}" for k, v in d_ora.items()})
+    assert d_hip["offset"] < 1.5 * d_ora["offset"] + 1e-3 and d_hip["loss"] < 1.5 * d_ora["loss"] + 1e-3
+    assert d_hip["cos_dz1"] > d_ora["cos_dz1"] - 0.1 and d_hip["cos_params"] > d_ora["cos_params"] - 0.05
+    assert d_ora["offset"] > 5e-3          # bf16 storage moves the result by much more than fp32 rounding does
 
 
 # --------------------------------------------------------------------------------------

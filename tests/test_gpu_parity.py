@@ -158,6 +158,30 @@ def test_spmm_strided_blocks_and_in_place_epilogue(fixture_meshes):
     assert rel(got, oracle_lhat(ei, odd[:, 1:C + 1].cpu())) < KERNEL_TOL
 
 
+def test_spmm_four_channel_bf16_rows_kernel_is_bit_identical_to_the_scalar_kernel(fixture_meshes):
+    """C = 4 in bf16 (8-byte rows: the input layer) runs one thread per ROW; it must reproduce the one-thread-per-element
+    kernel bit for bit -- same CSR-order fma chain -- with and without epilogue operands, strided operands, on a mesh, a
+    multigraph with a hub row and self-loops, and through a row-subset view."""
+    for ei, V in ((torch.from_numpy(fixture_meshes["torus"].edge_index), 240), (nasty_graph(), 500),
+                  (torch.from_numpy(synth.torus_mesh(70, 50, masks=False).edge_index), 3500)):
+        g = MeshGraph.from_edge_index(ei.to(DEV), V)
+        wide = torch.randn(V, 12, device=DEV).bfloat16()
+        x, x0, x1 = wide[:, 0:4], wide[:, 4:8], wide[:, 8:12]
+        for kw in ({}, {"X0": x0, "beta": -1.0, "alpha": 2.0}, {"X0": x0, "beta": 1.0, "X1": x1, "gamma": -1.0}):
+            ya = torch.zeros(V, 8, device=DEV, dtype=torch.bfloat16)
+            yb = torch.zeros_like(ya)
+            g.aggregate(x, ya[:, 4:8], **kw)
+            capi.tuning_set(capi.TUNE_FLAGS, 1 | 256)
+            try:
+                g.aggregate(x, yb[:, 4:8], **kw)
+            finally:
+                capi.tuning_set(capi.TUNE_FLAGS, 1)
+            assert torch.equal(ya, yb) and bool((ya[:, :4] == 0).all())
+            ref = oracle_lhat(ei, x.float().cpu(), kw.get("alpha", 1.0), None if "X0" not in kw else x0.float().cpu(),
+                              kw.get("beta", 0.0), None if "X1" not in kw else x1.float().cpu(), kw.get("gamma", 0.0))
+            assert rel(ya[:, 4:8].float(), ref) < 2.0 ** -7
+
+
 @pytest.mark.parametrize("C", [8, 16, 64, 256, 512, 24, 7])
 def test_spmm_bf16_storage(C, fixture_meshes):
     m = fixture_meshes["torus"]
@@ -561,6 +585,40 @@ def test_mgcn_reordering_is_transparent():
             assert GU.rel_l2(pa.cpu(), pb.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("skip", [False, True])
+def test_mgcn_bf16_feature_storage(skip):
+    """MGCN.set_feature_dtype(bf16) (util/meshnet.py:278-318 with bf16 rows between the kernels on every level): one
+    encoder stage on a bf16-rounded input is a few roundings from the same stage in fp32 (conv, pooled mean, BatchNorm,
+    activation, three more convs -- ~25 stored values deep); the whole network stays fp32 at its four outputs, finite in
+    its gradients, and as close to the fp32 network as 33 bf16 layers can be."""
+    from test_host_logic import _mgcn_from_golden
+    g3 = GU.load("g3_mgcn.npz")
+    net = _mgcn_from_golden(DEV, g3, skip=skip)
+    net.to(DEV).eval()                      # (eval: no dropout draws between the two passes)
+
+    class D:
+        z1 = torch.from_numpy(g3["z1"]).to(DEV).requires_grad_(True)
+        x_pos = None
+    with torch.no_grad():
+        p32 = net(D, None)
+        x = torch.randn(net.smposs_list[0].shape[0], 4, device=DEV).bfloat16()
+        e32 = net.encoder1(x.float())
+        e16 = net.encoder1(x)
+        assert e16.dtype == torch.bfloat16 and GU.rel_l2(e16.float().cpu(), e32.cpu()) < 3e-2
+        net.set_feature_dtype(torch.bfloat16)
+        p16 = net(D, None)
+    for a, b, sm in zip(p16, p32, net.smposs_list):
+        assert a.dtype == torch.float32 and GU.rel_l2((a - sm).cpu(), (b - sm).cpu()) < 0.25
+    net.train()
+    out = net(D, None)
+    sum((o ** 2).mean() for o in out).backward()
+    assert bool(torch.isfinite(D.z1.grad).all())
+    assert all(p.grad is None or (p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all())) for p in net.parameters())
+    net.set_feature_dtype(torch.float32)
+    with pytest.raises(ValueError):
+        net.set_feature_dtype(torch.float16)
+
+
 def test_mgcn_config_c3_size_runs():
     """BASELINE config c3: MGCN, 3 pool levels, 50 K-vertex mesh (synthetic hierarchy)."""
     from semigcn_amd.meshnet import MGCN
@@ -861,7 +919,7 @@ def test_device_hierarchy_artefacts():
     fine = meshprep.DeviceMesh(m.x_pos, m.faces, DEV)
     assert torch.equal(fine.edge_index.cpu(), torch.from_numpy(m.edge_index))
     target = int(V * 0.6)
-    coarse = fine.simplification(target_v=target)
+    coarse = fine.simplification(target_v=target, criterion="length")
     ph = coarse.pool_hash
     Vc = coarse.vs.shape[0]
     assert Vc == target and ph.shape == (V, 2) and np.array_equal(ph[:, 0], np.arange(V))
@@ -888,6 +946,121 @@ def test_device_hierarchy_artefacts():
     length = np.linalg.norm(m.x_pos[m.edges[:, 0]] - m.x_pos[m.edges[:, 1]], axis=1)
     taken = np.linalg.norm(m.x_pos[pairs[:, 0]] - m.x_pos[pairs[:, 1]], axis=1)
     assert taken.mean() < length.mean()
+
+
+def _cluster_quadric_error(vs, faces, coarse_of, coarse_pos):
+    """sum over coarse vertices of p^T (sum of the members' vertex quadrics) p: squared distances of the coarse vertex to
+    the planes of every original triangle around its cluster (the quantity util/mesh.py:394-482 ranks collapses by)."""
+    from semigcn_amd.meshprep import _vertex_quadrics
+    Q = _vertex_quadrics(vs, faces)
+    Qc = torch.zeros((coarse_pos.shape[0], 4, 4), dtype=torch.float64, device=vs.device).index_add_(0, coarse_of, Q)
+    p4 = torch.cat([coarse_pos.double(), torch.ones((coarse_pos.shape[0], 1), dtype=torch.float64, device=vs.device)], 1)
+    return float(torch.einsum("ci,cij,cj->c", p4, Qc, p4).sum())
+
+
+@pytest.mark.parametrize("which", ["torus", "sphere"])
+def test_device_hierarchy_by_quadric_error(which):
+    """The default criterion: the reference's quadric error with its valence penalty (util/mesh.py:394-482), collapsed in
+    rounds of a parallel matching.  Artefact contract as above; clusters of 1 .. 5 (the reference's range); the coarse
+    mesh stays a closed manifold of the same genus; and it is a BETTER approximation of the fine surface than the
+    shortest-edge matching of rounds 1-2 (lower summed quadric error)."""
+    from semigcn_amd import meshprep
+    m = synth.torus_mesh(200, 150, masks=False) if which == "torus" else synth.octahedron_sphere(5)
+    V = m.num_vertices
+    fine = meshprep.DeviceMesh(m.x_pos, m.faces, DEV)
+    target = int(V * 0.6)
+    coarse = fine.simplification(target_v=target)
+    ph = coarse.pool_hash
+    Vc = coarse.vs.shape[0]
+    assert Vc == target and ph.shape == (V, 2) and np.array_equal(ph[:, 0], np.arange(V))
+    sizes = np.bincount(ph[:, 1], minlength=Vc)
+    assert sizes.min() == 1 and 3 <= sizes.max() <= 5
+    order = np.argsort(ph[:, 1], kind="stable")
+    first = np.searchsorted(ph[order, 1], np.arange(Vc))
+    assert (np.diff(order[first]) > 0).all()            # cluster ids ascend with the smallest member
+    ce = ph[:, 1][m.edge_index]
+    ce = ce[:, ce[0] != ce[1]]
+    want = np.unique(np.minimum(ce[0], ce[1]) * Vc + np.maximum(ce[0], ce[1]))
+    got = coarse.edge_index.cpu().numpy()
+    half = got.shape[1] // 2
+    assert np.array_equal(got[0, :half] * Vc + got[1, :half], want) and np.array_equal(got[:, half:], got[::-1, :half])
+    cf = coarse.faces.cpu().numpy()
+    assert ((cf[:, 0] != cf[:, 1]) & (cf[:, 1] != cf[:, 2]) & (cf[:, 2] != cf[:, 0])).all() and cf.max() < Vc
+    e = np.sort(np.concatenate([cf[:, [0, 1]], cf[:, [1, 2]], cf[:, [2, 0]]]), 1)
+    key, cnt = np.unique(e[:, 0] * Vc + e[:, 1], return_counts=True)
+    assert (cnt == 2).all()                              # closed manifold: every edge in two triangles
+    assert Vc - key.shape[0] + cf.shape[0] == (0 if which == "torus" else 2)      # Euler characteristic kept
+    assert np.array_equal(key, want)                     # the quotient graph IS the edge set of the surviving triangles
+    by_len = fine.simplification(target_v=target, criterion="length")
+    co_q, co_l = torch.from_numpy(ph[:, 1]).to(DEV), torch.from_numpy(by_len.pool_hash[:, 1]).to(DEV)
+    e_q = _cluster_quadric_error(fine.vs, fine.faces, co_q, coarse.vs)
+    e_l = _cluster_quadric_error(fine.vs, fine.faces, co_l, by_len.vs)
+    print(which, "summed quadric error: qem matching", e_q, "shortest-edge matching", e_l)
+    assert e_q < 0.8 * e_l
+    # a second and third level from the first (what MGCN.__init__ does)
+    c2 = coarse.simplification(target_v=int(V * 0.36))
+    c3 = c2.simplification(target_v=int(V * 0.216))
+    assert c2.vs.shape[0] == int(V * 0.36) and c3.vs.shape[0] == int(V * 0.216)
+
+
+def test_mgcn_trains_on_the_device_hierarchy_as_on_the_references_own():
+    """is a hierarchy built on the device as good FOR THE NETWORK as the one the reference's QEM simplifier
+    builds?  Golden g3 holds the reference's own three-level hierarchy of the 258-vertex sphere (its Mesh.simplification
+    run through oracle/ref_shim.py).  The same MGCN (same seed, same data, 60 training iterations, Adam every 5th) is
+    trained on it and on the hierarchy DeviceMesh.simplification builds from the same faces; compared: the geometric
+    error of the three coarse levels and what the training reaches on the FINEST level (the level both share)."""
+    from test_host_logic import _mgcn_from_golden
+    from semigcn_amd import meshprep, train
+    from semigcn_amd.meshnet import MGCN
+    g3 = GU.load("g3_mgcn.npz")
+    m = synth.octahedron_sphere(3)
+    assert np.array_equal(m.edge_index, g3["edge_index/0"])          # the fixture mesh
+    V = m.num_vertices
+    smo = meshprep.DeviceMesh(g3["smposs/0"], m.faces, DEV)
+    ini = meshprep.DeviceMesh(g3["poss/0"], m.faces, DEV)
+    v_mask = torch.from_numpy(g3["v_masks/0"][:, 0] > 0)
+    faces = torch.from_numpy(m.faces).to(DEV)
+    target = torch.from_numpy(g3["poss/0"]).to(DEV)
+    v_keep = v_mask.float().view(-1, 1).to(DEV)
+    f_keep = v_keep[faces[:, 0]] * v_keep[faces[:, 1]] * v_keep[faces[:, 2]]
+    dms = torch.from_numpy(synth.make_dummy_masks(m.edge_index, V, dm_size=10, k=1, p=0.05)).to(DEV)
+
+    def run(build):
+        torch.manual_seed(7)
+        net = build().to(DEV)
+
+        class D:
+            z1 = torch.from_numpy(g3["z1"]).to(DEV).requires_grad_(True)
+            x_pos = None
+        batch = train.MeshBatch(D, faces, target, train.face_normals(target, faces), v_keep, f_keep, dms)
+        tr = train.MGCNTrainer(net, batch, lr=0.01)
+        losses = [float(tr.iteration_step()) for _ in range(60)]
+        net.eval()
+        with torch.no_grad():
+            p0 = net(D, None)[0]
+        rmse = float((((p0 - target) * v_keep) ** 2).sum().div(v_keep.sum()).sqrt())
+        return net, float(np.mean(losses[:5])), float(np.mean(losses[-5:])), rmse
+    net_r, first_r, last_r, rmse_r = run(lambda: _mgcn_from_golden(DEV, g3))
+    net_d, first_d, last_d, rmse_d = run(lambda: MGCN(DEV, smo, ini, v_mask))
+    assert [p.shape[0] for p in net_d.smposs_list] == [p.shape[0] for p in net_r.smposs_list] == [258, 154, 92, 55]
+    # geometry: summed quadric error of each coarse level against the FINE surface, device-built vs reference-built
+    fine_vs, fine_faces = smo.vs, smo.faces
+    for name, net in (("reference", net_r), ("device", net_d)):
+        comp = torch.arange(V, device=DEV)
+        errs = []
+        for l in range(3):
+            ph = torch.from_numpy(np.asarray(net._pool_pairs[l])).to(DEV)
+            comp = ph[:, 1][comp]                      # fine vertex -> its cluster on level l + 1
+            errs.append(_cluster_quadric_error(fine_vs, fine_faces, comp, net.smposs_list[l + 1]))
+        print(name, "hierarchy: quadric error per level", [f"{e:.3e}" for e in errs])
+        if name == "reference":
+            ref_errs = errs
+        else:
+            assert all(e < 2.0 * r + 1e-9 for e, r in zip(errs, ref_errs)), (errs, ref_errs)
+    print(f"training: reference hierarchy loss {first_r:.4f} -> {last_r:.4f}, finest-level RMSE {rmse_r:.4f}; "
+          f"device hierarchy loss {first_d:.4f} -> {last_d:.4f}, finest-level RMSE {rmse_d:.4f}")
+    assert last_r < 0.8 * first_r and last_d < 0.8 * first_d                 # both train
+    assert last_d < 1.25 * last_r and rmse_d < 1.25 * rmse_r                  # and to the same place
 
 
 def test_mgcn_reference_constructor_with_device_meshes_vs_oracle():

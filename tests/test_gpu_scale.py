@@ -314,5 +314,6 @@ def test_bench_supervisor_retries_without_replay_after_a_stall():
     d = json.loads(lines[0])["distributed"]
     assert d["attempt"] == 2 and "within 75 s" in d["first_attempt_failure"] and d["hip_graph_segments"] is None
     assert "starting a fresh worker without hipGraph replay" in r.stderr
+    env["SEMIGCN_BENCH_ATTEMPT_TIMEOUT"] = "50"
     r = subprocess.run(base + ["--stall-after-warmup", "-600"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and "both attempts failed" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
