@@ -342,6 +342,9 @@ SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, co
  * vertices.  workspace: float32 [sg_gemm_tn_slabs(M, N, Kp), N, Kp] (per-slab partial sums, added in slab order: the result
  * is deterministic).  N, Kp, lda, ldb multiples of 8, 16-byte aligned buffers, else SG_ERR_UNSUPPORTED. */
 SG_API int64_t sg_gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp);
+/* 1 when sg_gemm_tn serves this shape with the persistent 256 x 256 ring (N, Kp multiples of 256, N * Kp > 90 K, M >= 16 K:
+ * the weight gradients of the 256- and 512-channel layers), 0 when the 128 x 128 kernel does */
+SG_API int sg_gemm_tn_takes_big_tile(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
                       float* workspace, float* out, int64_t ldo, void* stream);
 /* sg_bn_stats_finalize for partials cut into uniform tiles of rows_per_tile rows (the last one shorter) */

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "sg_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                            c_int, c_void_p, c_void_p]),
     "sg_gemm_tn_slabs": (c_int64, [c_int64, c_int64, c_int64]),
+    "sg_gemm_tn_takes_big_tile": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
     "sg_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
                            c_void_p]),
     "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -648,6 +649,11 @@ def gemm_tn_supported(A: torch.Tensor, B: torch.Tensor) -> bool:
         return False
     return (A.shape[1] % 8 == 0 and B.shape[1] % 8 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0
             and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_tn_takes_big_tile(M: int, N: int, Kp: int, lda: int, ldb: int) -> bool:
+    """True when sg_gemm_tn serves this weight gradient with the persistent 256 x 256 ring (csrc/gemm_mfma256.hip)."""
+    return bool(_sizes("sg_gemm_tn_takes_big_tile", int(M), int(N), int(Kp), int(lda), int(ldb)))
 
 
 def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:

@@ -523,6 +523,10 @@ SG_API int sg_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, co
 
 SG_API int64_t sg_gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp) { return gemm_tn_slabs(M, N, Kp); }
 
+SG_API int sg_gemm_tn_takes_big_tile(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb) {
+  return gemm_tn_takes_big_tile(M, N, Kp, lda, ldb) ? 1 : 0;
+}
+
 SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
                       float* workspace, float* out, int64_t ldo, void* stream) {
   SG_REQUIRE(M >= 0 && N >= 0 && Kp >= 0, "sg_gemm_tn: negative size");

@@ -515,10 +515,25 @@ __global__ __launch_bounds__(1024) void tn_reduce(const float* __restrict__ W, i
 
 }  // namespace
 
-int64_t gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
+// automatic choice for the weight gradient: the 256 x 256 ring (gemm_mfma256.hip) serves the compute-bound products
+// (N, Kp multiples of 256, N x Kp above ~100 K elements), the 128 x 128 kernel below the rest
+bool gemm_tn_takes_big_tile(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb) {
+  if (g_gemm_tile == 1 || g_gemm_tile == 2 || !gemm_tn_256_supported(M, N, Kp, lda, ldb)) return false;
+  return g_gemm_tile == 3 || (N * Kp > kBigMinWeightElems && M >= kBigMinRows);
+}
+
+static int64_t small_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
   if (M <= 0) return 1;
   const int rows = tn_slab_rows(M, ((N + 127) / 128) * ((Kp + 127) / 128));
   return (M + rows - 1) / rows;
+}
+
+int64_t gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
+  // (sized for either kernel: the 256 x 256 ring's slabs plus one for the rows past the last full 64-row step)
+  int64_t big = 0;
+  if (gemm_tn_256_supported(M, N, Kp, 8, 8)) big = gemm_tn_256_slabs(M, N, Kp) + 1;
+  const int64_t small = small_tn_slabs(M, N, Kp);
+  return big > small ? big : small;
 }
 
 int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
@@ -532,6 +547,30 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
     return SG_ERR_UNSUPPORTED;
   }
   SG_REQUIRE(M > 0 && M <= INT32_MAX && N <= INT32_MAX && Kp <= INT32_MAX, "sg_gemm_tn: size out of range");
+  if (gemm_tn_takes_big_tile(M, N, Kp, lda, ldb)) {
+    const int64_t m_full = M / 64 * 64, elems = N * Kp;
+    int64_t slabs = gemm_tn_256_slabs(M, N, Kp);
+    const int rc = launch_gemm_tn_256(A, lda, B, ldb, M, N, Kp, workspace, stream);
+    if (rc != SG_OK) return rc;
+    if (m_full < M) {                                   // the last < 64 rows: one slab of the 128 x 128 kernel
+      TnArgs t;
+      t.A = (const uint16_t*)A + m_full * lda; t.lda = lda;
+      t.B = (const uint16_t*)B + m_full * ldb; t.ldb = ldb;
+      t.W = workspace + slabs * elems;
+      t.M = (int)(M - m_full); t.N = (int)N; t.Kp = (int)Kp;
+      t.tiles_n = (int)((N + 127) / 128);
+      t.tiles_k = (int)((Kp + 127) / 128);
+      t.n_tiles = t.tiles_n * t.tiles_k;
+      t.slab_rows = 512;
+      t.n_blocks = t.n_tiles;
+      gemm_tn_bf16<<<t.n_blocks, kThreads, 0, stream>>>(t);
+      SG_HIP_TRY(hipGetLastError());
+      ++slabs;
+    }
+    tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo);
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
+  }
   TnArgs g;
   g.A = (const uint16_t*)A; g.lda = lda;
   g.B = (const uint16_t*)B; g.ldb = ldb;
@@ -541,7 +580,7 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
   g.tiles_k = (int)((Kp + 127) / 128);
   g.n_tiles = g.tiles_n * g.tiles_k;
   g.slab_rows = tn_slab_rows(M, g.n_tiles);
-  const int64_t slabs = gemm_tn_slabs(M, N, Kp);
+  const int64_t slabs = small_tn_slabs(M, N, Kp);
   SG_REQUIRE(slabs * g.n_tiles <= INT32_MAX, "sg_gemm_tn: too many workgroups");
   g.n_blocks = (int)(slabs * g.n_tiles);
   gemm_tn_bf16<<<g.n_blocks, kThreads, 0, stream>>>(g);

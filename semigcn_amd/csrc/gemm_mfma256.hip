@@ -43,6 +43,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads256 = 512;
@@ -402,6 +403,213 @@ __global__ __launch_bounds__(kThreads256, 1) void gemm_nt_256(const Big g) {
 #endif
 }
 
+
+// =====================================================================================================================
+// Weight gradient of the compute-bound layers:  W[N, Kp] = A[M, N]^T * B[M, Kp]  (dOut^T [Tx0|Tx1|Tx2]; autograd of the
+// `lins[k]` calls, util/networks.py:42,49) on the same eight-wavefront ring.  The reduction index m is the ROW of both
+// operands, so a K step is 64 ROWS of A and B (two 64 x 256 tiles = 4 half-tiles of 64 rows x 128 columns, 16 KB each) and
+// the MFMA fragments are columns of the LDS tiles, read with ds_read_b64_tr_b16 (as sg::gemm_tn_bf16: 32-byte segments
+// XOR-swizzled by the row so that the eight rows a 32-lane half reads hit disjoint banks -- here the swizzle is applied
+// to the per-lane SOURCE address of the DMA).  One workgroup = one 256 x 256 tile of W for one SLAB of rows, walked with
+// the pipeline of gemm_nt_256 (four phases per K step, counted vmcnt(8), staggered halves); there are no stores inside
+// the loop.  Slab partials go to the fp32 workspace and are summed in slab order by sg::tn_reduce: deterministic.
+struct BigTn {
+  const uint16_t* A; int64_t lda;
+  const uint16_t* B; int64_t ldb;
+  float* W;                                // [slabs][N][Kp]
+  int N, Kp;
+  int tiles_k, n_tiles, slabs, steps;      // steps = full 64-row steps of the whole product
+};
+
+__device__ __forceinline__ int tn_swz256(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(kThreads256, 1) void gemm_tn_256(const BigTn g) {
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * kBuf];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int b = blockIdx.x;
+  const int slot = b >> 3;
+  const int tile = slot % g.n_tiles;
+  const int slab = (b & 7) + 8 * (slot / g.n_tiles);
+  const int n0 = (tile / g.tiles_k) * 256, k0 = (tile % g.tiles_k) * 256;
+  const int q = g.steps / g.slabs, rem = g.steps % g.slabs;
+  const int first = slab * q + (slab < rem ? slab : rem);
+  const int total = q + (slab < rem ? 1 : 0);
+  float* const W = g.W + (int64_t)slab * g.N * g.Kp;
+
+  // ---- LDS-DMA: a half-tile = 64 rows x 256 B = 16 instructions of 1 KB (4 rows); wavefront w issues blocks 2w, 2w + 1
+  const int s_slot = lane & 15;
+  uint32_t offA[2], offB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * wave + 4 * i + (lane >> 4);
+    const int src_chunk = (((s_slot >> 1) ^ tn_swz256(row)) << 1) | (s_slot & 1);
+    offA[i] = (uint32_t)(row * g.lda * 2 + src_chunk * 16);
+    offB[i] = (uint32_t)(row * g.ldb * 2 + src_chunk * 16);
+  }
+  const char* const Abase = (const char*)g.A + (int64_t)n0 * 2;
+  const char* const Bbase = (const char*)g.B + (int64_t)k0 * 2;
+  int ls = 0;                                           // load cursor: step of this slab, clamped to the last one
+  auto a_ptr = [&]() { return Abase + (int64_t)(first + ls) * 64 * g.lda * 2; };
+  auto b_ptr = [&]() { return Bbase + (int64_t)(first + ls) * 64 * g.ldb * 2; };
+  auto advance = [&]() { if (ls + 1 < total) ++ls; };
+  auto load_a = [&](int h, int buf) {
+    uint8_t* dst = lds + buf * kBuf + h * kHalf + wave * 2048;
+    const char* src = a_ptr() + h * 256;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(src + offA[i], dst + i * 1024);
+  };
+  auto load_b = [&](int h, int buf) {
+    uint8_t* dst = lds + buf * kBuf + (2 + h) * kHalf + wave * 2048;
+    const char* src = b_ptr() + h * 256;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(src + offB[i], dst + i * 1024);
+  };
+
+  // ---- transposing fragment reads (see sg::gemm_tn_bf16): lane = 16 fg + 4 fq + fp supplies row 32 ms + 8 fg + 4 hh + fq,
+  //      columns 4 fp .. + 3 of a 16-column segment; lane 16 fg + i receives column i of those 4 rows.
+  //      Issued as inline asm: in front of the ds_read_tr BUILTIN hipcc puts an `s_waitcnt vmcnt(0)` in every phase (it
+  //      cannot tell the read from the LDS-DMA in flight), which drains the ring; the asm form is invisible to that pass,
+  //      so the lgkmcnt wait that makes the fragments valid is written by hand and TIED to them (SG_TN_READY).
+  const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds;
+  uint32_t frow[2][2];                                  // byte offset of row (ms, hh) + fp * 8, and its swizzle
+  int fsw[2][2];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int row = 32 * ms + 8 * fg + 4 * hh + fq;
+      frow[ms][hh] = (uint32_t)(row * 256 + fp * 8);
+      fsw[ms][hh] = tn_swz256(row);
+    }
+  auto frag = [&](uint32_t half_off, int seg, int ms) -> bf16x8 {
+    bf16x4 h[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const uint32_t addr = lds0 + half_off + frow[ms][hh] + (uint32_t)((seg ^ fsw[ms][hh]) << 5);
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[hh]) : "v"(addr) : "memory");
+    }
+    return bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+  };
+#define SG_TN_READY4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory")
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (total > 0) {
+    load_a(0, 0);
+    load_b(0, 0);
+    load_b(1, 0);
+    load_a(1, 0);
+    advance();
+    load_a(0, 1);
+    load_b(0, 1);
+    SG_WAIT_VM(8);
+    SG_BARRIER();
+    if (wr == 1) SG_BARRIER2();
+
+    bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+    for (int s = 0; s < total; ++s) {
+      const int buf = s & 1;
+      const uint32_t boff = (uint32_t)(buf * kBuf);
+      // phase 0: A0 x B0
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) bf0[j][ms] = frag(boff + BH0 * kHalf, wc * 2 + j, ms);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) af[i][ms] = frag(boff + AH0 * kHalf, wr * 4 + i, ms);
+      load_b(1, buf ^ 1);
+      SG_WAIT_VM(8);
+      SG_BARRIER();
+      SG_TN_READY4(bf0[0][0], bf0[0][1], bf0[1][0], bf0[1][1]);
+      SG_TN_READY4(af[0][0], af[0][1], af[1][0], af[1][1]);
+      SG_TN_READY4(af[2][0], af[2][1], af[3][0], af[3][1]);
+      SG_PRIO(1);
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = SG_MFMA(af[i][ms], bf0[j][ms], acc[i][j], 0, 0, 0);
+      SG_PRIO(0);
+      SG_BARRIER2();
+      // phase 1: A0 x B1
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) bf1[j][ms] = frag(boff + BH1 * kHalf, wc * 2 + j, ms);
+      load_a(1, buf ^ 1);
+      advance();
+      SG_WAIT_VM(8);
+      SG_BARRIER();
+      SG_TN_READY4(bf1[0][0], bf1[0][1], bf1[1][0], bf1[1][1]);
+      SG_PRIO(1);
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][2 + j] = SG_MFMA(af[i][ms], bf1[j][ms], acc[i][2 + j], 0, 0, 0);
+      SG_PRIO(0);
+      SG_BARRIER2();
+      // phase 2: A1 x B1
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) af[i][ms] = frag(boff + AH1 * kHalf, wr * 4 + i, ms);
+      load_a(0, buf);
+      SG_WAIT_VM(8);
+      SG_BARRIER();
+      SG_TN_READY4(af[0][0], af[0][1], af[1][0], af[1][1]);
+      SG_TN_READY4(af[2][0], af[2][1], af[3][0], af[3][1]);
+      SG_PRIO(1);
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = SG_MFMA(af[i][ms], bf1[j][ms], acc[4 + i][2 + j], 0, 0, 0);
+      SG_PRIO(0);
+      SG_BARRIER2();
+      // phase 3: A1 x B0
+      load_b(0, buf);
+      SG_WAIT_VM(8);
+      SG_BARRIER();
+      SG_PRIO(1);
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[4 + i][j] = SG_MFMA(af[i][ms], bf0[j][ms], acc[4 + i][j], 0, 0, 0);
+      SG_PRIO(0);
+      SG_BARRIER2();
+    }
+    if (wr == 0) SG_BARRIER2();
+    SG_WAIT_VM(0);
+  }
+  // ---- the slab's partial tile: D row = n (4 (lane >> 4) + reg), column = k' (lane & 15) --------------------------------
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = k0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fg * 4 + r;
+        W[(int64_t)n * g.Kp + kk] = acc[i][j][r];
+      }
+    }
+}
+
 }  // namespace
 
 bool gemm_nt_256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc) {
@@ -431,6 +639,39 @@ int launch_gemm_nt_256(const void* A, int64_t lda, const void* B, int64_t ldb, c
   streams = streams > need ? need : streams;
   g.streams = streams;
   gemm_nt_256<<<streams * g.n_col_tiles, kThreads256, 0, stream>>>(g);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+bool gemm_tn_256_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb) {
+  return M >= 64 * 64 && N >= 256 && N % 256 == 0 && Kp >= 256 && Kp % 256 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+         64 * lda * 2 < (int64_t)1 << 31 && 64 * ldb * 2 < (int64_t)1 << 31;
+}
+
+// slabs the 256 x 256 kernel cuts the FULL 64-row steps of M into (one workgroup per CU: slabs x tiles <= CUs, slabs a
+// multiple of 8 so that the tiles of one slab share an XCD)
+int gemm_tn_256_slabs(int64_t M, int64_t N, int64_t Kp) {
+  const int n_tiles = (int)((N / 256) * (Kp / 256));
+  int slabs = (256 / n_tiles) / 8 * 8;
+  slabs = slabs < 8 ? 8 : slabs;
+  const int64_t steps = M / 64;
+  while (slabs > 8 && steps < slabs) slabs -= 8;
+  return slabs;
+}
+
+int launch_gemm_tn_256(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp,
+                       float* workspace, hipStream_t stream) {
+  SG_REQUIRE(gemm_tn_256_supported(M, N, Kp, lda, ldb), "sg_gemm_tn (256-tile kernel): unsupported shape");
+  BigTn g;
+  g.A = (const uint16_t*)A; g.lda = lda;
+  g.B = (const uint16_t*)B; g.ldb = ldb;
+  g.W = workspace;
+  g.N = (int)N; g.Kp = (int)Kp;
+  g.tiles_k = (int)(Kp / 256);
+  g.n_tiles = (int)((N / 256) * g.tiles_k);
+  g.slabs = gemm_tn_256_slabs(M, N, Kp);
+  g.steps = (int)(M / 64);
+  gemm_tn_256<<<g.slabs * g.n_tiles, kThreads256, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

@@ -174,6 +174,11 @@ bool gemm_nt_takes_big_tile(int64_t M, int64_t N, int64_t K, int64_t lda, int64_
 bool gemm_nt_256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc);
 int launch_gemm_nt_256(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
                        int64_t M, int64_t N, int64_t K, hipStream_t stream);
+bool gemm_tn_256_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
+int gemm_tn_256_slabs(int64_t M, int64_t N, int64_t Kp);
+int launch_gemm_tn_256(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp,
+                       float* workspace, hipStream_t stream);
+bool gemm_tn_takes_big_tile(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 int64_t gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp);
 int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
                    float* workspace, float* out, int64_t ldo, hipStream_t stream);

@@ -76,11 +76,20 @@ class _timed:
         return False
 
 
+def _tn_own(dout: torch.Tensor, T: torch.Tensor) -> bool:
+    """The weight gradient runs on the library's own MFMA kernels: the 128 x 128 kernel for small outputs, the persistent
+    256 x 256 ring for the wide layers (where it takes the shape); everything else on the BLAS library."""
+    if not (USE_MFMA_GEMM and dout.is_cuda and dout.dtype == torch.bfloat16 and capi.gemm_tn_supported(dout, T)):
+        return False
+    if dout.shape[1] * T.shape[1] <= MFMA_MAX_WEIGHT_ELEMS:
+        return True
+    return USE_MFMA_BIG_TILE and capi.gemm_tn_takes_big_tile(dout.shape[0], dout.shape[1], T.shape[1], dout.stride(0), T.stride(0))
+
+
 def weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     if _gemm_timer is None or not dout.is_cuda:
         return _weight_grad(dout, T)
-    own = (USE_MFMA_GEMM and dout.dtype == torch.bfloat16 and dout.shape[1] * T.shape[1] <= MFMA_MAX_WEIGHT_ELEMS
-           and capi.gemm_tn_supported(dout, T))
+    own = _tn_own(dout, T)
     with _timed(("tn", dout.shape[0], dout.shape[1], T.shape[1], str(dout.dtype).replace("torch.", ""), "mfma" if own else "blas")):
         return _weight_grad(dout, T)
 
@@ -92,9 +101,8 @@ def _weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     batched GEMM over the slabs and a sum over S runs 2-10x faster (2.7 / 0.45 ms) and is
     deterministic (tools/gemm_bench.py).  bf16 features take the library's own kernel (csrc/gemm_mfma.hip, gemm_tn)."""
     V = dout.shape[0]
-    if (USE_MFMA_GEMM and dout.is_cuda and dout.dtype == torch.bfloat16 and dout.shape[1] * T.shape[1] <= MFMA_MAX_WEIGHT_ELEMS
-            and capi.gemm_tn_supported(dout, T)):
-        return capi.gemm_tn(dout, T)       # own MFMA kernel (transposing LDS reads, slab partials summed in order)
+    if _tn_own(dout, T):
+        return capi.gemm_tn(dout, T)       # own MFMA kernels (transposing LDS reads, slab partials summed in order)
     S = min(128 if dout.dtype == torch.float32 else 64, V // 4096)
     if S <= 1 or not (dout.is_contiguous() and T.is_contiguous()):
         return _mm_f32_out(dout.t(), T)

@@ -267,3 +267,42 @@ def test_big_tile_kernel_serves_the_wide_layers_of_the_model():
     assert GU.rel_l2(y.detach().float().cpu(), y2.detach().float().cpu()) < 2.0 ** -8
     assert GU.rel_l2(gx.float().cpu(), x.grad.float().cpu()) < 2.0 ** -7
     assert GU.rel_l2(gw.cpu(), conv.lins[1].weight.grad.cpu()) < 2.0 ** -7
+
+
+BIG_TN_SHAPES = [  # (M, N, Kp): fewer 64-row steps than slabs .. ~190 steps per slab, a tail of 0 .. 63 rows, 1 .. 9 output tiles
+    (4096, 256, 256), (4113, 256, 256), (70001, 256, 768), (131077, 512, 768), (200003, 768, 512), (1_000_000, 256, 768),
+    (300_011, 768, 768),
+]
+
+
+@pytest.mark.parametrize("M,N,Kp", BIG_TN_SHAPES)
+def test_big_tile_weight_gradient_integer_data_is_bit_exact(M, N, Kp):
+    """dW = A^T B on the 256 x 256 ring (csrc/gemm_mfma256.hip, gemm_tn_256): exact integers, so the fp32 result must
+    EQUAL the 128 x 128 kernel's (and fp32 matmul's) whatever the slab cut and summation order -- every DMA chunk, source
+    swizzle, transposing fragment read and partial-tile store in its place; rows past the last full 64-row step go
+    through the 128 x 128 kernel's slab.  Repeated as a race screen."""
+    assert capi.gemm_tn_takes_big_tile(M, N, Kp, N, Kp) == (M >= 16384)
+    g = torch.Generator(device=DEV).manual_seed(M + N + 7 * Kp)
+    a = torch.randint(-2, 3, (M, N), device=DEV, generator=g).to(torch.bfloat16)
+    b = torch.randint(-1, 2, (M, Kp), device=DEV, generator=g).to(torch.bfloat16)
+    a[:, 1] = torch.arange(M, device=DEV).remainder(3).to(torch.bfloat16) - 1
+    b[:, 0] = torch.arange(M, device=DEV).remainder(5).to(torch.bfloat16) - 2
+    ref = _with_tile(1, lambda: capi.gemm_tn(a, b))
+    if M <= 200_003:
+        assert torch.equal(ref, a.float().t() @ b.float())
+    for rep in range(3):
+        out = _with_tile(3, lambda: capi.gemm_tn(a, b))
+        assert out.dtype == torch.float32 and torch.equal(out, ref), (rep, int((out != ref).sum()))
+
+
+def test_big_tile_weight_gradient_random_data_and_strides():
+    M, N, Kp = 70001, 512, 768
+    g = torch.Generator(device=DEV).manual_seed(11)
+    wa = torch.randn(M, N + 16, device=DEV, generator=g).to(torch.bfloat16)
+    wb = torch.randn(M, Kp + 8, device=DEV, generator=g).to(torch.bfloat16)
+    a, b = wa[:, 8:8 + N], wb[:, :Kp]
+    ref = a.double().t() @ b.double()
+    out = _with_tile(3, lambda: capi.gemm_tn(a, b))
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-5       # fp32 accumulation of exact bf16 products
+    out2 = _with_tile(3, lambda: capi.gemm_tn(a, b))
+    assert torch.equal(out, out2)                                                 # deterministic: fixed slab order

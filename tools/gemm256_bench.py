@@ -75,7 +75,51 @@ def main():
         print(f"{name:40s} 256: {row['tile256']['ms']:.3f} ms ({row['tile256']['mfma_frac']:.3f} mfma, {row['tile256']['hbm_frac']:.3f} hbm)  "
               f"128: {row['tile128']['ms']:.3f}  blas: {row['blas']['ms']:.3f} ({row['blas']['mfma_frac']:.3f})  err {err:.1e}", flush=True)
         del A, out
+    # the weight gradients of the same layers: out[N, Kp] = A[M, N]^T B[M, Kp]
+    from semigcn_amd import functional as F_sg
+    for name, N, Kp in (("L5/L8 dW  [256,V]x[V,768]", 256, 768), ("L6 dW  [512,V]x[V,768]", 512, 768), ("L7 dW  [768,V]x[V,512]", 768, 512)):
+        A = torch.randn(M, N, device=dev).to(torch.bfloat16)
+        B = torch.randn(M, Kp, device=dev).to(torch.bfloat16)
+
+        def own(tile):
+            def run():
+                capi.tuning_set(capi.TUNE_GEMM_TILE, tile)
+                r = capi.gemm_tn(A, B)
+                capi.tuning_set(capi.TUNE_GEMM_TILE, 0)
+                return r
+            return run
+
+        def blas():
+            old = F_sg.USE_MFMA_GEMM
+            F_sg.USE_MFMA_GEMM = False
+            try:
+                return F_sg._weight_grad(A, B)
+            finally:
+                F_sg.USE_MFMA_GEMM = old
+        variants = {"tile256": own(3), "tile128": own(1), "blas": blas}
+        times = {k: [] for k in variants}
+        for rnd in range(a.rounds + 1):
+            for k, fn in variants.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    times[k].append(e0.elapsed_time(e1) / a.reps)
+        err = float((own(3)() - blas()).abs().max() / blas().abs().max())
+        flops = 2.0 * M * N * Kp
+        row = {"product": name, "M": M, "N": N, "K": Kp, "rel_diff_256_vs_blas": err}
+        for k in variants:
+            ms = float(np.median(times[k]))
+            row[k] = {"ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1), "mfma_frac": round(flops / ms / 1e9 / 2500.0, 4)}
+        res.append(row)
+        print(f"{name:40s} 256: {row['tile256']['ms']:.3f} ms ({row['tile256']['mfma_frac']:.3f} mfma)  128: {row['tile128']['ms']:.3f}  "
+              f"blas: {row['blas']['ms']:.3f} ({row['blas']['mfma_frac']:.3f})  diff {err:.1e}", flush=True)
+        del A, B
     if a.json:
+        os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
         json.dump({"V": M, "rounds": a.rounds, "reps": a.reps, "products": res}, open(a.json, "w"), indent=1)
 
 

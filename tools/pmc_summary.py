@@ -28,6 +28,12 @@ def load(d):
 def main():
     root, out = sys.argv[1], sys.argv[2]
     cmd = sys.argv[3] if len(sys.argv) > 3 else ""
+    commit = sys.argv[4] if len(sys.argv) > 4 else None
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # the table describes the kernel it was collected from: bench.py nulls `roofline.traffic` once csrc/spmm.hip differs
+    sha = hashlib.sha256(open(os.path.join(here, "semigcn_amd", "csrc", "spmm.hip"), "rb").read()).hexdigest()[:16]
     per = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         agg = collections.defaultdict(list)
@@ -47,7 +53,7 @@ def main():
                     "launches": len(per["FETCH_SIZE"][key]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                     "read_bytes_corrected": round(2 * f * 1024), "write_bytes": round(w * 1024),
                     "traffic_bytes_per_launch": round(2 * f * 1024 + w * 1024)})
-    json.dump({"command": cmd, "correction": "reads = 2 * FETCH_SIZE * 1024 (gfx950 wide-read under-count), writes = WRITE_SIZE * 1024",
+    json.dump({"command": cmd, "commit": commit, "spmm_hip_sha16": sha, "correction": "reads = 2 * FETCH_SIZE * 1024 (gfx950 wide-read under-count), writes = WRITE_SIZE * 1024",
                "kernels": res}, open(out, "w"), indent=1)
     print("wrote", out, len(res), "kernel variants")
 
