@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32,
-             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256 };
+             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512 };
 
 // Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
 // one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
@@ -840,6 +840,75 @@ __global__ __launch_bounds__(kBlock) void spmm_quad_bf16(const SpmmArgs a) {
   }
 }
 
+// The same idea for bf16 rows of 8 / 16 / 32 channels (NV = 1 / 2 / 4 vectors of 16 bytes): one thread owns a whole ROW,
+// four neighbours in flight (NV loads each), CSR-order fma chain -- no LDS staging of the neighbour lists, no lane
+// groups.  Behind SG_TUNE_FLAGS bit 9 while it is being measured against spmm_rows<.., G = NV, ..>.
+template <int NV>
+__global__ __launch_bounds__(kBlock) void spmm_thread_rows_bf16(const SpmmArgs a) {
+  using V = Vt<bf16_tag>;
+  const uint16_t* __restrict__ X = (const uint16_t*)a.X;
+  const uint16_t* __restrict__ X0 = (const uint16_t*)a.X0;
+  const uint16_t* __restrict__ X1 = (const uint16_t*)a.X1;
+  uint16_t* __restrict__ Y = (uint16_t*)a.Y;
+  for (int row = blockIdx.x * kBlock + threadIdx.x; row < a.n_rows; row += gridDim.x * kBlock) {
+    const int k0 = a.rowptr[row], k1 = a.rowptr[row + 1];
+    float acc[NV * 8];
+#pragma unroll
+    for (int c = 0; c < NV * 8; ++c) acc[c] = 0.f;
+    for (int k = k0; k < k1; k += 4) {
+      u32x4 v[4][NV];
+      float w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k + u < k1 ? k + u : k1 - 1;
+        int j;
+        if (a.idx_w) {
+          const int2 e = a.idx_w[kk];
+          j = e.x;
+          w[u] = __int_as_float(e.y);
+        } else {
+          j = a.idx[kk];
+          w[u] = a.scale_src ? a.scale_src[j] : 1.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[u][q] = *(const u32x4*)(X + (int64_t)j * a.ldx + q * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k + u < k1) {
+#pragma unroll
+          for (int q = 0; q < NV; ++q) {
+            float x[8];
+            V::unpack(v[u][q], x);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[q * 8 + c] = fmaf(w[u], x[c], acc[q * 8 + c]);
+          }
+        }
+    }
+    const float sd = a.alpha * (a.scale_dst ? a.scale_dst[row] : 1.0f);
+    const int64_t orow = a.row_id ? a.row_id[row] : row;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      float y[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) y[c] = sd * acc[q * 8 + c];
+      if (X0) {
+        float x[8];
+        V::unpack(*(const u32x4*)(X0 + orow * a.ldx0 + q * 8), x);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) y[c] = fmaf(a.beta, x[c], y[c]);
+      }
+      if (X1) {
+        float x[8];
+        V::unpack(*(const u32x4*)(X1 + orow * a.ldx1 + q * 8), x);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) y[c] = fmaf(a.gamma, x[c], y[c]);
+      }
+      *(u32x4*)(Y + orow * a.ldy + q * 8) = V::pack(y);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void gather_rows_vec(const int32_t* __restrict__ rows, int64_t n,
                                                           const void* X, int64_t ldx, void* Y,
@@ -973,6 +1042,15 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
     return SG_OK;
   }
   const int nvec = a.C / VEC;
+  if (esz == 2 && (g_tuning.flags & kFlagThreadRows) && (nvec == 1 || nvec == 2 || nvec == 4)) {
+    int nb = (a.n_rows + kBlock - 1) / kBlock;
+    nb = nb > 256 * 64 ? 256 * 64 : nb;
+    if (nvec == 1) spmm_thread_rows_bf16<1><<<nb, kBlock, 0, stream>>>(a);
+    else if (nvec == 2) spmm_thread_rows_bf16<2><<<nb, kBlock, 0, stream>>>(a);
+    else spmm_thread_rows_bf16<4><<<nb, kBlock, 0, stream>>>(a);
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
+  }
   // Wide rows of a graph that carries mini-tiles: gather each distinct source row of 4 rows once.
   // Measured on the 1 M-vertex Morton-ordered mesh (tools/agg_bench.py, variants interleaved in one process):
   // it pays for fp32 rows of 2 KiB (C=512: 1.13 -> 0.97 ms plain, 1.40 -> 1.31 ms with an epilogue operand) and

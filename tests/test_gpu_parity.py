@@ -1506,3 +1506,57 @@ def test_lds_tile_kernel_bitwise_equals_generic(C, dtype):
         for a, b in zip(res[1], res[129]):
             assert torch.equal(a, b)
     assert rel(res[129][0].float(), oracle_lhat(ei.cpu(), x.float().cpu())) < (1e-5 if dtype == torch.float32 else 2.0 ** -7)
+
+
+# --------------------------------------------------------------------------------------
+# documented deviations from the reference's arithmetic (include/semigcn.h), one test each
+# --------------------------------------------------------------------------------------
+def test_non_finite_input_rows_stay_local_to_a_bounded_set_of_output_rows(fixture_meshes):
+    """semigcn.h, sg_spmm: "an Inf/NaN in X can turn into NaN in a few output rows that are not its neighbours" (the
+    switched-off slots of a gather batch carry weight ZERO on a row that is read anyway).  What that means in numbers: with
+    ONE non-finite input row every neighbour's output is non-finite (as with the reference's scatter_add), every output
+    row that is finite equals the oracle's, and the non-finite rows that are NOT neighbours are few and share a wavefront
+    chunk with a neighbour (within 32 rows of one)."""
+    m = synth.torus_mesh(60, 40, masks=False)
+    V = m.num_vertices
+    ei = torch.from_numpy(m.edge_index)
+    g = MeshGraph.from_edge_index(ei.to(DEV), V)
+    for C, dtype in ((64, torch.float32), (256, torch.bfloat16), (4, torch.bfloat16)):
+        x = torch.randn(V, C).to(dtype)
+        bad = 1234
+        x[bad, ::2] = float("inf")
+        x[bad, 1::2] = float("nan")
+        y = torch.empty(V, C, device=DEV, dtype=dtype)
+        g.aggregate(x.to(DEV), y)
+        ref = oracle_lhat(ei, x.float())
+        nonfinite = ~torch.isfinite(y.float().cpu()).all(1)
+        nbrs = torch.zeros(V, dtype=torch.bool)
+        nbrs[ei[1][ei[0] == bad]] = True
+        assert bool(nonfinite[nbrs].all())                                   # the neighbours, as in the reference
+        assert torch.equal(~torch.isfinite(ref).all(1), nbrs)                # (the oracle: exactly the neighbours)
+        fin = ~nonfinite
+        tol = KERNEL_TOL if dtype == torch.float32 else 2.0 ** -7
+        assert rel(y.float().cpu()[fin], ref[fin]) < tol                     # finite rows are the CSR sums
+        extra = torch.nonzero(nonfinite & ~nbrs).reshape(-1)
+        assert extra.numel() <= 64
+        nb_ids = torch.nonzero(nbrs).reshape(-1)
+        if extra.numel():
+            assert int((extra.view(-1, 1) - nb_ids.view(1, -1)).abs().min(1)[0].max()) <= 32
+
+
+def test_empty_coarse_cluster_yields_zero_where_the_reference_yields_nan():
+    """semigcn.h, sg_pool_mean: "a coarse row with no member yields 0 (the reference yields 0/0 = NaN there)":
+    util/meshnet.py:14-17 divides the summed rows by the row sums of the dense pool matrix."""
+    fine = torch.tensor([0, 1, 2, 3, 4], device=DEV)
+    coarse = torch.tensor([0, 0, 2, 2, 2], device=DEV)          # coarse vertex 1 has no member
+    pool = capi.PoolHandle(fine, coarse, 5, 3)
+    x = torch.arange(10, dtype=torch.float32, device=DEV).view(5, 2)
+    out = pool.pool_mean(x)
+    assert torch.equal(out.cpu(), torch.tensor([[1.0, 2.0], [0.0, 0.0], [6.0, 7.0]]))
+    dense = torch.zeros(3, 5)
+    dense[coarse.cpu(), fine.cpu()] = 1.0
+    ref = (dense @ x.cpu()) / dense.sum(1, keepdim=True)        # the reference's formula
+    assert bool(torch.isnan(ref[1]).all()) and torch.equal(ref[[0, 2]], out.cpu()[[0, 2]])
+    # and the gradient of the empty row goes nowhere
+    assert torch.equal(pool.pool_mean_bwd(torch.ones(3, 2, device=DEV)).cpu(),
+                       torch.tensor([[0.5] * 2] * 2 + [[1.0 / 3] * 2] * 3))
