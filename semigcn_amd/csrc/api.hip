@@ -81,6 +81,11 @@ int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64
       a.lt_uniq_w = c.lt_uniq_w;
     }
   }
+  if (ss != nullptr && ss == c.packed_scale && c.lt_rec && sd == c.rec_scale_dst && row_id == c.rec_row_id) {
+    a.lt_rec = c.lt_rec;
+    a.lt_nrec = c.lt_nrec;
+    a.lt_idx_w = c.idx_w;
+  }
   a.row_id = row_id;
   a.scale_dst = sd;
   a.scale_src = ss;
@@ -157,6 +162,8 @@ SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void
     }
     if ((rc = pack_source_scale(&g->fwd, g->dis_src, stream)) != SG_OK) break;
     if (!g->symmetric && (rc = pack_source_scale(&g->bwd, g->dis_src, stream)) != SG_OK) break;
+    if (ring_enabled() && (rc = build_ring_records(&g->fwd, g->dis_src, g->dis_dst, nullptr, stream)) != SG_OK) break;
+    if (ring_enabled() && !g->symmetric && (rc = build_ring_records(&g->bwd, g->dis_src, g->dis_dst, nullptr, stream)) != SG_OK) break;
     if (g->symmetric) {      // numbering without locality (a raw scan): process the rows in a graph-derived order
       if ((rc = locality_order(g->fwd, graph_reorder_mode(), stream, &g->row_id)) != SG_OK) break;
       if (g->row_id) {
@@ -169,6 +176,7 @@ SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void
         if ((rc = gather_floats(g->dis_dst, g->row_id, V, g->dis_dst_loc, stream)) != SG_OK) break;
         if (tiles_enabled() && (rc = build_tiles(&g->loc, stream)) != SG_OK) break;
         if ((rc = pack_source_scale(&g->loc, g->dis_src, stream)) != SG_OK) break;
+        if (ring_enabled() && (rc = build_ring_records(&g->loc, g->dis_src, g->dis_dst_loc, g->row_id, stream)) != SG_OK) break;
       }
     }
     if (hipStreamSynchronize(stream) != hipSuccess) {

@@ -22,6 +22,9 @@ void Csr::release() {
   if (lt_uniq) (void)hipFree(lt_uniq);
   if (lt_eloc) (void)hipFree(lt_eloc);
   if (lt_uniq_w) (void)hipFree(lt_uniq_w);
+  if (lt_rec) (void)hipFree(lt_rec);
+  lt_rec = nullptr;
+  lt_nrec = 0;
   lt_uptr = nullptr;
   lt_uniq = nullptr;
   lt_eloc = nullptr;
@@ -595,6 +598,172 @@ int pack_source_scale(Csr* c, const float* scale, hipStream_t stream) {
     }
   }
   c->packed_scale = scale;
+  return SG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile records of spmm.hip::spmm_ring.  One 64-thread block per 16 consecutive rows: if their distinct sources fit the LDS
+// budget the block is ONE tile; if not it is cut into two 8-row tiles (a compact patch of a triangle mesh in a locality
+// order: ~43 distinct sources for 16 rows, ~28 for 8); what still does not fit gets a record with nu = 0 and is gathered
+// from global memory by the kernel.  Records land in a [blocks][2] scratch array and are compacted after a scan.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kRecMaxEdges = 256;
+
+// all 64 threads of the block; returns true (block-uniform) when the tile fits, and then has written its record
+__device__ bool ring_record(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx, int r0, int nrows,
+                            const float* __restrict__ scale_src, const float* __restrict__ scale_dst,
+                            const int32_t* __restrict__ row_id, bool force, uint8_t* __restrict__ rec,
+                            int32_t* s_key, int32_t* s_rank, int32_t* s_flag) {
+  const int tid = threadIdx.x;
+  const int e0 = rowptr[r0], ne = rowptr[r0 + nrows] - e0;
+  __syncthreads();                                   // s_flag / s_key of the previous call are free
+  if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+  __syncthreads();
+  if (tid < nrows) {
+    const int a = rowptr[r0 + tid], b = rowptr[r0 + tid + 1];
+    bool bad = b - a > 16;
+    for (int e = a + 1; e < b; ++e) bad |= idx[e] == idx[e - 1];
+    if (bad) s_flag[0] = 1;
+  }
+  __syncthreads();
+  bool fits = ne <= kRecMaxEdges && ne > 0 && s_flag[0] == 0;
+  int nu = 0;
+  if (fits) {
+    int n2 = 1;
+    while (n2 < ne) n2 <<= 1;
+    for (int i = tid; i < n2; i += 64) s_key[i] = i < ne ? idx[e0 + i] : INT32_MAX;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < n2; i += 64) {
+          const int p = i ^ j;
+          if (p > i) {
+            const int a = s_key[i], b = s_key[p];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { s_key[i] = b; s_key[p] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    if (tid == 0) {
+      int r = -1;
+      for (int i = 0; i < ne; ++i) {
+        if (i == 0 || s_key[i] != s_key[i - 1]) ++r;
+        s_rank[i] = r;
+      }
+      s_flag[1] = r + 1;
+    }
+    __syncthreads();
+    nu = s_flag[1];
+    fits = nu <= kLdsSlots;
+  }
+  if (!fits && !force) return false;
+  if (!fits) nu = 0;
+  // ---- the record ----
+  for (int i = tid; i < kRecBytes / 4; i += 64) ((int32_t*)rec)[i] = 0;
+  __syncthreads();
+  if (nu > 0) {
+    for (int i = tid; i < ne; i += 64)
+      if (i == 0 || s_key[i] != s_key[i - 1]) {
+        const int u = s_rank[i];
+        ((int32_t*)(rec + kRecSrc))[u] = s_key[i];
+        ((float*)(rec + kRecW))[u] = scale_src ? scale_src[s_key[i]] : 1.0f;
+      }
+    __syncthreads();
+    for (int i = nu + tid; i < kLdsSlots; i += 64) {      // padding: the last source (weight 0: never referenced)
+      ((int32_t*)(rec + kRecSrc))[i] = ((const int32_t*)(rec + kRecSrc))[nu - 1];
+    }
+    for (int t = tid; t < kLdsRows * 16; t += 64) {
+      const int r = t >> 4, u = t & 15;
+      uint8_t v = 64;
+      if (r < nrows) {
+        const int a = rowptr[r0 + r], d = rowptr[r0 + r + 1] - a;
+        if (d > 0) {
+          const int e = a + (u < d ? u : d - 1);
+          const int key = idx[e];
+          int lo = 0, hi = ne - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_key[mid] < key) lo = mid + 1; else hi = mid;
+          }
+          v = (uint8_t)(s_rank[lo] | (u < d ? 0 : 64));
+        }
+      }
+      rec[kRecSlot + t] = v;
+    }
+  }
+  if (tid < kLdsRows) {
+    const int r = tid < nrows ? tid : nrows - 1;
+    rec[kRecDeg + tid] = (tid < nrows && nu > 0) ? (uint8_t)(rowptr[r0 + tid + 1] - rowptr[r0 + tid]) : (uint8_t)0;
+    ((float*)(rec + kRecSd))[tid] = tid < nrows ? (scale_dst ? scale_dst[r0 + tid] : 1.0f) : 0.0f;
+    ((int32_t*)(rec + kRecRow))[tid] = row_id ? row_id[r0 + r] : r0 + r;
+  }
+  if (tid == 0) {
+    *(int32_t*)(rec + kRecNu) = nu;
+    *(int32_t*)(rec + kRecE0) = e0;
+    *(int32_t*)(rec + kRecR0) = r0;
+    *(int32_t*)(rec + kRecNrows) = nrows;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(64) void ring_records_pass(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
+                                                         int64_t n_rows, const float* __restrict__ scale_src,
+                                                         const float* __restrict__ scale_dst,
+                                                         const int32_t* __restrict__ row_id, uint8_t* __restrict__ scratch,
+                                                         int32_t* __restrict__ counts) {
+  __shared__ int32_t s_key[kRecMaxEdges];
+  __shared__ int32_t s_rank[kRecMaxEdges];
+  __shared__ int32_t s_flag[2];
+  const int64_t blk = blockIdx.x;
+  const int r0 = (int)(blk * kLdsRows);
+  int nrows = (int)(n_rows - r0);
+  nrows = nrows > kLdsRows ? kLdsRows : nrows;
+  uint8_t* out = scratch + blk * 2 * kRecBytes;
+  int cnt = 1;
+  if (!ring_record(rowptr, idx, r0, nrows, scale_src, scale_dst, row_id, nrows <= 8, out, s_key, s_rank, s_flag)) {
+    ring_record(rowptr, idx, r0, 8, scale_src, scale_dst, row_id, true, out, s_key, s_rank, s_flag);
+    ring_record(rowptr, idx, r0 + 8, nrows - 8, scale_src, scale_dst, row_id, true, out + kRecBytes, s_key, s_rank, s_flag);
+    cnt = 2;
+  }
+  if (threadIdx.x == 0) counts[blk] = cnt;
+}
+
+__global__ __launch_bounds__(64) void ring_records_compact(const uint8_t* __restrict__ scratch, const int32_t* __restrict__ offs,
+                                                            uint8_t* __restrict__ rec) {
+  const int64_t blk = blockIdx.x;
+  const int o = offs[blk], n = offs[blk + 1] - o;
+  for (int i = threadIdx.x; i < n * (kRecBytes / 16); i += 64)
+    ((int4*)(rec + (int64_t)o * kRecBytes))[i] = ((const int4*)(scratch + blk * 2 * kRecBytes))[i];
+}
+}  // namespace
+
+int build_ring_records(Csr* c, const float* scale_src, const float* scale_dst, const int32_t* row_id, hipStream_t stream) {
+  if (c->lt_rec) { (void)hipFree(c->lt_rec); c->lt_rec = nullptr; c->lt_nrec = 0; }
+  if (c->n_rows == 0 || c->nnz == 0) return SG_OK;
+  const int64_t nb = (c->n_rows + kLdsRows - 1) / kLdsRows;
+  DeviceBuf scratch, counts, temp;
+  SG_HIP_TRY(hipMalloc(&scratch.p, (size_t)nb * 2 * kRecBytes));
+  SG_HIP_TRY(hipMalloc(&counts.p, (nb + 1) * sizeof(int32_t)));
+  SG_HIP_TRY(hipMemsetAsync(counts.p, 0, (nb + 1) * sizeof(int32_t), stream));
+  ring_records_pass<<<(int)nb, 64, 0, stream>>>(c->rowptr, c->idx, c->n_rows, scale_src, scale_dst, row_id,
+                                                (uint8_t*)scratch.p, (int32_t*)counts.p);
+  SG_HIP_TRY(hipGetLastError());
+  size_t tb = 0;
+  SG_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (int32_t*)counts.p, (int32_t*)counts.p, (int)nb + 1, stream));
+  SG_HIP_TRY(hipMalloc(&temp.p, tb ? tb : 16));
+  SG_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, tb, (int32_t*)counts.p, (int32_t*)counts.p, (int)nb + 1, stream));
+  int32_t total = 0;
+  SG_HIP_TRY(hipMemcpyAsync(&total, (int32_t*)counts.p + nb, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  SG_HIP_TRY(hipStreamSynchronize(stream));
+  SG_HIP_TRY(hipMalloc((void**)&c->lt_rec, (size_t)total * kRecBytes));
+  ring_records_compact<<<(int)nb, 64, 0, stream>>>((const uint8_t*)scratch.p, (const int32_t*)counts.p, c->lt_rec);
+  SG_HIP_TRY(hipGetLastError());
+  SG_HIP_TRY(hipStreamSynchronize(stream));
+  c->lt_nrec = total;
+  c->rec_scale_dst = scale_dst;
+  c->rec_row_id = row_id;
   return SG_OK;
 }
 

@@ -53,6 +53,11 @@ struct Csr {
   int32_t* lt_uniq = nullptr;
   uint8_t* lt_eloc = nullptr;
   int2* lt_uniq_w = nullptr;
+  // tile records of spmm.hip::spmm_ring (see kRec*), built for ONE (source scale, row scale, row id) triple
+  uint8_t* lt_rec = nullptr;
+  int32_t lt_nrec = 0;
+  const float* rec_scale_dst = nullptr;
+  const int32_t* rec_row_id = nullptr;
   const float* packed_scale = nullptr;
   void release();
 };
@@ -63,9 +68,35 @@ constexpr int kTileEdges = 128;    // max edges per mini-tile
 constexpr int kLdsRows = 16;       // rows per LDS tile
 constexpr int kLdsSlots = 48;      // max distinct source rows per LDS tile (16 rows + their ring in a locality order: ~36)
 constexpr int kLdsEdges = 256;     // max edges per LDS tile
+// Tile record of the pipelined LDS kernel (spmm.hip::spmm_ring): everything the reduction of one tile of <= kLdsRows
+// consecutive (processing-order) rows needs, in ONE contiguous piece that one LDS-DMA instruction brings in:
+//   int32 src[kLdsSlots]          distinct source rows, ascending, padded with the last one
+//   uint8 slot[kLdsRows][16]      slot of the u-th neighbour of row r in src[] (entries past the row's degree: last slot | 64)
+//   uint8 deg[kLdsRows]
+//   int32 nu                      number of distinct sources; 0: the tile does not fit (more than kLdsSlots sources, a row
+//                                 with more than 16 neighbours or a repeated one) and is gathered from global memory
+//   int32 e0, r0, nrows           first edge, first row, rows of the tile
+//   float sd[kLdsRows]            destination-row scale (1 when the operator has none)
+//   int32 row[kLdsRows]           the caller's row id of each row (Csr row_id view; r0 + i otherwise)
+//   float w[kLdsSlots]            source-row scale of every slot
+constexpr int kRecSrc = 0;
+constexpr int kRecSlot = kRecSrc + 4 * kLdsSlots;
+constexpr int kRecDeg = kRecSlot + 16 * kLdsRows;
+constexpr int kRecNu = kRecDeg + kLdsRows;
+constexpr int kRecE0 = kRecNu + 4;
+constexpr int kRecR0 = kRecE0 + 4;
+constexpr int kRecNrows = kRecR0 + 4;
+constexpr int kRecSd = kRecNrows + 4;
+constexpr int kRecRow = kRecSd + 4 * kLdsRows;
+constexpr int kRecW = kRecRow + 4 * kLdsRows;
+constexpr int kRecBytes = kRecW + 4 * kLdsSlots;
+static_assert(kRecBytes % 16 == 0 && kRecBytes <= 1024 && kRecSd % 16 == 0, "tile record layout");
 int build_tiles(Csr* c, hipStream_t stream);
 // Fills Csr::idx_w (and tile_uniq_w when the CSR carries tiles) for the source scale vector `scale` [n_cols].
 int pack_source_scale(Csr* c, const float* scale, hipStream_t stream);
+// Tile records for spmm_ring (when enabled): rows scaled by scale_dst (nullable), sources by scale_src, output rows row_id (nullable).
+int build_ring_records(Csr* c, const float* scale_src, const float* scale_dst, const int32_t* row_id, hipStream_t stream);
+bool ring_enabled();
 
 // Builds a Csr from (dst, src) int64 device pairs. Pairs with dst == src are dropped when
 // drop_self. If keys_out != nullptr the sorted (dst << 32 | src) keys (n entries, dropped
@@ -98,6 +129,8 @@ struct SpmmArgs {
   const uint8_t* lt_eloc = nullptr;
   const int2* lt_uniq_w = nullptr;
   const int2* lt_idx_w = nullptr;       // = idx_w, for the tiles that fall back to global gathers
+  const uint8_t* lt_rec = nullptr;      // tile records (see kRec*)
+  int32_t lt_nrec = 0;
   const int32_t* row_id = nullptr;      // non-null: the CSR is in PROCESSING order; row p is the caller's row row_id[p]
                                         // (Y / X0 / X1 are addressed by it; scale_dst is indexed by p)
   const float* scale_dst;  // nullable, [n_rows]

@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32,
-             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512 };
+             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512, kFlagLdsRing = 1024 };
 
 // Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
 // one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
@@ -746,6 +746,308 @@ int launch_lds(const SpmmArgs& a, hipStream_t stream) {
   return SG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// spmm_ring: the LDS-tile aggregation as a SOFTWARE PIPELINE with the reduction on the matrix cores (bf16 rows of 128 /
+// 256 channels; opt-in while it is measured: SG_TUNE_FLAGS bit 10 at graph creation and at launch).
+//
+// spmm_lds above pays, per tile and strictly one after the other, a metadata chain, the LDS-DMA round trip and the
+// reduction.  Here a persistent workgroup (4 wavefronts) walks a stream of tiles (<= 16 rows, <= 48 distinct sources:
+// csr_build.hip::build_ring_records) and keeps three of them in different stages:
+//
+//   iteration i:  counted s_waitcnt vmcnt (everything but the last stores)  ->  s_barrier
+//                 tile i+1: LDS-DMA of its distinct source rows and of its rows of the epilogue operand (buffer (i+1) & 1);
+//                           its 16 x 48 weight matrix, split into three bf16 pieces, scattered into LDS
+//                 tile i+2: LDS-DMA of its 800-byte record (sources, slot of every edge, scales, row ids)
+//                 tile i:   Y_tile = W_tile (16 x nu) * X_sources (nu x C) on v_mfma_f32_16x16x32_bf16, epilogue, store
+//
+// Why MFMA for an HBM-bound kernel: with the sources in LDS the VALU reduction of spmm_rows (8 unpack + 4 packed-fma
+// instructions per 16 bytes and neighbour, plus slot / weight addressing) became the bound at the 8-12 wavefronts per CU the
+// LDS budget allows (measured: 0.46 ms with, 0.21 ms without the reduction at C = 256).  The tile's weights are a dense
+// 16 x 48 matrix with ~6 nonzeros per row; multiplying it costs 12-24 MFMA instructions per wavefront and NO unpacking:
+// the bf16 source rows are MFMA operands as they lie in LDS (ds_read_b64_tr_b16 transposes them on the way).  The fp32
+// weights enter as hi + mid + lo bf16 pieces (3 x 8 mantissa bits: exact), products are exact in fp32, the accumulation
+// is the matrix core's -- so the result differs from spmm_rows' sequential fma chain in the last bits (same error
+// bound; deterministic; tested against it to 2 ulp of the output type and against the float64 oracle).
+//
+// EVERY global read is an LDS-DMA (no VGPR result), so hipcc has no load to put `s_waitcnt vmcnt(0)` in front of; the
+// waits on the vector-memory queue are the counted ones at the top of an iteration, which leave exactly the stores of
+// the tile just finished in flight.  One s_barrier per tile.  The source rows and the operand rows are stored XOR-
+// swizzled (applied to the per-lane SOURCE address of the DMA) so that the transposing reads and the epilogue reads are
+// bank-conflict-free.  Tiles that do not fit (record.nu == 0) are gathered from global memory inside the same loop.
+// LDS at C = 256: 2 x 24 KB sources + 2 x 8 KB per epilogue operand + 2 x 5 KB weights + 3 records = 61 / 77 KB.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRingThreads = 256;
+constexpr int kRingWaves = kRingThreads / 64;
+constexpr int kRingARow = 112;                       // bytes of one row of a weight piece: 48 bf16 + pad (conflict-free b128 reads)
+constexpr int kRingAPiece = kLdsRows * kRingARow;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ring_bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 ring_bf16x4;
+typedef __attribute__((ext_vector_type(4))) short ring_s16x4;
+
+template <int ROWB, int NEPI>
+struct RingLds {
+  static constexpr int kSrc = kLdsSlots * ROWB;          // one buffer of source rows
+  static constexpr int kEpi = kLdsRows * ROWB;           // one buffer of one epilogue operand
+  static constexpr int kA = 3 * kRingAPiece;             // one buffer of the three weight pieces
+  static constexpr int oSrc = 0;                         // [2][kSrc]
+  static constexpr int oEpi = 2 * kSrc;                  // [2][NEPI][kEpi]
+  static constexpr int oA = oEpi + 2 * NEPI * kEpi;      // [2][kA]
+  static constexpr int oRec = oA + 2 * kA;               // [3][kRecBytes]
+  static constexpr int total = oRec + 3 * kRecBytes;
+};
+
+__device__ __forceinline__ void ring_dma16(const void* src, uint8_t* lds) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                   (void __attribute__((address_space(3)))*)lds, 16, 0, 0);
+}
+__device__ __forceinline__ int ring_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+#define SG_RING_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int NBW, int NEPI>
+__global__ __launch_bounds__(kRingThreads) void spmm_ring(const SpmmArgs a, const int nt, const int flags) {
+  using V = Vt<bf16_tag>;
+  constexpr int VEC = 8;
+  constexpr int C = 64 * NBW;                       // channels: four wavefronts x NBW blocks of 16
+  constexpr int ROWB = 2 * C;                       // bytes of one feature row
+  constexpr int G = ROWB / 16;                      // lanes per row in a DMA instruction
+  constexpr int RPW = 64 / G;                       // rows one DMA instruction covers
+  constexpr int NST = NBW / 2;                      // 16-byte store instructions per wavefront and tile
+  static_assert(NBW == 2 || NBW == 4, "128 or 256 channels");
+  using L = RingLds<ROWB, NEPI>;
+  using raw_t = typename V::raw;
+  using elem_t = typename V::elem;
+
+  __shared__ __attribute__((aligned(16))) uint8_t smem[L::total];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane / G, gl = lane % G;            // DMA: row of the instruction, 16-byte chunk of the row
+  const int m = lane & 15, fg = lane >> 4;          // MFMA: tile row (operand / result column), k group
+  const int fq = (lane >> 2) & 3, fp = lane & 3;    // transposing reads: row and 8-byte column quad a lane SUPPLIES
+
+  // this workgroup's tiles: the workgroups of one XCD (block ids b, b + 8, ..) share ONE contiguous run of tiles and take
+  // them round-robin, so the rows in flight on an XCD are one thin front (its L2 serves the re-gathered neighbours)
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int nx = ((int)gridDim.x - xcd + 7) >> 3;
+  const int q = nt >> 3, rem = nt & 7;
+  const int tile_lo = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int tile_cnt = q + (xcd < rem ? 1 : 0);
+  const int n_my = jb < tile_cnt ? (tile_cnt - jb + nx - 1) / nx : 0;
+  if (n_my == 0) return;
+  const int t_first = tile_lo + jb;
+
+  const elem_t* __restrict__ X = (const elem_t*)a.X;
+  const elem_t* __restrict__ X0 = (const elem_t*)a.X0;
+  const elem_t* __restrict__ X1 = (const elem_t*)a.X1;
+  elem_t* __restrict__ Y = (elem_t*)a.Y;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)smem;
+
+  // LDS starts as zeros: stale slots are multiplied by zero weights and must be finite
+  for (int o = tid * 16; o < L::total; o += kRingThreads * 16) *(u32x4*)(smem + o) = u32x4{0u, 0u, 0u, 0u};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  auto issue_meta = [&](int tile, int slot) {
+    if (wave == 0 && lane < kRecBytes / 16)
+      ring_dma16(a.lt_rec + (int64_t)tile * kRecBytes + lane * 16, smem + L::oRec + slot * kRecBytes);
+  };
+  int a_off[2] = {-1, -1};                          // where this thread put its weight of the tile before last, per buffer
+  // everything tile `slot`'s reduction will read, into buffer `buf`
+  auto issue_tile = [&](int slot, int buf) {
+    const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
+    const int nu = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNu));
+    const int n_inst = (nu + RPW - 1) / RPW;
+    for (int i = wave; i < n_inst; i += kRingWaves) {
+      const int sl = i * RPW + g;
+      const int src = ((const int32_t*)(rec + kRecSrc))[sl];              // padded with the last source row
+      const int chunk = ((((gl >> 1) ^ ring_swz(sl)) << 1) | (gl & 1));   // 32-byte segments XOR-swizzled by the slot
+      ring_dma16(X + (int64_t)src * a.ldx + chunk * VEC, smem + L::oSrc + buf * L::kSrc + i * (RPW * ROWB));
+    }
+    // the slots the MFMA steps read beyond the list (k steps of 32 + 16 slots): zeros
+    const int kend = nu > 32 ? kLdsSlots : (nu > 0 ? 32 : 0);
+    for (int o = n_inst * RPW * ROWB + tid * 16; o < kend * ROWB; o += kRingThreads * 16)
+      *(u32x4*)(smem + L::oSrc + buf * L::kSrc + o) = u32x4{0u, 0u, 0u, 0u};
+    if (NEPI >= 1) {
+#pragma unroll
+      for (int p = 0; p < kLdsRows / (RPW * kRingWaves); ++p) {
+        const int lr = (p * kRingWaves + wave) * RPW + g;
+        const int row = ((const int32_t*)(rec + kRecRow))[lr];
+        const int chunk = gl ^ (lr & 15);                                   // 16-byte chunks XOR-swizzled by the row
+        ring_dma16(X0 + (int64_t)row * a.ldx0 + chunk * VEC, smem + L::oEpi + (buf * NEPI + 0) * L::kEpi + (p * kRingWaves + wave) * (RPW * ROWB));
+        if (NEPI >= 2)
+          ring_dma16(X1 + (int64_t)row * a.ldx1 + chunk * VEC, smem + L::oEpi + (buf * NEPI + 1) * L::kEpi + (p * kRingWaves + wave) * (RPW * ROWB));
+      }
+    }
+    // weight matrix: thread (row, u) owns the u-th neighbour of the row; fp32 weight = hi + mid + lo in bf16 (exact)
+    uint8_t* Ab = smem + L::oA + buf * L::kA;
+    if (a_off[buf] >= 0) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *(uint16_t*)(Ab + p * kRingAPiece + a_off[buf]) = 0;
+    }
+    const int ar = tid >> 4, au = tid & 15;
+    int off = -1;
+    if (au < (int)rec[kRecDeg + ar]) {
+      const int sl = rec[kRecSlot + tid] & 63;
+      const float w = ((const float*)(rec + kRecW))[sl];
+      const uint32_t hi = __float_as_uint(w) & 0xffff0000u;
+      const float r1 = w - __uint_as_float(hi);
+      const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
+      const float r2 = r1 - __uint_as_float(mid);
+      off = ar * kRingARow + sl * 2;
+      *(uint16_t*)(Ab + 0 * kRingAPiece + off) = (uint16_t)(hi >> 16);
+      *(uint16_t*)(Ab + 1 * kRingAPiece + off) = (uint16_t)(mid >> 16);
+      *(uint16_t*)(Ab + 2 * kRingAPiece + off) = (uint16_t)(__float_as_uint(r2) >> 16);
+    }
+    a_off[buf] = off;
+  };
+
+  issue_meta(t_first, 0);
+  for (int i = -1; i < n_my; ++i) {
+    // the rows, operands and weights of tile i and the record of tile i + 1 have landed (this wavefront's share; the
+    // barrier covers the others'); only the stores of tile i - 1 may still be in flight
+    if (i <= 0) {
+      SG_RING_WAIT_VM(0);
+    } else {
+      if (NST == 1) SG_RING_WAIT_VM(1);
+      else SG_RING_WAIT_VM(2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (i + 1 < n_my) issue_tile((i + 1) % 3, (i + 1) & 1);
+    if (i + 2 < n_my) issue_meta(t_first + (i + 2) * nx, (i + 2) % 3);
+    asm volatile("" ::: "memory");
+    if (i < 0) continue;
+
+    const int buf = i & 1;
+    const uint8_t* rec = smem + L::oRec + (i % 3) * kRecBytes;
+    const int nu = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNu));
+    const int nrows = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNrows));
+    float v[NST][8];                                  // per 32-channel pair: 8 consecutive channels of row m
+    if (nu > 0) {
+      f32x4 acc[NBW];
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const uint8_t* Ab = smem + L::oA + buf * L::kA;
+      const uint32_t xs = lds0 + L::oSrc + buf * L::kSrc;
+      {   // slots 0 .. 31
+        ring_bf16x8 wf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[p] = *(const ring_bf16x8*)(Ab + p * kRingAPiece + m * kRingARow + fg * 16);
+        ring_bf16x4 h[NBW][2];
+        const int sw = fq | ((fg & 1) << 2);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const uint32_t addr = xs + (uint32_t)((8 * fg + 4 * hh + fq) * ROWB + (((wave * NBW + nb) ^ sw) << 5) + fp * 8);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[nb][hh]) : "v"(addr) : "memory");
+          }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[nb][0]), "+v"(h[nb][1])::"memory");
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb) {
+            const ring_bf16x8 xf = {h[nb][0][0], h[nb][0][1], h[nb][0][2], h[nb][0][3], h[nb][1][0], h[nb][1][1], h[nb][1][2], h[nb][1][3]};
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf[p], acc[nb], 0, 0, 0);
+          }
+      }
+      if (nu > 32) {   // slots 32 .. 47
+        ring_s16x4 wf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[p] = *(const ring_s16x4*)(Ab + p * kRingAPiece + m * kRingARow + 64 + fg * 8);
+        ring_s16x4 h[NBW];
+        const int sw = fq | (((fg >> 1) & 1) << 2);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          const uint32_t addr = xs + (uint32_t)((32 + 4 * fg + fq) * ROWB + (((wave * NBW + nb) ^ sw) << 5) + fp * 8);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[nb]) : "v"(addr) : "memory");
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[nb])::"memory");
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h[nb], wf[p], acc[nb], 0, 0, 0);
+      }
+      // a lane holds 4 channels of row m per block; one exchange per value with the neighbouring 16-lane row -> 8
+#pragma unroll
+      for (int pr = 0; pr < NST; ++pr)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * pr][jj]), __float_as_uint(acc[2 * pr + 1][jj]), false, false);
+          v[pr][jj] = __uint_as_float(r[0]);
+          v[pr][4 + jj] = __uint_as_float(r[1]);
+        }
+    } else {          // rare: the tile's sources do not fit; its rows are gathered from global memory (sequential fma chain)
+      const int r0 = *(const int32_t*)(rec + kRecR0);
+#pragma unroll
+      for (int pr = 0; pr < NST; ++pr) {
+        const int col = (wave * NBW + 2 * pr) * 16 + (fg & 1) * 16 + (fg >> 1) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[pr][c] = 0.f;
+        if (m < nrows) {
+          const int gs = a.rowptr[r0 + m], ge = a.rowptr[r0 + m + 1];
+          for (int k = gs; k < ge; ++k) {
+            const int2 e = a.lt_idx_w[k];
+            float f[VEC];
+            V::unpack(*(const raw_t*)(X + (int64_t)e.x * a.ldx + col), f);
+            axpy<VEC>(__int_as_float(e.y), f, v[pr]);
+          }
+        }
+      }
+    }
+    const float sdst = a.alpha * ((const float*)(rec + kRecSd))[m];
+    const int row = ((const int32_t*)(rec + kRecRow))[m];
+#pragma unroll
+    for (int pr = 0; pr < NST; ++pr) {
+      const int col = (wave * NBW + 2 * pr) * 16 + (fg & 1) * 16 + (fg >> 1) * 8;
+      float y[VEC];
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) y[c] = sdst * v[pr][c];
+      if (NEPI >= 1) {
+        const raw_t x0v = *(const raw_t*)(smem + L::oEpi + (buf * NEPI + 0) * L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
+        float f[VEC];
+        V::unpack(x0v, f);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
+      }
+      if (NEPI >= 2) {
+        const raw_t x1v = *(const raw_t*)(smem + L::oEpi + (buf * NEPI + 1) * L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
+        float f[VEC];
+        V::unpack(x1v, f);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
+      }
+      if (m < nrows) *(raw_t*)(Y + (int64_t)row * a.ldy + col) = V::pack(y);
+    }
+  }
+  (void)flags;
+}
+
+template <int NBW>
+int launch_ring(const SpmmArgs& a, hipStream_t stream) {
+  SpmmArgs b = a;
+  if (!a.X0 && a.X1) { b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f; }
+  const int nepi = (b.X0 ? 1 : 0) + (b.X1 ? 1 : 0);
+  constexpr int ROWB = 128 * NBW;
+  const int lds = nepi == 2 ? RingLds<ROWB, 2>::total : nepi == 1 ? RingLds<ROWB, 1>::total : RingLds<ROWB, 0>::total;
+  int per_cu = (160 * 1024) / lds;
+  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+  if (g_tuning.unroll > 0 && g_tuning.unroll < per_cu) per_cu = g_tuning.unroll;     // A/B: workgroups per CU
+  int64_t nb = (int64_t)per_cu * 256;
+  if (nb > a.lt_nrec) nb = a.lt_nrec;
+  nb = (nb + 7) / 8 * 8;
+  if (nepi == 2) spmm_ring<NBW, 2><<<(int)nb, kRingThreads, 0, stream>>>(b, a.lt_nrec, g_tuning.flags);
+  else if (nepi == 1) spmm_ring<NBW, 1><<<(int)nb, kRingThreads, 0, stream>>>(b, a.lt_nrec, g_tuning.flags);
+  else spmm_ring<NBW, 0><<<(int)nb, kRingThreads, 0, stream>>>(b, a.lt_nrec, g_tuning.flags);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
 // Any C, any stride, any alignment: one thread per output element, lanes along the channel.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spmm_scalar(const SpmmArgs a) {
@@ -1063,6 +1365,11 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
   const bool pays = tmin > 0 && sizeof(typename Vt<T>::elem) == 4 && row_bytes >= tmin &&
                     (row_bytes >= 2 * tmin || !(a.X0 || a.X1));
   // LDS-tile kernel (opt-in while it is being measured: SG_TUNE_FLAGS bit 7): whole-row lane groups of 16 / 32 / 64 lanes
+  if ((g_tuning.flags & kFlagLdsRing) && esz == 2 && a.lt_rec && a.lt_nrec > 0 && a.n_cols < ((int64_t)1 << 31)) {
+    const int nepi = (a.X0 ? 1 : 0) + (a.X1 ? 1 : 0);
+    if (a.C == 128) return launch_ring<2>(a, stream);
+    if (a.C == 256 && (nepi < 2 || g_tuning.slab < 0)) return launch_ring<4>(a, stream);
+  }
   if ((g_tuning.flags & kFlagLdsTiles) && a.lt_uptr && a.ldx % VEC == 0 && a.n_cols < ((int64_t)1 << 31)) {
     if (nvec == 16) return launch_lds<T, 16>(a, stream);
     if (nvec == 32) return launch_lds<T, 32>(a, stream);
@@ -1110,6 +1417,7 @@ int launch_typed(const SpmmArgs& a, hipStream_t stream) {
 
 bool tiles_enabled() { return g_tuning.tiled_min_row_bytes != 0; }
 bool lds_tiles_enabled() { return (g_tuning.flags & kFlagLdsTiles) != 0; }
+bool ring_enabled() { return (g_tuning.flags & kFlagLdsRing) != 0; }
 
 int set_tuning(int knob, int value) {
   switch (knob) {

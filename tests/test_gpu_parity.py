@@ -1508,6 +1508,89 @@ def test_lds_tile_kernel_bitwise_equals_generic(C, dtype):
     assert rel(res[129][0].float(), oracle_lhat(ei.cpu(), x.float().cpu())) < (1e-5 if dtype == torch.float32 else 2.0 ** -7)
 
 
+def _ring_graph(ei, V):
+    capi.tuning_set(capi.TUNE_FLAGS, 1025)             # the tile records of the ring kernel are only built on request
+    try:
+        return capi.GraphHandle.from_edge_index(ei, V)
+    finally:
+        capi.tuning_set(capi.TUNE_FLAGS, 1)
+
+
+def _ring_and_rows(g, calls):
+    out = {}
+    for flags in (1, 1025):
+        capi.tuning_set(capi.TUNE_FLAGS, flags)
+        capi.tuning_set(capi.TUNE_SLAB, -1 if flags == 1025 else 0)      # ring: also with two epilogue operands
+        try:
+            out[flags] = [f() for f in calls]
+        finally:
+            capi.tuning_set(capi.TUNE_FLAGS, 1)
+            capi.tuning_set(capi.TUNE_SLAB, 0)
+    return out[1], out[1025]
+
+
+@pytest.mark.parametrize("C", [128, 256])
+def test_ring_kernel_matches_the_rows_kernel_and_the_float64_oracle(C):
+    """spmm_ring (SG_TUNE_FLAGS bit 10): a persistent workgroup pipelines LDS-DMA of each tile's distinct source rows under
+    the reduction of the tile before, and reduces on the matrix cores (the tile's fp32 weights as three bf16 pieces:
+    exact products, the MFMA's own accumulation order).  Against spmm_rows (sequential fma chain) the bf16 outputs may
+    differ by the rounding of the last accumulated bit: every element within one bf16 ulp (2^-7 relative; plus the fp32
+    rounding noise of a cancelling sum), almost all identical; against the float64 oracle it is as close as spmm_rows.
+    On a Morton-ordered mesh and through the locality view of a randomly numbered one, every epilogue arity, strided
+    column blocks, and deterministic run to run."""
+    from semigcn_amd import reorder
+    dtype = torch.bfloat16
+    for permute in (False, True):
+        m = synth.torus_mesh(320, 250, permute=permute, masks=False)
+        V = m.num_vertices
+        ei = torch.from_numpy(m.edge_index).to(DEV)
+        if not permute:
+            ei = reorder.permute_edge_index(ei, reorder.morton_order(torch.from_numpy(m.x_pos).to(DEV))[1])
+        g = _ring_graph(ei, V)
+        assert g.reordered == permute
+        gen = torch.Generator(device=DEV).manual_seed(C)
+        wide = torch.randn(V, 3 * C, device=DEV, generator=gen).to(dtype)
+        x, x0, x1 = wide[:, :C], wide[:, C:2 * C], wide[:, 2 * C:]
+        calls = [lambda: g.spmm(x, torch.empty((V, C), dtype=dtype, device=DEV)),
+                 lambda: g.spmm(x, torch.empty((V, C), dtype=dtype, device=DEV), alpha=2.0, X0=x0, beta=-1.0),
+                 lambda: g.spmm(x, torch.empty((V, C), dtype=dtype, device=DEV), alpha=1.0, X0=x0, beta=1.0, X1=x1, gamma=-1.0)]
+        rows, ring = _ring_and_rows(g, calls)
+        _, ring2 = _ring_and_rows(g, calls)
+        for a, b, b2 in zip(rows, ring, ring2):
+            assert torch.equal(b, b2)                                       # deterministic
+            d = (a.float() - b.float()).abs()
+            assert bool((d <= 2.0 ** -7 * a.float().abs() + 1e-5).all()), float(d.max())
+            assert float((d > 0).float().mean()) < 0.02                     # a different last bit is the exception
+        exact = oracle_lhat(ei.cpu(), x.float().cpu())
+        e_rows, e_ring = rel(rows[0].float(), exact), rel(ring[0].float(), exact)
+        assert e_ring < 1.02 * e_rows + 1e-6, (e_ring, e_rows)
+
+
+def test_ring_kernel_tiles_that_do_not_fit_gather_from_global_memory():
+    """A graph without locality (random sources, ~20 per row, repeated edges): no 16-row or 8-row tile fits the LDS budget
+    of spmm_ring (48 distinct sources, 16 neighbours per row, no repeats), every record says so and the kernel's in-loop
+    fallback sums the rows from global memory with the sequential fma chain of spmm_rows: identical bits."""
+    V, C = 5000, 256
+    gen = torch.Generator().manual_seed(7)
+    a = torch.randint(0, V, (50000,), generator=gen)
+    b = torch.randint(0, V, (50000,), generator=gen)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])]).to(DEV)
+    capi.tuning_set(capi.TUNE_GRAPH_REORDER, 1)
+    try:
+        g = _ring_graph(ei, V)
+    finally:
+        capi.tuning_set(capi.TUNE_GRAPH_REORDER, 0)
+    x = torch.randn(V, C, device=DEV).bfloat16()
+    x0 = torch.randn(V, C, device=DEV).bfloat16()
+    calls = [lambda: g.spmm(x, torch.empty((V, C), dtype=torch.bfloat16, device=DEV)),
+             lambda: g.spmm(x, torch.empty((V, C), dtype=torch.bfloat16, device=DEV), alpha=2.0, X0=x0, beta=-1.0)]
+    rows, ring = _ring_and_rows(g, calls)
+    for r, q in zip(rows, ring):
+        assert torch.equal(r, q)
+
+
 # --------------------------------------------------------------------------------------
 # documented deviations from the reference's arithmetic (include/semigcn.h), one test each
 # --------------------------------------------------------------------------------------
