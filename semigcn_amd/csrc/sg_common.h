@@ -89,8 +89,8 @@ constexpr int kRecNrows = kRecR0 + 4;
 constexpr int kRecSd = kRecNrows + 4;
 constexpr int kRecRow = kRecSd + 4 * kLdsRows;
 constexpr int kRecW = kRecRow + 4 * kLdsRows;
-constexpr int kRecBytes = kRecW + 4 * kLdsSlots;
-static_assert(kRecBytes % 16 == 0 && kRecBytes <= 1024 && kRecSd % 16 == 0, "tile record layout");
+constexpr int kRecBytes = 1024;   // padded: every wavefront of the kernel fetches an equal share
+static_assert(kRecW + 4 * kLdsSlots <= kRecBytes && kRecSd % 16 == 0, "tile record layout");
 int build_tiles(Csr* c, hipStream_t stream);
 // Fills Csr::idx_w (and tile_uniq_w when the CSR carries tiles) for the source scale vector `scale` [n_cols].
 int pack_source_scale(Csr* c, const float* scale, hipStream_t stream);

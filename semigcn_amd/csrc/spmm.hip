@@ -751,33 +751,33 @@ int launch_lds(const SpmmArgs& a, hipStream_t stream) {
 // 256 channels; opt-in while it is measured: SG_TUNE_FLAGS bit 10 at graph creation and at launch).
 //
 // spmm_lds above pays, per tile and strictly one after the other, a metadata chain, the LDS-DMA round trip and the
-// reduction.  Here a persistent workgroup (4 wavefronts) walks a stream of tiles (<= 16 rows, <= 48 distinct sources:
-// csr_build.hip::build_ring_records) and keeps three of them in different stages:
+// reduction.  Here ONE persistent workgroup per CU (8 wavefronts at 256 channels) walks a stream of tiles (<= 16 rows,
+// <= 48 distinct sources: csr_build.hip::build_ring_records) through a ring of D stages in LDS:
 //
-//   iteration i:  counted s_waitcnt vmcnt (everything but the last stores)  ->  s_barrier
-//                 tile i+1: LDS-DMA of its distinct source rows and of its rows of the epilogue operand (buffer (i+1) & 1);
-//                           its 16 x 48 weight matrix, split into three bf16 pieces, scattered into LDS
-//                 tile i+2: LDS-DMA of its 800-byte record (sources, slot of every edge, scales, row ids)
-//                 tile i:   Y_tile = W_tile (16 x nu) * X_sources (nu x C) on v_mfma_f32_16x16x32_bf16, epilogue, store
+//   iteration i:  counted s_waitcnt vmcnt  ->  s_barrier
+//                 tile i+D-1:  LDS-DMA of its 48 source-row slots and of its 16 rows of the epilogue operands; its 16 x 48
+//                              weight matrix, split into three bf16 pieces, scattered into LDS
+//                 tile i+2D-2: LDS-DMA of its 1 KB record (sources, slot of every edge, scales, row ids)
+//                 tile i:      Y_tile = W_tile (16 x 48) * X_sources (48 x C) on v_mfma_f32_16x16x{32,16}_bf16, epilogue, store
 //
+// Memory parallelism comes from the ring depth, not from occupancy: D - 1 tiles (24 + 8 KB each at 256 channels) are in
+// flight per CU under the tile being reduced, which is what the latency-bound spmm_rows cannot reach with registers.
 // Why MFMA for an HBM-bound kernel: with the sources in LDS the VALU reduction of spmm_rows (8 unpack + 4 packed-fma
-// instructions per 16 bytes and neighbour, plus slot / weight addressing) became the bound at the 8-12 wavefronts per CU the
-// LDS budget allows (measured: 0.46 ms with, 0.21 ms without the reduction at C = 256).  The tile's weights are a dense
-// 16 x 48 matrix with ~6 nonzeros per row; multiplying it costs 12-24 MFMA instructions per wavefront and NO unpacking:
-// the bf16 source rows are MFMA operands as they lie in LDS (ds_read_b64_tr_b16 transposes them on the way).  The fp32
-// weights enter as hi + mid + lo bf16 pieces (3 x 8 mantissa bits: exact), products are exact in fp32, the accumulation
-// is the matrix core's -- so the result differs from spmm_rows' sequential fma chain in the last bits (same error
-// bound; deterministic; tested against it to 2 ulp of the output type and against the float64 oracle).
+// instructions per 16 bytes and neighbour, plus slot / weight addressing) became the bound (measured: 0.46 ms with, 0.21 ms
+// without the reduction at C = 256).  The tile's weights are a dense 16 x 48 matrix with ~6 nonzeros per row; multiplying
+// it costs 12 MFMA instructions per wavefront and NO unpacking: the bf16 source rows are MFMA operands as they lie in LDS
+// (ds_read_b64_tr_b16 transposes them on the way).  The fp32 weights enter as hi + mid + lo bf16 pieces (3 x 8 mantissa
+// bits: exact), products are exact in fp32, the accumulation is the matrix core's -- so the result differs from
+// spmm_rows' sequential fma chain in the last bits (same error bound; deterministic; tested against it to one ulp of the
+// output type and against the float64 oracle).
 //
-// EVERY global read is an LDS-DMA (no VGPR result), so hipcc has no load to put `s_waitcnt vmcnt(0)` in front of; the
-// waits on the vector-memory queue are the counted ones at the top of an iteration, which leave exactly the stores of
-// the tile just finished in flight.  One s_barrier per tile.  The source rows and the operand rows are stored XOR-
-// swizzled (applied to the per-lane SOURCE address of the DMA) so that the transposing reads and the epilogue reads are
-// bank-conflict-free.  Tiles that do not fit (record.nu == 0) are gathered from global memory inside the same loop.
-// LDS at C = 256: 2 x 24 KB sources + 2 x 8 KB per epilogue operand + 2 x 5 KB weights + 3 records = 61 / 77 KB.
+// EVERY global read is an LDS-DMA (no VGPR result), so hipcc has no load to put `s_waitcnt vmcnt(0)` in front of, and
+// every wavefront issues the SAME number of vector-memory instructions per iteration (3 source + NEPI operand + 1 record
+// DMA + 1 store; the tail of the stream re-loads its last tile instead of issuing less), so the wait at the top of an
+// iteration is the constant vmcnt((D - 2) * (5 + NEPI)).  One s_barrier per tile.  Source rows and operand rows are
+// stored XOR-swizzled (applied to the per-lane SOURCE address of the DMA) so that the transposing reads and the epilogue
+// reads are bank-conflict-free.  Tiles that do not fit (record.nu == 0) are gathered from global memory inside the loop.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRingThreads = 256;
-constexpr int kRingWaves = kRingThreads / 64;
 constexpr int kRingARow = 112;                       // bytes of one row of a weight piece: 48 bf16 + pad (conflict-free b128 reads)
 constexpr int kRingAPiece = kLdsRows * kRingARow;
 
@@ -785,16 +785,17 @@ typedef __attribute__((ext_vector_type(8))) __bf16 ring_bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 ring_bf16x4;
 typedef __attribute__((ext_vector_type(4))) short ring_s16x4;
 
-template <int ROWB, int NEPI>
+template <int ROWB, int NEPI, int D>
 struct RingLds {
-  static constexpr int kSrc = kLdsSlots * ROWB;          // one buffer of source rows
-  static constexpr int kEpi = kLdsRows * ROWB;           // one buffer of one epilogue operand
-  static constexpr int kA = 3 * kRingAPiece;             // one buffer of the three weight pieces
-  static constexpr int oSrc = 0;                         // [2][kSrc]
-  static constexpr int oEpi = 2 * kSrc;                  // [2][NEPI][kEpi]
-  static constexpr int oA = oEpi + 2 * NEPI * kEpi;      // [2][kA]
-  static constexpr int oRec = oA + 2 * kA;               // [3][kRecBytes]
-  static constexpr int total = oRec + 3 * kRecBytes;
+  static constexpr int NREC = 2 * D - 1;
+  static constexpr int kSrc = kLdsSlots * ROWB;          // source rows of one stage
+  static constexpr int kEpi = kLdsRows * ROWB;           // one epilogue operand of one stage
+  static constexpr int kA = 3 * kRingAPiece;             // the three weight pieces of one stage
+  static constexpr int oSrc = 0;                         // [D][kSrc]
+  static constexpr int oEpi = D * kSrc;                  // [D][NEPI][kEpi]
+  static constexpr int oA = oEpi + D * NEPI * kEpi;      // [D][kA]
+  static constexpr int oRec = oA + D * kA;               // [NREC][kRecBytes]
+  static constexpr int total = oRec + NREC * kRecBytes;
 };
 
 __device__ __forceinline__ void ring_dma16(const void* src, uint8_t* lds) {
@@ -802,19 +803,25 @@ __device__ __forceinline__ void ring_dma16(const void* src, uint8_t* lds) {
                                    (void __attribute__((address_space(3)))*)lds, 16, 0, 0);
 }
 __device__ __forceinline__ int ring_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
-#define SG_RING_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <int N> __device__ __forceinline__ void ring_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NBW, int NEPI>
-__global__ __launch_bounds__(kRingThreads) void spmm_ring(const SpmmArgs a, const int nt, const int flags) {
+template <int NBW, int NEPI, int D>
+__global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, const int nt, const int flags) {
   using V = Vt<bf16_tag>;
   constexpr int VEC = 8;
-  constexpr int C = 64 * NBW;                       // channels: four wavefronts x NBW blocks of 16
+  constexpr int CW = 2 * NBW;                       // consumer wavefronts: each owns two 16-channel blocks
+  constexpr int PW = 4;                             // producer wavefronts: 256 threads = one per (row, neighbour) of a tile
+  constexpr int C = 64 * NBW;
   constexpr int ROWB = 2 * C;                       // bytes of one feature row
   constexpr int G = ROWB / 16;                      // lanes per row in a DMA instruction
   constexpr int RPW = 64 / G;                       // rows one DMA instruction covers
-  constexpr int NST = NBW / 2;                      // 16-byte store instructions per wavefront and tile
+  constexpr int SRC_PER_WAVE = kLdsSlots / RPW / PW;
+  constexpr int EPI_PER_WAVE = kLdsRows / RPW / PW;
+  constexpr int PER = SRC_PER_WAVE + NEPI * EPI_PER_WAVE + 1;      // DMA instructions per producer wavefront and iteration
   static_assert(NBW == 2 || NBW == 4, "128 or 256 channels");
-  using L = RingLds<ROWB, NEPI>;
+  static_assert(SRC_PER_WAVE * RPW * PW == kLdsSlots && EPI_PER_WAVE * RPW * PW == kLdsRows, "equal DMA shares");
+  static_assert((D - 2) * PER <= 63 && D >= 2, "vmcnt range");
+  using L = RingLds<ROWB, NEPI, D>;
   using raw_t = typename V::raw;
   using elem_t = typename V::elem;
 
@@ -822,9 +829,6 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring(const SpmmArgs a, cons
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane / G, gl = lane % G;            // DMA: row of the instruction, 16-byte chunk of the row
-  const int m = lane & 15, fg = lane >> 4;          // MFMA: tile row (operand / result column), k group
-  const int fq = (lane >> 2) & 3, fp = lane & 3;    // transposing reads: row and 8-byte column quad a lane SUPPLIES
 
   // this workgroup's tiles: the workgroups of one XCD (block ids b, b + 8, ..) share ONE contiguous run of tiles and take
   // them round-robin, so the rows in flight on an XCD are one thin front (its L2 serves the re-gathered neighbours)
@@ -838,119 +842,151 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring(const SpmmArgs a, cons
   const int t_first = tile_lo + jb;
 
   const elem_t* __restrict__ X = (const elem_t*)a.X;
-  const elem_t* __restrict__ X0 = (const elem_t*)a.X0;
-  const elem_t* __restrict__ X1 = (const elem_t*)a.X1;
-  elem_t* __restrict__ Y = (elem_t*)a.Y;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)smem;
 
-  // LDS starts as zeros: stale slots are multiplied by zero weights and must be finite
-  for (int o = tid * 16; o < L::total; o += kRingThreads * 16) *(u32x4*)(smem + o) = u32x4{0u, 0u, 0u, 0u};
+  // the weight pieces start as zeros (only the nonzeros are ever written and taken back)
+  for (int o = tid * 16; o < D * L::kA; o += (CW + PW) * 64 * 16) *(u32x4*)(smem + L::oA + o) = u32x4{0u, 0u, 0u, 0u};
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  auto issue_meta = [&](int tile, int slot) {
-    if (wave == 0 && lane < kRecBytes / 16)
-      ring_dma16(a.lt_rec + (int64_t)tile * kRecBytes + lane * 16, smem + L::oRec + slot * kRecBytes);
-  };
-  int a_off[2] = {-1, -1};                          // where this thread put its weight of the tile before last, per buffer
-  // everything tile `slot`'s reduction will read, into buffer `buf`
-  auto issue_tile = [&](int slot, int buf) {
-    const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
-    const int nu = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNu));
-    const int n_inst = (nu + RPW - 1) / RPW;
-    for (int i = wave; i < n_inst; i += kRingWaves) {
-      const int sl = i * RPW + g;
-      const int src = ((const int32_t*)(rec + kRecSrc))[sl];              // padded with the last source row
-      const int chunk = ((((gl >> 1) ^ ring_swz(sl)) << 1) | (gl & 1));   // 32-byte segments XOR-swizzled by the slot
-      ring_dma16(X + (int64_t)src * a.ldx + chunk * VEC, smem + L::oSrc + buf * L::kSrc + i * (RPW * ROWB));
-    }
-    // the slots the MFMA steps read beyond the list (k steps of 32 + 16 slots): zeros
-    const int kend = nu > 32 ? kLdsSlots : (nu > 0 ? 32 : 0);
-    for (int o = n_inst * RPW * ROWB + tid * 16; o < kend * ROWB; o += kRingThreads * 16)
-      *(u32x4*)(smem + L::oSrc + buf * L::kSrc + o) = u32x4{0u, 0u, 0u, 0u};
-    if (NEPI >= 1) {
+  if (wave >= CW) {
+    // =============================== producers: DMA + weight matrices, D - 1 tiles ahead ===============================
+    const int pw = wave - CW, ptid = tid - CW * 64;
+    const int g = lane / G, gl = lane % G;          // DMA: row of the instruction, 16-byte chunk of the row
+    const elem_t* __restrict__ X0 = (const elem_t*)a.X0;
+    const elem_t* __restrict__ X1 = (const elem_t*)a.X1;
+    auto tile_of = [&](int k) { return t_first + (k < n_my ? k : n_my - 1) * nx; };   // past the end: the last tile again
+    auto issue_meta = [&](int tile, int slot) {     // 1 KB record, an equal share per producer
+      constexpr int LPW = kRecBytes / 16 / PW;
+      if (lane < LPW)
+        ring_dma16(a.lt_rec + (int64_t)tile * kRecBytes + (pw * LPW + lane) * 16, smem + L::oRec + slot * kRecBytes + pw * LPW * 16);
+    };
+    uint32_t a_slots = 0xffffffffu;                 // 6 bits per stage: the slot this thread's weight went to (63: none)
+    auto issue_tile = [&](int slot, int st) {       // everything the reduction of the tile in record `slot` reads -> stage st
+      const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
+      int src[SRC_PER_WAVE], erow[EPI_PER_WAVE > 0 ? EPI_PER_WAVE : 1];
 #pragma unroll
-      for (int p = 0; p < kLdsRows / (RPW * kRingWaves); ++p) {
-        const int lr = (p * kRingWaves + wave) * RPW + g;
-        const int row = ((const int32_t*)(rec + kRecRow))[lr];
-        const int chunk = gl ^ (lr & 15);                                   // 16-byte chunks XOR-swizzled by the row
-        ring_dma16(X0 + (int64_t)row * a.ldx0 + chunk * VEC, smem + L::oEpi + (buf * NEPI + 0) * L::kEpi + (p * kRingWaves + wave) * (RPW * ROWB));
-        if (NEPI >= 2)
-          ring_dma16(X1 + (int64_t)row * a.ldx1 + chunk * VEC, smem + L::oEpi + (buf * NEPI + 1) * L::kEpi + (p * kRingWaves + wave) * (RPW * ROWB));
+      for (int j = 0; j < SRC_PER_WAVE; ++j) src[j] = ((const int32_t*)(rec + kRecSrc))[(pw + PW * j) * RPW + g];   // padded with the last source
+      if (NEPI >= 1) {
+#pragma unroll
+        for (int j = 0; j < EPI_PER_WAVE; ++j) erow[j] = ((const int32_t*)(rec + kRecRow))[(pw + PW * j) * RPW + g];
       }
-    }
-    // weight matrix: thread (row, u) owns the u-th neighbour of the row; fp32 weight = hi + mid + lo in bf16 (exact)
-    uint8_t* Ab = smem + L::oA + buf * L::kA;
-    if (a_off[buf] >= 0) {
+      const int ar = ptid >> 4, au = ptid & 15;
+      const int deg = rec[kRecDeg + ar];
+      const int sl_new = rec[kRecSlot + ptid] & 63;
+      const float w = ((const float*)(rec + kRecW))[sl_new];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *(uint16_t*)(Ab + p * kRingAPiece + a_off[buf]) = 0;
-    }
-    const int ar = tid >> 4, au = tid & 15;
-    int off = -1;
-    if (au < (int)rec[kRecDeg + ar]) {
-      const int sl = rec[kRecSlot + tid] & 63;
-      const float w = ((const float*)(rec + kRecW))[sl];
-      const uint32_t hi = __float_as_uint(w) & 0xffff0000u;
-      const float r1 = w - __uint_as_float(hi);
-      const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
-      const float r2 = r1 - __uint_as_float(mid);
-      off = ar * kRingARow + sl * 2;
-      *(uint16_t*)(Ab + 0 * kRingAPiece + off) = (uint16_t)(hi >> 16);
-      *(uint16_t*)(Ab + 1 * kRingAPiece + off) = (uint16_t)(mid >> 16);
-      *(uint16_t*)(Ab + 2 * kRingAPiece + off) = (uint16_t)(__float_as_uint(r2) >> 16);
-    }
-    a_off[buf] = off;
-  };
+      for (int j = 0; j < SRC_PER_WAVE; ++j) {
+        const int i = pw + PW * j;
+        const int sl = i * RPW + g;
+        const int chunk = ((((gl >> 1) ^ ring_swz(sl)) << 1) | (gl & 1));   // 32-byte segments XOR-swizzled by the slot
+        ring_dma16(X + (int64_t)src[j] * a.ldx + chunk * VEC, smem + L::oSrc + st * L::kSrc + i * (RPW * ROWB));
+      }
+      if (NEPI >= 1) {
+#pragma unroll
+        for (int j = 0; j < EPI_PER_WAVE; ++j) {
+          const int i = pw + PW * j;
+          const int lr = i * RPW + g;
+          const int chunk = gl ^ (lr & 15);                                 // 16-byte chunks XOR-swizzled by the row
+          ring_dma16(X0 + (int64_t)erow[j] * a.ldx0 + chunk * VEC, smem + L::oEpi + (st * NEPI + 0) * L::kEpi + i * (RPW * ROWB));
+          if (NEPI >= 2)
+            ring_dma16(X1 + (int64_t)erow[j] * a.ldx1 + chunk * VEC, smem + L::oEpi + (st * NEPI + 1) * L::kEpi + i * (RPW * ROWB));
+        }
+      }
+      // weight matrix: thread (row, u) owns the u-th neighbour of the row; fp32 weight = hi + mid + lo in bf16 (exact)
+      uint8_t* Ab = smem + L::oA + st * L::kA;
+      const int old = (a_slots >> (6 * st)) & 63;
+      if (old != 63) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *(uint16_t*)(Ab + p * kRingAPiece + ar * kRingARow + old * 2) = 0;
+      }
+      int sl = 63;
+      if (au < deg) {
+        sl = sl_new;
+        const uint32_t hi = __float_as_uint(w) & 0xffff0000u;
+        const float r1 = w - __uint_as_float(hi);
+        const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(mid);
+        const int off = ar * kRingARow + sl * 2;
+        *(uint16_t*)(Ab + 0 * kRingAPiece + off) = (uint16_t)(hi >> 16);
+        *(uint16_t*)(Ab + 1 * kRingAPiece + off) = (uint16_t)(mid >> 16);
+        *(uint16_t*)(Ab + 2 * kRingAPiece + off) = (uint16_t)(__float_as_uint(r2) >> 16);
+      }
+      a_slots = (a_slots & ~(63u << (6 * st))) | ((uint32_t)sl << (6 * st));
+    };
 
-  issue_meta(t_first, 0);
-  for (int i = -1; i < n_my; ++i) {
-    // the rows, operands and weights of tile i and the record of tile i + 1 have landed (this wavefront's share; the
-    // barrier covers the others'); only the stores of tile i - 1 may still be in flight
-    if (i <= 0) {
-      SG_RING_WAIT_VM(0);
-    } else {
-      if (NST == 1) SG_RING_WAIT_VM(1);
-      else SG_RING_WAIT_VM(2);
+    // prologue: the records of the first 2D - 2 tiles, then the rows of the first D - 1
+    for (int k = 0; k < 2 * D - 2; ++k) issue_meta(tile_of(k), k);
+    ring_wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // (P0) among the producers only in effect: consumers wait at it too
+    asm volatile("" ::: "memory");
+    for (int k = 0; k < D - 1; ++k) issue_tile(k, k);
+    asm volatile("" ::: "memory");
+    int st = 0, rs = 0;                             // stage and record slot of tile i
+    for (int i = 0; i < n_my; ++i) {
+      // the rows, operands and weights of tile i and the record of tile i + D - 1 have landed (this wavefront's share):
+      // everything issued up to iteration i - D + 1; the (D - 2) * PER younger DMA instructions may fly
+      if (i == 0) ring_wait_vm<0>();
+      else ring_wait_vm<(D - 2) * PER>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                 // tile i is ready for the consumers; they are done with tile i - 1
+      asm volatile("" ::: "memory");
+      const int st_n = st == 0 ? D - 1 : st - 1;                  // (i + D - 1) % D
+      const int rs_n = rs + D - 1 >= L::NREC ? rs + D - 1 - L::NREC : rs + D - 1;
+      const int rs_m = rs == 0 ? L::NREC - 1 : rs - 1;            // (i + 2D - 2) % (2D - 1)
+      issue_tile(rs_n, st_n);
+      issue_meta(tile_of(i + 2 * D - 2), rs_m);
+      asm volatile("" ::: "memory");
+      st = st + 1 == D ? 0 : st + 1;
+      rs = rs + 1 == L::NREC ? 0 : rs + 1;
     }
+    ring_wait_vm<0>();                              // no LDS-DMA may be in flight when the workgroup ends
+    return;
+  }
+
+  // ================================= consumers: MFMA reduction, epilogue, store =================================
+  elem_t* __restrict__ Y = (elem_t*)a.Y;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)smem;
+  const int m = lane & 15, fg = lane >> 4;          // MFMA: tile row (operand / result column), k group
+  const int fq = (lane >> 2) & 3, fp = lane & 3;    // transposing reads: row and 8-byte column quad a lane SUPPLIES
+  const int col = wave * 32 + (fg & 1) * 16 + (fg >> 1) * 8;     // this lane's 8 consecutive channels of row m
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                     // (P0)
+  asm volatile("" ::: "memory");
+  int st = 0, rs = 0;
+  for (int i = 0; i < n_my; ++i) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (i + 1 < n_my) issue_tile((i + 1) % 3, (i + 1) & 1);
-    if (i + 2 < n_my) issue_meta(t_first + (i + 2) * nx, (i + 2) % 3);
-    asm volatile("" ::: "memory");
-    if (i < 0) continue;
-
-    const int buf = i & 1;
-    const uint8_t* rec = smem + L::oRec + (i % 3) * kRecBytes;
+    const uint8_t* rec = smem + L::oRec + rs * kRecBytes;
     const int nu = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNu));
     const int nrows = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNrows));
-    float v[NST][8];                                  // per 32-channel pair: 8 consecutive channels of row m
+    const float sd = ((const float*)(rec + kRecSd))[m];
+    const int row = ((const int32_t*)(rec + kRecRow))[m];
+    float v[8];
     if (nu > 0) {
-      f32x4 acc[NBW];
-#pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const uint8_t* Ab = smem + L::oA + buf * L::kA;
-      const uint32_t xs = lds0 + L::oSrc + buf * L::kSrc;
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const uint8_t* Ab = smem + L::oA + st * L::kA;
+      const uint32_t xs = lds0 + L::oSrc + st * L::kSrc;
       {   // slots 0 .. 31
         ring_bf16x8 wf[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) wf[p] = *(const ring_bf16x8*)(Ab + p * kRingAPiece + m * kRingARow + fg * 16);
-        ring_bf16x4 h[NBW][2];
+        ring_bf16x4 h[2][2];
         const int sw = fq | ((fg & 1) << 2);
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            const uint32_t addr = xs + (uint32_t)((8 * fg + 4 * hh + fq) * ROWB + (((wave * NBW + nb) ^ sw) << 5) + fp * 8);
+            const uint32_t addr = xs + (uint32_t)((8 * fg + 4 * hh + fq) * ROWB + (((wave * 2 + nb) ^ sw) << 5) + fp * 8);
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[nb][hh]) : "v"(addr) : "memory");
           }
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[nb][0]), "+v"(h[nb][1])::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0][0]), "+v"(h[0][1]), "+v"(h[1][0]), "+v"(h[1][1])::"memory");
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-          for (int nb = 0; nb < NBW; ++nb) {
+          for (int nb = 0; nb < 2; ++nb) {
             const ring_bf16x8 xf = {h[nb][0][0], h[nb][0][1], h[nb][0][2], h[nb][0][3], h[nb][1][0], h[nb][1][1], h[nb][1][2], h[nb][1][3]};
             acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf[p], acc[nb], 0, 0, 0);
           }
@@ -959,73 +995,77 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring(const SpmmArgs a, cons
         ring_s16x4 wf[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) wf[p] = *(const ring_s16x4*)(Ab + p * kRingAPiece + m * kRingARow + 64 + fg * 8);
-        ring_s16x4 h[NBW];
+        ring_s16x4 h[2];
         const int sw = fq | (((fg >> 1) & 1) << 2);
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-          const uint32_t addr = xs + (uint32_t)((32 + 4 * fg + fq) * ROWB + (((wave * NBW + nb) ^ sw) << 5) + fp * 8);
+        for (int nb = 0; nb < 2; ++nb) {
+          const uint32_t addr = xs + (uint32_t)((32 + 4 * fg + fq) * ROWB + (((wave * 2 + nb) ^ sw) << 5) + fp * 8);
           asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[nb]) : "v"(addr) : "memory");
         }
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[nb])::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1])::"memory");
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-          for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h[nb], wf[p], acc[nb], 0, 0, 0);
+          for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h[nb], wf[p], acc[nb], 0, 0, 0);
       }
       // a lane holds 4 channels of row m per block; one exchange per value with the neighbouring 16-lane row -> 8
 #pragma unroll
-      for (int pr = 0; pr < NST; ++pr)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * pr][jj]), __float_as_uint(acc[2 * pr + 1][jj]), false, false);
-          v[pr][jj] = __uint_as_float(r[0]);
-          v[pr][4 + jj] = __uint_as_float(r[1]);
-        }
+      for (int jj = 0; jj < 4; ++jj) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][jj]), __float_as_uint(acc[1][jj]), false, false);
+        v[jj] = __uint_as_float(r[0]);
+        v[4 + jj] = __uint_as_float(r[1]);
+      }
     } else {          // rare: the tile's sources do not fit; its rows are gathered from global memory (sequential fma chain)
       const int r0 = *(const int32_t*)(rec + kRecR0);
 #pragma unroll
-      for (int pr = 0; pr < NST; ++pr) {
-        const int col = (wave * NBW + 2 * pr) * 16 + (fg & 1) * 16 + (fg >> 1) * 8;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[pr][c] = 0.f;
-        if (m < nrows) {
-          const int gs = a.rowptr[r0 + m], ge = a.rowptr[r0 + m + 1];
-          for (int k = gs; k < ge; ++k) {
-            const int2 e = a.lt_idx_w[k];
-            float f[VEC];
-            V::unpack(*(const raw_t*)(X + (int64_t)e.x * a.ldx + col), f);
-            axpy<VEC>(__int_as_float(e.y), f, v[pr]);
-          }
+      for (int c = 0; c < 8; ++c) v[c] = 0.f;
+      if (m < nrows) {
+        const int gs = a.rowptr[r0 + m], ge = a.rowptr[r0 + m + 1];
+        for (int k = gs; k < ge; ++k) {
+          const int2 e = a.lt_idx_w[k];
+          float f[VEC];
+          V::unpack(*(const raw_t*)(X + (int64_t)e.x * a.ldx + col), f);
+          axpy<VEC>(__int_as_float(e.y), f, v);
         }
       }
     }
-    const float sdst = a.alpha * ((const float*)(rec + kRecSd))[m];
-    const int row = ((const int32_t*)(rec + kRecRow))[m];
+    const float sdst = a.alpha * sd;
+    float y[VEC];
 #pragma unroll
-    for (int pr = 0; pr < NST; ++pr) {
-      const int col = (wave * NBW + 2 * pr) * 16 + (fg & 1) * 16 + (fg >> 1) * 8;
-      float y[VEC];
+    for (int c = 0; c < VEC; ++c) y[c] = sdst * v[c];
+    if (NEPI >= 1) {
+      const raw_t x0v = *(const raw_t*)(smem + L::oEpi + (st * NEPI + 0) * L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
+      float f[VEC];
+      V::unpack(x0v, f);
 #pragma unroll
-      for (int c = 0; c < VEC; ++c) y[c] = sdst * v[pr][c];
-      if (NEPI >= 1) {
-        const raw_t x0v = *(const raw_t*)(smem + L::oEpi + (buf * NEPI + 0) * L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
-        float f[VEC];
-        V::unpack(x0v, f);
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
-      }
-      if (NEPI >= 2) {
-        const raw_t x1v = *(const raw_t*)(smem + L::oEpi + (buf * NEPI + 1) * L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
-        float f[VEC];
-        V::unpack(x1v, f);
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
-      }
-      if (m < nrows) *(raw_t*)(Y + (int64_t)row * a.ldy + col) = V::pack(y);
+      for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
     }
+    if (NEPI >= 2) {
+      const raw_t x1v = *(const raw_t*)(smem + L::oEpi + (st * NEPI + 1) * L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
+      float f[VEC];
+      V::unpack(x1v, f);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
+    }
+    if (m < nrows) *(raw_t*)(Y + (int64_t)row * a.ldy + col) = V::pack(y);
+    st = st + 1 == D ? 0 : st + 1;
+    rs = rs + 1 == L::NREC ? 0 : rs + 1;
   }
   (void)flags;
+}
+
+template <int NBW, int NEPI, int D>
+int launch_ring_d(const SpmmArgs& b, hipStream_t stream) {
+  constexpr int lds = RingLds<128 * NBW, NEPI, D>::total;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  int per_cu = (160 * 1024) / lds;
+  per_cu = per_cu > 4 ? 4 : per_cu;
+  int64_t nb = (int64_t)per_cu * 256;
+  if (nb > b.lt_nrec) nb = b.lt_nrec;
+  nb = (nb + 7) / 8 * 8;
+  spmm_ring<NBW, NEPI, D><<<(int)nb, 128 * NBW + 256, 0, stream>>>(b, b.lt_nrec, g_tuning.flags);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
 }
 
 template <int NBW>
@@ -1033,19 +1073,15 @@ int launch_ring(const SpmmArgs& a, hipStream_t stream) {
   SpmmArgs b = a;
   if (!a.X0 && a.X1) { b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f; }
   const int nepi = (b.X0 ? 1 : 0) + (b.X1 ? 1 : 0);
-  constexpr int ROWB = 128 * NBW;
-  const int lds = nepi == 2 ? RingLds<ROWB, 2>::total : nepi == 1 ? RingLds<ROWB, 1>::total : RingLds<ROWB, 0>::total;
-  int per_cu = (160 * 1024) / lds;
-  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-  if (g_tuning.unroll > 0 && g_tuning.unroll < per_cu) per_cu = g_tuning.unroll;     // A/B: workgroups per CU
-  int64_t nb = (int64_t)per_cu * 256;
-  if (nb > a.lt_nrec) nb = a.lt_nrec;
-  nb = (nb + 7) / 8 * 8;
-  if (nepi == 2) spmm_ring<NBW, 2><<<(int)nb, kRingThreads, 0, stream>>>(b, a.lt_nrec, g_tuning.flags);
-  else if (nepi == 1) spmm_ring<NBW, 1><<<(int)nb, kRingThreads, 0, stream>>>(b, a.lt_nrec, g_tuning.flags);
-  else spmm_ring<NBW, 0><<<(int)nb, kRingThreads, 0, stream>>>(b, a.lt_nrec, g_tuning.flags);
-  SG_HIP_TRY(hipGetLastError());
-  return SG_OK;
+  const int d = g_tuning.unroll;                     // A/B: ring depth (0 = default)
+  if (NBW == 4) {                                    // 256 channels: one workgroup per CU
+    if (nepi == 2) return d == 2 ? launch_ring_d<NBW, 2, 2>(b, stream) : launch_ring_d<NBW, 2, 3>(b, stream);
+    if (nepi == 1) return d == 2 ? launch_ring_d<NBW, 1, 2>(b, stream) : d == 3 ? launch_ring_d<NBW, 1, 3>(b, stream) : launch_ring_d<NBW, 1, 4>(b, stream);
+    return d == 2 ? launch_ring_d<NBW, 0, 2>(b, stream) : d == 3 ? launch_ring_d<NBW, 0, 3>(b, stream) : d == 4 ? launch_ring_d<NBW, 0, 4>(b, stream) : launch_ring_d<NBW, 0, 5>(b, stream);
+  }
+  if (nepi == 2) return d == 2 ? launch_ring_d<NBW, 2, 2>(b, stream) : launch_ring_d<NBW, 2, 3>(b, stream);
+  if (nepi == 1) return d == 2 ? launch_ring_d<NBW, 1, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 1, 4>(b, stream) : launch_ring_d<NBW, 1, 3>(b, stream);
+  return d == 2 ? launch_ring_d<NBW, 0, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 0, 4>(b, stream) : launch_ring_d<NBW, 0, 3>(b, stream);
 }
 
 // Any C, any stride, any alignment: one thread per output element, lanes along the channel.
@@ -1366,9 +1402,8 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
                     (row_bytes >= 2 * tmin || !(a.X0 || a.X1));
   // LDS-tile kernel (opt-in while it is being measured: SG_TUNE_FLAGS bit 7): whole-row lane groups of 16 / 32 / 64 lanes
   if ((g_tuning.flags & kFlagLdsRing) && esz == 2 && a.lt_rec && a.lt_nrec > 0 && a.n_cols < ((int64_t)1 << 31)) {
-    const int nepi = (a.X0 ? 1 : 0) + (a.X1 ? 1 : 0);
     if (a.C == 128) return launch_ring<2>(a, stream);
-    if (a.C == 256 && (nepi < 2 || g_tuning.slab < 0)) return launch_ring<4>(a, stream);
+    if (a.C == 256) return launch_ring<4>(a, stream);
   }
   if ((g_tuning.flags & kFlagLdsTiles) && a.lt_uptr && a.ldx % VEC == 0 && a.n_cols < ((int64_t)1 << 31)) {
     if (nvec == 16) return launch_lds<T, 16>(a, stream);
