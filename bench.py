@@ -97,6 +97,8 @@ def algorithmic_bytes(V: int, E: int, C: int, elem: int, n_epilogue: int) -> flo
 
 def aggregation_kernel_name(C: int, esize: int, n_epi: int) -> str:
     """Which kernel sg_spmm dispatches to for this shape on a mesh graph (csrc/spmm.hip, launch_typed_one)."""
+    if esize == 2 and C in (128, 256):        # pipelined LDS-tile kernel (graphs that carry tile records: every mesh graph here)
+        return "spmm_ring"
     row_bytes = C * esize
     shared = esize == 4 and row_bytes >= 1024 and (row_bytes >= 2048 or n_epi == 0) and 16 < C // (16 // esize) <= 128
     return "spmm_shared" if shared else "spmm_rows"

@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32,
-             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512, kFlagLdsRing = 1024 };
+             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512, kFlagNoRing = 2048 };
 
 // Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
 // one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
@@ -748,7 +748,7 @@ int launch_lds(const SpmmArgs& a, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------
 // spmm_ring: the LDS-tile aggregation as a SOFTWARE PIPELINE with the reduction on the matrix cores (bf16 rows of 128 /
-// 256 channels; opt-in while it is measured: SG_TUNE_FLAGS bit 10 at graph creation and at launch).
+// 256 channels on graphs that carry tile records; SG_TUNE_FLAGS bit 11 switches it off at graph creation or at launch).
 //
 // spmm_lds above pays, per tile and strictly one after the other, a metadata chain, the LDS-DMA round trip and the
 // reduction.  Here ONE persistent workgroup per CU (8 wavefronts at 256 channels) walks a stream of tiles (<= 16 rows,
@@ -875,6 +875,7 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
       const int deg = rec[kRecDeg + ar];
       const int sl_new = rec[kRecSlot + ptid] & 63;
       const float w = ((const float*)(rec + kRecW))[sl_new];
+      if (!(flags & (1 << 17)))
 #pragma unroll
       for (int j = 0; j < SRC_PER_WAVE; ++j) {
         const int i = pw + PW * j;
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
         for (int p = 0; p < 3; ++p) *(uint16_t*)(Ab + p * kRingAPiece + ar * kRingARow + old * 2) = 0;
       }
       int sl = 63;
-      if (au < deg) {
+      if (au < deg && !(flags & (1 << 19))) {
         sl = sl_new;
         const uint32_t hi = __float_as_uint(w) & 0xffff0000u;
         const float r1 = w - __uint_as_float(hi);
@@ -965,7 +966,15 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
     const float sd = ((const float*)(rec + kRecSd))[m];
     const int row = ((const int32_t*)(rec + kRecRow))[m];
     float v[8];
-    if (nu > 0) {
+    if (flags & (1 << 20)) {
+      st = st + 1 == D ? 0 : st + 1;
+      rs = rs + 1 == L::NREC ? 0 : rs + 1;
+      continue;
+    }
+    if (flags & (1 << 16)) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = 0.f;
+    } else if (nu > 0) {
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       const uint8_t* Ab = smem + L::oA + st * L::kA;
       const uint32_t xs = lds0 + L::oSrc + st * L::kSrc;
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
 #pragma unroll
       for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
     }
-    if (m < nrows) *(raw_t*)(Y + (int64_t)row * a.ldy + col) = V::pack(y);
+    if (m < nrows && !((flags & (1 << 18)) && y[0] != 12345.f)) *(raw_t*)(Y + (int64_t)row * a.ldy + col) = V::pack(y);
     st = st + 1 == D ? 0 : st + 1;
     rs = rs + 1 == L::NREC ? 0 : rs + 1;
   }
@@ -1401,7 +1410,7 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
   const bool pays = tmin > 0 && sizeof(typename Vt<T>::elem) == 4 && row_bytes >= tmin &&
                     (row_bytes >= 2 * tmin || !(a.X0 || a.X1));
   // LDS-tile kernel (opt-in while it is being measured: SG_TUNE_FLAGS bit 7): whole-row lane groups of 16 / 32 / 64 lanes
-  if ((g_tuning.flags & kFlagLdsRing) && esz == 2 && a.lt_rec && a.lt_nrec > 0 && a.n_cols < ((int64_t)1 << 31)) {
+  if (!(g_tuning.flags & kFlagNoRing) && esz == 2 && a.lt_rec && a.lt_nrec > 0 && a.n_cols < ((int64_t)1 << 31)) {
     if (a.C == 128) return launch_ring<2>(a, stream);
     if (a.C == 256) return launch_ring<4>(a, stream);
   }
@@ -1452,7 +1461,7 @@ int launch_typed(const SpmmArgs& a, hipStream_t stream) {
 
 bool tiles_enabled() { return g_tuning.tiled_min_row_bytes != 0; }
 bool lds_tiles_enabled() { return (g_tuning.flags & kFlagLdsTiles) != 0; }
-bool ring_enabled() { return (g_tuning.flags & kFlagLdsRing) != 0; }
+bool ring_enabled() { return (g_tuning.flags & kFlagNoRing) == 0; }
 
 int set_tuning(int knob, int value) {
   switch (knob) {

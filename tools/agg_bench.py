@@ -44,8 +44,8 @@ def main():
         order, rank = reorder.morton_order(torch.from_numpy(m.vs).to(dev))
         ei = reorder.permute_edge_index(ei, rank)
     capi.tuning_set(capi.TUNE_GRAPH_REORDER, a.reorder)
-    if any("flags=" in v and int(dict(kv.split("=") for kv in v.split(","))["flags"]) & (128 | 1024) for v in a.variants):
-        capi.tuning_set(capi.TUNE_FLAGS, max(int(dict(kv.split('=') for kv in v.split(','))['flags']) & (128 | 1024) for v in a.variants if 'flags=' in v) | 1)      # experimental LDS tile lists / records are only built on request
+    if any("flags=" in v and int(dict(kv.split("=") for kv in v.split(","))["flags"]) & 128 for v in a.variants):
+        capi.tuning_set(capi.TUNE_FLAGS, 129)      # experimental LDS tile lists are only built on request
     torch.cuda.synchronize()
     import time
     t0 = time.perf_counter()

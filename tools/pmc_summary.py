@@ -38,8 +38,14 @@ def main():
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         agg = collections.defaultdict(list)
         for r in load(f"{root}/pmc_{cname}"):
+            if r["Counter_Name"] != cname:
+                continue
+            ring = re.search(r"spmm_ring<(\d+), (\d+), (\d+)>", r["Kernel_Name"])      # <channels / 64, epilogue operands, ring depth>
+            if ring:
+                agg[("ring", "bfloat16", 8 * int(ring.group(1)), 1, int(ring.group(2)))].append(float(r["Counter_Value"]))
+                continue
             m = re.search(r"spmm_(rows|shared)<(.+?), (\d+), (\d+), (\d+)(?:, (?:true|false))?(?:, \d+)?>", r["Kernel_Name"])
-            if not m or r["Counter_Name"] != cname:
+            if not m:
                 continue
             dt = "bfloat16" if "bf16" in m.group(2) else "float32"
             agg[(m.group(1), dt, int(m.group(3)), int(m.group(4)), int(m.group(5)))].append(float(r["Counter_Value"]))
