@@ -656,7 +656,7 @@ __device__ bool ring_record(const int32_t* __restrict__ rowptr, const int32_t* _
     }
     __syncthreads();
     nu = s_flag[1];
-    fits = nu <= kLdsSlots;
+    fits = nu <= kRingSlots;
   }
   if (!fits && !force) return false;
   if (!fits) nu = 0;
@@ -671,7 +671,7 @@ __device__ bool ring_record(const int32_t* __restrict__ rowptr, const int32_t* _
         ((float*)(rec + kRecW))[u] = scale_src ? scale_src[s_key[i]] : 1.0f;
       }
     __syncthreads();
-    for (int i = nu + tid; i < kLdsSlots; i += 64) {      // padding: the last source (weight 0: never referenced)
+    for (int i = nu + tid; i < kRingSlots; i += 64) {      // padding: the last source (weight 0: never referenced)
       ((int32_t*)(rec + kRecSrc))[i] = ((const int32_t*)(rec + kRecSrc))[nu - 1];
     }
     for (int t = tid; t < kLdsRows * 16; t += 64) {

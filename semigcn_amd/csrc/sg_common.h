@@ -68,19 +68,20 @@ constexpr int kTileEdges = 128;    // max edges per mini-tile
 constexpr int kLdsRows = 16;       // rows per LDS tile
 constexpr int kLdsSlots = 48;      // max distinct source rows per LDS tile (16 rows + their ring in a locality order: ~36)
 constexpr int kLdsEdges = 256;     // max edges per LDS tile
+constexpr int kRingSlots = 56;     // max distinct source rows per tile of spmm_ring (98 % of the 16-row blocks of a flipped Morton-ordered mesh)
 // Tile record of the pipelined LDS kernel (spmm.hip::spmm_ring): everything the reduction of one tile of <= kLdsRows
 // consecutive (processing-order) rows needs, in ONE contiguous piece that one LDS-DMA instruction brings in:
-//   int32 src[kLdsSlots]          distinct source rows, ascending, padded with the last one
+//   int32 src[kRingSlots]         distinct source rows, ascending, padded with the last one
 //   uint8 slot[kLdsRows][16]      slot of the u-th neighbour of row r in src[] (entries past the row's degree: last slot | 64)
 //   uint8 deg[kLdsRows]
-//   int32 nu                      number of distinct sources; 0: the tile does not fit (more than kLdsSlots sources, a row
+//   int32 nu                      number of distinct sources; 0: the tile does not fit (more than kRingSlots sources, a row
 //                                 with more than 16 neighbours or a repeated one) and is gathered from global memory
 //   int32 e0, r0, nrows           first edge, first row, rows of the tile
 //   float sd[kLdsRows]            destination-row scale (1 when the operator has none)
 //   int32 row[kLdsRows]           the caller's row id of each row (Csr row_id view; r0 + i otherwise)
-//   float w[kLdsSlots]            source-row scale of every slot
+//   float w[kRingSlots]           source-row scale of every slot
 constexpr int kRecSrc = 0;
-constexpr int kRecSlot = kRecSrc + 4 * kLdsSlots;
+constexpr int kRecSlot = kRecSrc + 4 * kRingSlots;
 constexpr int kRecDeg = kRecSlot + 16 * kLdsRows;
 constexpr int kRecNu = kRecDeg + kLdsRows;
 constexpr int kRecE0 = kRecNu + 4;
@@ -90,7 +91,7 @@ constexpr int kRecSd = kRecNrows + 4;
 constexpr int kRecRow = kRecSd + 4 * kLdsRows;
 constexpr int kRecW = kRecRow + 4 * kLdsRows;
 constexpr int kRecBytes = 1024;   // padded: every wavefront of the kernel fetches an equal share
-static_assert(kRecW + 4 * kLdsSlots <= kRecBytes && kRecSd % 16 == 0, "tile record layout");
+static_assert(kRecW + 4 * kRingSlots <= kRecBytes && kRecSd % 16 == 0, "tile record layout");
 int build_tiles(Csr* c, hipStream_t stream);
 // Fills Csr::idx_w (and tile_uniq_w when the CSR carries tiles) for the source scale vector `scale` [n_cols].
 int pack_source_scale(Csr* c, const float* scale, hipStream_t stream);

@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32,
-             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512, kFlagNoRing = 2048 };
+             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512, kFlagNoRing = 2048, kFlagRingRowStores = 4096 };
 
 // Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
 // one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
@@ -778,24 +778,27 @@ int launch_lds(const SpmmArgs& a, hipStream_t stream) {
 // stored XOR-swizzled (applied to the per-lane SOURCE address of the DMA) so that the transposing reads and the epilogue
 // reads are bank-conflict-free.  Tiles that do not fit (record.nu == 0) are gathered from global memory inside the loop.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRingARow = 112;                       // bytes of one row of a weight piece: 48 bf16 + pad (conflict-free b128 reads)
+constexpr int kRingARow = 144;                       // bytes of one row of a weight piece: 64 bf16 + pad (conflict-free b128 reads)
 constexpr int kRingAPiece = kLdsRows * kRingARow;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 ring_bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 ring_bf16x4;
 typedef __attribute__((ext_vector_type(4))) short ring_s16x4;
 
-template <int ROWB, int NEPI, int D>
+template <int ROWB, int NEPI, int D, bool ROWST = false>
 struct RingLds {
   static constexpr int NREC = 2 * D - 1;
-  static constexpr int kSrc = kLdsSlots * ROWB;          // source rows of one stage
+  static constexpr int kSrc = kRingSlots * ROWB;         // source rows of one stage
+  static constexpr int kA = 3 * kRingAPiece;             // the three weight pieces of one stage; directly BEHIND the source rows:
+                                                         // the last MFMA step reads 64 - kRingSlots "rows" of it (finite, weight 0)
   static constexpr int kEpi = kLdsRows * ROWB;           // one epilogue operand of one stage
-  static constexpr int kA = 3 * kRingAPiece;             // the three weight pieces of one stage
-  static constexpr int oSrc = 0;                         // [D][kSrc]
-  static constexpr int oEpi = D * kSrc;                  // [D][NEPI][kEpi]
-  static constexpr int oA = oEpi + D * NEPI * kEpi;      // [D][kA]
-  static constexpr int oRec = oA + D * kA;               // [NREC][kRecBytes]
-  static constexpr int total = oRec + NREC * kRecBytes;
+  static constexpr int kStage = kSrc + kA + NEPI * kEpi;
+  static constexpr int oA = kSrc;                        // inside a stage
+  static constexpr int oEpi = kSrc + kA;
+  static constexpr int oRec = D * kStage;                // [NREC][kRecBytes]
+  static constexpr int oStg = oRec + NREC * kRecBytes;   // output tile on its way to full-row stores (without an epilogue operand to overwrite)
+  static constexpr int total = oStg + (ROWST && NEPI == 0 ? kLdsRows * ROWB : 0);
+  static_assert((64 - kRingSlots) * ROWB <= kA, "the rows the last MFMA step reads behind the source slots lie in the weight pieces");
 };
 
 __device__ __forceinline__ void ring_dma16(const void* src, uint8_t* lds) {
@@ -804,8 +807,20 @@ __device__ __forceinline__ void ring_dma16(const void* src, uint8_t* lds) {
 }
 __device__ __forceinline__ int ring_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 template <int N> __device__ __forceinline__ void ring_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// s_waitcnt takes an immediate: the allowed number of outstanding DMA instructions is a (wave-uniform) runtime value
+__device__ __forceinline__ void ring_wait_vm_n(int n) {
+  switch (n) {
+#define SG_RING_CASE(k) case k: ring_wait_vm<k>(); break;
+    SG_RING_CASE(1) SG_RING_CASE(2) SG_RING_CASE(3) SG_RING_CASE(4) SG_RING_CASE(5) SG_RING_CASE(6) SG_RING_CASE(7) SG_RING_CASE(8)
+    SG_RING_CASE(9) SG_RING_CASE(10) SG_RING_CASE(11) SG_RING_CASE(12) SG_RING_CASE(13) SG_RING_CASE(14) SG_RING_CASE(15) SG_RING_CASE(16)
+    SG_RING_CASE(17) SG_RING_CASE(18) SG_RING_CASE(19) SG_RING_CASE(20) SG_RING_CASE(21) SG_RING_CASE(22) SG_RING_CASE(23) SG_RING_CASE(24)
+    SG_RING_CASE(25) SG_RING_CASE(26) SG_RING_CASE(27) SG_RING_CASE(28) SG_RING_CASE(29) SG_RING_CASE(30) SG_RING_CASE(31) SG_RING_CASE(32)
+#undef SG_RING_CASE
+    default: ring_wait_vm<0>(); break;
+  }
+}
 
-template <int NBW, int NEPI, int D>
+template <int NBW, int NEPI, int D, bool ROWST>
 __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, const int nt, const int flags) {
   using V = Vt<bf16_tag>;
   constexpr int VEC = 8;
@@ -815,13 +830,13 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
   constexpr int ROWB = 2 * C;                       // bytes of one feature row
   constexpr int G = ROWB / 16;                      // lanes per row in a DMA instruction
   constexpr int RPW = 64 / G;                       // rows one DMA instruction covers
-  constexpr int SRC_PER_WAVE = kLdsSlots / RPW / PW;
+  constexpr int SRC_MAX = (kRingSlots / RPW + PW - 1) / PW;        // source-row DMA instructions per producer, at most
   constexpr int EPI_PER_WAVE = kLdsRows / RPW / PW;
-  constexpr int PER = SRC_PER_WAVE + NEPI * EPI_PER_WAVE + 1;      // DMA instructions per producer wavefront and iteration
+  constexpr int FIXED = NEPI * EPI_PER_WAVE + 1;    // operand rows + record share: DMA instructions per producer and tile
   static_assert(NBW == 2 || NBW == 4, "128 or 256 channels");
-  static_assert(SRC_PER_WAVE * RPW * PW == kLdsSlots && EPI_PER_WAVE * RPW * PW == kLdsRows, "equal DMA shares");
-  static_assert((D - 2) * PER <= 63 && D >= 2, "vmcnt range");
-  using L = RingLds<ROWB, NEPI, D>;
+  static_assert(EPI_PER_WAVE * RPW * PW == kLdsRows, "equal DMA shares");
+  static_assert((D - 2) * (SRC_MAX + FIXED) <= 32 && D >= 2 && D <= 5, "vmcnt switch range");
+  using L = RingLds<ROWB, NEPI, D, ROWST>;
   using raw_t = typename V::raw;
   using elem_t = typename V::elem;
 
@@ -843,8 +858,8 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
 
   const elem_t* __restrict__ X = (const elem_t*)a.X;
 
-  // the weight pieces start as zeros (only the nonzeros are ever written and taken back)
-  for (int o = tid * 16; o < D * L::kA; o += (CW + PW) * 64 * 16) *(u32x4*)(smem + L::oA + o) = u32x4{0u, 0u, 0u, 0u};
+  // the weight pieces start as zeros (only the nonzeros are ever written and taken back); so do the source slots
+  for (int o = tid * 16; o < D * L::kStage; o += (CW + PW) * 64 * 16) *(u32x4*)(smem + o) = u32x4{0u, 0u, 0u, 0u};
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -862,11 +877,18 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
         ring_dma16(a.lt_rec + (int64_t)tile * kRecBytes + (pw * LPW + lane) * 16, smem + L::oRec + slot * kRecBytes + pw * LPW * 16);
     };
     uint32_t a_slots = 0xffffffffu;                 // 6 bits per stage: the slot this thread's weight went to (63: none)
-    auto issue_tile = [&](int slot, int st) {       // everything the reduction of the tile in record `slot` reads -> stage st
+    // everything the reduction of the tile in record `slot` reads -> stage st; returns the DMA instructions issued
+    auto issue_tile = [&](int slot, int st) -> int {
       const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
-      int src[SRC_PER_WAVE], erow[EPI_PER_WAVE > 0 ? EPI_PER_WAVE : 1];
+      uint8_t* stage = smem + st * L::kStage;
+      const int nu = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNu));
+      const int n_inst = (flags & (1 << 17)) ? 0 : (nu + RPW - 1) / RPW;
+      int src[SRC_MAX], erow[EPI_PER_WAVE];
 #pragma unroll
-      for (int j = 0; j < SRC_PER_WAVE; ++j) src[j] = ((const int32_t*)(rec + kRecSrc))[(pw + PW * j) * RPW + g];   // padded with the last source
+      for (int j = 0; j < SRC_MAX; ++j) {
+        const int sl = (pw + PW * j) * RPW + g;
+        src[j] = ((const int32_t*)(rec + kRecSrc))[sl < kRingSlots ? sl : kRingSlots - 1];   // padded with the last source
+      }
       if (NEPI >= 1) {
 #pragma unroll
         for (int j = 0; j < EPI_PER_WAVE; ++j) erow[j] = ((const int32_t*)(rec + kRecRow))[(pw + PW * j) * RPW + g];
@@ -874,35 +896,42 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
       const int ar = ptid >> 4, au = ptid & 15;
       const int deg = rec[kRecDeg + ar];
       const int sl_new = rec[kRecSlot + ptid] & 63;
-      const float w = ((const float*)(rec + kRecW))[sl_new];
-      if (!(flags & (1 << 17)))
+      const float w = ((const float*)(rec + kRecW))[sl_new < kRingSlots ? sl_new : 0];
+      int issued = 0;
 #pragma unroll
-      for (int j = 0; j < SRC_PER_WAVE; ++j) {
+      for (int j = 0; j < SRC_MAX; ++j) {
         const int i = pw + PW * j;
-        const int sl = i * RPW + g;
-        const int chunk = ((((gl >> 1) ^ ring_swz(sl)) << 1) | (gl & 1));   // 32-byte segments XOR-swizzled by the slot
-        ring_dma16(X + (int64_t)src[j] * a.ldx + chunk * VEC, smem + L::oSrc + st * L::kSrc + i * (RPW * ROWB));
+        if (i < n_inst) {                           // wave-uniform
+          const int sl = i * RPW + g;
+          const int chunk = ((((gl >> 1) ^ ring_swz(sl)) << 1) | (gl & 1));   // 32-byte segments XOR-swizzled by the slot
+          ring_dma16(X + (int64_t)src[j] * a.ldx + chunk * VEC, stage + i * (RPW * ROWB));
+          ++issued;
+        }
       }
+      // the slots of the last MFMA step behind the list: zeros (stale rows of an earlier tile must not meet a zero weight
+      // as Inf / NaN far from where they came from)
+      const int kend = nu > 48 ? kRingSlots : nu > 32 ? 48 : nu > 0 ? 32 : 0;
+      for (int o = n_inst * RPW * ROWB + ptid * 16; o < kend * ROWB; o += PW * 64 * 16) *(u32x4*)(stage + o) = u32x4{0u, 0u, 0u, 0u};
       if (NEPI >= 1) {
 #pragma unroll
         for (int j = 0; j < EPI_PER_WAVE; ++j) {
           const int i = pw + PW * j;
           const int lr = i * RPW + g;
           const int chunk = gl ^ (lr & 15);                                 // 16-byte chunks XOR-swizzled by the row
-          ring_dma16(X0 + (int64_t)erow[j] * a.ldx0 + chunk * VEC, smem + L::oEpi + (st * NEPI + 0) * L::kEpi + i * (RPW * ROWB));
-          if (NEPI >= 2)
-            ring_dma16(X1 + (int64_t)erow[j] * a.ldx1 + chunk * VEC, smem + L::oEpi + (st * NEPI + 1) * L::kEpi + i * (RPW * ROWB));
+          ring_dma16(X0 + (int64_t)erow[j] * a.ldx0 + chunk * VEC, stage + L::oEpi + i * (RPW * ROWB));
+          if (NEPI >= 2) ring_dma16(X1 + (int64_t)erow[j] * a.ldx1 + chunk * VEC, stage + L::oEpi + L::kEpi + i * (RPW * ROWB));
         }
+        issued += NEPI * EPI_PER_WAVE;
       }
       // weight matrix: thread (row, u) owns the u-th neighbour of the row; fp32 weight = hi + mid + lo in bf16 (exact)
-      uint8_t* Ab = smem + L::oA + st * L::kA;
+      uint8_t* Ab = stage + L::oA;
       const int old = (a_slots >> (6 * st)) & 63;
       if (old != 63) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) *(uint16_t*)(Ab + p * kRingAPiece + ar * kRingARow + old * 2) = 0;
       }
       int sl = 63;
-      if (au < deg && !(flags & (1 << 19))) {
+      if (au < deg) {
         sl = sl_new;
         const uint32_t hi = __float_as_uint(w) & 0xffff0000u;
         const float r1 = w - __uint_as_float(hi);
@@ -914,31 +943,49 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
         *(uint16_t*)(Ab + 2 * kRingAPiece + off) = (uint16_t)(__float_as_uint(r2) >> 16);
       }
       a_slots = (a_slots & ~(63u << (6 * st))) | ((uint32_t)sl << (6 * st));
+      return issued;
     };
 
     // prologue: the records of the first 2D - 2 tiles, then the rows of the first D - 1
     for (int k = 0; k < 2 * D - 2; ++k) issue_meta(tile_of(k), k);
     ring_wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                   // (P0) among the producers only in effect: consumers wait at it too
+    __builtin_amdgcn_s_barrier();                   // (P0) the consumers wait at it too
     asm volatile("" ::: "memory");
-    for (int k = 0; k < D - 1; ++k) issue_tile(k, k);
+    int inflight[D];                                // DMA instructions of the iterations i - D + 2 .. i - 1, oldest first
+#pragma unroll
+    for (int k = 0; k < D; ++k) inflight[k] = 0;
+    for (int k = 0; k < D - 1; ++k) (void)issue_tile(k, k);
     asm volatile("" ::: "memory");
     int st = 0, rs = 0;                             // stage and record slot of tile i
     for (int i = 0; i < n_my; ++i) {
       // the rows, operands and weights of tile i and the record of tile i + D - 1 have landed (this wavefront's share):
-      // everything issued up to iteration i - D + 1; the (D - 2) * PER younger DMA instructions may fly
-      if (i == 0) ring_wait_vm<0>();
-      else ring_wait_vm<(D - 2) * PER>();
+      // everything issued up to iteration i - D + 1; the DMA instructions of the D - 2 iterations after it may fly
+      if (i == 0) {
+        ring_wait_vm<0>();
+      } else {
+        int allowed = 0;
+#pragma unroll
+        for (int k = 0; k < D - 2; ++k) allowed += inflight[k];
+        ring_wait_vm_n(allowed);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                 // tile i is ready for the consumers; they are done with tile i - 1
       asm volatile("" ::: "memory");
       const int st_n = st == 0 ? D - 1 : st - 1;                  // (i + D - 1) % D
       const int rs_n = rs + D - 1 >= L::NREC ? rs + D - 1 - L::NREC : rs + D - 1;
       const int rs_m = rs == 0 ? L::NREC - 1 : rs - 1;            // (i + 2D - 2) % (2D - 1)
-      issue_tile(rs_n, st_n);
+      const int cnt = issue_tile(rs_n, st_n) + 1;
       issue_meta(tile_of(i + 2 * D - 2), rs_m);
+#pragma unroll
+      for (int k = D - 2; k > 0; --k) inflight[k] = inflight[k - 1];       // [0] = the youngest iteration
+      inflight[0] = cnt;
       asm volatile("" ::: "memory");
+      if (ROWST) {                                  // the consumers' output tile is complete in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
       st = st + 1 == D ? 0 : st + 1;
       rs = rs + 1 == L::NREC ? 0 : rs + 1;
     }
@@ -961,12 +1008,17 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const uint8_t* rec = smem + L::oRec + rs * kRecBytes;
+    uint8_t* stage = smem + st * L::kStage;
     const int nu = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNu));
     const int nrows = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNrows));
     const float sd = ((const float*)(rec + kRecSd))[m];
     const int row = ((const int32_t*)(rec + kRecRow))[m];
     float v[8];
     if (flags & (1 << 20)) {
+      if (ROWST) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       st = st + 1 == D ? 0 : st + 1;
       rs = rs + 1 == L::NREC ? 0 : rs + 1;
       continue;
@@ -976,8 +1028,8 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
       for (int c = 0; c < 8; ++c) v[c] = 0.f;
     } else if (nu > 0) {
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      const uint8_t* Ab = smem + L::oA + st * L::kA;
-      const uint32_t xs = lds0 + L::oSrc + st * L::kSrc;
+      const uint8_t* Ab = stage + L::oA;
+      const uint32_t xs = lds0 + st * L::kStage;
       {   // slots 0 .. 31
         ring_bf16x8 wf[3];
 #pragma unroll
@@ -1000,23 +1052,25 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
             acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf[p], acc[nb], 0, 0, 0);
           }
       }
-      if (nu > 32) {   // slots 32 .. 47
-        ring_s16x4 wf[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wf[p] = *(const ring_s16x4*)(Ab + p * kRingAPiece + m * kRingARow + 64 + fg * 8);
-        ring_s16x4 h[2];
-        const int sw = fq | (((fg >> 1) & 1) << 2);
+      for (int ks = 0; ks < 2; ++ks)
+        if (nu > 32 + 16 * ks) {   // slots 32 .. 47, 48 .. 63 (the rows behind slot kRingSlots - 1 are weight pieces: finite, weight 0)
+          ring_s16x4 wf[3];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const uint32_t addr = xs + (uint32_t)((32 + 4 * fg + fq) * ROWB + (((wave * 2 + nb) ^ sw) << 5) + fp * 8);
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[nb]) : "v"(addr) : "memory");
+          for (int p = 0; p < 3; ++p) wf[p] = *(const ring_s16x4*)(Ab + p * kRingAPiece + m * kRingARow + 64 + 32 * ks + fg * 8);
+          ring_s16x4 h[2];
+          const int sw = fq | (((fg >> 1) & 1) << 2);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const uint32_t addr = xs + (uint32_t)((32 + 16 * ks + 4 * fg + fq) * ROWB + (((wave * 2 + nb) ^ sw) << 5) + fp * 8);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[nb]) : "v"(addr) : "memory");
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1])::"memory");
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h[nb], wf[p], acc[nb], 0, 0, 0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1])::"memory");
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h[nb], wf[p], acc[nb], 0, 0, 0);
-      }
       // a lane holds 4 channels of row m per block; one exchange per value with the neighbouring 16-lane row -> 8
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -1043,38 +1097,57 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
 #pragma unroll
     for (int c = 0; c < VEC; ++c) y[c] = sdst * v[c];
     if (NEPI >= 1) {
-      const raw_t x0v = *(const raw_t*)(smem + L::oEpi + (st * NEPI + 0) * L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
+      const raw_t x0v = *(const raw_t*)(stage + L::oEpi + m * ROWB + (((col >> 3) ^ m) << 4));
       float f[VEC];
       V::unpack(x0v, f);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
     }
     if (NEPI >= 2) {
-      const raw_t x1v = *(const raw_t*)(smem + L::oEpi + (st * NEPI + 1) * L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
+      const raw_t x1v = *(const raw_t*)(stage + L::oEpi + L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
       float f[VEC];
       V::unpack(x1v, f);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
     }
-    if (m < nrows && !((flags & (1 << 18)) && y[0] != 12345.f)) *(raw_t*)(Y + (int64_t)row * a.ldy + col) = V::pack(y);
+    if (ROWST) {
+      // through LDS to FULL-ROW stores (a wavefront's MFMA result is 16 rows x 64 bytes: half a cache line per row and
+      // request): the tile is put where its first epilogue operand was (each lane overwrites exactly what it read)
+      uint8_t* stg = NEPI >= 1 ? stage + L::oEpi : smem + L::oStg;
+      *(raw_t*)(stg + m * ROWB + (((col >> 3) ^ m) << 4)) = V::pack(y);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int lr = wave * RPW + lane / G, gl = lane % G;
+      const raw_t out = *(const raw_t*)(stg + lr * ROWB + ((gl ^ (lr & 15)) << 4));
+      const int orow = ((const int32_t*)(rec + kRecRow))[lr];
+      if (lr < nrows && !((flags & (1 << 18)) && out[0] != 12345u)) *(raw_t*)(Y + (int64_t)orow * a.ldy + gl * VEC) = out;
+    } else {
+      if (m < nrows && !((flags & (1 << 18)) && y[0] != 12345.f)) *(raw_t*)(Y + (int64_t)row * a.ldy + col) = V::pack(y);
+    }
     st = st + 1 == D ? 0 : st + 1;
     rs = rs + 1 == L::NREC ? 0 : rs + 1;
   }
   (void)flags;
 }
 
-template <int NBW, int NEPI, int D>
-int launch_ring_d(const SpmmArgs& b, hipStream_t stream) {
-  constexpr int lds = RingLds<128 * NBW, NEPI, D>::total;
+template <int NBW, int NEPI, int D, bool ROWST>
+int launch_ring_ds(const SpmmArgs& b, hipStream_t stream) {
+  constexpr int lds = RingLds<128 * NBW, NEPI, D, ROWST>::total;
   static_assert(lds <= 160 * 1024, "LDS budget");
   int per_cu = (160 * 1024) / lds;
   per_cu = per_cu > 4 ? 4 : per_cu;
   int64_t nb = (int64_t)per_cu * 256;
   if (nb > b.lt_nrec) nb = b.lt_nrec;
   nb = (nb + 7) / 8 * 8;
-  spmm_ring<NBW, NEPI, D><<<(int)nb, 128 * NBW + 256, 0, stream>>>(b, b.lt_nrec, g_tuning.flags);
+  spmm_ring<NBW, NEPI, D, ROWST><<<(int)nb, 128 * NBW + 256, 0, stream>>>(b, b.lt_nrec, g_tuning.flags);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
+}
+template <int NBW, int NEPI, int D>
+int launch_ring_d(const SpmmArgs& b, hipStream_t stream) {
+  if (g_tuning.flags & kFlagRingRowStores) return launch_ring_ds<NBW, NEPI, D, true>(b, stream);
+  return launch_ring_ds<NBW, NEPI, D, false>(b, stream);
 }
 
 template <int NBW>
@@ -1083,14 +1156,15 @@ int launch_ring(const SpmmArgs& a, hipStream_t stream) {
   if (!a.X0 && a.X1) { b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f; }
   const int nepi = (b.X0 ? 1 : 0) + (b.X1 ? 1 : 0);
   const int d = g_tuning.unroll;                     // A/B: ring depth (0 = default)
-  if (NBW == 4) {                                    // 256 channels: one workgroup per CU
+  if constexpr (NBW == 4) {                          // 256 channels: one workgroup per CU, 3 - 4 stages of 34 - 51 KB
     if (nepi == 2) return d == 2 ? launch_ring_d<NBW, 2, 2>(b, stream) : launch_ring_d<NBW, 2, 3>(b, stream);
-    if (nepi == 1) return d == 2 ? launch_ring_d<NBW, 1, 2>(b, stream) : d == 3 ? launch_ring_d<NBW, 1, 3>(b, stream) : launch_ring_d<NBW, 1, 4>(b, stream);
-    return d == 2 ? launch_ring_d<NBW, 0, 2>(b, stream) : d == 3 ? launch_ring_d<NBW, 0, 3>(b, stream) : d == 4 ? launch_ring_d<NBW, 0, 4>(b, stream) : launch_ring_d<NBW, 0, 5>(b, stream);
+    if (nepi == 1) return d == 2 ? launch_ring_d<NBW, 1, 2>(b, stream) : launch_ring_d<NBW, 1, 3>(b, stream);
+    return d == 2 ? launch_ring_d<NBW, 0, 2>(b, stream) : d == 3 ? launch_ring_d<NBW, 0, 3>(b, stream) : launch_ring_d<NBW, 0, 4>(b, stream);
+  } else {                                           // 128 channels: two workgroups per CU
+    if (nepi == 2) return d == 2 ? launch_ring_d<NBW, 2, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 2, 4>(b, stream) : launch_ring_d<NBW, 2, 3>(b, stream);
+    if (nepi == 1) return d == 2 ? launch_ring_d<NBW, 1, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 1, 4>(b, stream) : launch_ring_d<NBW, 1, 3>(b, stream);
+    return d == 2 ? launch_ring_d<NBW, 0, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 0, 4>(b, stream) : launch_ring_d<NBW, 0, 3>(b, stream);
   }
-  if (nepi == 2) return d == 2 ? launch_ring_d<NBW, 2, 2>(b, stream) : launch_ring_d<NBW, 2, 3>(b, stream);
-  if (nepi == 1) return d == 2 ? launch_ring_d<NBW, 1, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 1, 4>(b, stream) : launch_ring_d<NBW, 1, 3>(b, stream);
-  return d == 2 ? launch_ring_d<NBW, 0, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 0, 4>(b, stream) : launch_ring_d<NBW, 0, 3>(b, stream);
 }
 
 // Any C, any stride, any alignment: one thread per output element, lanes along the channel.
