@@ -90,7 +90,7 @@ constexpr int kRecNrows = kRecR0 + 4;
 constexpr int kRecSd = kRecNrows + 4;
 constexpr int kRecRow = kRecSd + 4 * kLdsRows;
 constexpr int kRecW = kRecRow + 4 * kLdsRows;
-constexpr int kRecBytes = 1024;   // padded: every wavefront of the kernel fetches an equal share
+constexpr int kRecBytes = 896;    // padded to whole 128-byte lines: every producer wavefront of the kernel fetches an equal share
 static_assert(kRecW + 4 * kRingSlots <= kRecBytes && kRecSd % 16 == 0, "tile record layout");
 int build_tiles(Csr* c, hipStream_t stream);
 // Fills Csr::idx_w (and tile_uniq_w when the CSR carries tiles) for the source scale vector `scale` [n_cols].

@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32,
-             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512, kFlagNoRing = 2048, kFlagRingRowStores = 4096 };
+             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512, kFlagNoRing = 2048, kFlagRingDirectStores = 4096 };
 
 // Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
 // one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
@@ -785,19 +785,26 @@ typedef __attribute__((ext_vector_type(8))) __bf16 ring_bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 ring_bf16x4;
 typedef __attribute__((ext_vector_type(4))) short ring_s16x4;
 
-template <int ROWB, int NEPI, int D, bool ROWST = false>
+// MODE: how the finished tile leaves.  0: straight from the MFMA layout (16 rows x 64 bytes per store instruction: half a cache
+// line per row and request).  2: through one of two LDS buffers as FULL ROWS; the stores are issued behind the NEXT tile's
+// barrier (no barrier of their own).  Measured at 256 channels: 2 is 1.5 - 2.5 % faster with <= 1 epilogue operand; with
+// two there is no LDS left for it.  (A variant with one more barrier per tile and the tile staged in place of its first
+// epilogue operand was level with 2; two instead of three weight pieces bought nothing: the MFMAs are not the bound.)
+constexpr int kRingPieces = 3;                       // the fp32 weights enter the MFMA as hi + mid + lo bf16 pieces: exact
+template <int ROWB, int NEPI, int D, int MODE>
 struct RingLds {
-  static constexpr int NREC = 2 * D - 1;
+  static constexpr int NP = kRingPieces;
+  static constexpr int NREC = 2 * D;
   static constexpr int kSrc = kRingSlots * ROWB;         // source rows of one stage
-  static constexpr int kA = 3 * kRingAPiece;             // the three weight pieces of one stage; directly BEHIND the source rows:
+  static constexpr int kA = NP * kRingAPiece;            // the weight pieces of one stage; directly BEHIND the source rows:
                                                          // the last MFMA step reads 64 - kRingSlots "rows" of it (finite, weight 0)
   static constexpr int kEpi = kLdsRows * ROWB;           // one epilogue operand of one stage
   static constexpr int kStage = kSrc + kA + NEPI * kEpi;
   static constexpr int oA = kSrc;                        // inside a stage
   static constexpr int oEpi = kSrc + kA;
   static constexpr int oRec = D * kStage;                // [NREC][kRecBytes]
-  static constexpr int oStg = oRec + NREC * kRecBytes;   // output tile on its way to full-row stores (without an epilogue operand to overwrite)
-  static constexpr int total = oStg + (ROWST && NEPI == 0 ? kLdsRows * ROWB : 0);
+  static constexpr int oStg = oRec + NREC * kRecBytes;   // output tiles on their way to full-row stores
+  static constexpr int total = oStg + (MODE == 2 ? 2 : 0) * kLdsRows * ROWB;
   static_assert((64 - kRingSlots) * ROWB <= kA, "the rows the last MFMA step reads behind the source slots lie in the weight pieces");
 };
 
@@ -819,9 +826,15 @@ __device__ __forceinline__ void ring_wait_vm_n(int n) {
     default: ring_wait_vm<0>(); break;
   }
 }
+#define SG_RING_BARRIER()                                   \
+  do {                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                           \
+    asm volatile("" ::: "memory");                          \
+  } while (0)
 
-template <int NBW, int NEPI, int D, bool ROWST>
-__global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, const int nt, const int flags) {
+template <int NBW, int NEPI, int D, int MODE>
+__global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, const int nt) {
   using V = Vt<bf16_tag>;
   constexpr int VEC = 8;
   constexpr int CW = 2 * NBW;                       // consumer wavefronts: each owns two 16-channel blocks
@@ -834,9 +847,11 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
   constexpr int EPI_PER_WAVE = kLdsRows / RPW / PW;
   constexpr int FIXED = NEPI * EPI_PER_WAVE + 1;    // operand rows + record share: DMA instructions per producer and tile
   static_assert(NBW == 2 || NBW == 4, "128 or 256 channels");
-  static_assert(EPI_PER_WAVE * RPW * PW == kLdsRows, "equal DMA shares");
+  static_assert(EPI_PER_WAVE * RPW * PW == kLdsRows && CW * RPW == kLdsRows, "equal shares");
   static_assert((D - 2) * (SRC_MAX + FIXED) <= 32 && D >= 2 && D <= 5, "vmcnt switch range");
-  using L = RingLds<ROWB, NEPI, D, ROWST>;
+  constexpr int NP = kRingPieces;
+  static_assert(MODE == 0 || MODE == 2, "store modes");
+  using L = RingLds<ROWB, NEPI, D, MODE>;
   using raw_t = typename V::raw;
   using elem_t = typename V::elem;
 
@@ -860,9 +875,7 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
 
   // the weight pieces start as zeros (only the nonzeros are ever written and taken back); so do the source slots
   for (int o = tid * 16; o < D * L::kStage; o += (CW + PW) * 64 * 16) *(u32x4*)(smem + o) = u32x4{0u, 0u, 0u, 0u};
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  SG_RING_BARRIER();
 
   if (wave >= CW) {
     // =============================== producers: DMA + weight matrices, D - 1 tiles ahead ===============================
@@ -876,27 +889,26 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
       if (lane < LPW)
         ring_dma16(a.lt_rec + (int64_t)tile * kRecBytes + (pw * LPW + lane) * 16, smem + L::oRec + slot * kRecBytes + pw * LPW * 16);
     };
-    uint32_t a_slots = 0xffffffffu;                 // 6 bits per stage: the slot this thread's weight went to (63: none)
-    // everything the reduction of the tile in record `slot` reads -> stage st; returns the DMA instructions issued
-    auto issue_tile = [&](int slot, int st) -> int {
+    // what the DMA of a tile needs from its record, fetched ONE ITERATION EARLY so that the DMA starts right behind the barrier
+    int f_nu, f_src[SRC_MAX], f_erow[EPI_PER_WAVE];
+    auto fetch = [&](int slot) {
       const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
-      uint8_t* stage = smem + st * L::kStage;
-      const int nu = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNu));
-      const int n_inst = (flags & (1 << 17)) ? 0 : (nu + RPW - 1) / RPW;
-      int src[SRC_MAX], erow[EPI_PER_WAVE];
+      f_nu = *(const int32_t*)(rec + kRecNu);
 #pragma unroll
       for (int j = 0; j < SRC_MAX; ++j) {
         const int sl = (pw + PW * j) * RPW + g;
-        src[j] = ((const int32_t*)(rec + kRecSrc))[sl < kRingSlots ? sl : kRingSlots - 1];   // padded with the last source
+        f_src[j] = ((const int32_t*)(rec + kRecSrc))[sl < kRingSlots ? sl : kRingSlots - 1];   // padded with the last source
       }
-      if (NEPI >= 1) {
 #pragma unroll
-        for (int j = 0; j < EPI_PER_WAVE; ++j) erow[j] = ((const int32_t*)(rec + kRecRow))[(pw + PW * j) * RPW + g];
-      }
-      const int ar = ptid >> 4, au = ptid & 15;
-      const int deg = rec[kRecDeg + ar];
-      const int sl_new = rec[kRecSlot + ptid] & 63;
-      const float w = ((const float*)(rec + kRecW))[sl_new < kRingSlots ? sl_new : 0];
+      for (int j = 0; j < EPI_PER_WAVE; ++j) f_erow[j] = ((const int32_t*)(rec + kRecRow))[(pw + PW * j) * RPW + g];
+    };
+    uint32_t a_slots = 0xffffffffu;                 // 6 bits per stage: the slot this thread's weight went to (63: none)
+    // everything the reduction of the tile in record `slot` (fetched) reads -> stage st; returns the DMA instructions issued
+    auto issue_tile = [&](int slot, int st) -> int {
+      const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
+      uint8_t* stage = smem + st * L::kStage;
+      const int nu = __builtin_amdgcn_readfirstlane(f_nu);
+      const int n_inst = (nu + RPW - 1) / RPW;
       int issued = 0;
 #pragma unroll
       for (int j = 0; j < SRC_MAX; ++j) {
@@ -904,31 +916,35 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
         if (i < n_inst) {                           // wave-uniform
           const int sl = i * RPW + g;
           const int chunk = ((((gl >> 1) ^ ring_swz(sl)) << 1) | (gl & 1));   // 32-byte segments XOR-swizzled by the slot
-          ring_dma16(X + (int64_t)src[j] * a.ldx + chunk * VEC, stage + i * (RPW * ROWB));
+          ring_dma16(X + (int64_t)f_src[j] * a.ldx + chunk * VEC, stage + i * (RPW * ROWB));
           ++issued;
         }
       }
-      // the slots of the last MFMA step behind the list: zeros (stale rows of an earlier tile must not meet a zero weight
-      // as Inf / NaN far from where they came from)
-      const int kend = nu > 48 ? kRingSlots : nu > 32 ? 48 : nu > 0 ? 32 : 0;
-      for (int o = n_inst * RPW * ROWB + ptid * 16; o < kend * ROWB; o += PW * 64 * 16) *(u32x4*)(stage + o) = u32x4{0u, 0u, 0u, 0u};
       if (NEPI >= 1) {
 #pragma unroll
         for (int j = 0; j < EPI_PER_WAVE; ++j) {
           const int i = pw + PW * j;
           const int lr = i * RPW + g;
           const int chunk = gl ^ (lr & 15);                                 // 16-byte chunks XOR-swizzled by the row
-          ring_dma16(X0 + (int64_t)erow[j] * a.ldx0 + chunk * VEC, stage + L::oEpi + i * (RPW * ROWB));
-          if (NEPI >= 2) ring_dma16(X1 + (int64_t)erow[j] * a.ldx1 + chunk * VEC, stage + L::oEpi + L::kEpi + i * (RPW * ROWB));
+          ring_dma16(X0 + (int64_t)f_erow[j] * a.ldx0 + chunk * VEC, stage + L::oEpi + i * (RPW * ROWB));
+          if (NEPI >= 2) ring_dma16(X1 + (int64_t)f_erow[j] * a.ldx1 + chunk * VEC, stage + L::oEpi + L::kEpi + i * (RPW * ROWB));
         }
         issued += NEPI * EPI_PER_WAVE;
       }
-      // weight matrix: thread (row, u) owns the u-th neighbour of the row; fp32 weight = hi + mid + lo in bf16 (exact)
+      // the slots of the last MFMA step behind the list: zeros (stale rows of an earlier tile must not meet a zero weight
+      // as Inf / NaN far from where they came from)
+      const int kend = nu > 48 ? kRingSlots : nu > 32 ? 48 : nu > 0 ? 32 : 0;
+      for (int o = ((nu + RPW - 1) / RPW) * RPW * ROWB + ptid * 16; o < kend * ROWB; o += PW * 64 * 16) *(u32x4*)(stage + o) = u32x4{0u, 0u, 0u, 0u};
+      // weight matrix: thread (row, u) owns the u-th neighbour of the row; fp32 weight = hi + mid (+ lo) in bf16
+      const int ar = ptid >> 4, au = ptid & 15;
+      const int deg = rec[kRecDeg + ar];
+      const int sl_new = rec[kRecSlot + ptid] & 63;
+      const float w = ((const float*)(rec + kRecW))[sl_new < kRingSlots ? sl_new : 0];
       uint8_t* Ab = stage + L::oA;
       const int old = (a_slots >> (6 * st)) & 63;
       if (old != 63) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *(uint16_t*)(Ab + p * kRingAPiece + ar * kRingARow + old * 2) = 0;
+        for (int p = 0; p < NP; ++p) *(uint16_t*)(Ab + p * kRingAPiece + ar * kRingARow + old * 2) = 0;
       }
       int sl = 63;
       if (au < deg) {
@@ -936,30 +952,32 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
         const uint32_t hi = __float_as_uint(w) & 0xffff0000u;
         const float r1 = w - __uint_as_float(hi);
         const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(mid);
         const int off = ar * kRingARow + sl * 2;
         *(uint16_t*)(Ab + 0 * kRingAPiece + off) = (uint16_t)(hi >> 16);
         *(uint16_t*)(Ab + 1 * kRingAPiece + off) = (uint16_t)(mid >> 16);
+        const float r2 = r1 - __uint_as_float(mid);
         *(uint16_t*)(Ab + 2 * kRingAPiece + off) = (uint16_t)(__float_as_uint(r2) >> 16);
       }
       a_slots = (a_slots & ~(63u << (6 * st))) | ((uint32_t)sl << (6 * st));
       return issued;
     };
 
-    // prologue: the records of the first 2D - 2 tiles, then the rows of the first D - 1
-    for (int k = 0; k < 2 * D - 2; ++k) issue_meta(tile_of(k), k);
+    // prologue: the records of the first 2D - 1 tiles, then the rows of the first D - 1
+    for (int k = 0; k < 2 * D - 1; ++k) issue_meta(tile_of(k), k);
     ring_wait_vm<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                   // (P0) the consumers wait at it too
-    asm volatile("" ::: "memory");
-    int inflight[D];                                // DMA instructions of the iterations i - D + 2 .. i - 1, oldest first
+    SG_RING_BARRIER();                              // (P0) the consumers wait at it too
+    int inflight[D];                                // DMA instructions of the iterations i - 1, i - 2, ..
 #pragma unroll
     for (int k = 0; k < D; ++k) inflight[k] = 0;
-    for (int k = 0; k < D - 1; ++k) (void)issue_tile(k, k);
+    for (int k = 0; k < D - 1; ++k) {
+      fetch(k);
+      (void)issue_tile(k, k);
+    }
+    fetch(D - 1);
     asm volatile("" ::: "memory");
     int st = 0, rs = 0;                             // stage and record slot of tile i
     for (int i = 0; i < n_my; ++i) {
-      // the rows, operands and weights of tile i and the record of tile i + D - 1 have landed (this wavefront's share):
+      // the rows, operands and weights of tile i and the record of tile i + D have landed (this wavefront's share):
       // everything issued up to iteration i - D + 1; the DMA instructions of the D - 2 iterations after it may fly
       if (i == 0) {
         ring_wait_vm<0>();
@@ -969,26 +987,22 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
         for (int k = 0; k < D - 2; ++k) allowed += inflight[k];
         ring_wait_vm_n(allowed);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                 // tile i is ready for the consumers; they are done with tile i - 1
-      asm volatile("" ::: "memory");
+      SG_RING_BARRIER();                            // tile i is ready for the consumers; they are done with tile i - 1
       const int st_n = st == 0 ? D - 1 : st - 1;                  // (i + D - 1) % D
       const int rs_n = rs + D - 1 >= L::NREC ? rs + D - 1 - L::NREC : rs + D - 1;
-      const int rs_m = rs == 0 ? L::NREC - 1 : rs - 1;            // (i + 2D - 2) % (2D - 1)
+      const int rs_f = rs + D >= L::NREC ? rs + D - L::NREC : rs + D;
+      const int rs_m = rs == 0 ? L::NREC - 1 : rs - 1;            // (i + 2D - 1) % 2D
       const int cnt = issue_tile(rs_n, st_n) + 1;
-      issue_meta(tile_of(i + 2 * D - 2), rs_m);
+      issue_meta(tile_of(i + 2 * D - 1), rs_m);
+      fetch(rs_f);
 #pragma unroll
       for (int k = D - 2; k > 0; --k) inflight[k] = inflight[k - 1];       // [0] = the youngest iteration
       inflight[0] = cnt;
       asm volatile("" ::: "memory");
-      if (ROWST) {                                  // the consumers' output tile is complete in LDS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
       st = st + 1 == D ? 0 : st + 1;
       rs = rs + 1 == L::NREC ? 0 : rs + 1;
     }
+    if (MODE == 2) SG_RING_BARRIER();               // the last output tile is complete in LDS
     ring_wait_vm<0>();                              // no LDS-DMA may be in flight when the workgroup ends
     return;
   }
@@ -999,78 +1013,103 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
   const int m = lane & 15, fg = lane >> 4;          // MFMA: tile row (operand / result column), k group
   const int fq = (lane >> 2) & 3, fp = lane & 3;    // transposing reads: row and 8-byte column quad a lane SUPPLIES
   const int col = wave * 32 + (fg & 1) * 16 + (fg >> 1) * 8;     // this lane's 8 consecutive channels of row m
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                     // (P0)
-  asm volatile("" ::: "memory");
+  const int olr = wave * RPW + lane / G, ogl = lane % G;          // full-row stores: row of the tile, 16-byte chunk
+  SG_RING_BARRIER();                                // (P0): the first records are there
+  // the record fields of a tile are read one iteration early
+  int c_nu, c_nrows, c_row, c_orow;
+  float c_sd;
+  auto fetch = [&](int slot) {
+    const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
+    c_nu = *(const int32_t*)(rec + kRecNu);
+    c_nrows = *(const int32_t*)(rec + kRecNrows);
+    c_sd = ((const float*)(rec + kRecSd))[m];
+    c_row = ((const int32_t*)(rec + kRecRow))[m];
+    c_orow = ((const int32_t*)(rec + kRecRow))[olr];
+  };
+  fetch(0);
   int st = 0, rs = 0;
+  int p_nrows = 0, p_orow = 0;                      // MODE 2: the tile whose stores are still to be issued
   for (int i = 0; i < n_my; ++i) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    SG_RING_BARRIER();
     const uint8_t* rec = smem + L::oRec + rs * kRecBytes;
     uint8_t* stage = smem + st * L::kStage;
-    const int nu = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNu));
-    const int nrows = __builtin_amdgcn_readfirstlane(*(const int32_t*)(rec + kRecNrows));
-    const float sd = ((const float*)(rec + kRecSd))[m];
-    const int row = ((const int32_t*)(rec + kRecRow))[m];
-    float v[8];
-    if (flags & (1 << 20)) {
-      if (ROWST) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      st = st + 1 == D ? 0 : st + 1;
-      rs = rs + 1 == L::NREC ? 0 : rs + 1;
-      continue;
+    const int nu = __builtin_amdgcn_readfirstlane(c_nu);
+    const int nrows = __builtin_amdgcn_readfirstlane(c_nrows);
+    const float sd = c_sd;
+    const int row = c_row, orow = c_orow;
+    // ---- every LDS read of this iteration is issued here, in one batch ----
+    raw_t out_prev = raw_t{0u, 0u, 0u, 0u};
+    if (MODE == 2) out_prev = *(const raw_t*)(smem + L::oStg + ((i + 1) & 1) * (kLdsRows * ROWB) + olr * ROWB + ((ogl ^ (olr & 15)) << 4));
+    const uint8_t* Ab = stage + L::oA;
+    ring_bf16x8 wf0[NP];
+    ring_s16x4 wf1[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      wf0[p] = *(const ring_bf16x8*)(Ab + p * kRingAPiece + m * kRingARow + fg * 16);
+      wf1[p] = *(const ring_s16x4*)(Ab + p * kRingAPiece + m * kRingARow + 64 + fg * 8);
     }
-    if (flags & (1 << 16)) {
+    raw_t x0v = raw_t{0u, 0u, 0u, 0u}, x1v = raw_t{0u, 0u, 0u, 0u};
+    if (NEPI >= 1) x0v = *(const raw_t*)(stage + L::oEpi + m * ROWB + (((col >> 3) ^ m) << 4));
+    if (NEPI >= 2) x1v = *(const raw_t*)(stage + L::oEpi + L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
+    fetch(rs + 1 == L::NREC ? 0 : rs + 1);          // (past the end: a copy of the last record)
+    const uint32_t xs = lds0 + st * L::kStage;
+    ring_bf16x4 h0[2][2];
+    ring_s16x4 h1[2];
+    {
+      const int sw = fq | ((fg & 1) << 2);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) v[c] = 0.f;
-    } else if (nu > 0) {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      const uint8_t* Ab = stage + L::oA;
-      const uint32_t xs = lds0 + st * L::kStage;
-      {   // slots 0 .. 31
-        ring_bf16x8 wf[3];
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wf[p] = *(const ring_bf16x8*)(Ab + p * kRingAPiece + m * kRingARow + fg * 16);
-        ring_bf16x4 h[2][2];
-        const int sw = fq | ((fg & 1) << 2);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const uint32_t addr = xs + (uint32_t)((8 * fg + 4 * hh + fq) * ROWB + (((wave * 2 + nb) ^ sw) << 5) + fp * 8);
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[nb][hh]) : "v"(addr) : "memory");
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0][0]), "+v"(h[0][1]), "+v"(h[1][0]), "+v"(h[1][1])::"memory");
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            const ring_bf16x8 xf = {h[nb][0][0], h[nb][0][1], h[nb][0][2], h[nb][0][3], h[nb][1][0], h[nb][1][1], h[nb][1][2], h[nb][1][3]};
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf[p], acc[nb], 0, 0, 0);
-          }
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        if (nu > 32 + 16 * ks) {   // slots 32 .. 47, 48 .. 63 (the rows behind slot kRingSlots - 1 are weight pieces: finite, weight 0)
-          ring_s16x4 wf[3];
-#pragma unroll
-          for (int p = 0; p < 3; ++p) wf[p] = *(const ring_s16x4*)(Ab + p * kRingAPiece + m * kRingARow + 64 + 32 * ks + fg * 8);
-          ring_s16x4 h[2];
-          const int sw = fq | (((fg >> 1) & 1) << 2);
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            const uint32_t addr = xs + (uint32_t)((32 + 16 * ks + 4 * fg + fq) * ROWB + (((wave * 2 + nb) ^ sw) << 5) + fp * 8);
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[nb]) : "v"(addr) : "memory");
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1])::"memory");
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h[nb], wf[p], acc[nb], 0, 0, 0);
+        for (int hh = 0; hh < 2; ++hh) {
+          const uint32_t addr = xs + (uint32_t)((8 * fg + 4 * hh + fq) * ROWB + (((wave * 2 + nb) ^ sw) << 5) + fp * 8);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h0[nb][hh]) : "v"(addr) : "memory");
         }
+      const int sw1 = fq | (((fg >> 1) & 1) << 2);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const uint32_t addr = xs + (uint32_t)((32 + 4 * fg + fq) * ROWB + (((wave * 2 + nb) ^ sw1) << 5) + fp * 8);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h1[nb]) : "v"(addr) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0[0][0]), "+v"(h0[0][1]), "+v"(h0[1][0]), "+v"(h0[1][1]), "+v"(h1[0]), "+v"(h1[1])::"memory");
+    if (MODE == 2) {                                // the previous tile leaves: full rows, 16 bytes per lane
+      if (olr < p_nrows) *(raw_t*)(Y + (int64_t)p_orow * a.ldy + ogl * VEC) = out_prev;
+      p_nrows = nrows;
+      p_orow = orow;
+    }
+    float v[8];
+    if (nu > 0) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int p = 0; p < NP; ++p)                  // slots 0 .. 31
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const ring_bf16x8 xf = {h0[nb][0][0], h0[nb][0][1], h0[nb][0][2], h0[nb][0][3], h0[nb][1][0], h0[nb][1][1], h0[nb][1][2], h0[nb][1][3]};
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf0[p], acc[nb], 0, 0, 0);
+        }
+      if (nu > 32) {                                // slots 32 .. 47
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h1[nb], wf1[p], acc[nb], 0, 0, 0);
+      }
+      if (nu > 48) {   // slots 48 .. 63 (the rows behind slot kRingSlots - 1 are weight pieces: finite, weight 0)
+        ring_s16x4 wf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) wf[p] = *(const ring_s16x4*)(Ab + p * kRingAPiece + m * kRingARow + 96 + fg * 8);
+        ring_s16x4 h[2];
+        const int sw = fq | (((fg >> 1) & 1) << 2);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const uint32_t addr = xs + (uint32_t)((48 + 4 * fg + fq) * ROWB + (((wave * 2 + nb) ^ sw) << 5) + fp * 8);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[nb]) : "v"(addr) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1])::"memory");
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h[nb], wf[p], acc[nb], 0, 0, 0);
+      }
       // a lane holds 4 channels of row m per block; one exchange per value with the neighbouring 16-lane row -> 8
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -1097,73 +1136,63 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
 #pragma unroll
     for (int c = 0; c < VEC; ++c) y[c] = sdst * v[c];
     if (NEPI >= 1) {
-      const raw_t x0v = *(const raw_t*)(stage + L::oEpi + m * ROWB + (((col >> 3) ^ m) << 4));
       float f[VEC];
       V::unpack(x0v, f);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.beta, f[c], y[c]);
     }
     if (NEPI >= 2) {
-      const raw_t x1v = *(const raw_t*)(stage + L::oEpi + L::kEpi + m * ROWB + (((col >> 3) ^ m) << 4));
       float f[VEC];
       V::unpack(x1v, f);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) y[c] = fmaf(a.gamma, f[c], y[c]);
     }
-    if (ROWST) {
-      // through LDS to FULL-ROW stores (a wavefront's MFMA result is 16 rows x 64 bytes: half a cache line per row and
-      // request): the tile is put where its first epilogue operand was (each lane overwrites exactly what it read)
-      uint8_t* stg = NEPI >= 1 ? stage + L::oEpi : smem + L::oStg;
-      *(raw_t*)(stg + m * ROWB + (((col >> 3) ^ m) << 4)) = V::pack(y);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int lr = wave * RPW + lane / G, gl = lane % G;
-      const raw_t out = *(const raw_t*)(stg + lr * ROWB + ((gl ^ (lr & 15)) << 4));
-      const int orow = ((const int32_t*)(rec + kRecRow))[lr];
-      if (lr < nrows && !((flags & (1 << 18)) && out[0] != 12345u)) *(raw_t*)(Y + (int64_t)orow * a.ldy + gl * VEC) = out;
+    if (MODE == 0) {
+      if (m < nrows) *(raw_t*)(Y + (int64_t)row * a.ldy + col) = V::pack(y);
     } else {
-      if (m < nrows && !((flags & (1 << 18)) && y[0] != 12345.f)) *(raw_t*)(Y + (int64_t)row * a.ldy + col) = V::pack(y);
+      *(raw_t*)(smem + L::oStg + (i & 1) * (kLdsRows * ROWB) + m * ROWB + (((col >> 3) ^ m) << 4)) = V::pack(y);
     }
     st = st + 1 == D ? 0 : st + 1;
     rs = rs + 1 == L::NREC ? 0 : rs + 1;
   }
-  (void)flags;
+  if (MODE == 2) {
+    SG_RING_BARRIER();
+    const raw_t out = *(const raw_t*)(smem + L::oStg + ((n_my + 1) & 1) * (kLdsRows * ROWB) + olr * ROWB + ((ogl ^ (olr & 15)) << 4));
+    if (olr < p_nrows) *(raw_t*)(Y + (int64_t)p_orow * a.ldy + ogl * VEC) = out;
+  }
 }
 
-template <int NBW, int NEPI, int D, bool ROWST>
-int launch_ring_ds(const SpmmArgs& b, hipStream_t stream) {
-  constexpr int lds = RingLds<128 * NBW, NEPI, D, ROWST>::total;
+template <int NBW, int NEPI, int D, int MODE>
+int launch_ring_k(const SpmmArgs& b, hipStream_t stream) {
+  constexpr int lds = RingLds<128 * NBW, NEPI, D, MODE>::total;
   static_assert(lds <= 160 * 1024, "LDS budget");
   int per_cu = (160 * 1024) / lds;
   per_cu = per_cu > 4 ? 4 : per_cu;
   int64_t nb = (int64_t)per_cu * 256;
   if (nb > b.lt_nrec) nb = b.lt_nrec;
   nb = (nb + 7) / 8 * 8;
-  spmm_ring<NBW, NEPI, D, ROWST><<<(int)nb, 128 * NBW + 256, 0, stream>>>(b, b.lt_nrec, g_tuning.flags);
+  spmm_ring<NBW, NEPI, D, MODE><<<(int)nb, 128 * NBW + 256, 0, stream>>>(b, b.lt_nrec);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
-template <int NBW, int NEPI, int D>
-int launch_ring_d(const SpmmArgs& b, hipStream_t stream) {
-  if (g_tuning.flags & kFlagRingRowStores) return launch_ring_ds<NBW, NEPI, D, true>(b, stream);
-  return launch_ring_ds<NBW, NEPI, D, false>(b, stream);
-}
 
+// Ring depth and store mode per shape (tools/agg_bench.py on the 1 M-vertex mesh; LDS decides most of it):
+//   256 channels: one workgroup (8 + 4 wavefronts) per CU, 3 stages of 35 / 43 / 51 KB; full-row stores while LDS lasts
+//   128 channels: two workgroups (4 + 4 wavefronts) per CU: 3 stages (2 with two epilogue operands), 76 / 80 / 61 KB
 template <int NBW>
 int launch_ring(const SpmmArgs& a, hipStream_t stream) {
   SpmmArgs b = a;
   if (!a.X0 && a.X1) { b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f; }
   const int nepi = (b.X0 ? 1 : 0) + (b.X1 ? 1 : 0);
-  const int d = g_tuning.unroll;                     // A/B: ring depth (0 = default)
-  if constexpr (NBW == 4) {                          // 256 channels: one workgroup per CU, 3 - 4 stages of 34 - 51 KB
-    if (nepi == 2) return d == 2 ? launch_ring_d<NBW, 2, 2>(b, stream) : launch_ring_d<NBW, 2, 3>(b, stream);
-    if (nepi == 1) return d == 2 ? launch_ring_d<NBW, 1, 2>(b, stream) : launch_ring_d<NBW, 1, 3>(b, stream);
-    return d == 2 ? launch_ring_d<NBW, 0, 2>(b, stream) : d == 3 ? launch_ring_d<NBW, 0, 3>(b, stream) : launch_ring_d<NBW, 0, 4>(b, stream);
-  } else {                                           // 128 channels: two workgroups per CU
-    if (nepi == 2) return d == 2 ? launch_ring_d<NBW, 2, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 2, 4>(b, stream) : launch_ring_d<NBW, 2, 3>(b, stream);
-    if (nepi == 1) return d == 2 ? launch_ring_d<NBW, 1, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 1, 4>(b, stream) : launch_ring_d<NBW, 1, 3>(b, stream);
-    return d == 2 ? launch_ring_d<NBW, 0, 2>(b, stream) : d == 4 ? launch_ring_d<NBW, 0, 4>(b, stream) : launch_ring_d<NBW, 0, 3>(b, stream);
+  const bool direct = (g_tuning.flags & kFlagRingDirectStores) != 0;       // A/B
+  if constexpr (NBW == 4) {
+    if (nepi == 2) return launch_ring_k<NBW, 2, 3, 0>(b, stream);
+    if (nepi == 1) return direct ? launch_ring_k<NBW, 1, 3, 0>(b, stream) : launch_ring_k<NBW, 1, 3, 2>(b, stream);
+    return direct ? launch_ring_k<NBW, 0, 3, 0>(b, stream) : launch_ring_k<NBW, 0, 3, 2>(b, stream);
+  } else {
+    if (nepi == 2) return launch_ring_k<NBW, 2, 2, 0>(b, stream);
+    if (nepi == 1) return launch_ring_k<NBW, 1, 3, 0>(b, stream);
+    return direct ? launch_ring_k<NBW, 0, 3, 0>(b, stream) : launch_ring_k<NBW, 0, 3, 2>(b, stream);
   }
 }
 

@@ -1529,19 +1529,20 @@ def _ring_graph(ei, V):
     return capi.GraphHandle.from_edge_index(ei, V)
 
 
-def _ring_and_rows(g, calls):
+def _ring_and_rows(g, calls, ring_flags=1):
     out = {}
-    for flags in (1 | NO_RING, 1):
+    for flags in (1 | NO_RING, ring_flags):
         capi.tuning_set(capi.TUNE_FLAGS, flags)
         try:
             out[flags] = [f() for f in calls]
         finally:
             capi.tuning_set(capi.TUNE_FLAGS, 1)
-    return out[1 | NO_RING], out[1]
+    return out[1 | NO_RING], out[ring_flags]
 
 
+@pytest.mark.parametrize("ring_flags", [1, 1 | 4096])   # how the tile leaves: full rows through LDS (default where LDS lasts) / direct
 @pytest.mark.parametrize("C", [128, 256])
-def test_ring_kernel_matches_the_rows_kernel_and_the_float64_oracle(C):
+def test_ring_kernel_matches_the_rows_kernel_and_the_float64_oracle(C, ring_flags):
     """spmm_ring (the default for bf16 rows of 128 / 256 channels; SG_TUNE_FLAGS bit 11 switches it off): a persistent workgroup pipelines LDS-DMA of each tile's distinct source rows under
     the reduction of the tile before, and reduces on the matrix cores (the tile's fp32 weights as three bf16 pieces:
     exact products, the MFMA's own accumulation order).  Against spmm_rows (sequential fma chain) the bf16 outputs may
@@ -1565,8 +1566,8 @@ def test_ring_kernel_matches_the_rows_kernel_and_the_float64_oracle(C):
         calls = [lambda: g.spmm(x, torch.empty((V, C), dtype=dtype, device=DEV)),
                  lambda: g.spmm(x, torch.empty((V, C), dtype=dtype, device=DEV), alpha=2.0, X0=x0, beta=-1.0),
                  lambda: g.spmm(x, torch.empty((V, C), dtype=dtype, device=DEV), alpha=1.0, X0=x0, beta=1.0, X1=x1, gamma=-1.0)]
-        rows, ring = _ring_and_rows(g, calls)
-        _, ring2 = _ring_and_rows(g, calls)
+        rows, ring = _ring_and_rows(g, calls, ring_flags)
+        _, ring2 = _ring_and_rows(g, calls, ring_flags)
         for a, b, b2 in zip(rows, ring, ring2):
             assert torch.equal(b, b2)                                       # deterministic
             d = (a.float() - b.float()).abs()
