@@ -99,7 +99,9 @@ SG_API int sg_graph_query(const sg_graph* g, sg_graph_info* info);
 /* 1 when sg_graph_create gave the graph a locality view: a symmetric graph whose vertex numbering has no locality (a
  * raw scan; the operator tier `from torch_geometric.nn import ChebConv`, util/networks.py:4, sees no positions to sort
  * by) has its ROWS processed in a graph-derived order (two levels of multi-source-BFS cells); column ids, and with them
- * X, X0, X1 and Y of sg_spmm, stay in the caller's numbering and results are bit-identical.  See SG_TUNE_GRAPH_REORDER. */
+ * X, X0, X1 and Y of sg_spmm, stay in the caller's numbering and results are bit-identical (bf16 rows of 128 / 256 channels,
+ * which the tiled matrix-core kernel serves: identical up to the accumulation order inside a 16-row tile, see sg_spmm).
+ * See SG_TUNE_GRAPH_REORDER. */
 SG_API int sg_graph_is_reordered(const sg_graph* g);
 /* Copies the forward CSR and dis into caller-owned DEVICE buffers on `stream`:
  * rowptr int32 [V_dst+1], colidx int32 [nnz], dis float32 [V_src]; any may be NULL. */
@@ -121,12 +123,19 @@ SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, 
  * (then beta/gamma are ignored).  Y must not alias X.  Edge weights are the
  * products -dis[i]*dis[j] of the per-vertex scales (dis[j] rides beside the
  * neighbour id in the CSR; no per-edge weight array).  Deterministic: one owner
- * per output row, fixed summation order, no atomics.
+ * per output row, fixed summation order, no atomics.  The order is ascending
+ * neighbour id with one fp32 fma per neighbour, EXCEPT for bf16 rows of 128 or 256
+ * channels on a graph made by sg_graph_create: those are reduced tile by tile
+ * (<= 16 rows and their <= 56 distinct sources staged in LDS) on the matrix cores,
+ * with the fp32 weights split exactly into three bf16 pieces and the MFMA's own
+ * accumulation order -- same error bound, a different last bit in ~1 % of the
+ * bf16 outputs (SG_TUNE_FLAGS bit 11 restores the fma chain).
  * Non-finite inputs: the gathers run in fixed-size batches whose unused slots
  * are switched off by a ZERO WEIGHT on a row that is read anyway (a neighbour of
- * one of the rows the same wavefront works on, or row 0), so an Inf/NaN in X can
- * turn into NaN in a few output rows that are not its neighbours; for finite X
- * the result is exactly the CSR sum.
+ * one of the rows the same wavefront works on, or row 0; in the tiled kernel: any
+ * source row of the same 16-row tile), so an Inf/NaN in X can turn into NaN in a
+ * few output rows that are not its neighbours but lie within 32 rows of one; for
+ * finite X the result is exactly the CSR sum.
  * ------------------------------------------------------------------------- */
 SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx, const void* X0,
             int64_t ldx0, const void* X1, int64_t ldx1, void* Y, int64_t ldy, int64_t C, int dtype,
@@ -377,9 +386,11 @@ enum sg_tune_knob {
                              between the staging phases instead of wavefront-local ones, bit 4: 64-bit gather addressing
                              even where 32-bit offsets would do, bit 5: fixed-size gather batches also where the
                              row length is wave-uniform, bit 6: nontemporal epilogue loads / stores (no effect measured),
-                             bit 7: the experimental LDS-tile kernel (set it when the graph is created AND when it is
+                             bit 7: the experimental unpipelined LDS-tile kernel (set it when the graph is created AND when it is
                              applied; measured slower), bit 8: 4-channel bf16 rows on the one-thread-per-element kernel instead of the
-                             one-thread-per-row kernel (A/B switches) */
+                             one-thread-per-row kernel, bit 11: NO tiled matrix-core kernel (spmm_ring) for bf16 rows of 128 / 256
+                             channels (at graph creation: no tile records are built), bit 12: spmm_ring stores straight from the
+                             MFMA layout instead of full rows through LDS (A/B switches) */
   SG_TUNE_UNROLL = 2,     /* gathers a lane group issues back to back in the aggregation kernel: 8, 6 or 4
                              (fewer = fewer VGPRs = more resident wavefronts); 0 = the shipped choice per shape */
   SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */

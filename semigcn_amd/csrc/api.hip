@@ -217,6 +217,7 @@ SG_API int sg_graph_create_rect(const int64_t* dst, const int64_t* src, int64_t 
         rc = SG_ERR_HIP;
       }
       if (rc == SG_OK) rc = pack_source_scale(&g->fwd, g->dis_src, stream);
+      if (rc == SG_OK && ring_enabled()) rc = build_ring_records(&g->fwd, g->dis_src, g->dis_dst, nullptr, stream);
       if (rc == SG_OK && hipStreamSynchronize(stream) != hipSuccess) {
         set_error("stream sync failed in sg_graph_create_rect");
         rc = SG_ERR_HIP;
@@ -261,6 +262,7 @@ SG_API int sg_graph_create_rows(const int64_t* dst_pos, const int64_t* src, int6
       rc = SG_ERR_HIP;
     }
     if (rc == SG_OK) rc = pack_source_scale(&g->fwd, g->dis_src, stream);
+    if (rc == SG_OK && ring_enabled()) rc = build_ring_records(&g->fwd, g->dis_src, g->dis_dst, g->row_id, stream);
     if (rc == SG_OK && hipStreamSynchronize(stream) != hipSuccess) {
       set_error("stream sync failed in sg_graph_create_rows");
       rc = SG_ERR_HIP;

@@ -260,9 +260,11 @@ def test_whole_iteration_graph_with_the_rccl_calls_captured_one_rank():
     assert "SEGMENT_REPLAY_OK" in r.stdout
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [2, 4] + ([8] if os.environ.get("SEMIGCN_TEST_8_RANKS") == "1" else []))
 def test_segmented_replay_ranks_sharing_the_gpu(world):
-    """Same, 2 and 8 ranks on one device with the collectives staged through the host (gloo): real halos, real peers."""
+    """Same, 2 and 4 ranks on one device with the collectives staged through the host (gloo): real halos, real peers.
+    (8 ranks with SEMIGCN_TEST_8_RANKS=1: eight processes starting torch on one box took 2 - 11 minutes of the suite; the
+    8-way partition itself is covered in-process by test_eight_ranks_on_a_200k_vertex_mesh_equal_single_rank.)"""
     r = _run_segment_replay(world, "gloo")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "SEGMENT_REPLAY_OK" in r.stdout
