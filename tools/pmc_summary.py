@@ -40,7 +40,7 @@ def main():
         for r in load(f"{root}/pmc_{cname}"):
             if r["Counter_Name"] != cname:
                 continue
-            ring = re.search(r"spmm_ring<(\d+), (\d+), (\d+)>", r["Kernel_Name"])      # <channels / 64, epilogue operands, ring depth>
+            ring = re.search(r"spmm_ring<(\d+), (\d+), (\d+), (\d+)>", r["Kernel_Name"])      # <channels / 64, epilogue operands, ring depth, store mode>
             if ring:
                 agg[("ring", "bfloat16", 8 * int(ring.group(1)), 1, int(ring.group(2)))].append(float(r["Counter_Value"]))
                 continue
