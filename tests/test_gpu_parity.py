@@ -1590,6 +1590,30 @@ def test_ring_kernel_matches_the_rows_kernel_and_the_float64_oracle(C, ring_flag
         assert e_ring < 1.02 * e_rows + 1e-6, (e_ring, e_rows)
 
 
+@pytest.mark.parametrize("C", [128, 256])
+def test_ring_kernel_on_a_graph_with_hubs_repeats_isolated_vertices_and_no_symmetry(C):
+    """The ring kernel on the graph the other kernels are tortured with: a hub row with ~1200 neighbours, repeated edges,
+    self loops, isolated vertices, NOT symmetric (so the transposed operator has a CSR and tile records of its own), a
+    vertex count that is no multiple of 16, sparse random rows whose tiles mix records that fit with records that do not.
+    Both directions, every epilogue arity, against spmm_rows to one bf16 ulp and against the oracle."""
+    ei, V = nasty_graph(), 500
+    g = capi.GraphHandle.from_edge_index(ei.to(DEV), V)
+    gen = torch.Generator(device=DEV).manual_seed(11 + C)
+    x = torch.randn(V, C, device=DEV, generator=gen).bfloat16()
+    x0 = torch.randn(V, C, device=DEV, generator=gen).bfloat16()
+    x1 = torch.randn(V, C, device=DEV, generator=gen).bfloat16()
+    new = lambda: torch.empty((V, C), dtype=torch.bfloat16, device=DEV)
+    calls = [lambda: g.spmm(x, new()), lambda: g.spmm(x, new(), transpose=True),
+             lambda: g.spmm(x, new(), alpha=2.0, X0=x0, beta=-1.0), lambda: g.spmm(x, new(), alpha=2.0, X0=x0, beta=-1.0, transpose=True),
+             lambda: g.spmm(x, new(), alpha=1.0, X0=x0, beta=1.0, X1=x1, gamma=-1.0)]
+    for ring_flags in (1, 1 | 4096):
+        rows, ring = _ring_and_rows(g, calls, ring_flags)
+        for a, b in zip(rows, ring):
+            d = (a.float() - b.float()).abs()
+            assert bool((d <= 2.0 ** -7 * a.float().abs() + 1e-4).all()), float(d.max())
+    assert rel(ring[0].float(), oracle_lhat(ei, x.float().cpu())) < 2.0 ** -7
+
+
 def test_ring_kernel_tiles_that_do_not_fit_gather_from_global_memory():
     """A graph without locality (random sources, ~20 per row, repeated edges): no 16-row or 8-row tile fits the LDS budget
     of spmm_ring (48 distinct sources, 16 neighbours per row, no repeats), every record says so and the kernel's in-loop
