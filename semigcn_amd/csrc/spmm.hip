@@ -21,6 +21,8 @@
 //    256 B per lane in flight); the batch size (2/4/6/8) follows the longest row in flight.
 //  * Chunks are dealt to workgroups so that the workgroups sharing an XCD (blockIdx % 8)
 //    sweep one contiguous range of rows: neighbouring rows' gathers then hit that XCD's L2.
+//  * bf16 rows of 128 / 256 channels (the launches that dominate the iteration) take spmm_ring further down: 16-row tiles
+//    whose distinct source rows are staged ONCE in LDS by a pipelined LDS-DMA ring and reduced on the matrix cores.
 #include "sg_common.h"
 
 namespace sg {
@@ -751,32 +753,35 @@ int launch_lds(const SpmmArgs& a, hipStream_t stream) {
 // 256 channels on graphs that carry tile records; SG_TUNE_FLAGS bit 11 switches it off at graph creation or at launch).
 //
 // spmm_lds above pays, per tile and strictly one after the other, a metadata chain, the LDS-DMA round trip and the
-// reduction.  Here ONE persistent workgroup per CU (8 wavefronts at 256 channels) walks a stream of tiles (<= 16 rows,
-// <= 48 distinct sources: csr_build.hip::build_ring_records) through a ring of D stages in LDS:
+// reduction.  Here ONE persistent workgroup per CU (256 channels: 8 consumer + 4 producer wavefronts; 128 channels: 4 + 4,
+// two workgroups per CU) walks a stream of tiles (<= 16 rows, <= 56 distinct sources: csr_build.hip::build_ring_records)
+// through a ring of D = 3 stages in LDS.  Iteration i, behind ONE s_barrier:
 //
-//   iteration i:  counted s_waitcnt vmcnt  ->  s_barrier
-//                 tile i+D-1:  LDS-DMA of its 48 source-row slots and of its 16 rows of the epilogue operands; its 16 x 48
-//                              weight matrix, split into three bf16 pieces, scattered into LDS
-//                 tile i+2D-2: LDS-DMA of its 1 KB record (sources, slot of every edge, scales, row ids)
-//                 tile i:      Y_tile = W_tile (16 x 48) * X_sources (48 x C) on v_mfma_f32_16x16x{32,16}_bf16, epilogue, store
+//   producers   tile i+D-1:  LDS-DMA of its distinct source rows and of its rows of the epilogue operands (the addresses
+//                            were read from its record one iteration earlier); its 16 x 64 weight matrix, split into three
+//                            bf16 pieces, scattered into LDS
+//               tile i+2D-1: LDS-DMA of its 896-byte record (sources, slot of every edge, scales, row ids)
+//   consumers   tile i:      Y_tile = W_tile (16 x nu) * X_sources (nu x C) on v_mfma_f32_16x16x{32,16}_bf16, epilogue, into LDS
+//               tile i-1:    leaves LDS as full rows (16-byte stores)
 //
-// Memory parallelism comes from the ring depth, not from occupancy: D - 1 tiles (24 + 8 KB each at 256 channels) are in
+// Memory parallelism comes from the ring depth, not from occupancy: D - 1 tiles (~22 + 8 KB each at 256 channels) are in
 // flight per CU under the tile being reduced, which is what the latency-bound spmm_rows cannot reach with registers.
 // Why MFMA for an HBM-bound kernel: with the sources in LDS the VALU reduction of spmm_rows (8 unpack + 4 packed-fma
 // instructions per 16 bytes and neighbour, plus slot / weight addressing) became the bound (measured: 0.46 ms with, 0.21 ms
-// without the reduction at C = 256).  The tile's weights are a dense 16 x 48 matrix with ~6 nonzeros per row; multiplying
-// it costs 12 MFMA instructions per wavefront and NO unpacking: the bf16 source rows are MFMA operands as they lie in LDS
-// (ds_read_b64_tr_b16 transposes them on the way).  The fp32 weights enter as hi + mid + lo bf16 pieces (3 x 8 mantissa
+// without the reduction at C = 256).  The tile's weights are a dense 16 x 56 matrix with ~6 nonzeros per row; multiplying
+// it costs 12-18 MFMA instructions per wavefront and NO unpacking: the bf16 source rows are MFMA operands as they lie in
+// LDS (ds_read_b64_tr_b16 transposes them on the way).  The fp32 weights enter as hi + mid + lo bf16 pieces (3 x 8 mantissa
 // bits: exact), products are exact in fp32, the accumulation is the matrix core's -- so the result differs from
 // spmm_rows' sequential fma chain in the last bits (same error bound; deterministic; tested against it to one ulp of the
 // output type and against the float64 oracle).
 //
-// EVERY global read is an LDS-DMA (no VGPR result), so hipcc has no load to put `s_waitcnt vmcnt(0)` in front of, and
-// every wavefront issues the SAME number of vector-memory instructions per iteration (3 source + NEPI operand + 1 record
-// DMA + 1 store; the tail of the stream re-loads its last tile instead of issuing less), so the wait at the top of an
-// iteration is the constant vmcnt((D - 2) * (5 + NEPI)).  One s_barrier per tile.  Source rows and operand rows are
-// stored XOR-swizzled (applied to the per-lane SOURCE address of the DMA) so that the transposing reads and the epilogue
-// reads are bank-conflict-free.  Tiles that do not fit (record.nu == 0) are gathered from global memory inside the loop.
+// EVERY global read is an LDS-DMA (no VGPR result), so hipcc has no load to put `s_waitcnt vmcnt(0)` in front of; only the
+// producers wait on the vector-memory queue, at the top of an iteration, for everything but the DMA instructions they
+// issued in the last D - 2 iterations -- a runtime count (the number of source rows varies), served by a jump table of
+// s_waitcnt immediates; the tail of the stream re-loads its last tile instead of issuing nothing.  Source rows and operand
+// rows are stored XOR-swizzled (applied to the per-lane SOURCE address of the DMA) so that the transposing reads, the
+// epilogue reads and the row-wise read-back are bank-conflict-free.  Tiles that do not fit (record.nu == 0) are gathered
+// from global memory inside the loop with the fma chain of spmm_rows.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRingARow = 144;                       // bytes of one row of a weight piece: 64 bf16 + pad (conflict-free b128 reads)
 constexpr int kRingAPiece = kLdsRows * kRingARow;
@@ -880,6 +885,7 @@ __global__ __launch_bounds__(128 * NBW + 256) void spmm_ring(const SpmmArgs a, c
   if (wave >= CW) {
     // =============================== producers: DMA + weight matrices, D - 1 tiles ahead ===============================
     const int pw = wave - CW, ptid = tid - CW * 64;
+    __builtin_amdgcn_s_setprio(3);                  // the DMA issue goes ahead of the consumers' arithmetic (2 - 5 % measured)
     const int g = lane / G, gl = lane % G;          // DMA: row of the instruction, 16-byte chunk of the row
     const elem_t* __restrict__ X0 = (const elem_t*)a.X0;
     const elem_t* __restrict__ X1 = (const elem_t*)a.X1;
