@@ -1614,6 +1614,35 @@ def test_ring_kernel_on_a_graph_with_hubs_repeats_isolated_vertices_and_no_symme
     assert rel(ring[0].float(), oracle_lhat(ei, x.float().cpu())) < 2.0 ** -7
 
 
+def test_ring_kernel_on_tiny_and_random_graphs():
+    """Sizes around the tile and workgroup boundaries (1 .. 4099 vertices: fewer tiles than workgroups, a last tile of one
+    row), random asymmetric graphs from half an edge to eight edges per vertex (records that fit, records that do not,
+    empty rows), both directions, every epilogue arity, both store modes: finite, and within one bf16 ulp of spmm_rows."""
+    rs = np.random.RandomState(0)
+    checked = 0
+    try:
+        for V in (1, 2, 5, 15, 16, 17, 31, 32, 33, 47, 100, 257, 1000, 4099):
+            for density in (0.5, 3, 8):
+                ei = torch.from_numpy(rs.randint(0, V, size=(2, max(1, int(V * density))))).long().to(DEV)
+                g = capi.GraphHandle.from_edge_index(ei, V)
+                for C in (128, 256):
+                    x, x0, x1 = (torch.randn(V, C, device=DEV).bfloat16() for _ in range(3))
+                    for kw in ({}, {"alpha": 2.0, "X0": x0, "beta": -1.0}, {"alpha": 1.0, "X0": x0, "beta": 1.0, "X1": x1, "gamma": -1.0},
+                               {"transpose": True}):
+                        outs = []
+                        for flags in (1 | NO_RING, 1, 1 | 4096):
+                            capi.tuning_set(capi.TUNE_FLAGS, flags)
+                            outs.append(g.spmm(x, torch.full((V, C), 7.0, device=DEV, dtype=torch.bfloat16), **kw))
+                        for o in outs[1:]:
+                            d = (o.float() - outs[0].float()).abs()
+                            assert bool(torch.isfinite(o.float()).all()) and bool((d <= 2.0 ** -7 * outs[0].float().abs() + 1e-4).all()), \
+                                (V, density, C, list(kw), float(d.max()))
+                            checked += 1
+    finally:
+        capi.tuning_set(capi.TUNE_FLAGS, 1)
+    assert checked == 672
+
+
 def test_ring_kernel_tiles_that_do_not_fit_gather_from_global_memory():
     """A graph without locality (random sources, ~20 per row, repeated edges): no 16-row or 8-row tile fits the LDS budget
     of spmm_ring (48 distinct sources, 16 neighbours per row, no repeats), every record says so and the kernel's in-loop
