@@ -482,7 +482,7 @@ def dense_products(timer, steps: int, dt: float):
             "achieved": round(tot_flops / tot_ms / 1e9, 1), "frac": round(tot_flops / tot_ms / 1e9 / MFMA_PEAK_TFLOPS[dt_name], 4),
             "ms_per_iteration": round(tot_ms / steps, 3), "share_of_step": round(tot_ms / (dt * 1e3), 4),
             "measured_over": f"{steps} iterations after the timed region (HIP events on the launching stream)",
-            "by_engine": by_engine, "shapes": shapes[:12]}
+            "by_engine": by_engine, "shapes": shapes[:12] + [s for s in shapes[12:] if s["engine"] != "mfma"]}
 
 
 def free_port() -> int:

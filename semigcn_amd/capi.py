@@ -74,6 +74,11 @@ _SIGNATURES = {
     "sg_gemm_tn_takes_big_tile": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
     "sg_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
                            c_void_p]),
+    "sg_thin_tn_blocks": (c_int64, [c_int64]),
+    "sg_thin_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,
+                           c_void_p]),
+    "sg_thin_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
+                           c_void_p]),
     "sg_bn_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
     "sg_bn_merge_tiles": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
@@ -640,6 +645,51 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
         _check(load().sg_gemm_nt(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), _ptr(bias), _ptr(out),
                                  _rows2d(out, "out"), M, N, K, SG_BF16, _ptr(mom), _stream(A)), "sg_gemm_nt")
     return (out, mom) if moments else out
+
+
+THIN_MAX = 16      # sg_thin_nt / sg_thin_tn: weight matrices of at most 16 x 16
+
+
+def thin_supported(A: torch.Tensor, N: int, K: int) -> bool:
+    """Shapes the thin products take: a device tensor [V, *] with unit column stride, fp32 or bf16, 1 <= N, K <= 16."""
+    return (A.is_cuda and A.dim() == 2 and A.stride(1) == 1 and A.dtype in (torch.float32, torch.bfloat16)
+            and 1 <= N <= THIN_MAX and 1 <= K <= THIN_MAX and A.shape[0] > 0)
+
+
+def thin_nt(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out = X @ W.T (+ bias)`` for a tiny weight matrix W [N, K] (N, K <= 16; fp32, any row stride): X [V, K] and out
+    [V, N] fp32 or bf16 (same dtype, unit column stride), fp32 accumulation (csrc/thin_gemm.hip)."""
+    _require_device(X, "X")
+    V, K = X.shape
+    N = W.shape[0]
+    W = W if (W.dtype == torch.float32 and W.stride(1) == 1) else W.float().contiguous()
+    if out is None:
+        out = torch.empty((V, N), dtype=X.dtype, device=X.device)
+    if out.shape != (V, N) or out.dtype != X.dtype or W.shape[1] != K or out.stride(1) != 1 or X.stride(1) != 1:
+        raise SemigcnLibraryError(f"thin_nt shape mismatch: X {tuple(X.shape)} W {tuple(W.shape)} out {tuple(out.shape)}")
+    if bias is not None:
+        _f32vec(bias, N, "bias")
+    with _on_device(X.device):
+        _check(load().sg_thin_nt(_ptr(X), _rows2d(X, "X"), _ptr(W), _rows2d(W, "W"), _ptr(bias), _ptr(out), _rows2d(out, "out"),
+                                 V, N, K, dtype_code(X), _stream(X)), "sg_thin_nt")
+    return out
+
+
+def thin_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """``A.T @ B`` in float32 for A [V, N], B [V, K] (N, K <= 16; both fp32 or both bf16, unit column stride): the
+    weight gradient of a tiny layer, per-block partial sums added in block order (deterministic)."""
+    _require_device(A, "A")
+    _require_device(B, "B")
+    V, N = A.shape
+    K = B.shape[1]
+    if B.shape[0] != V or A.dtype != B.dtype or A.stride(1) != 1 or B.stride(1) != 1:
+        raise SemigcnLibraryError(f"thin_tn shape mismatch: A {tuple(A.shape)} B {tuple(B.shape)}")
+    out = torch.empty((N, K), dtype=torch.float32, device=A.device)
+    ws = torch.empty((_sizes("sg_thin_tn_blocks", V), THIN_MAX * THIN_MAX), dtype=torch.float32, device=A.device)
+    with _on_device(A.device):
+        _check(load().sg_thin_tn(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), V, N, K, dtype_code(A), _ptr(ws), _ptr(out),
+                                 K, _stream(A)), "sg_thin_tn")
+    return out
 
 
 def gemm_tn_supported(A: torch.Tensor, B: torch.Tensor) -> bool:

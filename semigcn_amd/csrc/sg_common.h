@@ -95,6 +95,13 @@ static_assert(kRecW + 4 * kRingSlots <= kRecBytes && kRecSd % 16 == 0, "tile rec
 int build_tiles(Csr* c, hipStream_t stream);
 // Fills Csr::idx_w (and tile_uniq_w when the CSR carries tiles) for the source scale vector `scale` [n_cols].
 int pack_source_scale(Csr* c, const float* scale, hipStream_t stream);
+// Products with a tiny weight matrix (thin_gemm.hip)
+bool thin_shape(int64_t N, int64_t K);
+int64_t thin_tn_blocks(int64_t V);
+int launch_thin_nt(const void* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t V,
+                   int64_t N, int64_t K, int dtype, hipStream_t stream);
+int launch_thin_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t V, int64_t N, int64_t K, int dtype,
+                   float* workspace, float* out, int64_t ldo, hipStream_t stream);
 // Tile records for spmm_ring (when enabled): rows scaled by scale_dst (nullable), sources by scale_src, output rows row_id (nullable).
 int build_ring_records(Csr* c, const float* scale_src, const float* scale_dst, const int32_t* row_id, hipStream_t stream);
 bool ring_enabled();

@@ -86,11 +86,17 @@ def _tn_own(dout: torch.Tensor, T: torch.Tensor) -> bool:
     return USE_MFMA_BIG_TILE and capi.gemm_tn_takes_big_tile(dout.shape[0], dout.shape[1], T.shape[1], dout.stride(0), T.stride(0))
 
 
+def _tn_thin(dout: torch.Tensor, T: torch.Tensor) -> bool:
+    return (dout.is_cuda and dout.dim() == 2 and T.dim() == 2 and dout.dtype == T.dtype and T.stride(1) == 1
+            and dout.shape[0] == T.shape[0] and _thin_ok(dout, dout.shape[1], T.shape[1]))
+
+
 def weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     if _gemm_timer is None or not dout.is_cuda:
         return _weight_grad(dout, T)
     own = _tn_own(dout, T)
-    with _timed(("tn", dout.shape[0], dout.shape[1], T.shape[1], str(dout.dtype).replace("torch.", ""), "mfma" if own else "blas")):
+    engine = "mfma" if own else ("thin" if _tn_thin(dout, T) else "blas")
+    with _timed(("tn", dout.shape[0], dout.shape[1], T.shape[1], str(dout.dtype).replace("torch.", ""), engine)):
         return _weight_grad(dout, T)
 
 
@@ -103,6 +109,8 @@ def _weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     V = dout.shape[0]
     if _tn_own(dout, T):
         return capi.gemm_tn(dout, T)       # own MFMA kernels (transposing LDS reads, slab partials summed in order)
+    if _tn_thin(dout, T):
+        return capi.thin_tn(dout, T)       # a tiny weight matrix: per-block partial sums, added in block order
     S = min(128 if dout.dtype == torch.float32 else 64, V // 4096)
     if S <= 1 or not (dout.is_contiguous() and T.is_contiguous()):
         return _mm_f32_out(dout.t(), T)
@@ -226,13 +234,15 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
+        if x.is_cuda and x.dim() == 2 and _thin_ok(x, weight.shape[0], weight.shape[1]) and x.dtype == weight.dtype:
+            return capi.thin_nt(x, weight, bias)
         return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dx = dense_nn(dy, weight) if ctx.needs_input_grad[0] else None
         dw = weight_grad(dy, x.contiguous()).to(weight.dtype) if ctx.needs_input_grad[1] else None
         db = column_sums(dy).to(weight.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if dy.is_cuda and _sink(ctx.params, (dw, db)):
@@ -273,6 +283,15 @@ def _wcat(weights, dtype):
 #: rules allow; False sends every product back to the BLAS library (hipBLASLt through torch), e.g. for A/B timing
 USE_MFMA_GEMM = True
 
+#: products with a tiny weight matrix (<= 16 x 16: the 4 -> 16 input layer with its K = 12 columns, the 16 -> 3 output
+#: layer, their autograd) on the library's thin-product kernels (csrc/thin_gemm.hip); False leaves them with the BLAS library
+USE_THIN_GEMM = os.environ.get("SEMIGCN_NO_THIN_GEMM") != "1"
+
+
+def _thin_ok(a: torch.Tensor, N: int, K: int, out: Optional[torch.Tensor] = None) -> bool:
+    return (USE_THIN_GEMM and capi.thin_supported(a, N, K)
+            and (out is None or (out.dtype == a.dtype and out.dim() == 2 and out.stride(1) == 1 and out.data_ptr() != a.data_ptr())))
+
 
 #: The 128-row-tile kernel streams A and C at 45-75 % of the HBM rate, which is what bounds the products with small
 #: and medium weight matrices; the few compute-bound ones (K*N > ~100 K: the 256/512-channel layers, where a
@@ -310,7 +329,8 @@ def dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = No
         return _dense_nt(a, b, bias, out, moments)
     ldc = b.shape[0] if out is None else out.stride(0)
     own = _mfma_ok(a, b, ldc) and (out is None or (out.stride(1) == 1 and out.data_ptr() % 16 == 0))
-    with _timed(("nt", a.shape[0], b.shape[0], a.shape[1], str(a.dtype).replace("torch.", ""), "mfma" if own else "blas")):
+    engine = "mfma" if own else ("thin" if _thin_ok(a, b.shape[0], a.shape[1], out) else "blas")
+    with _timed(("nt", a.shape[0], b.shape[0], a.shape[1], str(a.dtype).replace("torch.", ""), engine)):
         return _dense_nt(a, b, bias, out, moments)
 
 
@@ -327,16 +347,25 @@ def _dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = N
             moments["tiles"], moments["rows"] = mom, capi.gemm_tile_rows(b.shape[0])
             return res
         return capi.gemm_nt(a, b, bias32, out=out)
+    if _thin_ok(a, b.shape[0], a.shape[1], out):        # a tiny weight matrix (K = 12 is no MFMA step): one thread per row
+        bias32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float()).contiguous()
+        return capi.thin_nt(a, b, bias32, out=out)
     if bias is not None:
         return torch.addmm(bias.to(a.dtype), a, b.t()) if out is None else torch.addmm(bias.to(a.dtype), a, b.t(), out=out)
     return a @ b.t() if out is None else torch.mm(a, b.t(), out=out)
 
 
 def dense_nn(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``a @ w`` on the BLAS library (the input-gradient product where no transposed weight copy is kept: fp32 features)."""
+    """``a @ w`` on the BLAS library (the input-gradient product where no transposed weight copy is kept: fp32 features);
+    a tiny ``w`` (<= 16 x 16) on the thin-product kernel."""
+    thin = a.is_cuda and a.dim() == 2 and w.dim() == 2 and _thin_ok(a, w.shape[1], a.shape[1], out)
     if _gemm_timer is None or not a.is_cuda:
+        if thin:
+            return capi.thin_nt(a, w.t(), None, out=out)
         return a @ w if out is None else torch.mm(a, w, out=out)
-    with _timed(("nt", a.shape[0], w.shape[1], a.shape[1], str(a.dtype).replace("torch.", ""), "blas")):
+    with _timed(("nt", a.shape[0], w.shape[1], a.shape[1], str(a.dtype).replace("torch.", ""), "thin" if thin else "blas")):
+        if thin:
+            return capi.thin_nt(a, w.t(), None, out=out)
         return a @ w if out is None else torch.mm(a, w, out=out)
 
 

@@ -1,6 +1,8 @@
 """``-m gpu``: the MFMA product sg_gemm_nt (csrc/gemm_mfma.hip) -- the dense per-vertex feature x weight GEMM of
 ChebConv.forward [3P] (util/networks.py:42,49) and its input gradient -- against fp32 matmul on the same bf16 inputs,
 bit-exact on integer data, plus the BatchNorm tile moments it leaves behind and the layer-level wiring."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -306,3 +308,56 @@ def test_big_tile_weight_gradient_random_data_and_strides():
     assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-5       # fp32 accumulation of exact bf16 products
     out2 = _with_tile(3, lambda: capi.gemm_tn(a, b))
     assert torch.equal(out, out2)                                                 # deterministic: fixed slab order
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V,N,K", [(1, 1, 1), (257, 16, 12), (70001, 12, 16), (100000, 3, 16), (4099, 16, 3), (5000, 16, 16), (333, 7, 5)])
+def test_thin_products_match_float64(V, N, K, dtype):
+    """sg_thin_nt / sg_thin_tn (weight matrices of at most 16 x 16: the 4 -> 16 input layer, the 16 -> 3 output layer and
+    their autograd) against float64: fp32 accumulation error only, on strided operands, with and without bias; the
+    weight gradient deterministic run to run."""
+    from semigcn_amd import capi
+    g = torch.Generator(device=DEV).manual_seed(V + 31 * N + K)
+    wide = torch.randn(V, K + 5, device=DEV, generator=g).to(dtype)
+    x = wide[:, 2:2 + K]                                           # row stride K + 5, unit column stride
+    w = torch.randn(N, K, device=DEV, generator=g)
+    b = torch.randn(N, device=DEV, generator=g)
+    out_wide = torch.full((V, N + 3), 7.0, device=DEV, dtype=dtype)
+    y = capi.thin_nt(x, w, b, out=out_wide[:, :N])
+    assert y.data_ptr() == out_wide.data_ptr() and bool((out_wide[:, N:] == 7.0).all())
+    want = x.double() @ w.double().t() + b.double()
+    tol = 2e-6 if dtype == torch.float32 else 2.0 ** -8
+    assert float((y.double() - want).abs().max()) <= tol * float(want.abs().max() + 1.0)
+    y0 = capi.thin_nt(x, w)
+    assert float((y0.double() - x.double() @ w.double().t()).abs().max()) <= tol * float(want.abs().max() + 1.0)
+    a = torch.randn(V, N, device=DEV, generator=g).to(dtype)
+    dw = capi.thin_tn(a, x)
+    want_w = a.double().t() @ x.double()
+    assert dw.dtype == torch.float32 and dw.shape == (N, K)
+    assert float((dw.double() - want_w).abs().max()) <= 2e-6 * float((a.double().abs().t() @ x.double().abs()).max() + 1.0)
+    assert torch.equal(dw, capi.thin_tn(a, x))
+
+
+def test_bf16_training_iteration_uses_no_blas_product():
+    """With bf16 features every dense product of an SGCN training iteration is served by the library's own kernels (MFMA
+    or thin): the per-call records of functional's timer name no "blas" engine."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from semigcn_amd import networks, train
+    import bench
+    mesh = bench.make_mesh(160, 128, "survey")           # >= 16 K vertices: the wide layers take the 256 x 256 ring
+    batch = bench.build_mesh_batch(mesh, DEV, 5)
+    torch.manual_seed(0)
+    net = networks.SingleScaleGCN(DEV).to(DEV).set_feature_dtype(torch.bfloat16)
+    tr = train.SGCNTrainer(net, batch)
+    tr.iteration_step()
+    timer = capi.LaunchTimer()
+    F_sg.set_gemm_timer(timer)
+    try:
+        tr.iteration_step()
+        torch.cuda.synchronize()
+    finally:
+        F_sg.set_gemm_timer(None)
+    keys = list(timer.results())
+    assert keys and not [k for k in keys if k[-1] == "blas"], [k for k in keys if k[-1] == "blas"]
+    assert {"mfma", "thin"} <= {k[-1] for k in keys}
