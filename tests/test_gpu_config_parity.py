@@ -286,8 +286,8 @@ def _blas_layers(V, post):
         cin, cout = CHANNELS[i], CHANNELS[i + 1]
         wshape = (3 * cout, cin) if (post and cout < cin) else (cout, 3 * cin)
         a = torch.empty((V, wshape[1]), dtype=torch.bfloat16, device=DEV)
-        if not F_sg._mfma_ok(a, torch.empty(wshape, dtype=torch.bfloat16, device=DEV), wshape[0]):
-            blas.append(i)
+        if not F_sg._mfma_ok(a, torch.empty(wshape, dtype=torch.bfloat16, device=DEV), wshape[0]) and not F_sg._thin_ok(a, wshape[0], wshape[1]):
+            blas.append(i)      # (bias rounded to bf16 by addmm; the library's own kernels add the fp32 bias)
     return blas
 
 

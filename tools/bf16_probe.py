@@ -37,7 +37,7 @@ for i in range(13):
     cin, cout = CHANNELS[i], CHANNELS[i + 1]
     wshape = (3 * cout, cin) if (post and cout < cin) else (cout, 3 * cin)
     a = torch.empty((V, wshape[1]), dtype=torch.bfloat16, device=DEV)
-    if not F_sg._mfma_ok(a, torch.empty(wshape, dtype=torch.bfloat16, device=DEV), wshape[0]):
+    if not F_sg._mfma_ok(a, torch.empty(wshape, dtype=torch.bfloat16, device=DEV), wshape[0]) and not F_sg._thin_ok(a, wshape[0], wshape[1]):
         blas.append(i)
 print("layers whose product goes to the BLAS library:", blas)
 ora = OB.SGCNOracleBf16(post_when_narrowing=post, bias_bf16_layers=blas)
