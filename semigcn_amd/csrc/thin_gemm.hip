@@ -6,7 +6,7 @@
 // (five launches, 0.05 - 0.12 ms each at V = 1 M for 24 - 64 MB of traffic).
 //
 //   thin_nt:  Y[v, n] = sum_k X[v, k] * W[n, k] (+ bias[n])        X, Y fp32 or bf16 (same type), W and bias fp32
-//   thin_tn:  out[n, k] = sum_v A[v, n] * B[v, k]  (fp32 out)       per-block partial sums in block order: deterministic
+//   thin_tn:  out[n, k] = sum_v A[v, n] * B[v, k]  (fp32 out)       per-block partial sums added in a fixed tree: deterministic
 #include "sg_common.h"
 
 namespace sg {
@@ -22,31 +22,99 @@ template <typename T> __device__ __forceinline__ void thin_store(T* p, float v);
 template <> __device__ __forceinline__ void thin_store<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void thin_store<uint16_t>(uint16_t* p, float v) { *p = __builtin_bit_cast(uint16_t, (__bf16)v); }
 
+// rows x W elements from global memory (row stride ld) into LDS (row stride lds_ld floats), converted to fp32, with the
+// widest loads the shape allows: VEC elements per load (16 bytes, 8 bytes, or one element)
+template <typename T, int VEC>
+__device__ __forceinline__ void thin_stage_in(const T* __restrict__ src, int64_t ld, int rows, int W, float* __restrict__ dst, int lds_ld) {
+  const int per_row = W / VEC;
+  for (int i = threadIdx.x; i < rows * per_row; i += kThinBlock) {
+    const int r = i / per_row, c = (i - r * per_row) * VEC;
+    const T* p = src + (int64_t)r * ld + c;
+    float* q = dst + r * lds_ld + c;
+    if constexpr (VEC == 1) {
+      q[0] = thin_load<T>(p);
+    } else if constexpr (sizeof(T) == 4) {
+      if constexpr (VEC == 4) { const float4 v = *(const float4*)p; q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+      else { const float2 v = *(const float2*)p; q[0] = v.x; q[1] = v.y; }
+    } else {
+      uint32_t w[VEC / 2];
+      if constexpr (VEC == 8) { const uint4 v = *(const uint4*)p; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+      else if constexpr (VEC == 4) { const uint2 v = *(const uint2*)p; w[0] = v.x; w[1] = v.y; }
+      else { w[0] = *(const uint32_t*)p; }
+#pragma unroll
+      for (int j = 0; j < VEC / 2; ++j) {
+        q[2 * j] = __uint_as_float(w[j] << 16);
+        q[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+      }
+    }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void thin_stage_rows(const T* __restrict__ src, int64_t ld, int rows, int W, float* __restrict__ dst, int lds_ld) {
+  constexpr int V16 = 16 / (int)sizeof(T), V8 = 8 / (int)sizeof(T), V4 = 4 / (int)sizeof(T);
+  const uintptr_t a = (uintptr_t)src;
+  if (W % V16 == 0 && ld % V16 == 0 && a % 16 == 0) thin_stage_in<T, V16>(src, ld, rows, W, dst, lds_ld);
+  else if (W % V8 == 0 && ld % V8 == 0 && a % 8 == 0) thin_stage_in<T, V8>(src, ld, rows, W, dst, lds_ld);
+  else if (V4 > 1 && W % V4 == 0 && ld % V4 == 0 && a % 4 == 0) thin_stage_in<T, (V4 > 1 ? V4 : 1)>(src, ld, rows, W, dst, lds_ld);
+  else thin_stage_in<T, 1>(src, ld, rows, W, dst, lds_ld);
+}
+
+// One block = 256 consecutive rows.  Rows pass through LDS in both directions so that consecutive lanes touch consecutive
+// addresses (a row is 6 - 64 bytes: one thread per row straight from global memory runs at ~1 TB/s).
 template <typename T>
 __global__ __launch_bounds__(kThinBlock) void thin_nt(const T* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw,
                                                       const float* __restrict__ bias, T* __restrict__ Y, int64_t ldy, int64_t V,
                                                       int N, int K) {
   __shared__ float s_w[kThinMax * kThinMax];
   __shared__ float s_b[kThinMax];
+  __shared__ float s_x[kThinBlock * (kThinMax + 1)];
+  __shared__ float s_y[kThinBlock * (kThinMax + 1)];
   for (int i = threadIdx.x; i < N * K; i += kThinBlock) s_w[i] = W[(int64_t)(i / K) * ldw + i % K];
   if (threadIdx.x < N) s_b[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  const int64_t row0 = (int64_t)blockIdx.x * kThinBlock;
+  const int rows = (int)(V - row0 < kThinBlock ? V - row0 : kThinBlock);
+  thin_stage_rows<T>(X + row0 * ldx, ldx, rows, K, s_x, kThinMax + 1);
   __syncthreads();
-  for (int64_t v = (int64_t)blockIdx.x * kThinBlock + threadIdx.x; v < V; v += (int64_t)gridDim.x * kThinBlock) {
+  if ((int)threadIdx.x < rows) {
     float x[kThinMax];
 #pragma unroll
-    for (int k = 0; k < kThinMax; ++k) x[k] = k < K ? thin_load<T>(X + v * ldx + k) : 0.f;
+    for (int k = 0; k < kThinMax; ++k) x[k] = k < K ? s_x[threadIdx.x * (kThinMax + 1) + k] : 0.f;
     for (int n = 0; n < N; ++n) {
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < kThinMax; ++k)
         if (k < K) acc = fmaf(x[k], s_w[n * K + k], acc);
-      thin_store<T>(Y + v * ldy + n, acc + s_b[n]);
+      s_y[threadIdx.x * (kThinMax + 1) + n] = acc + s_b[n];
+    }
+  }
+  __syncthreads();
+  constexpr int V8 = 8 / (int)sizeof(T);               // 8-byte stores where the rows allow (4 bf16 / 2 fp32)
+  T* const Y0 = Y + row0 * ldy;
+  if (N % V8 == 0 && ldy % V8 == 0 && (uintptr_t)Y0 % 8 == 0) {
+    const int per_row = N / V8;
+    for (int i = threadIdx.x; i < rows * per_row; i += kThinBlock) {
+      const int r = i / per_row, c = (i - r * per_row) * V8;
+      const float* q = s_y + r * (kThinMax + 1) + c;
+      if constexpr (sizeof(T) == 4) {
+        *(float2*)(Y0 + (int64_t)r * ldy + c) = make_float2(q[0], q[1]);
+      } else {
+        uint16_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = __builtin_bit_cast(uint16_t, (__bf16)q[j]);
+        *(uint2*)(Y0 + (int64_t)r * ldy + c) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < rows * N; i += kThinBlock) {
+      const int r = i / N, n = i - r * N;
+      thin_store<T>(Y0 + (int64_t)r * ldy + n, s_y[r * (kThinMax + 1) + n]);
     }
   }
 }
 
 // one thread per output element (n, k) of the block's partial; the block's rows pass through LDS in chunks
 constexpr int kThinChunk = 128;
+constexpr int kThinTnRows = 512;      // rows per block: >= 8 blocks per CU at V = 1 M
 template <typename T>
 __global__ __launch_bounds__(kThinBlock) void thin_tn_partial(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
                                                               int64_t V, int N, int K, int64_t rows_per_block,
@@ -61,22 +129,40 @@ __global__ __launch_bounds__(kThinBlock) void thin_tn_partial(const T* __restric
   for (int64_t c0 = r0; c0 < r1; c0 += kThinChunk) {
     const int rows = (int)(r1 - c0 < kThinChunk ? r1 - c0 : kThinChunk);
     __syncthreads();
-    for (int i = threadIdx.x; i < rows * N; i += kThinBlock) s_a[i] = thin_load<T>(A + (c0 + i / N) * lda + i % N);
-    for (int i = threadIdx.x; i < rows * K; i += kThinBlock) s_b[i] = thin_load<T>(B + (c0 + i / K) * ldb + i % K);
+    thin_stage_rows<T>(A + c0 * lda, lda, rows, N, s_a, N);
+    thin_stage_rows<T>(B + c0 * ldb, ldb, rows, K, s_b, K);
     __syncthreads();
-    if (n < N && k < K)
-      for (int r = 0; r < rows; ++r) acc = fmaf(s_a[r * N + n], s_b[r * K + k], acc);
+    if (n < N && k < K) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;         // four independent chains; added in a fixed order
+      int r = 0;
+      for (; r + 4 <= rows; r += 4) {
+        a0 = fmaf(s_a[(r + 0) * N + n], s_b[(r + 0) * K + k], a0);
+        a1 = fmaf(s_a[(r + 1) * N + n], s_b[(r + 1) * K + k], a1);
+        a2 = fmaf(s_a[(r + 2) * N + n], s_b[(r + 2) * K + k], a2);
+        a3 = fmaf(s_a[(r + 3) * N + n], s_b[(r + 3) * K + k], a3);
+      }
+      for (; r < rows; ++r) a0 = fmaf(s_a[r * N + n], s_b[r * K + k], a0);
+      acc += (a0 + a1) + (a2 + a3);
+    }
   }
   part[(int64_t)blockIdx.x * (kThinMax * kThinMax) + threadIdx.x] = acc;
 }
 
+// one block per output element: 256 threads add the blocks' partials (thread t: blocks t, t + 256, ..), then a fixed tree
 __global__ __launch_bounds__(kThinBlock) void thin_tn_reduce(const float* __restrict__ part, int nblocks, int N, int K,
                                                              float* __restrict__ out, int64_t ldo) {
-  const int n = threadIdx.x / kThinMax, k = threadIdx.x % kThinMax;
+  __shared__ float s_p[kThinBlock];
+  const int slot = blockIdx.x, n = slot / kThinMax, k = slot % kThinMax;
   if (n >= N || k >= K) return;
   float acc = 0.f;
-  for (int b = 0; b < nblocks; ++b) acc += part[(int64_t)b * (kThinMax * kThinMax) + threadIdx.x];      // fixed order
-  out[(int64_t)n * ldo + k] = acc;
+  for (int b = threadIdx.x; b < nblocks; b += kThinBlock) acc += part[(int64_t)b * (kThinMax * kThinMax) + slot];
+  s_p[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = kThinBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_p[threadIdx.x] += s_p[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(int64_t)n * ldo + k] = s_p[0];
 }
 
 }  // namespace
@@ -84,15 +170,15 @@ __global__ __launch_bounds__(kThinBlock) void thin_tn_reduce(const float* __rest
 bool thin_shape(int64_t N, int64_t K) { return N >= 1 && K >= 1 && N <= kThinMax && K <= kThinMax; }
 
 int64_t thin_tn_blocks(int64_t V) {
-  int64_t nb = (V + 4095) / 4096;
-  return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+  int64_t nb = (V + kThinTnRows - 1) / kThinTnRows;
+  return nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
 }
 
 int launch_thin_nt(const void* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t V,
                    int64_t N, int64_t K, int dtype, hipStream_t stream) {
   if (V == 0) return SG_OK;
-  int64_t nb = (V + kThinBlock - 1) / kThinBlock;
-  nb = nb > 256 * 16 ? 256 * 16 : nb;
+  SG_REQUIRE(V < ((int64_t)1 << 31) * kThinBlock, "sg_thin_nt: too many rows");
+  const int64_t nb = (V + kThinBlock - 1) / kThinBlock;
   if (dtype == SG_F32)
     thin_nt<float><<<(int)nb, kThinBlock, 0, stream>>>((const float*)X, ldx, W, ldw, bias, (float*)Y, ldy, V, (int)N, (int)K);
   else if (dtype == SG_BF16)
@@ -118,7 +204,7 @@ int launch_thin_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
     return SG_ERR_UNSUPPORTED;
   }
   SG_HIP_TRY(hipGetLastError());
-  thin_tn_reduce<<<1, kThinBlock, 0, stream>>>(workspace, (int)nb, (int)N, (int)K, out, ldo);
+  thin_tn_reduce<<<kThinMax * kThinMax, kThinBlock, 0, stream>>>(workspace, (int)nb, (int)N, (int)K, out, ldo);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
