@@ -98,3 +98,30 @@ def test_product_never_touches_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 # citations of /root/reference in docstrings are fine; reading it at run time is not
                 assert not re.search(r"(sys\.path[^\n]*reference|open\([^\n]*reference|REFERENCE_ROOT)", src), f
+
+
+def test_ring_kernel_isa_keeps_only_the_hand_written_vector_memory_waits(tmp_path):
+    """csrc/spmm.hip::spmm_ring lives on the LDS-DMA of three tiles staying in flight across the barrier: every global
+    read is an LDS-DMA and the only waits on the vector-memory queue are the hand-written ones.  hipcc once put an
+    `s_waitcnt vmcnt(0)` in front of an LDS read it could not tell from a pending DMA (a load folded into a reference
+    argument had lost its alias tag), which drains the ring and costs the kernel its lead silently.  Compile the file to
+    ISA and count: per ring kernel 4 full drains in the producers (prologue, first iteration, the jump table's default, the
+    end) + 3 in the consumers' rarely taken global-gather fallback, whose 3 loads are the only plain global loads."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "spmm.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", f"-I{root}/include", "-DNDEBUG", "-S", "--cuda-device-only",
+                    "-o", str(out), os.path.join(root, "semigcn_amd", "csrc", "spmm.hip")], check=True, capture_output=True, timeout=900)
+    asm = out.read_text()
+    kernels = list(re.finditer(r"^(_ZN2sg12_GLOBAL__N_19spmm_ring\w+):", asm, flags=re.M))
+    assert len(kernels) >= 9
+    for m in kernels:
+        body = asm[m.end():asm.index(".Lfunc_end", m.end())]
+        drains = len(re.findall(r"s_waitcnt vmcnt\(0\)", body))
+        plain = len(re.findall(r"global_load_dword", body))
+        assert drains <= 7 and plain == 3 and "global_load_lds_dwordx4" in body, (m.group(1), drains, plain)
