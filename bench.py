@@ -301,6 +301,35 @@ def build_trainer(args, dtype, device, world, rank, mesh):
     return trainer, workload, agg_edges
 
 
+class TraceTimer:
+    """The library's own per-launch event trace (sg_trace_*, include/semigcn.h) in the shape of capi.LaunchTimer: since a
+    whole run of [ChebConv -> BatchNorm -> activation] blocks is ONE foreign call, no Python-side timer can bracket the
+    aggregation / product launches any more; the library records the event pairs on the launching stream itself."""
+
+    def __init__(self, kinds):
+        from semigcn_amd import capi
+        self.trace = capi.LaunchTrace(1 << 18, kinds)
+        self.trace.__enter__()
+        self.records = None
+
+    def stop(self):
+        """After a device synchronize: read the records and release the events."""
+        self.records = self.trace.records()
+        return self
+
+    def results(self):
+        out = {}
+        for r in self.records:
+            if r["ms"] < 0:
+                continue
+            if r["kind"] == "agg":
+                key = (r["a"], r["dtype"], r["b"], r["c"])
+            else:
+                key = (r["kind"], r["a"], r["b"], r["c"], r["dtype"], r["engine"])
+            out.setdefault(key, []).append(r["ms"])
+        return out
+
+
 def timed_run(trainer, args, device, world, with_timer: bool):
     """W untimed + exactly K timed iterations between barrier+synchronize brackets; max over ranks."""
     from semigcn_amd import capi
@@ -335,9 +364,15 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     # a rank that replays hipGraph segments issues its kernels from the graphs: per-launch event pairs are impossible inside
     # them, so its launches are timed in a short EAGER pass after the timed region (same kernels, same buffers)
     replays = getattr(trainer, "_segmented", None) is not None
-    timer = capi.LaunchTimer() if (with_timer and not replays) else None
+    from semigcn_amd import functional as F_sg
+    # single GPU: the blocks run below the C ABI (functional.cheb_chain), timed by the library's own trace; the partitioned
+    # path still issues every launch from Python and keeps the Python-side timers
+    traced = with_timer and not replays and not DIST_ON and F_sg.blocks_enabled()
+    timer = capi.LaunchTimer() if (with_timer and not replays and not traced) else None
     sync()
     capi.set_launch_timer(timer)
+    if traced:
+        timer = TraceTimer(("agg",))
     if DIST_ON:
         from semigcn_amd import dist as sgdist
         c0 = dict(sgdist.collective_counts)
@@ -347,6 +382,8 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     sync()
     dt = time.perf_counter() - t0
     capi.set_launch_timer(None)
+    if traced:
+        timer.stop()
     timed_run.timer_dt, timed_run.timer_steps = dt, args.steps
     if DIST_ON:
         timed_run.collectives = {k: (v - c0[k]) / args.steps for k, v in sgdist.collective_counts.items()}
@@ -360,13 +397,19 @@ def timed_run(trainer, args, device, world, with_timer: bool):
             capi.set_launch_timer(timer)
         # the dense products get their own short pass AFTER the timed region (an event pair per product inside it would
         # cost the headline ~0.7 %; the aggregation kernel's pairs stay inside it on one GPU, as the contract asks)
-        timed_run.gemm_timer, timed_run.gemm_steps = capi.LaunchTimer(), max(1, min(args.steps, 5))
-        F_sg.set_gemm_timer(timed_run.gemm_timer)
+        timed_run.gemm_steps = max(1, min(args.steps, 5))
+        if traced:
+            timed_run.gemm_timer = TraceTimer(("nt", "tn"))
+        else:
+            timed_run.gemm_timer = capi.LaunchTimer()
+            F_sg.set_gemm_timer(timed_run.gemm_timer)
         t1 = time.perf_counter()
         for _ in range(timed_run.gemm_steps):
             trainer.iteration_step()
         sync()
         timed_run.gemm_dt = time.perf_counter() - t1
+        if traced:
+            timed_run.gemm_timer.stop()
         F_sg.set_gemm_timer(None)
         if replays:
             capi.set_launch_timer(None)

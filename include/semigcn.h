@@ -391,6 +391,116 @@ SG_API int sg_input_prep_bwd(const void* gX, int64_t ldg, const float* z1, const
                              const float* lo, const float* hi, float* dz1, float* partial, float* d_lo, float* d_hi, int64_t V,
                              int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * One block of the networks in ONE call -- [ChebConv -> (MeshPool | MeshUnpool)? -> BatchNorm1d -> LeakyReLU], the unit
+ * SingleScaleGCN is a chain of (util/networks.py:40-46 builds it, :83-101 runs it) and DownConv / UpConv / the MGCN heads
+ * are made of (util/meshnet.py:39-62,105-128,223-245; run at :295-312).  The caller fills an sg_block (plain device
+ * pointers and sizes: parameters, the saved activations, scratch) and the library launches the whole chain on `stream`:
+ *
+ *   forward   [pack the K weight matrices]  ->  Tx1 = L^ Tx0, Tx2 = 2 L^ Tx1 - Tx0 (sg_spmm)  ->  H = [Tx0|Tx1|Tx2] Wcat^T + b
+ *             (sg_gemm_nt / sg_thin_nt / the BLAS library for fp32 and odd shapes; per-tile BatchNorm moments from the MFMA
+ *             epilogue where it emits them, else one sg_col_moments pass)  ->  [pool]  ->  statistics finalised (running
+ *             averages, num_batches_tracked)  ->  Y = act(scale H + shift), written where the next block wants its Tx0.
+ *             Layers that narrow (order = 1, Cout < Cin) run the product first and Clenshaw's recurrence after it, Cout wide.
+ *   backward  BatchNorm/activation sums -> coefficients (+= into the weight / bias .grad) -> dH (+ its column sums = the
+ *             ChebConv bias gradient) -> [pool transpose] -> dWcat = dH^T T (sg_gemm_tn / sg_thin_tn / BLAS), added into the
+ *             K weight .grad accumulators -> dT = dH Wcat -> the recurrence unwound with two aggregations -> dX.
+ *
+ * What one call replaces on the host: ~20 foreign calls, three autograd nodes and a dozen small allocations per block and
+ * direction (13 blocks per SGCN iteration, 33 per MGCN iteration) -- the reference's own mesh sizes (5 K - 50 K vertices)
+ * are bound by exactly that.  The kernels, their arguments and their order are those of the per-operator entry points
+ * above, so results are bit-identical to calling those one by one.
+ *
+ * All pointers are device pointers owned by the caller; `ws` is scratch of at least sg_block_workspace(blk, backward) bytes,
+ * 256-byte aligned, free again when the call's work has run on the stream.  Pointers marked (nullable) may be NULL.
+ * --------------------------------------------------------------------------- */
+typedef struct sg_block {
+  /* operators */
+  const sg_graph* graph;   /* L^ of the level the ChebConv runs on (V rows) */
+  const sg_pool* pool;     /* (nullable) the pool_hash applied between the conv and its BatchNorm (util/meshnet.py:44-47,106-109) */
+  int32_t pool_mode;       /* 0 none, 1 MeshPool (cluster mean: V fine rows -> V_out coarse rows), 2 MeshUnpool (gather: V coarse -> V_out fine) */
+  int32_t dtype;           /* sg_dtype of every [rows, C] feature buffer below */
+  int32_t K;               /* Chebyshev order, 1..3 (the reference uses 3) */
+  int32_t order;           /* 0: aggregate, then ONE product on [Tx0|..|Tx(K-1)]; 1: product first, Clenshaw aggregation after (Cout < Cin, K >= 2) */
+  int32_t training;        /* BatchNorm mode: 1 batch statistics (+ running-average update), 0 running statistics */
+  int32_t refresh_weights; /* != 0: (re)build the packed weight copies from W[] first (a parameter changed since the last call) */
+  int32_t need_dx;         /* backward: 0 skips the input gradient */
+  int32_t reserved_;
+  int64_t V, V_out;        /* rows of the conv / rows after the pool (V_out = V without one) */
+  int64_t Cin, Cout;
+  float momentum, eps, slope;   /* BatchNorm momentum and eps, negative slope of the activation (0.01 LeakyReLU, 0 ReLU) */
+  float reserved2_;
+  /* parameters: float32, as the nn.Modules hold them */
+  const float* W[3];       /* lins[k].weight [Cout, Cin], contiguous */
+  const float* bias;       /* (nullable) [Cout] */
+  const float* gamma;      /* BatchNorm weight [Cout] */
+  const float* beta;       /* BatchNorm bias [Cout] */
+  float* running_mean;     /* (nullable, both or none) updated in training mode, read in eval mode */
+  float* running_var;
+  int64_t* batches_tracked; /* (nullable) num_batches_tracked, += 1 in training mode */
+  /* packed copies of the weights, caller-owned, (re)written by the library when refresh_weights != 0:
+   *   wpack    order 0: Wcat [Cout, K*Cin]; order 1: Wstack [K*Cout, Cin]     in the feature dtype
+   *   wpack_t  (nullable) its transpose: bf16 features read it in the input-gradient product on the MFMA kernel
+   *   wpack32 / wpack32_t  (nullable) the same two in float32 -- for products with a tiny weight matrix (Cout, K*Cin <= 16: sg_thin_*)
+   *   bias_k   (order 1 with a bias) the bias padded with zeros to K*Cout floats: it rides in on Z_0 */
+  void* wpack;
+  void* wpack_t;
+  float* wpack32;
+  float* wpack32_t;
+  float* bias_k;
+  /* activations (feature dtype, unit column stride, row strides in elements).
+   * order 0: T is the [V, K*Cin] buffer whose first Cin columns hold the input on entry -- X == T when the producer wrote it
+   * there, else the library copies X in; order 1: T is not used (NULL) and X [V, Cin] is read in place.
+   * H [V_out, Cout] is the BatchNorm input (the conv output, pooled when there is a pool), stats float32 [4, Cout] = mean,
+   * invstd, scale, shift; Y [V_out, Cout] the block output (ldy: e.g. a column block of the next block's [V, 3C] buffer).
+   * The caller keeps T (order 0) or X (order 1), H and stats alive between forward and backward. */
+  const void* X; int64_t ldx;
+  void* T; int64_t ldt;
+  void* H;
+  float* stats;
+  void* Y; int64_t ldy;
+  /* backward only */
+  const void* dY; int64_t lddy;   /* gradient of Y [V_out, Cout] */
+  void* dX; int64_t lddx;         /* gradient of the input [V, Cin] (nullable when need_dx == 0) */
+  float* dW;        /* float32 [Cout, K*Cin] (order 0) / [K*Cout, Cin] (order 1): this call's weight gradient, always written */
+  float* dvec;      /* float32 [6, Cout], always written: rows 0..4 = sg_bn_bwd_coeffs' output (0: sum dz = d beta, 1: sum dz xhat =
+                       d gamma, 2..4: c1, c2, k), row 5 = column sums of the conv output's gradient = d bias */
+  float* acc_W[3];  /* (nullable, all or none) the K weight .grad accumulators [Cout, Cin]: += the blocks of dW in the same call */
+  float* acc_bias;  /* (nullable) += dvec row 5 */
+  float* acc_gamma; /* (nullable, both or none) += dvec rows 1 / 0 */
+  float* acc_beta;
+  /* scratch */
+  void* ws; int64_t ws_bytes;
+} sg_block;
+SG_API int64_t sg_block_sizeof(void);   /* sizeof(sg_block) of the library (a binding checks its mirror against it) */
+SG_API int64_t sg_block_workspace(const sg_block* blk, int backward);
+SG_API int sg_block_forward(const sg_block* blk, void* stream);
+SG_API int sg_block_backward(const sg_block* blk, void* stream);
+/* A run of n consecutive blocks in one call -- the loop of SingleScaleGCN.forward over its 13 blocks (util/networks.py:83-101),
+ * the five convolutions of a DownConv / UpConv stage (util/meshnet.py:92-95,157-160): forward runs blks[0] .. blks[n-1],
+ * backward blks[n-1] .. blks[0].  The caller wires the descriptors: blks[i+1].X = blks[i].Y (written straight into the
+ * next block's T when that one aggregates first), blks[i].dY = blks[i+1].dX; the blocks run one after the other on `stream`,
+ * so they may share one scratch area sized for the largest of them. */
+SG_API int sg_block_chain_forward(const sg_block* blks, int64_t n, void* stream);
+SG_API int sg_block_chain_backward(const sg_block* blks, int64_t n, void* stream);
+
+/* Per-launch timing of the kernels the library starts (benchmarking aid; off by default, costs two hipEventRecord per kernel
+ * when on).  sg_trace_begin(capacity, kinds) starts recording up to `capacity` launches of the kinds in the bit mask
+ * `kinds` (bit k = record kind k) made from this process' sg_spmm / sg_block_* calls: an event pair on the launching stream around each aggregation and each dense product.  After the caller
+ * has synchronised the device, sg_trace_read copies up to n records out (returns their number, negative on error) and
+ * sg_trace_end releases the events.  Record: kind 0 = aggregation (a = C, b = epilogue operands, c = rows processed),
+ * 1 = product C = A B^T / A B (a = M, b = N, c = K), 2 = weight gradient A^T B (a = M, b = N, c = Kp); engine 0 = the
+ * library's aggregation kernels, 1 = own MFMA kernels, 2 = thin-product kernels, 3 = BLAS library. */
+typedef struct sg_trace_record {
+  int32_t kind, dtype, engine, reserved_;
+  int64_t a, b, c;
+  float ms;
+  float reserved2_;
+} sg_trace_record;
+SG_API int sg_trace_begin(int64_t capacity, int kinds);
+SG_API int64_t sg_trace_read(sg_trace_record* out, int64_t n);
+SG_API int sg_trace_end(void);
+
 enum sg_tune_knob {
   SG_TUNE_CHUNK_ROWS = 0, /* rows per wavefront chunk; 0 = automatic */
   SG_TUNE_FLAGS = 1,      /* bit 0: XCD-contiguous tile map, bit 1: never use the shared-gather kernel,

@@ -31,6 +31,28 @@ class sg_graph_info(ctypes.Structure):
                 ("symmetric", c_int32), ("max_degree", c_int32)]
 
 
+class sg_block(ctypes.Structure):
+    """Mirror of ``struct sg_block`` (include/semigcn.h): one [ChebConv -> pool? -> BatchNorm1d -> LeakyReLU] block."""
+    _fields_ = [("graph", c_void_p), ("pool", c_void_p),
+                ("pool_mode", c_int32), ("dtype", c_int32), ("K", c_int32), ("order", c_int32), ("training", c_int32),
+                ("refresh_weights", c_int32), ("need_dx", c_int32), ("reserved_", c_int32),
+                ("V", c_int64), ("V_out", c_int64), ("Cin", c_int64), ("Cout", c_int64),
+                ("momentum", c_float), ("eps", c_float), ("slope", c_float), ("reserved2_", c_float),
+                ("W", c_void_p * 3), ("bias", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("running_mean", c_void_p), ("running_var", c_void_p), ("batches_tracked", c_void_p),
+                ("wpack", c_void_p), ("wpack_t", c_void_p), ("wpack32", c_void_p), ("wpack32_t", c_void_p), ("bias_k", c_void_p),
+                ("X", c_void_p), ("ldx", c_int64), ("T", c_void_p), ("ldt", c_int64), ("H", c_void_p), ("stats", c_void_p),
+                ("Y", c_void_p), ("ldy", c_int64),
+                ("dY", c_void_p), ("lddy", c_int64), ("dX", c_void_p), ("lddx", c_int64), ("dW", c_void_p), ("dvec", c_void_p),
+                ("acc_W", c_void_p * 3), ("acc_bias", c_void_p), ("acc_gamma", c_void_p), ("acc_beta", c_void_p),
+                ("ws", c_void_p), ("ws_bytes", c_int64)]
+
+
+class sg_trace_record(ctypes.Structure):
+    _fields_ = [("kind", c_int32), ("dtype", c_int32), ("engine", c_int32), ("reserved_", c_int32),
+                ("a", c_int64), ("b", c_int64), ("c", c_int64), ("ms", c_float), ("reserved2_", c_float)]
+
+
 # name -> (restype, argtypes); mirrors include/semigcn.h one to one
 _SIGNATURES = {
     "sg_last_error": (c_char_p, []),
@@ -104,6 +126,15 @@ _SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p]),
     "sg_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
                                c_void_p]),
+    "sg_block_sizeof": (c_int64, []),
+    "sg_block_workspace": (c_int64, [POINTER(sg_block), c_int]),
+    "sg_block_forward": (c_int, [POINTER(sg_block), c_void_p]),
+    "sg_block_backward": (c_int, [POINTER(sg_block), c_void_p]),
+    "sg_block_chain_forward": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
+    "sg_block_chain_backward": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
+    "sg_trace_begin": (c_int, [c_int64, c_int]),
+    "sg_trace_read": (c_int64, [POINTER(sg_trace_record), c_int64]),
+    "sg_trace_end": (c_int, []),
     "sg_mesh_edges": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64), POINTER(c_int),
                               c_void_p]),
     "sg_mask_dilate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -162,6 +193,9 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.sg_abi_version() != 1:
         raise SemigcnLibraryError(f"ABI version mismatch: library reports {lib.sg_abi_version()}")
+    if lib.sg_block_sizeof() != ctypes.sizeof(sg_block):
+        raise SemigcnLibraryError(f"struct sg_block: the library's has {lib.sg_block_sizeof()} bytes, the binding's "
+                                  f"{ctypes.sizeof(sg_block)} -- rebuild the library (make -C semigcn_amd/csrc)")
     _lib = lib
     return lib
 
@@ -980,3 +1014,80 @@ def face_mask_bits(faces: torch.Tensor, vbits: torch.Tensor) -> torch.Tensor:
         _check(load().sg_face_mask(_ptr(faces), faces.shape[0], vbits.shape[0], _ptr(vbits), _ptr(out),
                                    vbits.shape[1], _stream(faces)), "sg_face_mask")
     return out
+
+
+# ---- one [ChebConv -> pool? -> BatchNorm -> activation] block per foreign call ---------------------------------------
+def block_workspace(blk: sg_block, backward: bool) -> int:
+    """Bytes of scratch sg_block_forward / sg_block_backward need for this block (depends on its shape fields only)."""
+    n = load().sg_block_workspace(byref(blk), 1 if backward else 0)
+    if n < 0:
+        _check(int(n), "sg_block_workspace")
+    return int(n)
+
+
+#: host seconds spent inside the two chain entry points since import (tools/host_profile.py reads them): [forward, backward]
+chain_host_seconds = [0.0, 0.0]
+_PROFILE_CHAINS = os.environ.get("SEMIGCN_PROFILE_CHAINS") == "1"
+
+
+def block_chain_forward(blks, n: int, stream: int) -> None:
+    """``blks``: a ctypes array of sg_block (n of them are run, first to last)."""
+    if _PROFILE_CHAINS:
+        import time
+        t0 = time.perf_counter()
+        rc = _lib.sg_block_chain_forward(blks, n, stream)
+        chain_host_seconds[0] += time.perf_counter() - t0
+    else:
+        rc = _lib.sg_block_chain_forward(blks, n, stream)
+    if rc:
+        _check(rc, "sg_block_chain_forward")
+
+
+def block_chain_backward(blks, n: int, stream: int) -> None:
+    if _PROFILE_CHAINS:
+        import time
+        t0 = time.perf_counter()
+        rc = _lib.sg_block_chain_backward(blks, n, stream)
+        chain_host_seconds[1] += time.perf_counter() - t0
+    else:
+        rc = _lib.sg_block_chain_backward(blks, n, stream)
+    if rc:
+        _check(rc, "sg_block_chain_backward")
+
+
+class LaunchTrace:
+    """Per-launch HIP-event timing INSIDE the library (sg_trace_*): the aggregations and dense products a block call
+    launches, which no Python-side timer can bracket any more.  ``with LaunchTrace(capacity) as t: ...`` then, after a
+    device synchronize, ``t.records()`` -> list of dicts (kind "agg" / "nt" / "tn", dtype, engine, a, b, c, ms)."""
+    KINDS = {0: "agg", 1: "nt", 2: "tn"}
+    ENGINES = {0: "agg", 1: "mfma", 2: "thin", 3: "blas"}
+
+    def __init__(self, capacity: int = 1 << 16, kinds=("agg", "nt", "tn")):
+        self.capacity = int(capacity)
+        self.mask = sum(1 << k for k, name in self.KINDS.items() if name in kinds)
+        self._out = None
+
+    def __enter__(self):
+        _check(load().sg_trace_begin(self.capacity, self.mask), "sg_trace_begin")
+        return self
+
+    def stop(self):
+        """Read the records (call after torch.cuda.synchronize()) and release the events."""
+        if self._out is None:
+            buf = (sg_trace_record * self.capacity)()
+            n = load().sg_trace_read(buf, self.capacity)
+            if n < 0:
+                _check(int(n), "sg_trace_read")
+            self._out = [{"kind": self.KINDS.get(r.kind, r.kind), "dtype": "bfloat16" if r.dtype == SG_BF16 else "float32",
+                          "engine": self.ENGINES.get(r.engine, r.engine), "a": r.a, "b": r.b, "c": r.c, "ms": r.ms}
+                         for r in buf[:n]]
+            load().sg_trace_end()
+        return self._out
+
+    def records(self):
+        return self.stop()
+
+    def __exit__(self, *exc):
+        if exc[0] is not None:
+            load().sg_trace_end()
+        return False

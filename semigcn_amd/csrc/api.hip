@@ -324,6 +324,9 @@ SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx,
               "apply it owner-computes on exchanged gradient rows");
     return SG_ERR_UNSUPPORTED;
   }
+  // (benchmarking aid, off by default: an event pair around the launch, sg_trace_begin)
+  TraceScope trace(0, dtype, 0, C, (X0 ? 1 : 0) + (X1 ? 1 : 0), (t && !g->symmetric) ? g->bwd.n_rows : g->fwd.n_rows,
+                   (hipStream_t)stream);
   // L^[i,j] = -dis[i] dis[j] (#edges j->i); the transposed CSR carries the same scales
   if (g->square && g->symmetric && g->row_id && g->loc.rowptr)   // locality view: rows in processing order, output rows addressed through row_id
     return run_csr(g->loc, g->dis_dst_loc, g->dis_src, X, ldx, X0, ldx0, X1, ldx1, Y, ldy, C, dtype, -alpha, beta, gamma,

@@ -1,0 +1,456 @@
+// sg_block_forward / sg_block_backward: one [ChebConv -> (MeshPool | MeshUnpool)? -> BatchNorm1d -> LeakyReLU] block of
+// the reference's networks per foreign call (semigcn.h; util/networks.py:40-46,83-101; util/meshnet.py:39-62,105-128,
+// 223-245,295-312).  Nothing here computes: the functions below launch, in the order the per-operator host code used to,
+// the kernels of spmm.hip (aggregation), gemm_mfma*.hip / thin_gemm.hip / the BLAS library (products, dense.hip) and
+// bn_act.hip (BatchNorm + activation), on buffers the caller owns.  What moves below the ABI is the HOST work between
+// those launches -- ~20 ctypes calls, three autograd nodes and a dozen small allocations per block and direction -- which is
+// what bounds an iteration on the reference's own mesh sizes (5 K - 50 K vertices).
+#include <math.h>
+
+#include "sg_common.h"
+
+namespace sg {
+namespace {
+
+inline int64_t esize(int dtype) { return dtype == SG_F32 ? 4 : 2; }
+inline int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+// bump allocator over the caller's scratch; with base == nullptr it only counts
+struct Carver {
+  char* base;
+  int64_t cap, at = 0;
+  bool overflow = false;
+  Carver(void* b, int64_t c) : base((char*)b), cap(c) {}
+  void* take(int64_t bytes) {
+    const int64_t off = at;
+    at += align_up(bytes > 0 ? bytes : 1);
+    if (!base) return nullptr;
+    if (at > cap) {
+      overflow = true;
+      return nullptr;
+    }
+    return base + off;
+  }
+};
+
+// ---- weights: K fp32 [Cout, Cin] matrices -> the concatenated / stacked copies the products read ---------------------------
+struct PackArgs {
+  const float* W[3];
+  const float* bias;
+  void* wpack;
+  void* wpack_t;
+  float* wpack32;
+  float* wpack32_t;
+  float* bias_k;
+  int K, Cin, Cout, order, dtype;
+};
+
+__device__ __forceinline__ void put(void* p, int dtype, int64_t i, float v) {
+  if (dtype == SG_F32) ((float*)p)[i] = v;
+  else ((uint16_t*)p)[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+}
+
+__global__ __launch_bounds__(256) void pack_weights(const PackArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_el = (int64_t)a.K * a.Cin * a.Cout;
+  if (e < n_el) {
+    int64_t r, c, rows, cols;     // position in wpack [rows, cols]
+    float v;
+    if (a.order == 0) {           // Wcat [Cout, K*Cin]: block k of row n = W_k[n, :]
+      rows = a.Cout; cols = (int64_t)a.K * a.Cin;
+      r = e / cols; c = e % cols;
+      v = a.W[c / a.Cin][r * a.Cin + c % a.Cin];
+    } else {                      // Wstack [K*Cout, Cin]: rows k*Cout .. of it = W_k
+      rows = (int64_t)a.K * a.Cout; cols = a.Cin;
+      r = e / cols; c = e % cols;
+      v = a.W[r / a.Cout][(r % a.Cout) * a.Cin + c];
+    }
+    put(a.wpack, a.dtype, e, v);
+    if (a.wpack_t) put(a.wpack_t, a.dtype, c * rows + r, v);
+    // (the float32 copies for the thin kernels hold the weights AS STORED for this feature dtype: rounded to bf16 for bf16
+    // features, like the MFMA kernels' operands -- one rounding rule for a layer whatever kernel serves it)
+    const float v32 = a.dtype == SG_BF16 ? (float)(__bf16)v : v;
+    if (a.wpack32) a.wpack32[e] = v32;
+    if (a.wpack32_t) a.wpack32_t[c * rows + r] = v32;
+  }
+  if (a.bias_k && e < (int64_t)a.K * a.Cout) a.bias_k[e] = (a.bias && e < a.Cout) ? a.bias[e] : 0.f;
+}
+
+// eval-mode BatchNorm: (mean, invstd, scale, shift) from the running statistics, with nn.BatchNorm1d's own operation order
+__global__ void bn_eval_coeffs(const float* __restrict__ rm, const float* __restrict__ rv, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, float eps, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = rm[c];
+  const float invstd = rsqrtf(__fadd_rn(rv[c], eps));
+  const float scale = __fmul_rn(gamma[c], invstd);
+  out[c] = mean;
+  out[C + c] = invstd;
+  out[2 * C + c] = scale;
+  out[3 * C + c] = __fsub_rn(beta[c], __fmul_rn(mean, scale));
+}
+
+int copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype, hipStream_t s) {
+  const int64_t e = esize(dtype);
+  SG_HIP_TRY(hipMemcpy2DAsync(dst, (size_t)(ldd * e), src, (size_t)(lds * e), (size_t)(cols * e), (size_t)rows,
+                              hipMemcpyDeviceToDevice, s));
+  return SG_OK;
+}
+
+struct Shape {
+  int64_t V, Vo, Ci, Co, KCi, KCo, e;
+  int K;
+  bool thin, blas_fwd, blas_dx, blas_dw;
+  int64_t nb;            // sg_col_blocks(V_out)
+  int64_t mom_floats;    // the larger of the tile-moment / block-moment buffers
+  int64_t tn_floats;
+};
+
+int shape_of(const sg_block& b, Shape* s) {
+  SG_REQUIRE(b.graph != nullptr, "sg_block: null graph");
+  SG_REQUIRE(b.dtype == SG_F32 || b.dtype == SG_BF16, "sg_block: unknown dtype %d", b.dtype);
+  SG_REQUIRE(b.K >= 1 && b.K <= 3, "sg_block: K = %d (1..3 are implemented)", b.K);
+  SG_REQUIRE(b.order == 0 || (b.order == 1 && b.K >= 2), "sg_block: order %d with K = %d", b.order, b.K);
+  SG_REQUIRE(b.V > 0 && b.V_out > 0 && b.Cin > 0 && b.Cout > 0, "sg_block: empty shape");
+  SG_REQUIRE(b.graph->square && b.graph->fwd.n_rows == b.V, "sg_block: the graph has %lld rows, V = %lld (square graphs only)",
+             (long long)b.graph->fwd.n_rows, (long long)b.V);
+  if (b.pool_mode == 0) {
+    SG_REQUIRE(b.pool == nullptr && b.V_out == b.V, "sg_block: V_out != V without a pool");
+  } else if (b.pool_mode == 1) {
+    SG_REQUIRE(b.pool && b.pool->by_coarse.n_cols == b.V && b.pool->by_coarse.n_rows == b.V_out,
+               "sg_block: MeshPool handle does not map %lld fine rows onto %lld coarse rows", (long long)b.V, (long long)b.V_out);
+  } else if (b.pool_mode == 2) {
+    SG_REQUIRE(b.pool && b.pool->by_fine.n_cols == b.V && b.pool->by_fine.n_rows == b.V_out,
+               "sg_block: MeshUnpool handle does not map %lld coarse rows onto %lld fine rows", (long long)b.V, (long long)b.V_out);
+  } else {
+    set_error("sg_block: pool_mode %d", b.pool_mode);
+    return SG_ERR_INVALID;
+  }
+  if (b.training) SG_REQUIRE(b.V_out > 1, "sg_block: BatchNorm in training mode needs more than one row");
+  s->V = b.V; s->Vo = b.V_out; s->Ci = b.Cin; s->Co = b.Cout; s->K = b.K;
+  s->KCi = b.K * b.Cin; s->KCo = b.K * b.Cout; s->e = esize(b.dtype);
+  // the fused column sums of dH (= the conv's bias gradient) come from the row-owning apply kernel
+  if (col_apply_blocks(b.V_out, b.Cout, b.dtype) == 0) {
+    set_error("sg_block: Cout = %lld is not served (whole 16-byte vectors, at most 256 of them per row)", (long long)b.Cout);
+    return SG_ERR_UNSUPPORTED;
+  }
+  if (b.order == 0) {
+    s->thin = thin_shape(s->Co, s->KCi);
+    s->blas_fwd = !s->thin && !dense_nt_own(b.dtype, s->V, s->Co, s->KCi, s->KCi, s->KCi, s->Co);
+    s->blas_dx = !s->thin && !dense_nt_own(b.dtype, s->V, s->KCi, s->Co, s->Co, s->Co, s->KCi);
+    s->blas_dw = !s->thin && !dense_tn_own(b.dtype, s->V, s->Co, s->KCi, s->Co, s->KCi);
+    s->tn_floats = dense_tn_workspace(b.dtype, s->V, s->Co, s->KCi);
+  } else {
+    s->thin = false;
+    s->blas_fwd = !dense_nt_own(b.dtype, s->V, s->KCo, s->Ci, s->Ci, s->Ci, s->KCo);
+    s->blas_dx = !dense_nt_own(b.dtype, s->V, s->Ci, s->KCo, s->KCo, s->KCo, s->Ci);
+    s->blas_dw = !dense_tn_own(b.dtype, s->V, s->KCo, s->Ci, s->KCo, s->Ci) || thin_shape(s->KCo, s->Ci);
+    s->tn_floats = thin_shape(s->KCo, s->Ci) ? 0 : dense_tn_workspace(b.dtype, s->V, s->KCo, s->Ci);
+    if (thin_shape(s->KCo, s->Ci)) {      // (never a layer of the reference: order 1 has K*Cout >= 2 and Cin > Cout)
+      set_error("sg_block: order 1 with a %lld x %lld weight stack is not served", (long long)s->KCo, (long long)s->Ci);
+      return SG_ERR_UNSUPPORTED;
+    }
+  }
+  s->nb = col_blocks(s->Vo);
+  const int64_t R = gemm_tile_rows(s->Co);
+  const int64_t tiles = (s->V + R - 1) / R;
+  s->mom_floats = (tiles > s->nb ? tiles : s->nb) * 2 * s->Co;
+  return SG_OK;
+}
+
+// scratch layout of the two passes (one routine walks it for sizing and for the pointers)
+struct FwdWs {
+  float* moments;
+  void* Z;        // order 1: [V, K*Cout]
+  void* Hc;       // with a pool: [V, Cout]
+  void* blas;
+};
+void carve_fwd(const sg_block& b, const Shape& s, Carver& c, FwdWs* w) {
+  w->moments = (float*)c.take(s.mom_floats * 4);
+  w->Z = b.order == 1 ? c.take(s.V * s.KCo * s.e) : nullptr;
+  w->Hc = b.pool_mode ? c.take(s.V * s.Co * s.e) : nullptr;
+  w->blas = s.blas_fwd ? c.take((int64_t)kBlasWorkspace) : nullptr;
+}
+
+struct BwdWs {
+  float* part;      // [nb, 2, Cout]
+  float* colsum;    // [apply blocks, Cout]
+  void* dHp;        // [V_out, Cout]: gradient of the BatchNorm input (order 0, or with a pool)
+  void* dHc;        // order 0 with a pool: [V, Cout]
+  void* G;          // order 0: dT [V, K*Cin]; order 1: [V, K*Cout]
+  float* tn;
+  void* blas;
+};
+void carve_bwd(const sg_block& b, const Shape& s, Carver& c, BwdWs* w) {
+  w->part = (float*)c.take(s.nb * 2 * s.Co * 4);
+  w->colsum = (float*)c.take(col_apply_blocks(s.Vo, s.Co, b.dtype) * s.Co * 4);
+  const bool sep = b.order == 0 || b.pool_mode != 0;
+  w->dHp = sep ? c.take(s.Vo * s.Co * s.e) : nullptr;
+  w->dHc = (b.order == 0 && b.pool_mode) ? c.take(s.V * s.Co * s.e) : nullptr;
+  w->G = c.take(s.V * (b.order == 0 ? s.KCi : s.KCo) * s.e);     // (sized without looking at need_dx: one size per shape)
+  w->tn = (float*)c.take(s.tn_floats * 4);
+  w->blas = (s.blas_dx || s.blas_dw) ? c.take((int64_t)kBlasWorkspace) : nullptr;
+}
+
+int spmm(const sg_block& b, bool transpose, const void* X, int64_t ldx, const void* X0, int64_t ldx0, const void* X1,
+         int64_t ldx1, void* Y, int64_t ldy, int64_t C, float alpha, float beta, float gamma, hipStream_t s) {
+  return sg_spmm(b.graph, transpose ? 1 : 0, X, ldx, X0, ldx0, X1, ldx1, Y, ldy, C, b.dtype, alpha, beta, gamma, (void*)s);
+}
+
+inline char* col(void* base, int64_t cols, int64_t e) { return (char*)base + cols * e; }
+
+int pack(const sg_block& b, hipStream_t stream) {
+  SG_REQUIRE(b.wpack != nullptr, "sg_block: wpack is null");
+  PackArgs a;
+  for (int k = 0; k < 3; ++k) a.W[k] = k < b.K ? b.W[k] : nullptr;
+  for (int k = 0; k < b.K; ++k) SG_REQUIRE(b.W[k] != nullptr, "sg_block: W[%d] is null", k);
+  a.bias = b.bias;
+  a.wpack = b.wpack; a.wpack_t = b.wpack_t; a.wpack32 = b.wpack32; a.wpack32_t = b.wpack32_t;
+  a.bias_k = (b.order == 1 && b.bias) ? b.bias_k : nullptr;
+  a.K = b.K; a.Cin = (int)b.Cin; a.Cout = (int)b.Cout; a.order = b.order; a.dtype = b.dtype;
+  const int64_t n = (int64_t)b.K * b.Cin * b.Cout;
+  pack_weights<<<(int)((n + 255) / 256), 256, 0, stream>>>(a);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int forward(const sg_block& b, hipStream_t stream) {
+  Shape s;
+  int rc = shape_of(b, &s);
+  if (rc != SG_OK) return rc;
+  SG_REQUIRE(b.X && b.H && b.Y && b.stats && b.gamma && b.beta && b.wpack, "sg_block_forward: null pointer");
+  SG_REQUIRE(b.ldy >= s.Co && b.ldx >= s.Ci, "sg_block_forward: row stride shorter than the row");
+  SG_REQUIRE((b.running_mean == nullptr) == (b.running_var == nullptr), "sg_block_forward: give both running buffers or none");
+  SG_REQUIRE(b.training || b.running_mean, "sg_block_forward: eval mode needs the running statistics");
+  if (s.thin) SG_REQUIRE(b.wpack32 && b.wpack32_t, "sg_block_forward: a tiny weight matrix needs wpack32 / wpack32_t");
+  if (b.order == 1 && b.bias) SG_REQUIRE(b.bias_k != nullptr, "sg_block_forward: order 1 with a bias needs bias_k");
+  Carver c(b.ws, b.ws_bytes);
+  FwdWs w;
+  carve_fwd(b, s, c, &w);
+  SG_REQUIRE(b.ws != nullptr && !c.overflow, "sg_block_forward: scratch too small (%lld bytes given, %lld needed)",
+             (long long)b.ws_bytes, (long long)c.at);
+  if (b.refresh_weights && (rc = pack(b, stream)) != SG_OK) return rc;
+
+  void* const Hc = b.pool_mode ? w.Hc : b.H;
+  bool tile_moments = false;
+  if (b.order == 0) {
+    SG_REQUIRE(b.T && b.ldt >= s.KCi, "sg_block_forward: order 0 needs the [V, K*Cin] buffer T");
+    if (b.X != b.T && (rc = copy_rows(b.X, b.ldx, b.T, b.ldt, s.V, s.Ci, b.dtype, stream)) != SG_OK) return rc;
+    for (int k = 1; k < b.K; ++k) {     // Tx1 = L^ Tx0;  Txk = 2 L^ Tx(k-1) - Tx(k-2)
+      rc = spmm(b, false, col(b.T, (k - 1) * s.Ci, s.e), b.ldt, k >= 2 ? col(b.T, (k - 2) * s.Ci, s.e) : nullptr, b.ldt, nullptr, 0,
+                col(b.T, k * s.Ci, s.e), b.ldt, s.Ci, k == 1 ? 1.f : 2.f, -1.f, 0.f, stream);
+      if (rc != SG_OK) return rc;
+    }
+    const bool want = b.training && b.pool_mode == 0;      // (pooled rows have other statistics than the tiles of Hc)
+    rc = dense_nt(b.T, b.ldt, b.wpack, b.wpack32, s.KCi, b.bias, Hc, s.Co, s.V, s.Co, s.KCi, b.dtype, want ? w.moments : nullptr,
+                  &tile_moments, w.blas, kBlasWorkspace, stream);
+    if (rc != SG_OK) return rc;
+  } else {
+    // Z = X Wstack^T (+ bias on Z_0); Clenshaw in place: b_k = Z_k + 2 L^ b_(k+1) - b_(k+2); out = Z_0 + L^ b_1 - b_2
+    rc = dense_nt(b.X, b.ldx, b.wpack, nullptr, s.Ci, b.bias ? b.bias_k : nullptr, w.Z, s.KCo, s.V, s.KCo, s.Ci, b.dtype, nullptr,
+                  nullptr, w.blas, kBlasWorkspace, stream);
+    if (rc != SG_OK) return rc;
+    auto z = [&](int k) { return col(w.Z, k * s.Co, s.e); };
+    for (int k = b.K - 2; k >= 1; --k) {
+      rc = spmm(b, false, z(k + 1), s.KCo, z(k), s.KCo, k + 2 <= b.K - 1 ? z(k + 2) : nullptr, s.KCo, z(k), s.KCo, s.Co, 2.f, 1.f,
+                -1.f, stream);
+      if (rc != SG_OK) return rc;
+    }
+    rc = spmm(b, false, z(1), s.KCo, z(0), s.KCo, b.K >= 3 ? z(2) : nullptr, s.KCo, Hc, s.Co, s.Co, 1.f, 1.f, -1.f, stream);
+    if (rc != SG_OK) return rc;
+  }
+  if (b.pool_mode == 1) rc = sg_pool_mean(b.pool, Hc, s.Co, b.H, s.Co, s.Co, b.dtype, (void*)stream);
+  else if (b.pool_mode == 2) rc = sg_unpool(b.pool, Hc, s.Co, b.H, s.Co, s.Co, b.dtype, (void*)stream);
+  if (rc != SG_OK) return rc;
+
+  if (b.training) {
+    if (tile_moments) {
+      const int64_t R = gemm_tile_rows(s.Co);
+      rc = launch_bn_stats_finalize_tiles(w.moments, (s.V + R - 1) / R, R, s.Vo, s.Co, b.gamma, b.beta, b.running_mean,
+                                          b.running_var, b.momentum, b.eps, b.stats, b.batches_tracked, stream);
+    } else {
+      rc = launch_col_reduce(0, b.H, s.Co, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, w.moments, s.nb, s.Vo, s.Co,
+                             b.dtype, stream);
+      if (rc != SG_OK) return rc;
+      rc = launch_bn_stats_finalize(w.moments, s.nb, s.Vo, s.Co, b.gamma, b.beta, b.running_mean, b.running_var, b.momentum,
+                                    b.eps, b.stats, b.batches_tracked, stream);
+    }
+    if (rc != SG_OK) return rc;
+  } else {
+    bn_eval_coeffs<<<(int)((s.Co + 127) / 128), 128, 0, stream>>>(b.running_mean, b.running_var, b.gamma, b.beta, b.eps,
+                                                                 (int)s.Co, b.stats);
+    SG_HIP_TRY(hipGetLastError());
+  }
+  return launch_col_apply(0, b.H, s.Co, nullptr, 0, b.stats + 2 * s.Co, b.stats + 3 * s.Co, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, b.slope, b.Y, b.ldy, s.Vo, s.Co, b.dtype, stream);
+}
+
+int backward(const sg_block& b, hipStream_t stream) {
+  Shape s;
+  int rc = shape_of(b, &s);
+  if (rc != SG_OK) return rc;
+  SG_REQUIRE(b.dY && b.H && b.stats && b.gamma && b.dW && b.dvec && b.wpack, "sg_block_backward: null pointer");
+  SG_REQUIRE(b.lddy >= s.Co, "sg_block_backward: row stride of dY shorter than the row");
+  SG_REQUIRE(!b.need_dx || (b.dX && b.lddx >= s.Ci), "sg_block_backward: need_dx without dX");
+  SG_REQUIRE((b.acc_gamma == nullptr) == (b.acc_beta == nullptr), "sg_block_backward: give both BatchNorm accumulators or none");
+  const bool sink_w = b.acc_W[0] != nullptr;
+  for (int k = 0; k < b.K; ++k)
+    SG_REQUIRE((b.acc_W[k] != nullptr) == sink_w, "sg_block_backward: give all K weight accumulators or none");
+  if (s.thin) SG_REQUIRE(b.wpack32 && b.wpack32_t, "sg_block_backward: a tiny weight matrix needs wpack32 / wpack32_t");
+  Carver c(b.ws, b.ws_bytes);
+  BwdWs w;
+  carve_bwd(b, s, c, &w);
+  SG_REQUIRE(b.ws != nullptr && !c.overflow, "sg_block_backward: scratch too small (%lld bytes given, %lld needed)",
+             (long long)b.ws_bytes, (long long)c.at);
+  const float *mean = b.stats, *invstd = b.stats + s.Co, *scale = b.stats + 2 * s.Co, *shift = b.stats + 3 * s.Co;
+  float* const co = b.dvec;                  // [5, Cout]: sum dz, sum dz xhat, c1, c2, k
+  float* const db = b.dvec + 5 * s.Co;       // conv bias gradient
+
+  // BatchNorm + activation: sums -> coefficients (eval mode: N = inf makes c1 = c2 = 0, k = gamma invstd = scale) -> dH
+  rc = launch_col_reduce(1, b.dY, b.lddy, b.H, s.Co, scale, shift, mean, invstd, b.slope, w.part, s.nb, s.Vo, s.Co, b.dtype, stream);
+  if (rc != SG_OK) return rc;
+  rc = launch_bn_bwd_coeffs(w.part, s.nb, s.Co, b.training ? (double)s.Vo : (double)INFINITY, b.gamma, invstd, co, b.acc_gamma,
+                            b.acc_beta, nullptr, stream);
+  if (rc != SG_OK) return rc;
+  // where dH goes: order 1 runs its recurrence on the gradient, dH is block 0 of G; a pool sits in between in either order
+  void* dHp = w.dHp;
+  int64_t lddh = s.Co;
+  if (b.order == 1 && b.pool_mode == 0) {
+    dHp = w.G;
+    lddh = s.KCo;
+  }
+  rc = launch_col_apply(1, b.dY, b.lddy, b.H, s.Co, scale, shift, mean, invstd, co + 4 * s.Co, co + 2 * s.Co, co + 3 * s.Co, b.slope,
+                        dHp, lddh, s.Vo, s.Co, b.dtype, stream, w.colsum);
+  if (rc != SG_OK) return rc;
+  // d bias = column sums of the conv output's gradient; through a pool they equal the column sums of dH (every cluster's
+  // members share its gradient / count, an unpooled row's gradient goes to one parent)
+  rc = launch_colsum_finalize(w.colsum, col_apply_blocks(s.Vo, s.Co, b.dtype), s.Co, db, stream);
+  if (rc != SG_OK) return rc;
+  void* dHc = dHp;          // gradient of the conv output [V, Cout]
+  int64_t lddc = lddh;
+  if (b.pool_mode) {
+    dHc = b.order == 0 ? w.dHc : w.G;
+    lddc = b.order == 0 ? s.Co : s.KCo;
+    if (b.pool_mode == 1) rc = sg_pool_mean_bwd(b.pool, dHp, s.Co, dHc, lddc, s.Co, b.dtype, (void*)stream);
+    else rc = sg_unpool_bwd(b.pool, dHp, s.Co, dHc, lddc, s.Co, b.dtype, (void*)stream);
+    if (rc != SG_OK) return rc;
+  }
+  const bool tr = !b.graph->symmetric;
+
+  if (b.order == 0) {
+    SG_REQUIRE(b.T && b.ldt >= s.KCi, "sg_block_backward: order 0 needs the saved [V, K*Cin] buffer T");
+    rc = dense_tn(dHc, lddc, b.T, b.ldt, s.V, s.Co, s.KCi, b.dtype, w.tn, b.dW, s.KCi, w.blas, kBlasWorkspace, stream);
+    if (rc != SG_OK) return rc;
+    if (b.need_dx) {
+      // dT = dH Wcat: block k = dL/dTx_k before the recurrence is unwound
+      void* const dT = b.K == 1 ? b.dX : w.G;
+      const int64_t ldt = b.K == 1 ? b.lddx : s.KCi;
+      rc = dense_nn(dHc, lddc, b.wpack, s.KCi, b.wpack_t, s.Co, b.wpack32_t, dT, ldt, s.V, s.KCi, s.Co, b.dtype, w.blas,
+                    kBlasWorkspace, stream);
+      if (rc != SG_OK) return rc;
+      if (b.K > 1) {
+        auto g = [&](int k) { return col(dT, k * s.Ci, s.e); };
+        for (int k = b.K - 2; k >= 1; --k) {     // g_k += 2 L^T g_(k+1) - g_(k+2), in place
+          rc = spmm(b, tr, g(k + 1), ldt, g(k), ldt, k + 2 <= b.K - 1 ? g(k + 2) : nullptr, ldt, g(k), ldt, s.Ci, 2.f, 1.f, -1.f, stream);
+          if (rc != SG_OK) return rc;
+        }
+        rc = spmm(b, tr, g(1), ldt, g(0), ldt, b.K >= 3 ? g(2) : nullptr, ldt, b.dX, b.lddx, s.Ci, 1.f, 1.f, -1.f, stream);
+        if (rc != SG_OK) return rc;
+      }
+    }
+  } else {
+    SG_REQUIRE(b.X && b.ldx >= s.Ci, "sg_block_backward: order 1 needs the saved input X");
+    auto g = [&](int k) { return col(w.G, k * s.Co, s.e); };
+    // G = [T_0 | T_1 | ..](L^T) dH: the forward Chebyshev recurrence applied to the gradient
+    rc = spmm(b, tr, g(0), s.KCo, nullptr, 0, nullptr, 0, g(1), s.KCo, s.Co, 1.f, 0.f, 0.f, stream);
+    if (rc != SG_OK) return rc;
+    for (int k = 2; k < b.K; ++k) {
+      rc = spmm(b, tr, g(k - 1), s.KCo, g(k - 2), s.KCo, nullptr, 0, g(k), s.KCo, s.Co, 2.f, -1.f, 0.f, stream);
+      if (rc != SG_OK) return rc;
+    }
+    if (b.need_dx) {
+      rc = dense_nn(w.G, s.KCo, b.wpack, s.Ci, b.wpack_t, s.KCo, nullptr, b.dX, b.lddx, s.V, s.Ci, s.KCo, b.dtype, w.blas,
+                    kBlasWorkspace, stream);
+      if (rc != SG_OK) return rc;
+    }
+    rc = dense_tn(w.G, s.KCo, b.X, b.ldx, s.V, s.KCo, s.Ci, b.dtype, w.tn, b.dW, s.Ci, w.blas, kBlasWorkspace, stream);
+    if (rc != SG_OK) return rc;
+  }
+
+  if (sink_w || b.acc_bias) {      // += into the parameters' .grad accumulators, one launch
+    const float* srcs[4];
+    float* dsts[4];
+    int64_t ld[4], rows[4], cols[4];
+    int n = 0;
+    if (b.acc_bias) {
+      srcs[n] = db; dsts[n] = b.acc_bias; ld[n] = s.Co; rows[n] = 1; cols[n] = s.Co; ++n;
+    }
+    if (sink_w)
+      for (int k = 0; k < b.K; ++k) {
+        srcs[n] = b.order == 0 ? b.dW + k * s.Ci : b.dW + k * s.Co * s.Ci;
+        ld[n] = b.order == 0 ? s.KCi : s.Ci;
+        dsts[n] = b.acc_W[k]; rows[n] = s.Co; cols[n] = s.Ci; ++n;
+      }
+    rc = launch_multi_add(n, srcs, ld, rows, cols, dsts, stream);
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
+}
+
+}  // namespace
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+SG_API int64_t sg_block_sizeof(void) { return (int64_t)sizeof(sg_block); }
+
+SG_API int64_t sg_block_workspace(const sg_block* blk, int backward_pass) {
+  if (!blk) {
+    set_error("sg_block_workspace: null block");
+    return SG_ERR_INVALID;
+  }
+  Shape s;
+  const int rc = shape_of(*blk, &s);
+  if (rc != SG_OK) return rc;
+  Carver c(nullptr, 0);
+  if (backward_pass) {
+    BwdWs w;
+    carve_bwd(*blk, s, c, &w);
+  } else {
+    FwdWs w;
+    carve_fwd(*blk, s, c, &w);
+  }
+  return c.at;
+}
+
+SG_API int sg_block_forward(const sg_block* blk, void* stream) {
+  SG_REQUIRE(blk != nullptr, "sg_block_forward: null block");
+  return forward(*blk, (hipStream_t)stream);
+}
+
+SG_API int sg_block_backward(const sg_block* blk, void* stream) {
+  SG_REQUIRE(blk != nullptr, "sg_block_backward: null block");
+  return backward(*blk, (hipStream_t)stream);
+}
+
+SG_API int sg_block_chain_forward(const sg_block* blks, int64_t n, void* stream) {
+  SG_REQUIRE(n >= 0 && (n == 0 || blks != nullptr), "sg_block_chain_forward: bad argument");
+  for (int64_t i = 0; i < n; ++i) {
+    const int rc = forward(blks[i], (hipStream_t)stream);
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
+}
+
+SG_API int sg_block_chain_backward(const sg_block* blks, int64_t n, void* stream) {
+  SG_REQUIRE(n >= 0 && (n == 0 || blks != nullptr), "sg_block_chain_backward: bad argument");
+  for (int64_t i = n - 1; i >= 0; --i) {
+    const int rc = backward(blks[i], (hipStream_t)stream);
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
+}
+
+}  // extern "C"

@@ -244,6 +244,37 @@ int launch_mesh_loss_bwd_corners(const float* pos, const int64_t* faces, const f
 int launch_mesh_loss_bwd_vertex_add(const float* pos, const float* tpos, const float* vkeep, const float* g, int64_t V,
                                     float* grad, hipStream_t stream);
 
+// trace.hip -- optional per-launch event timing (sg_trace_*)
+extern bool g_trace_on;
+void trace_open(int kind, int dtype, int engine, int64_t a, int64_t b, int64_t c, hipStream_t stream, int64_t* slot);
+void trace_close(int64_t slot, hipStream_t stream);
+struct TraceScope {
+  int64_t slot = -1;
+  hipStream_t stream;
+  TraceScope(int kind, int dtype, int engine, int64_t a, int64_t b, int64_t c, hipStream_t s) : stream(s) {
+    if (g_trace_on) trace_open(kind, dtype, engine, a, b, c, s, &slot);
+  }
+  ~TraceScope() {
+    if (slot >= 0) trace_close(slot, stream);
+  }
+};
+
+// dense.hip -- the three product shapes of a ChebConv layer behind one engine choice (thin kernels / own MFMA / BLAS library)
+constexpr size_t kBlasWorkspace = 32u << 20;     // scratch handed to the BLAS library per call
+bool dense_nt_own(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc);
+bool dense_tn_own(int dtype, int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
+int64_t dense_tn_workspace(int dtype, int64_t M, int64_t N, int64_t Kp);
+// C[M, N] = A[M, K] Bp[N, K]^T (+ bias): Bp in the feature dtype, B32 (nullable) the same matrix in float32 for the thin kernels
+int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64_t ldb, const float* bias, void* C, int64_t ldc,
+             int64_t M, int64_t N, int64_t K, int dtype, float* moments, bool* moments_done, void* blas_ws, size_t blas_ws_bytes,
+             hipStream_t stream);
+// C[M, N] = A[M, K] Bp[K, N]; Bt (nullable) = Bp^T [N, K] in the feature dtype, Bt32 (nullable) in float32
+int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void* Bt, int64_t ldbt, const float* Bt32, void* C,
+             int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream);
+// out[N, Kp] (float32) = A[M, N]^T B[M, Kp]; ws: dense_tn_workspace() floats
+int dense_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype, float* ws,
+             float* out, int64_t ldo, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream);
+
 }  // namespace sg
 
 struct sg_graph {

@@ -866,3 +866,472 @@ def mesh_loss_sums(pos: torch.Tensor, faces: torch.Tensor, target_pos: torch.Ten
     """[S_p, S_n] = [sum_kept |pos - target|^2, sum_kept_faces |n(pos) - n_target|_1], differentiable in
     ``pos`` ([V_ext, 3]; rows beyond ``target_pos.shape[0]`` are halo rows that only faces read)."""
     return _MeshLossFn.apply(pos, faces, target_pos, v_keep.reshape(-1), target_fn, f_keep.reshape(-1))
+
+
+# --------------------------------------------------------------------------------------------
+# [ChebConv -> (MeshPool | MeshUnpool)? -> BatchNorm1d -> LeakyReLU] blocks below the C ABI
+# (sg_block_chain_forward / sg_block_chain_backward, csrc/block.hip): the unit SingleScaleGCN.forward loops over
+# (util/networks.py:83-101) and DownConv / UpConv / the MGCN heads are made of (util/meshnet.py:39-62,105-128,
+# 223-245).  The library launches the kernel chain of a whole RUN of consecutive blocks; this side keeps one
+# autograd node, three allocations and one ctypes call per run and direction.
+# --------------------------------------------------------------------------------------------
+#: False (or SEMIGCN_NO_BLOCK_CALLS=1): nn.Sequential runs every module on its own, as before (A/B switch; the two paths
+#: launch the same kernels with the same arguments)
+USE_BLOCK_CALLS = os.environ.get("SEMIGCN_NO_BLOCK_CALLS") != "1"
+
+#: False (or SEMIGCN_NO_BLOCK_CHAINS=1): every block is a call (and an autograd node) of its own
+USE_BLOCK_CHAINS = os.environ.get("SEMIGCN_NO_BLOCK_CHAINS") != "1"
+
+#: blocks run since import (forward, backward) and foreign calls that ran them (forward, backward)
+block_calls = [0, 0]
+chain_calls = [0, 0]
+
+
+#: runs of blocks share one call (and keep their activations in one arena until backward) up to this many vertices: the
+#: meshes where an iteration is bound by host work; above it every block is a call of its own, freed on its own
+CHAIN_MAX_ROWS = 1 << 19
+
+
+def blocks_enabled() -> bool:
+    """The process-wide part of the test "may this block go through sg_block_*": the A/B switches are at their defaults and
+    no Python-side launch timer is installed (those bracket single launches)."""
+    return (USE_BLOCK_CALLS and USE_MFMA_GEMM and USE_THIN_GEMM and USE_MFMA_BIG_TILE and FUSE_BIAS_GRAD
+            and _gemm_timer is None and capi._timer is None)
+
+
+def chaining_allowed() -> bool:
+    """Runs of consecutive blocks may share one call unless something wants to see every block's output."""
+    return USE_BLOCK_CHAINS and not bn_act_observers
+
+
+def _f32_dev(t, dev) -> bool:
+    return t is not None and t.dtype == torch.float32 and t.device == dev and t.is_contiguous()
+
+
+class BlockPlan:
+    """What stays the same between calls of one block: its modules, the evaluation order, references to its parameter
+    tensors and the packed weight copies per feature dtype."""
+
+    def __init__(self, conv, bn, slope: float, pool=None):
+        self.conv, self.bn, self.pool, self.slope = conv, bn, pool, float(slope)
+        self.K, self.Cin, self.Cout = conv.K, conv.in_channels, conv.out_channels
+        self.order = 1 if (AGGREGATE_AFTER_GEMM_WHEN_NARROWING and self.K >= 2 and self.Cout < self.Cin) else 0
+        self.pool_mode = 0 if pool is None else int(pool.sg_pool_mode)
+        self._packs: dict = {}         # dtype -> [version sum at the last packing, wpack, wpack_t, wpack32, wpack32_t, bias_k]
+        self._static: dict = {}        # (dtype, device) -> bool, for the parameter tensors of `_mark`
+        self._mark = None
+        self.fingerprint()
+        conv.__dict__.setdefault("_block_plans_of", []).append(weakref.ref(self))    # (ChebConv.invalidate_weight_cache finds us)
+
+    def fingerprint(self):
+        """Identity and address of the first weight and of the BatchNorm weight: when they are what they were, the cached
+        references to all parameter tensors (and every address derived from them) are taken to be current.  (``.to()``,
+        ``load_state_dict`` and optimiser steps keep the Parameter objects; a module whose parameter OBJECT is replaced by
+        hand also gets new first-weight / BatchNorm-weight objects in every case the reference or these tests produce.)"""
+        w0 = self.conv.lins[0]._parameters["weight"]
+        g = self.bn._parameters["weight"]
+        mark = (id(w0), w0.data_ptr(), id(g), g.data_ptr(), self.bn._buffers["running_mean"] is None)
+        if mark != self._mark:
+            conv, bn = self.conv, self.bn
+            self.weights = [lin.weight for lin in conv.lins]
+            self.cbias, self.gamma, self.beta = conv.bias, bn.weight, bn.bias
+            self.rm, self.rv, self.nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+            self.param_tuple = (self.cbias, *self.weights, self.gamma, self.beta)
+            self._static.clear()
+            self._mark = mark
+        return mark
+
+    def init_descriptor(self, blk) -> None:
+        blk.K, blk.order, blk.Cin, blk.Cout, blk.slope, blk.pool_mode = self.K, self.order, self.Cin, self.Cout, self.slope, self.pool_mode
+
+    def usable(self, x: torch.Tensor) -> bool:
+        return x.is_cuda and x.dim() == 2 and self.usable_for(x.dtype, x.device, x.shape[0], x.shape[1])
+
+    def rows_out(self, rows: int) -> int:
+        """Rows of the block's output for ``rows`` input rows (a pool between conv and BatchNorm changes them)."""
+        if self.pool is None:
+            return rows
+        h = self.pool._pool()
+        return h.n_coarse if self.pool_mode == 1 else h.n_fine
+
+    def usable_for(self, dtype, dev, rows: int, cin: int) -> bool:
+        """[rows, cin] device features of a dtype and width the block kernels take, fp32 parameters on that device, a
+        BatchNorm with running statistics and a momentum (the reference's) whose statistics are this device's own."""
+        if cin != self.Cin or rows < 2:
+            return False
+        self.fingerprint()
+        bn = self.bn
+        key = (dtype, dev, bn.momentum is None)
+        ok = self._static.get(key)
+        if ok is None:
+            vec = 4 if dtype == torch.float32 else (8 if dtype == torch.bfloat16 else 0)
+            ok = bool(vec) and self.Cout % vec == 0 and self.Cout // vec <= 256 and self.K <= 3 \
+                and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.num_features == self.Cout \
+                and all(_f32_dev(w, dev) for w in self.weights) and _f32_dev(self.gamma, dev) \
+                and _f32_dev(self.beta, dev) and _f32_dev(self.rm, dev) and _f32_dev(self.rv, dev) \
+                and (self.cbias is None or _f32_dev(self.cbias, dev))
+            self._static[key] = ok
+        if not ok:
+            return False
+        if getattr(bn, "sg_mesh_wide", False) and ctx_group_active(getattr(bn, "group", False)):
+            return False
+        if self.pool is not None:
+            if self.pool._dist is not None:
+                return False
+            h = self.pool._pool()
+            if (h.n_fine if self.pool_mode == 1 else h.n_coarse) != rows or self.rows_out(rows) < 2:
+                return False
+        return True
+
+    def bind(self, blk, dtype: torch.dtype, dev) -> None:
+        """Parameter addresses and the packed-weight buffers for ``dtype`` into the descriptor."""
+        for k, w in enumerate(self.weights):
+            blk.W[k] = w.data_ptr()
+        blk.bias = None if self.cbias is None else self.cbias.data_ptr()
+        blk.gamma, blk.beta = self.gamma.data_ptr(), self.beta.data_ptr()
+        blk.running_mean, blk.running_var = self.rm.data_ptr(), self.rv.data_ptr()
+        nbt = self.nbt
+        blk.batches_tracked = nbt.data_ptr() if (nbt is not None and nbt.device == dev) else None
+        blk.momentum, blk.eps = float(self.bn.momentum), float(self.bn.eps)
+        ent = self._packs.get(dtype)
+        if ent is None or ent[1].device != dev:
+            n = self.K * self.Cin * self.Cout
+            thin = self.order == 0 and self.Cout <= capi.THIN_MAX and self.K * self.Cin <= capi.THIN_MAX
+            ent = [None, torch.empty(n, dtype=dtype, device=dev),
+                   torch.empty(n, dtype=dtype, device=dev) if dtype == torch.bfloat16 else None,
+                   torch.empty(n, dtype=torch.float32, device=dev) if thin else None,
+                   torch.empty(n, dtype=torch.float32, device=dev) if thin else None,
+                   torch.empty(self.K * self.Cout, dtype=torch.float32, device=dev) if (self.order == 1 and self.cbias is not None) else None]
+            self._packs[dtype] = ent
+        blk.wpack = ent[1].data_ptr()
+        blk.wpack_t = None if ent[2] is None else ent[2].data_ptr()
+        blk.wpack32 = None if ent[3] is None else ent[3].data_ptr()
+        blk.wpack32_t = None if ent[4] is None else ent[4].data_ptr()
+        blk.bias_k = None if ent[5] is None else ent[5].data_ptr()
+
+    def stale(self, dtype: torch.dtype, capturing: bool) -> int:
+        """1 when the packed copies for ``dtype`` are older than the parameters (version counters: optimiser steps and
+        every autograd-visible in-place update bump them) -- the library then rebuilds them in the same call; inside a
+        hipGraph capture always (the packing is part of the graph: replays see new weights)."""
+        v = 0 if self.cbias is None else self.cbias._version
+        for w in self.weights:
+            v += w._version
+        key = (self._mark, v)
+        ent = self._packs[dtype]
+        if ent[0] != key or capturing:
+            ent[0] = key
+            return 1
+        return 0
+
+    def invalidate(self) -> None:
+        """Forget the packed copies' state (after a write through ``.data`` that the version counters do not see)."""
+        for ent in self._packs.values():
+            ent[0] = None
+
+
+def _up256(n: int) -> int:
+    return (n + 255) & ~255
+
+
+class _Layout:
+    """Where everything of one run of blocks lives for one input shape: offsets into the activation arena (kept until
+    backward), the gradient buffer, and the scratch sizes."""
+    __slots__ = ("rows", "off_in", "off_H", "off_stats", "arena_bytes", "ws_fwd", "ws_bwd", "dx_bytes", "off_dW", "off_dvec",
+                 "grad_floats")
+
+
+class BlockChain:
+    """A run of consecutive blocks served by ONE foreign call per direction: the descriptor arrays, the cached layouts, and
+    what the descriptors were last filled with (a steady-state training loop gets the same buffers from the caching
+    allocator iteration after iteration: then a call fills in nothing)."""
+
+    def __init__(self, plans):
+        self.plans = list(plans)
+        n = len(self.plans)
+        self.fwd, self.bwd = (capi.sg_block * n)(), (capi.sg_block * n)()
+        for i, p in enumerate(self.plans):
+            p.init_descriptor(self.fwd[i])
+            p.init_descriptor(self.bwd[i])
+        self._layouts: dict = {}
+        self._sig = [None, None]        # static part last written into fwd / bwd
+        self._dyn = [None, None]        # buffer addresses last written
+        self._train = [None, None]
+        self._acc = None                # gradient-accumulator addresses last written into bwd
+
+    def layout(self, dtype: torch.dtype, rows, in_place: bool, handles) -> _Layout:
+        key = (dtype, rows, in_place)
+        lay = self._layouts.get(key)
+        if lay is not None:
+            return lay
+        e = 4 if dtype == torch.float32 else 2
+        lay = _Layout()
+        lay.rows = rows
+        lay.off_in, lay.off_H, lay.off_stats, lay.off_dW, lay.off_dvec = [], [], [], [], []
+        at = gat = 0
+        ws_f = ws_b = dxb = 0
+        probe = capi.sg_block()
+        for i, (p, (V, Vo)) in enumerate(zip(self.plans, rows)):
+            # the block's input buffer: [V, K*Cin] when it aggregates first (block 0 may find its input already inside such
+            # a buffer: in_place), the plain [V, Cin] input otherwise (block 0 reads the caller's tensor)
+            if (i == 0 and (in_place or p.order == 1)):
+                lay.off_in.append(-1)
+            else:
+                lay.off_in.append(at)
+                at += _up256(V * (p.K * p.Cin if p.order == 0 else p.Cin) * e)
+            lay.off_H.append(at)
+            at += _up256(Vo * p.Cout * e)
+            lay.off_stats.append(at)
+            at += _up256(4 * p.Cout * 4)
+            lay.off_dW.append(gat)
+            gat += p.Cout * p.K * p.Cin
+            lay.off_dvec.append(gat)
+            gat += 6 * p.Cout
+            p.init_descriptor(probe)
+            probe.graph, probe.pool = handles[i]
+            probe.dtype, probe.V, probe.V_out, probe.training = capi._DTYPES[dtype], V, Vo, 1
+            ws_f = max(ws_f, capi.block_workspace(probe, False))
+            ws_b = max(ws_b, capi.block_workspace(probe, True))
+            dxb = max(dxb, _up256(V * p.Cin * e))
+        lay.arena_bytes, lay.ws_fwd, lay.ws_bwd, lay.dx_bytes, lay.grad_floats = max(at, 256), max(ws_f, 256), max(ws_b, 256), dxb, gat
+        if len(self._layouts) > 16:
+            self._layouts.clear()
+        self._layouts[key] = lay
+        return lay
+
+    def fill_static(self, which: int, lay: _Layout, dtype, dev, graphs, pools) -> bool:
+        """Write what does not depend on this call's buffers into the descriptors of direction ``which`` (0 forward, 1
+        backward) unless it is what they hold already; True when something was written."""
+        marks = tuple(p.fingerprint() for p in self.plans)
+        sig = (lay, dtype, graphs, tuple(pools), marks)
+        old = self._sig[which]
+        if old is not None and old[0] is lay and old[1] == dtype and old[2] == graphs and old[3] == sig[3] and old[4] == marks:
+            return False
+        blks = self.bwd if which else self.fwd
+        code = capi._DTYPES[dtype]
+        for i, p in enumerate(self.plans):
+            blk = blks[i]
+            blk.graph = graphs[i].handle._h
+            blk.pool = None if pools[i] is None else pools[i]._h
+            blk.dtype, blk.V, blk.V_out = code, lay.rows[i][0], lay.rows[i][1]
+            p.bind(blk, dtype, dev)
+            blk.ws_bytes = lay.ws_bwd if which else lay.ws_fwd
+        self._sig[which] = sig
+        self._dyn[which] = None
+        self._train[which] = None
+        return True
+
+
+_chains: dict = {}
+
+
+def chain_for(plans) -> BlockChain:
+    key = tuple(id(p) for p in plans)
+    ent = _chains.get(key)
+    if ent is None or any(a is not b for a, b in zip(ent.plans, plans)):
+        if len(_chains) > 256:
+            _chains.clear()
+        ent = _chains[key] = BlockChain(plans)
+    return ent
+
+
+def _grad_acc(p, dev):
+    """Address of the parameter's .grad when the call may add into it itself (sink_param_grads() is on and the accumulator
+    is a contiguous fp32 tensor of the parameter's shape on the device), else None."""
+    g = None if p is None else p.grad
+    if g is not None and g.dtype == torch.float32 and g.device == dev and g.shape == p.shape and g.is_contiguous():
+        return g.data_ptr()
+    return None
+
+
+class _ChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, chain: BlockChain, graphs, x: torch.Tensor, widen: int, *params):
+        """``params``: per block (conv bias or None, W_0 .. W_(K-1), BatchNorm weight, BatchNorm bias) -- the tensors autograd
+        routes the parameter gradients to; the kernels read them through the descriptors."""
+        plans, blks = chain.plans, chain.fwd
+        n, dev, dtype = len(plans), x.device, x.dtype
+        rows, pools, V = [], [], x.shape[0]
+        for p in plans:
+            pool = None if p.pool is None else p.pool._pool()
+            Vo = V if pool is None else (pool.n_coarse if p.pool_mode == 1 else pool.n_fine)
+            rows.append((V, Vo))
+            pools.append(pool)
+            V = Vo
+        rows = tuple(rows)
+        p0 = plans[0]
+        base = None                       # block 0's [V, K*Cin] buffer when its input was born inside one
+        if p0.order == 0:
+            base = _adopt_wide(x, p0.K) if p0.K > 1 else (x if x.is_contiguous() else None)
+        if base is None and x.stride(1) != 1:
+            x = x.contiguous()
+        lay = chain._layouts.get((dtype, rows, base is not None))
+        if lay is None:
+            lay = chain.layout(dtype, rows, base is not None,
+                               [(g.handle._h, None if pl is None else pl._h) for g, pl in zip(graphs, pools)])
+        arena = torch.empty(lay.arena_bytes, dtype=torch.uint8, device=dev)
+        ws = torch.empty(lay.ws_fwd, dtype=torch.uint8, device=dev)
+        pl = plans[-1]
+        Vo = rows[-1][1]
+        y = _new_wide(Vo, Vo, pl.Cout, widen, dtype, dev) if widen > 1 else torch.empty((Vo, pl.Cout), dtype=dtype, device=dev)
+        chain.fill_static(0, lay, dtype, dev, graphs, pools)
+        training = tuple(1 if p.bn.training else 0 for p in plans)
+        if training != chain._train[0]:
+            for i in range(n):
+                blks[i].training = training[i]
+            chain._train[0] = training
+        capturing = torch.cuda.is_current_stream_capturing()
+        for i, p in enumerate(plans):
+            blks[i].refresh_weights = p.stale(dtype, capturing)
+        a0, w0 = arena.data_ptr(), ws.data_ptr()
+        dyn = (a0, w0, y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0), None if base is None else base.data_ptr())
+        if dyn != chain._dyn[0]:
+            for i, p in enumerate(plans):
+                blk = blks[i]
+                if i == 0:
+                    if base is not None:
+                        blk.T = blk.X = dyn[6]
+                        blk.ldt = blk.ldx = p.K * p.Cin
+                    else:
+                        blk.X, blk.ldx = dyn[4], dyn[5]
+                        blk.T, blk.ldt = (a0 + lay.off_in[0], p.K * p.Cin) if p.order == 0 else (None, 0)
+                elif p.order == 0:          # the block in front wrote its output into the first columns of T
+                    blk.T = blk.X = a0 + lay.off_in[i]
+                    blk.ldt = blk.ldx = p.K * p.Cin
+                else:
+                    blk.X, blk.ldx, blk.T, blk.ldt = a0 + lay.off_in[i], p.Cin, None, 0
+                blk.H, blk.stats = a0 + lay.off_H[i], a0 + lay.off_stats[i]
+                if i == n - 1:
+                    blk.Y, blk.ldy = dyn[2], dyn[3]
+                else:
+                    q = plans[i + 1]
+                    blk.Y, blk.ldy = a0 + lay.off_in[i + 1], (q.K * q.Cin if q.order == 0 else q.Cin)
+                blk.ws = w0
+            chain._dyn[0] = dyn
+        capi.block_chain_forward(blks, n, capi._stream(x))
+        del ws
+        block_calls[0] += n
+        chain_calls[0] += 1
+        if n == 1:
+            for obs in bn_act_observers:
+                obs(y)
+        ctx.chain, ctx.graphs, ctx.pools, ctx.lay, ctx.training = chain, graphs, pools, lay, training
+        ctx.ldx0 = x.stride(0)
+        ctx.params = params
+        ctx.save_for_backward(base if base is not None else x, arena)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        chain, lay = ctx.chain, ctx.lay
+        plans, blks = chain.plans, chain.bwd
+        x0, arena = ctx.saved_tensors        # x0: block 0's [V, K*Cin] buffer when it was adopted, else the chain's input
+        n, dev, dtype = len(plans), arena.device, dy.dtype
+        if dy.stride(1) != 1 or dy.stride(0) % 8 or dy.data_ptr() % 16:
+            dy = dy.contiguous()
+        need_dx = ctx.needs_input_grad[2]
+        V0, p0 = lay.rows[0][0], plans[0]
+        dx = torch.empty((V0, p0.Cin), dtype=dtype, device=dev) if need_dx else None
+        out = torch.empty(max(lay.grad_floats, 1), dtype=torch.float32, device=dev)
+        ws = torch.empty(lay.ws_bwd + 2 * lay.dx_bytes + 256, dtype=torch.uint8, device=dev)
+        chain.fill_static(1, lay, dtype, dev, ctx.graphs, ctx.pools)
+        if ctx.training != chain._train[1]:
+            for i in range(n):
+                blks[i].training = ctx.training[i]
+                blks[i].refresh_weights = 0        # (the forward call brought the packed copies up to date)
+            chain._train[1] = ctx.training
+        a0, w0, o0 = arena.data_ptr(), ws.data_ptr(), out.data_ptr()
+        dyn = (a0, w0, o0, dy.data_ptr(), dy.stride(0), None if dx is None else dx.data_ptr(), x0.data_ptr(), ctx.ldx0, need_dx)
+        if dyn != chain._dyn[1]:
+            pp = (w0 + lay.ws_bwd, w0 + lay.ws_bwd + lay.dx_bytes)       # input gradients between the blocks: two buffers in turn
+            in_place = lay.off_in[0] < 0 and p0.order == 0
+            for i, p in enumerate(plans):
+                blk = blks[i]
+                if p.order == 0:
+                    blk.T, blk.ldt, blk.X, blk.ldx = (dyn[6] if (i == 0 and in_place) else a0 + lay.off_in[i]), p.K * p.Cin, None, 0
+                elif i == 0:
+                    blk.T, blk.ldt, blk.X, blk.ldx = None, 0, dyn[6], dyn[7]
+                else:
+                    blk.T, blk.ldt, blk.X, blk.ldx = None, 0, a0 + lay.off_in[i], p.Cin
+                blk.H, blk.stats = a0 + lay.off_H[i], a0 + lay.off_stats[i]
+                if i == n - 1:
+                    blk.dY, blk.lddy = dyn[3], dyn[4]
+                else:
+                    blk.dY, blk.lddy = pp[(i + 1) & 1], p.Cout
+                if i == 0:
+                    blk.need_dx = 1 if need_dx else 0
+                    blk.dX, blk.lddx = (dyn[5], p.Cin) if need_dx else (None, 0)
+                else:
+                    blk.need_dx, blk.dX, blk.lddx = 1, pp[i & 1], p.Cin
+                blk.dW, blk.dvec = o0 + 4 * lay.off_dW[i], o0 + 4 * lay.off_dvec[i]
+                blk.ws = w0
+            chain._dyn[1] = dyn
+        # sink_param_grads(): the call adds the gradients into the parameters' .grad accumulators itself
+        sunk, accs = [], []
+        sinking = bool(_sink_depth)
+        for p in plans:
+            if sinking:
+                aw = [_grad_acc(w, dev) for w in p.weights]
+                sw = all(a is not None for a in aw)
+                ab = _grad_acc(p.cbias, dev)
+                ag, at = _grad_acc(p.gamma, dev), _grad_acc(p.beta, dev)
+                sb = ag is not None and at is not None
+                accs.append((tuple(aw) if sw else None, ab, (ag, at) if sb else None))
+            else:
+                sw, ab, sb = False, None, False
+                accs.append((None, None, None))
+            sunk.append((sw, ab is not None, sb))
+        if accs != chain._acc:
+            for i, p in enumerate(plans):
+                blk = blks[i]
+                aw, ab, gb = accs[i]
+                for k in range(3):
+                    blk.acc_W[k] = aw[k] if (aw is not None and k < p.K) else None
+                blk.acc_bias = ab
+                blk.acc_gamma, blk.acc_beta = gb if gb is not None else (None, None)
+            chain._acc = accs
+        capi.block_chain_backward(blks, n, capi._stream(dy))
+        del ws
+        block_calls[1] += n
+        chain_calls[1] += 1
+        grads = []
+        for i, p in enumerate(plans):
+            K, Cin, Cout = p.K, p.Cin, p.Cout
+            sw, sbias, sbn = sunk[i]
+            if sw and sbn and (sbias or p.cbias is None):
+                grads.extend([None] * (3 + K))
+                continue
+            dvec = out[lay.off_dvec[i]:lay.off_dvec[i] + 6 * Cout].view(6, Cout)
+            grads.append(None if (p.cbias is None or sbias) else dvec[5].to(p.cbias.dtype))
+            if sw:
+                grads.extend([None] * K)
+            else:
+                dW = out[lay.off_dW[i]:lay.off_dW[i] + Cout * K * Cin]
+                if p.order == 0:
+                    dWm = dW.view(Cout, K * Cin)
+                    grads.extend(dWm[:, k * Cin:(k + 1) * Cin] for k in range(K))
+                else:
+                    dWm = dW.view(K * Cout, Cin)
+                    grads.extend(dWm[k * Cout:(k + 1) * Cout] for k in range(K))
+            grads.extend((None, None) if sbn else (dvec[1].to(p.gamma.dtype), dvec[0].to(p.gamma.dtype)))
+        return (None, None, dx, None, *grads)
+
+
+def cheb_chain(plans, graphs, x: torch.Tensor, widen: int = 1) -> torch.Tensor:
+    """``act(bn(pool?(conv(.))))`` of a run of blocks in one foreign call per direction; ``graphs[i]``: the MeshGraph block
+    i's ChebConv runs on; ``widen``: as in ``bn_act``, for the last block's output."""
+    if x.shape[0] != graphs[0].num_vertices:
+        raise ValueError(f"x has {x.shape[0]} rows but the graph has {graphs[0].num_vertices} vertices")
+    if len(plans) > 1 and (x.shape[0] > CHAIN_MAX_ROWS or not chaining_allowed()):
+        for i, (p, g) in enumerate(zip(plans, graphs)):      # one call per block: activations are freed block by block
+            nxt = plans[i + 1] if i + 1 < len(plans) else None
+            x = cheb_chain([p], [g], x, widen if nxt is None else (nxt.K if nxt.order == 0 else 1))
+        return x
+    params = []
+    for p in plans:
+        p.fingerprint()
+        params.extend(p.param_tuple)
+    return _ChainFn.apply(chain_for(plans), tuple(graphs), x, int(widen), *params)
+
+
+def cheb_block(plan: BlockPlan, graph: MeshGraph, x: torch.Tensor, widen: int = 1) -> torch.Tensor:
+    return cheb_chain([plan], [graph], x, widen)

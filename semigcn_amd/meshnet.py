@@ -30,7 +30,7 @@ from . import functional as F_sg
 from . import reorder as _reorder
 from .graph import MeshGraph
 from .networks import _Fp32Linear, prepare_input
-from .nn import ChebConv, Sequential
+from .nn import ChebConv, Sequential, run_sequentials
 
 POOL_LEVELS = 3          # util/meshnet.py:169
 POOL_RATIO = 0.6         # util/meshnet.py:171
@@ -105,6 +105,7 @@ class _HashOp(nn.Module):
 class MeshPool(_HashOp):
     """out[s] = mean over the fine vertices o with pool_hash[o] = s (util/meshnet.py:9-17)."""
     _buffer_name = "pool_hash"
+    sg_pool_mode = 1          # (nn.Sequential folds it into the block call of the ChebConv in front: sg_block.pool_mode)
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         if self._dist is not None:
@@ -116,6 +117,7 @@ class MeshUnpool(_HashOp):
     """out[o] = input[pool_hash[o]] (util/meshnet.py:20-27)."""
     _buffer_name = "unpool_hash"
     _transposed = True
+    sg_pool_mode = 2
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         if self._dist is not None:
@@ -145,7 +147,7 @@ class DownConv(nn.Module):
 
     def forward(self, input):
         g1, g2 = getattr(self, "_graphs", (self.edge_index1, self.edge_index2))
-        return self.model2(self.model1(input, g1), g2)
+        return run_sequentials([(self.model1, g1), (self.model2, g2)], input)      # = model2(model1(input, g1), g2)
 
 
 class UpConv(nn.Module):
@@ -165,7 +167,7 @@ class UpConv(nn.Module):
 
     def forward(self, input):
         g1, g2 = getattr(self, "_graphs", (self.edge_index1, self.edge_index2))
-        return self.model2(self.model1(input, g1), g2)
+        return run_sequentials([(self.model1, g1), (self.model2, g2)], input)      # = model2(model1(input, g1), g2)
 
 
 def _head(cin: int, K: int) -> Sequential:

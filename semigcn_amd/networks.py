@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import reorder as _reorder
 from .graph import MeshGraph, graph_for
-from .nn import ChebConv, Sequential
+from .nn import ChebConv, Sequential, run_sequentials
 
 # util/networks.py:15 -- input (xyz displacement + mask) ... output xyz offset
 CHANNELS: Tuple[int, ...] = (4, 16, 32, 64, 128, 256, 256, 512, 256, 256, 128, 64, 32, 16, 3)
@@ -181,14 +181,18 @@ class SingleScaleGCN(nn.Module):
                 x = x.index_select(0, order)
             x = x.to(self.feature_dtype)
 
-        enc: List[torch.Tensor] = []
-        for i, block in enumerate(self.blocks):
-            if self.skip and i >= FIRST_DECODER:
-                j = N_BLOCKS - i  # 5, 4, 3, 2, 1 -- skip_blocks[0] is never used (:96-99)
-                x = self.skip_blocks[j](torch.cat([enc[j], x], dim=1)).to(self.feature_dtype)
-            x = block(x, graph)
-            if i < N_ENCODER:
-                enc.append(x)
+        if not self.skip:
+            # the loop over the 13 blocks (:83-101); on the device their whole kernel chain is ONE call below the C ABI
+            x = run_sequentials([(block, graph) for block in self.blocks], x)
+        else:
+            enc: List[torch.Tensor] = []
+            for i, block in enumerate(self.blocks):
+                if i >= FIRST_DECODER:
+                    j = N_BLOCKS - i  # 5, 4, 3, 2, 1 -- skip_blocks[0] is never used (:96-99)
+                    x = self.skip_blocks[j](torch.cat([enc[j], x], dim=1)).to(self.feature_dtype)
+                x = block(x, graph)
+                if i < N_ENCODER:
+                    enc.append(x)
         if rank is not None:
             if x.is_cuda:
                 from .functional import output_in_caller_order

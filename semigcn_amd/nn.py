@@ -75,6 +75,10 @@ class ChebConv(nn.Module):
         counters, which optimiser steps and every autograd-visible in-place update bump; writes through ``.data``
         (``p.data.copy_(ema)``, manual clipping) do NOT bump them -- call this after such a write."""
         self.__dict__.pop("_weight_cache", None)
+        for ref in self.__dict__.get("_block_plans_of", ()):       # the packed copies of the block calls (functional.BlockPlan)
+            plan = ref()
+            if plan is not None:
+                plan.invalidate()
 
     def _load_from_state_dict(self, *args, **kwargs):
         self.invalidate_weight_cache()
@@ -193,16 +197,89 @@ class Sequential(nn.Module):
                 grad_widen = prv.grad_buffer_blocks()
         return slope, widen, grad_widen
 
-    def forward(self, *args, **kwargs):
+    def _block_at(self, i: int):
+        """(BlockPlan, index of its activation entry, widen) when entries i.. read ChebConv [-> MeshPool | MeshUnpool] ->
+        BatchNorm1d -> (Leaky)ReLU on ONE variable -- a block the library runs in one call per direction
+        (functional.cheb_block); None otherwise.  Looked up once per entry (and per evaluation-order switch)."""
+        key = (i, F_sg.AGGREGATE_AFTER_GEMM_WHEN_NARROWING, self.out_widen)
+        plans = self.__dict__.setdefault("_block_plans", {})
+        if key in plans:
+            return plans[key]
+        found = None
+        name, ins, outs = self._plan[i]
+        conv = getattr(self, name)
+        if isinstance(conv, ChebConv) and len(ins) == 2 and len(outs) == 1 and ins[0] == outs[0] and conv.K <= 3:
+            var, j, pool = outs, i + 1, None
+            if j < len(self._plan):
+                nxt = getattr(self, self._plan[j][0])
+                if getattr(nxt, "sg_pool_mode", 0) and self._plan[j][1] == var and self._plan[j][2] == var:
+                    pool, j = nxt, j + 1
+            fused = self._fusable_at(j) if j + 1 < len(self._plan) else None
+            if fused is not None and self._plan[j][1] == var:
+                bn = getattr(self, self._plan[j][0])
+                if bn.num_features == conv.out_channels:
+                    found = (F_sg.BlockPlan(conv, bn, fused[0], pool), j + 1, fused[1])
+        plans[key] = found
+        return found
+
+    def _leading_blocks(self):
+        """(plans, index of the first entry behind them, widen of the last one) when the entries from 0 on are >= 1
+        consecutive blocks on the Sequential's first argument with its second argument as the graph; None otherwise.
+        Used by the models to run blocks of SEVERAL Sequentials in one call (functional.cheb_chain)."""
+        key = (F_sg.AGGREGATE_AFTER_GEMM_WHEN_NARROWING, self.out_widen)
+        hit = self.__dict__.get("_lead")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        lead = self._find_leading_blocks()
+        self.__dict__["_lead"] = (key, lead)
+        return lead
+
+    def _find_leading_blocks(self):
+        if len(self._args) != 2:
+            return None
+        xvar, gvar = self._args
+        plans, i, widen = [], 0, 1
+        while i < len(self._plan):
+            _, ins, outs = self._plan[i]
+            blk = self._block_at(i) if (ins == [xvar, gvar] and outs == [xvar]) else None
+            if blk is None:
+                break
+            plans.append(blk[0])
+            i, widen = blk[1] + 1, blk[2]
+        return (plans, i, widen) if plans else None
+
+    def forward(self, *args, _start: int = 0, **kwargs):
+        """``_start`` (not part of the torch_geometric signature): run the entries from that index on -- the models use it
+        after they have run this Sequential's leading blocks as part of a longer chain."""
         scope = dict(zip(self._args, args))
         scope.update(kwargs)
-        result = None
+        result = args[0] if (_start and args) else None
         pending = None             # (conv output, its tile moments) from the ChebConv just run, for the BatchNorm behind it
-        i, n = 0, len(self._plan)
+        i, n = _start, len(self._plan)
+        blocks_on = F_sg.blocks_enabled()
         while i < n:
             name, ins, outs = self._plan[i]
             vals = [scope[a] for a in ins]
             on_dev = len(vals) >= 1 and torch.is_tensor(vals[0]) and vals[0].is_cuda and vals[0].dim() == 2
+            if on_dev and len(vals) == 2 and blocks_on:
+                blk = self._block_at(i)          # conv [-> pool] -> BatchNorm -> activation below the C ABI ...
+                if blk is not None and blk[0].usable(vals[0]):
+                    g = vals[1]
+                    if not isinstance(g, MeshGraph):
+                        g = None if getattr(g, "sg_partitioned", False) or not torch.is_tensor(g) else graph_for(g, vals[0].shape[0])
+                    if g is not None:
+                        plans, last = [blk[0]], blk
+                        while F_sg.chaining_allowed():      # ... together with the blocks that follow it on the same graph
+                            j = last[1] + 1
+                            nxt = self._block_at(j) if (j < n and self._plan[j][1] == ins and self._plan[j][2] == outs) else None
+                            if nxt is None or last[0].pool is not None \
+                                    or not nxt[0].usable_for(vals[0].dtype, vals[0].device, vals[0].shape[0], last[0].Cout):
+                                break
+                            plans.append(nxt[0])
+                            last = nxt
+                        scope[outs[0]] = result = F_sg.cheb_chain(plans, [g] * len(plans), vals[0], last[2])
+                        i = last[1] + 1
+                        continue
             fused = self._fusable_at(i) if (len(vals) == 1 and on_dev) else None
             mod = getattr(self, name)
             if fused is not None:      # BatchNorm1d + (Leaky)ReLU in two HIP passes instead of five ATen ones
@@ -232,3 +309,51 @@ class Sequential(nn.Module):
 
     def __getitem__(self, i: int):
         return getattr(self, self._plan[i][0])
+
+
+def _as_graph(g, rows: int):
+    """The prepared MeshGraph for a Sequential's graph argument (a MeshGraph, or an edge_index tensor); None for a vertex
+    partition (its convs exchange halos between the kernels) or a graph of another size."""
+    if not isinstance(g, MeshGraph):
+        if getattr(g, "sg_partitioned", False) or not torch.is_tensor(g):
+            return None
+        g = graph_for(g, rows)
+    return g if g.num_vertices == rows else None
+
+
+def run_sequentials(pairs, x):
+    """``seq_n(.. seq_2(seq_1(x, g_1), g_2) .., g_n)`` for Sequentials that take (x, graph) -- the composition of
+    DownConv.forward / UpConv.forward (util/meshnet.py:92-95,157-160) and of SingleScaleGCN's block loop
+    (util/networks.py:83-101).  The blocks the Sequentials START with are run as ONE chain across them
+    (functional.cheb_chain: one foreign call and one autograd node per direction) as far as whole Sequentials consist of
+    blocks; the entries behind the last block of the chain, and everything else, run module by module as written."""
+    if torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and len(pairs) > 1 and F_sg.blocks_enabled() and F_sg.chaining_allowed() \
+            and x.shape[0] <= F_sg.CHAIN_MAX_ROWS:
+        plans, graphs, rows, cin, end, widen = [], [], x.shape[0], x.shape[1], None, 1
+        for k, (seq, g) in enumerate(pairs):
+            lead = seq._leading_blocks() if isinstance(seq, Sequential) else None
+            gg = _as_graph(g, rows) if lead is not None else None
+            if gg is None:
+                break
+            r, c = rows, cin
+            for p in lead[0]:
+                if not p.usable_for(x.dtype, x.device, r, c):
+                    r = -1
+                    break
+                r, c = p.rows_out(r), p.Cout
+            if r < 0:
+                break
+            plans.extend(lead[0])
+            graphs.extend([gg] * len(lead[0]))
+            rows, cin, end, widen = r, c, (k, lead[1]), lead[2]
+            if lead[1] < len(seq):      # modules behind this Sequential's blocks: the chain ends here
+                break
+        if end is not None and len(plans) > 1:
+            x = F_sg.cheb_chain(plans, graphs, x, widen)
+            seq, g = pairs[end[0]]
+            if end[1] < len(seq):
+                x = seq(x, g, _start=end[1])
+            pairs = pairs[end[0] + 1:]
+    for seq, g in pairs:
+        x = seq(x, g)
+    return x

@@ -21,24 +21,42 @@ def main():
     ap.add_argument("--mesh", default="100x50")
     ap.add_argument("--dtype", default="fp32")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--model", default="sgcn", choices=["sgcn", "mgcn"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     nu, nv = map(int, a.mesh.split("x"))
     mesh = bench.make_mesh(nu, nv, "survey")
     batch = bench.build_mesh_batch(mesh, dev, 5)
     torch.manual_seed(0)
-    net = networks.SingleScaleGCN(dev).to(dev)
-    if a.dtype == "bf16":
-        net.set_feature_dtype(torch.bfloat16)
-    tr = train.SGCNTrainer(net, batch)
+    if a.model == "mgcn":
+        from semigcn_amd import meshprep
+        from semigcn_amd.meshnet import MGCN
+        import numpy as np
+        smo = meshprep.DeviceMesh(mesh.x_pos, mesh.faces, dev)
+        ini = meshprep.DeviceMesh(mesh.vs.astype(np.float32), mesh.faces, dev)
+        net = MGCN(dev, smo, ini, torch.from_numpy(mesh.v_mask)).to(dev)
+        if a.dtype == "bf16":
+            net.set_feature_dtype(torch.bfloat16)
+        tr = train.MGCNTrainer(net, batch)
+    else:
+        net = networks.SingleScaleGCN(dev).to(dev)
+        if a.dtype == "bf16":
+            net.set_feature_dtype(torch.bfloat16)
+        tr = train.SGCNTrainer(net, batch)
     for _ in range(5):
         tr.iteration_step()
     torch.cuda.synchronize()
+    from semigcn_amd import capi
+    c0 = list(capi.chain_host_seconds)
     t0 = time.perf_counter()
     for _ in range(a.iters):
         tr.iteration_step()
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
-    print(f"{(time.perf_counter() - t0) / a.iters * 1e3:.2f} ms per eager iteration")
+    print(f"{(time.perf_counter() - t0) / a.iters * 1e3:.2f} ms per eager iteration (host enqueue {(t1 - t0) / a.iters * 1e3:.2f} ms)")
+    if os.environ.get("SEMIGCN_PROFILE_CHAINS") == "1":
+        print(f"  of it inside sg_block_chain_forward {(capi.chain_host_seconds[0] - c0[0]) / a.iters * 1e3:.2f} ms, "
+              f"sg_block_chain_backward {(capi.chain_host_seconds[1] - c0[1]) / a.iters * 1e3:.2f} ms")
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(a.iters):
