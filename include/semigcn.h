@@ -125,7 +125,8 @@ SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, 
  * neighbour id in the CSR; no per-edge weight array).  Deterministic: one owner
  * per output row, fixed summation order, no atomics.  The order is ascending
  * neighbour id with one fp32 fma per neighbour, EXCEPT for bf16 rows of 128 or 256
- * channels on a graph made by sg_graph_create: those are reduced tile by tile
+ * channels (on any graph handle: sg_graph_create, _rect and _rows all carry the
+ * tile records): those are reduced tile by tile
  * (<= 16 rows and their <= 56 distinct sources staged in LDS) on the matrix cores,
  * with the fp32 weights split exactly into three bf16 pieces and the MFMA's own
  * accumulation order -- same error bound, a different last bit in ~1 % of the

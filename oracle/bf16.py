@@ -189,3 +189,30 @@ class SGCNOracleBf16(nn.Module):
             if i <= 5:
                 kept.append(x)
         return x_pos + x
+
+
+class MGCNOracleBf16(nn.Module):
+    """oracle.models.MGCNOracle (util/meshnet.py:31-160,212-248,278-318) with bf16 feature storage on every level, as
+    ``semigcn_amd.meshnet.MGCN.set_feature_dtype(torch.bfloat16)`` stores them: the [V,4] input, every Chebyshev term, conv
+    output and BatchNorm+LeakyReLU output (ChebConvBf16 / _StoredAct, as in SGCNOracleBf16), and in addition the pooled /
+    unpooled rows between a conv and its BatchNorm (util/meshnet.py:44-47,106-109), the Dropout outputs (:62,128) and the
+    skip Linears' outputs.  The three heads' and the decoder's Linear(., 3) and ``smposs + x`` stay fp32.  Same modules and
+    state-dict keys as MGCNOracle.  ``act``: factory of the activation modules (the tests inject a prescribed pattern);
+    ``bias_bf16_convs``: names of ChebConvs whose bias enters the product rounded to bf16 (products served by the BLAS
+    library, which takes the bias in the operand type)."""
+
+    def __new__(cls, edge_inds, pool_hashes, smposs, K: int = 3, skip: bool = False, drop=(0.0, 0.2, 0.2),
+                post_when_narrowing: bool = True, act=None, bias_bf16_convs: Sequence[str] = ()):
+        from .models import MGCNOracle
+
+        def conv(cin, cout, K=3):
+            c = ChebConvBf16(cin, cout, K=K)
+            c.post_when_narrowing = post_when_narrowing
+            return c
+        inner = (lambda: nn.LeakyReLU()) if act is None else act
+        net = MGCNOracle(edge_inds, pool_hashes, smposs, K=K, skip=skip, drop=drop, conv=conv,
+                         act=lambda: _StoredAct(inner()), store=round_st)
+        mods = dict(net.named_modules())
+        for name in bias_bf16_convs:
+            mods[name].bias_to_bf16 = True
+        return net

@@ -132,40 +132,65 @@ def unpool_gather(pool_hash: np.ndarray, x: torch.Tensor, n_fine: Optional[int] 
     return out.index_add_(0, fine, x[coarse])
 
 
+def _ident(x):
+    return x
+
+
 class _Pool(nn.Module):
-    def __init__(self, h):
+    def __init__(self, h, store=_ident):
         super().__init__()
-        self.h = h
+        self.h, self.store = h, store
 
     def forward(self, x):
-        return pool_mean(self.h, x)
+        return self.store(pool_mean(self.h, x))
 
 
 class _Unpool(nn.Module):
-    def __init__(self, h):
+    def __init__(self, h, store=_ident):
         super().__init__()
-        self.h = h
+        self.h, self.store = h, store
 
     def forward(self, x):
-        return unpool_gather(self.h, x)
+        return self.store(unpool_gather(self.h, x))
 
 
-def _cbl(cin, cout, K):
-    return [(ChebConv(cin, cout, K=K), "x, edge_index -> x"),
-            (nn.BatchNorm1d(cout), "x -> x"), (nn.LeakyReLU(), "x -> x")]
+class Drop(nn.Module):
+    """``nn.Dropout(p)`` (util/meshnet.py:62,128) whose Bernoulli draws can be PRESCRIBED: with ``masks`` set (a list of
+    0/1 tensors of the input's shape, one per call), call i keeps exactly ``masks[i]`` and scales by 1 / (1 - p), as
+    ``nn.Dropout`` does with its own draw -- so that two implementations of the network can be run on the same draws.
+    ``store``: applied to the result (the bf16-storage oracle rounds there)."""
+
+    def __init__(self, p: float, store=_ident):
+        super().__init__()
+        self.p, self.store = float(p), store
+        self.drop = nn.Dropout(p)
+        self.masks, self.calls = None, 0
+
+    def forward(self, x):
+        if self.masks is None or not self.training or self.p == 0.0:
+            return self.store(self.drop(x))
+        m = self.masks[self.calls % len(self.masks)].to(x.dtype)
+        self.calls += 1
+        return self.store(x * (m * (1.0 / (1.0 - self.p))))
+
+
+def _cbl(cin, cout, K, conv=ChebConv, act=None):
+    return [(conv(cin, cout, K=K), "x, edge_index -> x"),
+            (nn.BatchNorm1d(cout), "x -> x"), ((nn.LeakyReLU() if act is None else act()), "x -> x")]
 
 
 class DownOracle(nn.Module):
     """util/meshnet.py:31-95: the pool sits between the 2nd ChebConv and its BN."""
 
-    def __init__(self, cin, cout, ei1, ei2, pool_hash, K=3, drop=0.0):
+    def __init__(self, cin, cout, ei1, ei2, pool_hash, K=3, drop=0.0, conv=ChebConv, act=None, store=_ident):
         super().__init__()
         self.ei1, self.ei2 = ei1, ei2
-        self.model1 = Sequential("x, edge_index", _cbl(cin, cout, K) + [
-            (ChebConv(cout, cout, K=K), "x, edge_index -> x"), (_Pool(pool_hash), "x -> x"),
-            (nn.BatchNorm1d(cout), "x -> x"), (nn.LeakyReLU(), "x -> x")])
-        self.model2 = Sequential("x, edge_index", _cbl(cout, cout, K) + _cbl(cout, cout, K)
-                                 + _cbl(cout, cout, K) + [(nn.Dropout(drop), "x -> x")])
+        a = (lambda: nn.LeakyReLU()) if act is None else act
+        self.model1 = Sequential("x, edge_index", _cbl(cin, cout, K, conv, a) + [
+            (conv(cout, cout, K=K), "x, edge_index -> x"), (_Pool(pool_hash, store), "x -> x"),
+            (nn.BatchNorm1d(cout), "x -> x"), (a(), "x -> x")])
+        self.model2 = Sequential("x, edge_index", _cbl(cout, cout, K, conv, a) + _cbl(cout, cout, K, conv, a)
+                                 + _cbl(cout, cout, K, conv, a) + [(Drop(drop, store), "x -> x")])
 
     def forward(self, x):
         return self.model2(self.model1(x, self.ei1), self.ei2)
@@ -174,15 +199,16 @@ class DownOracle(nn.Module):
 class UpOracle(nn.Module):
     """util/meshnet.py:98-160: the unpool sits between the 1st ChebConv and its BN."""
 
-    def __init__(self, cin, cout, ei1, ei2, pool_hash, K=3, drop=0.0):
+    def __init__(self, cin, cout, ei1, ei2, pool_hash, K=3, drop=0.0, conv=ChebConv, act=None, store=_ident):
         super().__init__()
         self.ei1, self.ei2 = ei1, ei2
+        a = (lambda: nn.LeakyReLU()) if act is None else act
         self.model1 = Sequential("x, edge_index", [
-            (ChebConv(cin, cout, K=K), "x, edge_index -> x"), (_Unpool(pool_hash), "x -> x"),
-            (nn.BatchNorm1d(cout), "x -> x"), (nn.LeakyReLU(), "x -> x")])
-        self.model2 = Sequential("x, edge_index", _cbl(cout, cout, K) + _cbl(cout, cout, K)
-                                 + _cbl(cout, cout, K) + _cbl(cout, cout, K)
-                                 + [(nn.Dropout(drop), "x -> x")])
+            (conv(cin, cout, K=K), "x, edge_index -> x"), (_Unpool(pool_hash, store), "x -> x"),
+            (nn.BatchNorm1d(cout), "x -> x"), (a(), "x -> x")])
+        self.model2 = Sequential("x, edge_index", _cbl(cout, cout, K, conv, a) + _cbl(cout, cout, K, conv, a)
+                                 + _cbl(cout, cout, K, conv, a) + _cbl(cout, cout, K, conv, a)
+                                 + [(Drop(drop, store), "x -> x")])
 
     def forward(self, x):
         return self.model2(self.model1(x, self.ei1), self.ei2)
@@ -192,23 +218,28 @@ class MGCNOracle(nn.Module):
     """MGCN over a PRECOMPUTED 3-level hierarchy (the reference builds it in
     ``__init__`` with its QEM simplifier, util/meshnet.py:182-201 -- out of scope).
     ``edge_inds``: 4 edge_index tensors (fine..coarse); ``pool_hashes``: 3 arrays of
-    (fine_i, coarse_i) rows; ``smposs``: 4 smooth-position tensors."""
+    (fine_i, coarse_i) rows; ``smposs``: 4 smooth-position tensors.
+    ``conv`` / ``act`` / ``store``: the ChebConv class, a factory for the activation modules and what is applied to every
+    stored row that is not a conv or activation output (pool, unpool, dropout, network input, skip Linear) -- the
+    bf16-storage variant (oracle/bf16.py::MGCNOracleBf16) passes its rounding versions; the defaults are the reference's."""
 
     def __init__(self, edge_inds: Sequence[torch.Tensor], pool_hashes: Sequence[np.ndarray],
                  smposs: Sequence[torch.Tensor], K: int = 3, skip: bool = False,
-                 drop=(0.0, 0.2, 0.2)):
+                 drop=(0.0, 0.2, 0.2), conv=ChebConv, act=None, store=_ident):
         super().__init__()
         e, p = list(edge_inds), list(pool_hashes)
-        self.skip, self.edge_inds, self.smposs_list = skip, e, list(smposs)
-        self.encoder1 = DownOracle(4, 32, e[0], e[1], p[0], K, drop[0])
-        self.encoder2 = DownOracle(32, 128, e[1], e[2], p[1], K, drop[1])
-        self.encoder3 = DownOracle(128, 256, e[2], e[3], p[2], K, drop[2])
-        self.decoder3 = UpOracle(256, 128, e[3], e[2], p[2], K, drop[2])
-        self.decoder2 = UpOracle(128, 32, e[2], e[1], p[1], K, drop[1])
-        self.decoder1 = nn.Sequential(UpOracle(32, 16, e[1], e[0], p[0], K, drop[0]), nn.Linear(16, 3))
+        self.skip, self.edge_inds, self.smposs_list, self.store = skip, e, list(smposs), store
+        kw = dict(conv=conv, act=act, store=store)
+        self.encoder1 = DownOracle(4, 32, e[0], e[1], p[0], K, drop[0], **kw)
+        self.encoder2 = DownOracle(32, 128, e[1], e[2], p[1], K, drop[1], **kw)
+        self.encoder3 = DownOracle(128, 256, e[2], e[3], p[2], K, drop[2], **kw)
+        self.decoder3 = UpOracle(256, 128, e[3], e[2], p[2], K, drop[2], **kw)
+        self.decoder2 = UpOracle(128, 32, e[2], e[1], p[1], K, drop[1], **kw)
+        self.decoder1 = nn.Sequential(UpOracle(32, 16, e[1], e[0], p[0], K, drop[0], **kw), nn.Linear(16, 3))
+        a = (lambda: nn.LeakyReLU()) if act is None else act
 
         def head(c):
-            return Sequential("x, edge_index", _cbl(c, 32, K) + [(nn.Linear(32, 3), "x -> x")])
+            return Sequential("x, edge_index", _cbl(c, 32, K, conv, a) + [(nn.Linear(32, 3), "x -> x")])
 
         self.mcnn3, self.mcnn2, self.mcnn1 = head(256), head(128), head(32)
         self.skip2, self.skip1 = nn.Linear(256, 128), nn.Linear(64, 32)
@@ -216,22 +247,28 @@ class MGCNOracle(nn.Module):
     def forward(self, z1, dm=None):
         # util/meshnet.py:287-290: anything that is not an ndarray becomes all-ones
         dm = torch.from_numpy(dm) if isinstance(dm, np.ndarray) else torch.ones(z1.shape[0], 1)
-        x = normalise_input(z1, dm.to(z1.dtype))
+        st = self.store
+        x = st(normalise_input(z1, dm.to(z1.dtype)))
         r1 = self.encoder1(x)
         r2 = self.encoder2(r1)
         r3 = self.encoder3(r2)
         o3 = self.mcnn3(r3, self.edge_inds[3])
         d2 = self.decoder3(r3)
         if self.skip:
-            d2 = self.skip2(torch.cat([d2, r2], dim=1))
+            d2 = st(self.skip2(torch.cat([st(d2), st(r2)], dim=1)))
         o2 = self.mcnn2(d2, self.edge_inds[2])
         d1 = self.decoder2(d2)
         if self.skip:
-            d1 = self.skip1(torch.cat([d1, r1], dim=1))
+            d1 = st(self.skip1(torch.cat([st(d1), st(r1)], dim=1)))
         o1 = self.mcnn1(d1, self.edge_inds[1])
         o0 = self.decoder1(d1)
         s = self.smposs_list
         return s[0] + o0, s[1] + o1, s[2] + o2, s[3] + o3
+
+    def dropouts(self):
+        """The six Drop modules in execution order (encoder1..3, decoder3..1): a test prescribes their draws."""
+        return [self.encoder1.model2.module_9, self.encoder2.model2.module_9, self.encoder3.model2.module_9,
+                self.decoder3.model2.module_12, self.decoder2.model2.module_12, self.decoder1[0].model2.module_12]
 
 
 # ---- per-iteration geometry + losses (SURVEY.md section 8(f)-1; plain torch) ----

@@ -162,10 +162,15 @@ SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void
     }
     if ((rc = pack_source_scale(&g->fwd, g->dis_src, stream)) != SG_OK) break;
     if (!g->symmetric && (rc = pack_source_scale(&g->bwd, g->dis_src, stream)) != SG_OK) break;
-    if (ring_enabled() && (rc = build_ring_records(&g->fwd, g->dis_src, g->dis_dst, nullptr, stream)) != SG_OK) break;
     if (ring_enabled() && !g->symmetric && (rc = build_ring_records(&g->bwd, g->dis_src, g->dis_dst, nullptr, stream)) != SG_OK) break;
     if (g->symmetric) {      // numbering without locality (a raw scan): process the rows in a graph-derived order
       if ((rc = locality_order(g->fwd, graph_reorder_mode(), stream, &g->row_id)) != SG_OK) break;
+    }
+    // tile records of the forward CSR only where sg_spmm will read them: a graph that gets a locality view is always
+    // applied through that view (its records are built below), so records of the plain row order would be dead weight
+    // (896 bytes per 16 rows for the graph's lifetime, a sort and two stream syncs at creation)
+    if (ring_enabled() && !g->row_id && (rc = build_ring_records(&g->fwd, g->dis_src, g->dis_dst, nullptr, stream)) != SG_OK) break;
+    if (g->symmetric) {
       if (g->row_id) {
         if ((rc = permute_rows(g->fwd, g->row_id, stream, &g->loc)) != SG_OK) break;
         if (hipMalloc((void**)&g->dis_dst_loc, V * sizeof(float)) != hipSuccess) {

@@ -153,21 +153,26 @@ int lt_gemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const void* A, in
     SG_LT_TRY(lt.PrefCreate(&pref));
     const uint64_t max_ws = ws_bytes;
     hipblasStatus_t st = lt.PrefSet(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws));
-    hipblasLtMatmulHeuristicResult_t res;
-    int found = 0;
+    constexpr int kAsk = 8;
+    hipblasLtMatmulHeuristicResult_t res[kAsk];
+    int found = 0, pick = -1;
     if (st == HIPBLAS_STATUS_SUCCESS) {
       // (the bias pointer takes part in the heuristic's validity check of some solutions: set a plausible one)
       if (bias) st = lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
-      if (st == HIPBLAS_STATUS_SUCCESS) st = lt.Heuristic(g_lt_handle[dev], p.desc, p.la, p.lb, p.lc, p.lc, pref, 1, &res, &found);
+      if (st == HIPBLAS_STATUS_SUCCESS) st = lt.Heuristic(g_lt_handle[dev], p.desc, p.la, p.lb, p.lc, p.lc, pref, kAsk, res, &found);
     }
     lt.PrefDestroy(pref);
-    if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
-      set_error("hipBLASLt has no solution for the product M=%lld N=%lld K=%lld (opA=%d opB=%d dtype %d -> %d, batch %d; status %d)",
-                (long long)M, (long long)N, (long long)K, opA, opB, dt_in, dt_out, batch, (int)st);
+    // the library's ranking, first entry whose scratch fits (it has been seen to rank a solution above the stated limit first)
+    for (int i = 0; i < found && pick < 0; ++i)
+      if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= ws_bytes) pick = i;
+    if (st != HIPBLAS_STATUS_SUCCESS || pick < 0) {
+      set_error("hipBLASLt has no solution for the product M=%lld N=%lld K=%lld (opA=%d opB=%d dtype %d -> %d, batch %d; status %d, "
+                "%d candidates, %zu bytes of scratch)", (long long)M, (long long)N, (long long)K, opA, opB, dt_in, dt_out, batch,
+                (int)st, found, ws_bytes);
       return SG_ERR_UNSUPPORTED;
     }
-    p.algo = res.algo;
-    p.ws = res.workspaceSize;
+    p.algo = res[pick].algo;
+    p.ws = res[pick].workspaceSize;
     it = g_plans.emplace(key, p).first;
   }
   Plan& p = it->second;

@@ -260,7 +260,7 @@ struct TraceScope {
 };
 
 // dense.hip -- the three product shapes of a ChebConv layer behind one engine choice (thin kernels / own MFMA / BLAS library)
-constexpr size_t kBlasWorkspace = 32u << 20;     // scratch handed to the BLAS library per call
+constexpr size_t kBlasWorkspace = 76u << 20;     // scratch handed to the BLAS library per call (PyTorch's default for this GPU family)
 bool dense_nt_own(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc);
 bool dense_tn_own(int dtype, int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 int64_t dense_tn_workspace(int dtype, int64_t M, int64_t N, int64_t Kp);

@@ -235,7 +235,10 @@ class _LinearFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
         if x.is_cuda and x.dim() == 2 and _thin_ok(x, weight.shape[0], weight.shape[1]) and x.dtype == weight.dtype:
-            return capi.thin_nt(x, weight, bias)
+            # (the thin kernels take fp32 parameters: a module whose parameters were moved to bf16 gets them widened here,
+            # as _dense_nt does)
+            bias32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float()).contiguous()
+            return capi.thin_nt(x, weight, bias32)
         return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
 
     @staticmethod

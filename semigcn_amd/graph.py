@@ -58,10 +58,22 @@ def _fingerprint(edge_index: torch.Tensor) -> Tuple[int, int, int]:
     return int(fp[0]), int(fp[1]), int(fp[2])
 
 
+def _same_edges(a: torch.Tensor, b: torch.Tensor, num_vertices: int) -> bool:
+    """True iff the two [2, E] tensors hold the same edge MULTISET: elementwise equal (the usual case -- the same data
+    uploaded again: one comparison kernel), or equal after sorting the (source, target) keys."""
+    if a.shape != b.shape:
+        return False
+    if torch.equal(a, b):
+        return True
+    n = max(int(num_vertices), 1)
+    return torch.equal(torch.sort(a[0] * n + a[1])[0], torch.sort(b[0] * n + b[1])[0])
+
+
 class _Cache:
     """Level 1: the graph rides on the edge_index tensor object itself (valid while the object lives and its version
     counter is unchanged): no device work at all.  Level 2, for a tensor OBJECT not seen before: keyed by (device, shape,
-    V, content fingerprint) -- never by address, which the caching allocator may or may not hand out again -- so a caller
+    V, content fingerprint) and VERIFIED against a copy of the edges the cached graph was built from (a fingerprint
+    collision must not hand back another graph's CSR) -- never by address, which the caching allocator may or may not hand out again -- so a caller
     that re-creates the device tensor on every forward (util/networks.py:65: ``data.edge_index.to(self.device)`` on
     CPU-resident data) pays three E-sized reductions and one host synchronisation per forward, but ``sg_graph_create``
     runs once per distinct graph.  ``compat.Data`` removes even that: its ``edge_index`` hands the SAME device tensor back
@@ -69,7 +81,7 @@ class _Cache:
 
     def __init__(self, capacity: int = 16):
         self.capacity = capacity
-        self._lvl2: Dict[tuple, MeshGraph] = {}
+        self._lvl2: Dict[tuple, tuple] = {}
 
     def get(self, edge_index: torch.Tensor, num_vertices: int) -> MeshGraph:
         hit = getattr(edge_index, _ATTR, None)
@@ -78,12 +90,17 @@ class _Cache:
             if ver == edge_index._version and nv == num_vertices:
                 return g
         key = (str(edge_index.device), tuple(edge_index.shape), num_vertices, _fingerprint(edge_index))
-        g = self._lvl2.get(key)
-        if g is None:
+        ent = self._lvl2.get(key)
+        if ent is not None and not _same_edges(edge_index, ent[1], num_vertices):
+            ent = None              # three equal 64-bit sums over DIFFERENT edges: a collision, not a hit
+        if ent is None:
             g = MeshGraph.from_edge_index(edge_index, num_vertices)
             if len(self._lvl2) >= self.capacity:
                 self._lvl2.pop(next(iter(self._lvl2)))
-            self._lvl2[key] = g
+            # (the edges the graph was built from are kept beside it: a later fingerprint hit is verified against them)
+            self._lvl2[key] = (g, edge_index.detach().clone())
+        else:
+            g = ent[0]
         try:
             setattr(edge_index, _ATTR, (edge_index._version, num_vertices, g))
         except Exception:  # pragma: no cover

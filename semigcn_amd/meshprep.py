@@ -189,7 +189,7 @@ def _vertex_quadrics(vs: torch.Tensor, faces: torch.Tensor) -> torch.Tensor:
     return Q
 
 
-def qem_contract(vs: torch.Tensor, faces: torch.Tensor, target_v: int, max_cluster: int = 5, rounds: int = 6):
+def qem_contract(vs: torch.Tensor, faces: torch.Tensor, target_v: int, max_cluster: int = 5, rounds: int = 8):
     """The reference's simplification criterion (util/mesh.py:394-482: quadric error of the edge MIDPOINT under the sum of
     the two end vertices' quadrics, times the valence penalty |valence_new - 6| + 1, x 1e5 for a valence of 3), applied
     in parallel: instead of one heap-ordered collapse at a time, ``rounds`` rounds of a locally-dominant matching on the
@@ -197,7 +197,9 @@ def qem_contract(vs: torch.Tensor, faces: torch.Tensor, target_v: int, max_clust
     -- each round taking its share of the vertices still to remove.  Like the reference, the surviving vertex (the
     lower id) moves to the midpoint and KEEPS its own quadric (util/mesh.py:564-571), a vertex that has been merged
     into can be merged again in a later round (clusters of 1 .. ``max_cluster``; the reference's reach 5), and an edge
-    whose ends share other than two neighbours is not collapsed (util/mesh.py:460-464: it would fold the surface).
+    with other than two faces, or whose ends share other than two neighbours, is not collapsed (util/mesh.py:455-464: the
+    boundary test and the link condition -- it would fold the surface).  Within a round no edge on the one-ring of a
+    collapse is taken: everything a round uses (costs, valences, link tests) is computed on the mesh the round began with.
     Returns ``coarse_of`` int64 [V] (ids ascend with the cluster's smallest member) and V_coarse."""
     dev = vs.device
     V = vs.shape[0]
@@ -219,8 +221,20 @@ def qem_contract(vs: torch.Tensor, faces: torch.Tensor, target_v: int, max_clust
         key, cnt = torch.unique(lo * V + hi, return_counts=True)
         ea, eb = key // V, key % V                      # undirected edges, ea < eb
         nf = torch.bincount(f.reshape(-1), minlength=V)                     # faces around a vertex (= its valence)
-        # shared neighbours of the two ends = faces on the edge for a manifold interior edge: exactly two, else skip
-        ok = (cnt == 2) & (size[ea] + size[eb] <= max_cluster)
+        # the reference's two tests (util/mesh.py:455-464): two faces on the edge (not a boundary), and the LINK condition --
+        # the two ends share exactly two neighbours.  An edge next to a valence-3 vertex has two faces but three shared
+        # neighbours; collapsing it folds the surface onto itself (duplicate / opposite faces in the coarse level).
+        nb_key = torch.cat([key, eb * V + ea])                              # directed adjacency (u, n) as u * V + n, ...
+        nb_key = torch.sort(nb_key)[0]                                      # ... sorted: u's neighbours are one run
+        deg = torch.bincount(nb_key // V, minlength=V)
+        start = torch.cumsum(deg, 0) - deg
+        e_id = torch.repeat_interleave(torch.arange(key.numel(), device=dev), deg[ea])      # every (edge, neighbour of ea)
+        n_of_a = nb_key[start[ea][e_id] + (torch.arange(e_id.numel(), device=dev) - torch.repeat_interleave(
+            torch.cumsum(deg[ea], 0) - deg[ea], deg[ea]))] % V
+        probe = eb[e_id] * V + n_of_a                                       # is that neighbour adjacent to eb as well?
+        at = torch.searchsorted(nb_key, probe).clamp_(max=nb_key.numel() - 1)
+        shared = torch.bincount(e_id[nb_key[at] == probe], minlength=key.numel())
+        ok = (cnt == 2) & (shared == 2) & (size[ea] + size[eb] <= max_cluster)
         val_new = nf[ea] + nf[eb] - 4
         pen = (val_new - OPTIM_VALENCE).abs().double() * VALENCE_WEIGHT + 1.0
         pen = torch.where(val_new == 3, pen * 100000.0, pen)
@@ -257,6 +271,13 @@ def qem_contract(vs: torch.Tensor, faces: torch.Tensor, target_v: int, max_clust
             rep = rep_b[rep]
             used[a] = True
             used[b] = True
+            # costs, valences and link tests of this round were taken on the mesh as it was when the round began: an edge
+            # with an end on the one-ring of a collapse no longer has the valence / shared neighbours it was priced with
+            # -- it waits for the next round, which prices everything again
+            ring = nb_key[torch.repeat_interleave(start[torch.cat([a, b])], deg[torch.cat([a, b])]) + (
+                torch.arange(int(deg[torch.cat([a, b])].sum()), device=dev) - torch.repeat_interleave(
+                    torch.cumsum(deg[torch.cat([a, b])], 0) - deg[torch.cat([a, b])], deg[torch.cat([a, b])]))] % V
+            used[ring] = True
             taken += int(w.numel())
             cand = cand[~win]
             cand = cand[~(used[ea[cand]] | used[eb[cand]])]

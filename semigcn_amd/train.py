@@ -306,32 +306,87 @@ def _ranks_that_failed_to_record(uid: int, timeout_s: float = 300.0):
     return bad
 
 
-def replay_matches_eager(trainer, mask_index: int = 0, rtol: float = 1e-6) -> bool:
+def replay_matches_eager(trainer, mask_index: int = 0, rtol: float = 1e-6, grad_rtol: float = 1e-4) -> bool:
     """Trust a replaying trainer only after ONE replayed iteration has reproduced an eager one: both run on the same mask
     with the same parameters (no optimiser step lies between them; BatchNorm normalises with batch statistics in training
     mode, so the running averages moving in between do not matter), and their loss values -- on a partition the mesh-wide,
     all-reduced value, hence the same number on every rank -- must agree to ``rtol`` (the replay tests find them
-    bit-identical).  Costs two iterations.  Not for models with active Dropout (MGCN: two passes draw different
-    masks).  Returns False (and leaves the trainer on its EAGER path) otherwise; every
-    rank reaches the same verdict without further communication."""
+    bit-identical), AND the gradient increment each of the two iterations adds to every parameter's ``.grad`` and the
+    BatchNorm running statistics they leave must agree to ``grad_rtol``: the corrupted replays this guards against
+    (tools/graph_replay_check.py) keep the forward pass intact and return wrong gradients.  Costs two iterations.  Not for
+    models with active Dropout (MGCN: two passes draw different masks) -- bench.py does not replay those by default.
+    Returns False (and leaves the trainer on its EAGER path) otherwise.  On a partition the gradient verdict is local to a
+    rank; the callers all-reduce it where ranks must agree (bench.py)."""
     rep = getattr(trainer, "_segmented", None) or getattr(trainer, "_graphed", None)
     if rep is None:
         return True
     attr = "_segmented" if getattr(trainer, "_segmented", None) is not None else "_graphed"
     while getattr(rep, "rec", None) is None and getattr(rep, "graph", None) is None:
         trainer.iteration_step(mask_index)              # still warming up / recording
-    while (trainer.iteration + 1) % trainer.accumulate == 0:
-        trainer.iteration_step(mask_index)              # keep the pair clear of the optimiser step
+    if trainer.accumulate < 3:
+        # the pair of iterations below must not straddle an optimiser step (it would change the parameters between them),
+        # which takes two steps in a row without one: impossible here -- stay eager rather than trust an unchecked replay
+        import sys
+        print("semigcn_amd: accumulate < 3 leaves no room for the replay == eager check; hipGraph replay switched off for this "
+              "trainer", file=sys.stderr, flush=True)
+        setattr(trainer, attr, None)
+        return False
+    for _ in range(trainer.accumulate):                 # keep the pair clear of the optimiser step
+        if (trainer.iteration + 1) % trainer.accumulate and (trainer.iteration + 2) % trainer.accumulate:
+            break
+        trainer.iteration_step(mask_index)
+    # what a bad replay corrupts is the BACKWARD pass (tools/graph_replay_check.py: gradients off by rel-L2 ~20 with an intact
+    # forward): compare the gradient INCREMENT of the two iterations and the BatchNorm running statistics they leave,
+    # not the loss alone
+    params = [p for p in getattr(trainer, "params", None) or trainer.model.parameters() if p.requires_grad and p.grad is not None]
+    bns = [m for m in trainer.model.modules() if isinstance(m, torch.nn.BatchNorm1d) and m.running_mean is not None]
+
+    def snap():
+        return ([p.grad.detach().clone() for p in params],
+                [(m.running_mean.detach().clone(), m.running_var.detach().clone()) for m in bns])
+
+    def restore(state):
+        with torch.no_grad():
+            for m, (rm, rv) in zip(bns, state[1]):
+                m.running_mean.copy_(rm)
+                m.running_var.copy_(rv)
+    g0 = snap()
     setattr(trainer, attr, None)
     try:
         eager = float(trainer.iteration_step(mask_index))
     finally:
         setattr(trainer, attr, rep)
+    g1 = snap()
+    restore(g0)                                         # both iterations start from the same running statistics
     replayed = float(trainer.iteration_step(mask_index))
+    g2 = snap()
     ok = abs(replayed - eager) <= rtol * max(abs(eager), 1e-30)
+    worst = 0.0
+    if ok:
+        for a, b, c in zip(g0[0], g1[0], g2[0]):
+            de, dr = (b - a).double(), (c - b).double()
+            scale = float(de.norm())
+            if scale > 0:
+                worst = max(worst, float((dr - de).norm()) / scale)
+        for (_, _), (rm1, rv1), (rm2, rv2) in zip(g0[1], g1[1], g2[1]):
+            for x1, x2 in ((rm1, rm2), (rv1, rv2)):
+                scale = float(x1.double().norm())
+                if scale > 0:
+                    worst = max(worst, float((x2.double() - x1.double()).norm()) / scale)
+        ok = worst <= grad_rtol
+    try:            # on a partition every rank must reach the SAME verdict (a rank that went eager alone would stop pairing
+        import torch.distributed as tdist      # its collectives with the replaying ranks')
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(getattr(trainer, "group", None)) > 1:
+            from . import dist as _d
+            flag = torch.tensor([1.0 if ok else 0.0], device=params[0].device if params else "cpu")
+            _d._all_reduce(flag, tdist.ReduceOp.MIN, getattr(trainer, "group", None))
+            ok = bool(float(flag) > 0.5)
+    except ImportError:
+        pass
     if not ok:
         import sys
-        print(f"semigcn_amd: replayed iteration loss {replayed!r} != eager {eager!r}; hipGraph replay switched off for this "
+        print(f"semigcn_amd: replayed iteration differs from the eager one (loss {replayed!r} vs {eager!r}, worst relative "
+              f"difference of a gradient increment / running statistic {worst:.3g}); hipGraph replay switched off for this "
               "trainer", file=sys.stderr, flush=True)
         setattr(trainer, attr, None)
     return ok
@@ -386,7 +441,37 @@ class GradBuffer:
                 p.grad.zero_()
 
 
-class SGCNTrainer:
+class _Epochs:
+    """Epoch-level semantics of the reference's loop (sgcn.py:110-148, mgcn.py:112-160) on top of ``iteration_step``: every
+    epoch visits all ``n_data`` dummy masks in a fresh ``torch.randperm`` order, ``accumulate`` of them per optimiser step
+    (``batch_index = torch.randperm(n_data).reshape(-1, args.batch)``), and ends with ``scheduler.step()`` (StepLR(50,
+    0.5)).  ``iteration_step()`` without an index keeps cycling through the masks in storage order (benchmarking); a
+    training run calls ``train_epoch()``."""
+    epoch = 0
+
+    def train_epoch(self, order=None):
+        """One epoch; returns the mean loss over its iterations as a device scalar (no host synchronisation).  ``order``:
+        the mask order to use instead of a fresh ``torch.randperm(n_data)`` (tests)."""
+        n = self.mesh.dummy_masks.shape[1]
+        if n % self.accumulate:
+            raise ValueError(f"{n} dummy masks cannot be cut into batches of {self.accumulate} (sgcn.py:112 reshapes the "
+                             "permutation to [-1, batch])")
+        if self.iteration % self.accumulate:
+            raise RuntimeError("train_epoch() in the middle of an accumulation cycle")
+        order = torch.randperm(n).tolist() if order is None else [int(k) for k in order]
+        total = torch.zeros((), device=self.loss_sum.device)
+        for k in order:
+            total = total + self.iteration_step(k)
+        self.epoch_end()
+        return total / n
+
+    def epoch_end(self) -> None:
+        """``scheduler.step()`` (sgcn.py:148): the learning rate halves every 50 epochs."""
+        self.sched.step()
+        self.epoch += 1
+
+
+class SGCNTrainer(_Epochs):
     """optimizer = Adam(lr), StepLR(50, 0.5) as sgcn.py:79-80; k1 = 4 (sgcn.py:47)."""
 
     def __init__(self, model: torch.nn.Module, batch: MeshBatch, lr: float = 0.01, k1: float = 4.0,
@@ -445,9 +530,10 @@ class SGCNTrainer:
         return loss
 
 
-class MGCNTrainer:
+class MGCNTrainer(_Epochs):
     """The loop of /root/reference/mgcn.py:121-160: multi-resolution weighted position RMSE
-    (weights 0.35/0.3/0.2/0.15, mgcn.py:82,138-143) + k1 x normal L1 on the finest level."""
+    (weights 0.35/0.3/0.2/0.15, mgcn.py:82,138-143) + k1 x normal L1 on the finest level; Adam + StepLR(50, 0.5)
+    (mgcn.py:72-73)."""
 
     def __init__(self, model: torch.nn.Module, batch: MeshBatch, lr: float = 0.01, k1: float = 4.0,
                  accumulate: int = 5, weights=(0.35, 0.3, 0.2, 0.15), k2: float = 0.0, capture: bool = False):
@@ -455,6 +541,7 @@ class MGCNTrainer:
         if k2 > 0 and batch.f2f is None:
             raise ValueError("k2 > 0 (the -CAD bilateral normal term, mgcn.py:146-148) needs MeshBatch.f2f")
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
+        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=50, gamma=0.5)
         self.iteration = 0
         self.loss_sum = torch.zeros((), device=batch.target_pos.device)
         self.keeps = [m.to(batch.target_pos.device) for m in model.v_masks_list]

@@ -1,0 +1,311 @@
+"""MGCN (BASELINE configs[2], "c3": 3 pool levels on the 50 K-vertex mesh) against the oracle at CONFIGURATION SIZE and in
+TRAIN mode -- the reference's path util/meshnet.py:31-160,278-318 with the training-step shape of mgcn.py:121-160.
+
+What makes a tight comparison possible (as for the SGCN, tests/test_gpu_config_parity.py):
+  * the SAME Bernoulli dropout draws on both sides: the four active ``nn.Dropout(0.2)`` (util/meshnet.py:62,128) are
+    replaced by modules that keep a prescribed 0/1 mask (oracle.models.Drop on the oracle, PrescribedDropout here);
+  * the oracle runs with the LeakyReLU sign pattern of the HIP forward (golden_util.PrescribedLeakyReLU), so that a
+    BatchNorm output within rounding of zero does not put the two gradients on different linear pieces;
+  * float64 evaluation of the oracle as the arbiter: the HIP fp32 path may be no further from exact arithmetic than a
+    small factor times what the fp32 oracle is.
+The hierarchy (pool_hash, coarse edge_index, smooth / target positions per level) is the one the device builder made for the
+HIP model (meshprep.DeviceMesh.simplification); the oracle gets exactly those artefacts.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as GU
+from oracle import bf16 as OB, models as OM
+from semigcn_amd import functional as F_sg, meshprep, synth, train
+from semigcn_amd.meshnet import MGCN
+from test_gpu_config_parity import _assert_fp32_parity, _assert_pattern_only_overridden_at_kinks, _batch, _errors
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+WEIGHTS = (0.35, 0.3, 0.2, 0.15)       # mgcn.py:82
+K1 = 4.0                                # mgcn.py:47
+
+
+class PrescribedDropout(torch.nn.Module):
+    """``nn.Dropout(p)`` with prescribed draws (see oracle.models.Drop): call i keeps ``masks[i]`` ([V_level, C], caller's
+    vertex order; ``order`` brings the rows into the model's processing order) and scales by 1 / (1 - p); one rounding to
+    the feature dtype, as the dropout kernel does."""
+
+    def __init__(self, p, order):
+        super().__init__()
+        self.p, self.order, self.masks, self.calls = float(p), order, None, 0
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        m = self.masks[self.calls % len(self.masks)]
+        self.calls += 1
+        m = m if self.order is None else m.index_select(0, self.order)
+        return (x.float() * (m * (1.0 / (1.0 - self.p)))).to(x.dtype)
+
+
+def _dropouts(net):
+    return [net.encoder1.model2, net.encoder2.model2, net.encoder3.model2, net.decoder3.model2, net.decoder2.model2,
+            net.decoder1[0].model2]
+
+
+# (level, channels) of the rows the six dropouts see: encoder1..3 end on the coarse level of their stage, decoder3..1 on the fine one
+DROP_AT = ((1, 32), (2, 128), (3, 256), (2, 128), (1, 32), (0, 16))
+
+
+class _Setup:
+    """HIP model + oracle over one device-built hierarchy, dropout draws shared."""
+
+    def __init__(self, nu, nv, seed, n_masks=1, n_draws=1, feature_dtype=torch.float32):
+        m = synth.torus_mesh(nu, nv)
+        self.m = m
+        smo = meshprep.DeviceMesh(m.x_pos, m.faces, DEV)
+        ini = meshprep.DeviceMesh(m.vs.astype(np.float32), m.faces, DEV)
+        net = MGCN(DEV, smo, ini, torch.from_numpy(m.v_mask))
+        GU.fill_state(net, seed=seed)
+        self.state0 = {k: v.clone().cpu() for k, v in net.state_dict().items() if not k.endswith("pool_hash")}
+        net.to(DEV).train()
+        if feature_dtype != torch.float32:
+            net.set_feature_dtype(feature_dtype)
+        self.net = net
+        self.sizes = [int(s.shape[0]) for s in net.smposs_list]
+        assert len(set(self.sizes)) == 4, self.sizes
+        self.ranks = {s: net._orders[l][1] for l, s in enumerate(self.sizes)}      # rows of a level -> its processing-order map
+        # shared dropout draws, caller's vertex order
+        gen = torch.Generator().manual_seed(1000 + seed)
+        self.draws = [[(torch.rand(self.sizes[l], c, generator=gen) >= 0.2).float() for _ in range(n_draws)] for l, c in DROP_AT]
+        for seq, (l, c), masks in zip(_dropouts(net), DROP_AT, self.draws):
+            name = seq._plan[-1][0]
+            old = getattr(seq, name)
+            assert isinstance(old, torch.nn.Dropout)
+            pd = PrescribedDropout(old.p, net._orders[l][0])
+            pd.masks = [mk.to(DEV) for mk in masks]
+            setattr(seq, name, pd)
+        self.hip_drops = [getattr(seq, seq._plan[-1][0]) for seq in _dropouts(net)]
+        self.batch = _batch(m, n_masks=n_masks)
+        self.eis = [e.cpu() for e in net.edge_inds]
+        self.phs = [np.asarray(p) for p in net._pool_pairs]
+        self.sms = [s.cpu() for s in net.smposs_list]
+        self.targets = [p.cpu() for p in net.poss_list]
+        self.vmasks = [(v[:, 0] > 0).numpy() for v in net.v_masks_list]
+        self.faces = torch.from_numpy(m.faces)
+        self.tfn = OM.compute_fn(self.targets[0], self.faces)
+        self.f_mask = m.v_mask[m.faces].all(1)
+
+    def oracle(self, act, bf16=False, bias_bf16=()):
+        a = (lambda: act)
+        if bf16:
+            ora = OB.MGCNOracleBf16(self.eis, self.phs, self.sms, act=a, bias_bf16_convs=bias_bf16)
+        else:
+            ora = OM.MGCNOracle(self.eis, self.phs, self.sms, act=a)
+        ora.load_state_dict(self.state0)
+        for d, masks in zip(ora.dropouts(), self.draws):
+            d.masks, d.calls = masks, 0
+        return ora.train()
+
+    def reset_draws(self):
+        for d in self.hip_drops:
+            d.calls = 0
+
+    def oracle_loss(self, outs, dtype):
+        """mgcn.py:138-143: weighted masked position RMSE per resolution + k1 x masked normal L1 on the finest."""
+        loss = K1 * OM.mask_norm_rec_loss(OM.compute_fn(outs[0], self.faces), self.tfn.to(dtype), self.f_mask)
+        for w, p, t, mk in zip(WEIGHTS, outs, self.targets, self.vmasks):
+            loss = loss + w * OM.mask_pos_rec_loss(p, t.to(dtype), mk)
+        return loss
+
+    def hip_iteration(self, record=True):
+        """forward + loss + backward on the HIP path; returns (concatenated outputs, loss, dz1, grads, bn) in float64 on the
+        host, and the activation masks in the caller's vertex order."""
+        net, b = self.net, self.batch
+        tr = getattr(self, "trainer", None)
+        if tr is None:
+            tr = self.trainer = train.MGCNTrainer(net, b)
+        self.reset_draws()
+        net.zero_grad(set_to_none=True)
+        b.data.z1.grad = None
+        masks = []
+        obs = (lambda y: masks.append((y.detach() > 0).index_select(0, self.ranks[y.shape[0]]))) if record else None
+        if obs is not None:
+            F_sg.bn_act_observers.append(obs)
+        try:
+            outs = net(b.data, None)
+        finally:
+            if obs is not None:
+                F_sg.bn_act_observers.remove(obs)
+        s0 = F_sg.mesh_loss_sums(outs[0], b.faces, net.poss_list[0], tr.keeps[0], b.target_fn, b.f_keep)
+        loss = WEIGHTS[0] * torch.sqrt(s0[0] / tr.counts[0] + 1.0e-6) + K1 * (s0[1] / b.n_f_keep)
+        for w, p, t, keep, n in list(zip(WEIGHTS, outs, net.poss_list, tr.keeps, tr.counts))[1:]:
+            loss = loss + w * train.masked_position_rmse(p, t, keep, n)
+        loss.backward()
+        torch.cuda.synchronize()
+        hip = (torch.cat([o.detach().cpu().double() for o in outs]), float(loss.detach()), b.data.z1.grad.detach().cpu().double(),
+               {n: p.grad.detach().cpu().double() for n, p in net.named_parameters() if p.grad is not None},
+               {k: v.detach().cpu().double() for k, v in net.state_dict().items() if "running" in k})
+        return hip, [mk.cpu() for mk in masks]
+
+    def oracle_iteration(self, ora, dtype):
+        ora = ora.to(dtype).train()
+        for d in ora.dropouts():
+            d.calls = 0
+        ora.smposs_list = [s.to(dtype) for s in self.sms]
+        z1 = torch.from_numpy(self.m.z1).to(dtype).requires_grad_(True)
+        outs = ora(z1, None)
+        loss = self.oracle_loss(outs, dtype)
+        loss.backward()
+        return (torch.cat([o.detach().double() for o in outs]), float(loss.detach()), z1.grad.detach().double(),
+                {n: p.grad.detach().double() for n, p in ora.named_parameters() if p.grad is not None},
+                {k: v.detach().double() for k, v in ora.state_dict().items() if "running" in k})
+
+
+# --------------------------------------------------------------------------------------
+# (a) c3 in fp32, train mode, one iteration: 4 outputs, loss, BatchNorm statistics, every gradient
+# --------------------------------------------------------------------------------------
+def test_c3_mgcn_train_iteration_vs_oracle():
+    s = _Setup(250, 200, seed=70)
+    assert s.sizes[0] == 50000 and 0.55 < s.sizes[1] / s.sizes[0] < 0.65, s.sizes
+    before = list(F_sg.block_calls)
+    hip, masks = s.hip_iteration()
+    assert [F_sg.block_calls[0] - before[0], F_sg.block_calls[1] - before[1]] == [33, 33], "every block below the C ABI"
+    assert len(masks) == 33
+    act = GU.PrescribedLeakyReLU(masks)
+    xp = torch.cat(s.sms).double()
+    o32 = s.oracle_iteration(s.oracle(act), torch.float32)
+    res = {"hip_vs_oracle": _errors(hip, o32, xp), "flips": act.flips, "flip_frac": act.flips / max(act.elements, 1),
+           "max_flip_z": act.max_flip_z}
+    act.reset()
+    o64 = s.oracle_iteration(s.oracle(act), torch.float64)
+    res["hip_vs_fp64"], res["oracle_vs_fp64"] = _errors(hip, o64, xp), _errors(o32, o64, xp)
+    for k, v in res.items():
+        print(k, {kk: (f"{vv:.3e}" if isinstance(vv, float) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v)
+    _assert_pattern_only_overridden_at_kinks(res, frac=1e-4)
+    _assert_fp32_parity(res)
+    # each of the four resolutions on its own, north_star's bound
+    at = 0
+    for l, n in enumerate(s.sizes):
+        assert GU.rel_l2(hip[0][at:at + n], o64[0][at:at + n]) < 1e-5, l
+        at += n
+
+
+# --------------------------------------------------------------------------------------
+# (b) bf16 feature storage: stages teacher-forced against the bf16-storage oracle; end to end no further from fp32 than
+#     the storage oracle itself
+# --------------------------------------------------------------------------------------
+MGCN_BF16_STAGE_TOL = {"out": 1.2e-2, "dx": 0.13}      # measured (five blocks deep, no forcing inside a stage): 7.8e-3, 8.7e-2 (encoder3)
+
+
+def _blas_convs(net):
+    """Names of the ChebConvs whose bias enters the product rounded to bf16: none on the block path -- every engine behind
+    sg_block_forward (MFMA, thin, and the library's own hipBLASLt call for the K = 12 columns of the 4 -> 32 input layer)
+    adds the fp32 parameter in its epilogue.  (torch.addmm, which served that layer on the per-module path, takes the bias
+    in the operand type.)"""
+    return () if F_sg.blocks_enabled() else tuple(
+        name for name, mod in net.named_modules() if type(mod).__name__ == "ChebConv" and mod.in_channels * mod.K % 8)
+
+
+def test_mgcn_bf16_stages_teacher_forced_vs_bf16_storage_oracle():
+    """Every encoder / decoder stage (five ChebConvs, a pool or unpool, five BatchNorms, a dropout) of the bf16 HIP model on
+    the ORACLE's stage input and output gradient (teacher forcing: two bf16 evaluations do not stay together over 33 layers,
+    see test_gpu_config_parity.py) against the same stage of MGCNOracleBf16."""
+    s = _Setup(100, 50, seed=71, feature_dtype=torch.bfloat16)
+    net = s.net
+    ora = s.oracle(torch.nn.LeakyReLU(), bf16=True, bias_bf16=_blas_convs(net))
+    z1 = torch.from_numpy(s.m.z1)
+    caps = {}
+
+    def grab(name):
+        def hook(mod, inp, out):
+            out.retain_grad()
+            caps[name] = (inp[0], out)
+        return hook
+    stages = ["encoder1", "encoder2", "encoder3", "decoder3", "decoder2"]
+    hooks = [getattr(ora, n).register_forward_hook(grab(n)) for n in stages] + [ora.decoder1[0].register_forward_hook(grab("decoder1"))]
+    outs = ora(z1.requires_grad_(True), None)
+    s.oracle_loss(outs, torch.float32).backward()
+    for h in hooks:
+        h.remove()
+    level_in = {"encoder1": 0, "encoder2": 1, "encoder3": 2, "decoder3": 3, "decoder2": 2, "decoder1": 1}
+    level_out = {"encoder1": 1, "encoder2": 2, "encoder3": 3, "decoder3": 2, "decoder2": 1, "decoder1": 0}
+    worst = {"out": (0.0, None), "dx": (0.0, None)}
+    for name in stages + ["decoder1"]:
+        stage = net.decoder1[0] if name == "decoder1" else getattr(net, name)
+        xin, yout = caps[name]
+        # the oracle's gradient of THIS stage's input (the stage outputs feed a head as well: the tensor's .grad is a sum):
+        # the oracle stage once more on its own, same input, same draw, same output gradient
+        ostage = ora.decoder1[0] if name == "decoder1" else getattr(ora, name)
+        for d in ora.dropouts():
+            d.calls = 0
+        xo = xin.detach().clone().requires_grad_(True)
+        ostage(xo).backward(yout.grad)
+        gin = xo.grad
+        oi, oo = net._orders[level_in[name]][0], net._orders[level_out[name]]
+        s.reset_draws()                       # (this stage's dropout then uses the draw the oracle's stage used)
+        x = xin.detach().to(DEV).index_select(0, oi).to(torch.bfloat16).requires_grad_(True)
+        y = stage(x)
+        y.backward(yout.grad.to(DEV).index_select(0, oo[0]).to(y.dtype))
+        e_out = GU.rel_l2(y.detach().float().index_select(0, oo[1]).cpu(), yout.detach())
+        e_dx = GU.rel_l2(x.grad.float().index_select(0, net._orders[level_in[name]][1]).cpu(), gin)
+        print(f"{name}: out {e_out:.2e}  dx {e_dx:.2e}")
+        for k, e in (("out", e_out), ("dx", e_dx)):
+            if e > worst[k][0]:
+                worst[k] = (e, name)
+    print("worst", worst)
+    for k, (e, name) in worst.items():
+        assert e < MGCN_BF16_STAGE_TOL[k], (k, name, e)
+
+
+def test_mgcn_bf16_end_to_end_no_further_from_fp32_than_the_storage_oracle():
+    s = _Setup(100, 50, seed=72, feature_dtype=torch.bfloat16)
+    hip, _ = s.hip_iteration(record=False)
+    xp = torch.cat(s.sms).double()
+    runs = {}
+    for key, ora in (("fp32", s.oracle(torch.nn.LeakyReLU())),
+                     ("bf16", s.oracle(torch.nn.LeakyReLU(), bf16=True, bias_bf16=_blas_convs(s.net)))):
+        o = s.oracle_iteration(ora, torch.float32)
+        runs[key] = (o[0] - xp, o[1])
+    ref = runs["fp32"]
+    d_hip = {"offset": GU.rel_l2(hip[0] - xp, ref[0]), "loss": abs(hip[1] - ref[1]) / abs(ref[1])}
+    d_ora = {"offset": GU.rel_l2(runs["bf16"][0], ref[0]), "loss": abs(runs["bf16"][1] - ref[1]) / abs(ref[1])}
+    print("HIP bf16 vs fp32 oracle", d_hip, " bf16-storage oracle vs fp32 oracle", d_ora)
+    assert d_hip["offset"] < 1.5 * d_ora["offset"] + 1e-3 and d_hip["loss"] < 2.0 * d_ora["loss"] + 1e-2
+    assert d_ora["offset"] > 5e-3
+
+
+# --------------------------------------------------------------------------------------
+# (c) the loop of mgcn.py:121-160: five accumulated iterations + one Adam step, re-synchronised at the step
+# --------------------------------------------------------------------------------------
+def test_mgcn_training_trajectory_resynchronised_at_the_optimiser_step():
+    s = _Setup(100, 50, seed=73, n_masks=5, n_draws=5)
+    net, b = s.net, s.batch
+    tr = train.MGCNTrainer(net, b)
+    s.trainer = tr
+    ora = s.oracle(torch.nn.LeakyReLU())
+    opt = torch.optim.Adam(ora.parameters(), lr=0.01)
+    opt.zero_grad()
+    z1 = torch.from_numpy(s.m.z1)
+    errs = []
+    for k in range(5):
+        lh = float(tr.iteration_step(k))                    # (the 5th call also applies Adam on the HIP side)
+        lo = s.oracle_loss(ora(z1, None), torch.float32)    # mgcn.py:128-134: the Tensor mask is ignored by MGCN.forward
+        lo.backward()
+        errs.append(abs(lh - float(lo)) / abs(float(lo)))
+    opt.step()
+    print("loss errors", [f"{e:.2e}" for e in errs])
+    assert max(errs) < 1e-5, errs
+    # the Adam step: same direction wherever the oracle's accumulated gradient is above its noise floor
+    po = dict(ora.named_parameters())
+    n_above = n_off = 0
+    # (a ChebConv bias in front of a BatchNorm has a true gradient of exactly zero: its step is pure rounding noise)
+    conv_bias = {n + ".bias" for n, mod in net.named_modules() if type(mod).__name__ == "ChebConv"}
+    for name, p in net.named_parameters():
+        g = po[name].grad
+        if g is None or name in conv_bias:
+            continue
+        d = (p.detach().cpu() - po[name].detach()).abs()
+        assert float(d.max()) <= 2.0 * 0.01 + 1e-6, name
+        above = g.abs() > 5e-2 * g.pow(2).mean().sqrt()
+        n_above += int(above.sum())
+        n_off += int((d[above] > 0.02 * 0.01).sum())
+    print("entries above the noise floor", n_above, "of them stepping differently", n_off)
+    assert n_off <= 2e-3 * n_above, (n_off, n_above)

@@ -607,8 +607,21 @@ def test_mgcn_bf16_feature_storage(skip):
         assert e16.dtype == torch.bfloat16 and GU.rel_l2(e16.float().cpu(), e32.cpu()) < 3e-2
         net.set_feature_dtype(torch.bfloat16)
         p16 = net(D, None)
-    for a, b, sm in zip(p16, p32, net.smposs_list):
-        assert a.dtype == torch.float32 and GU.rel_l2((a - sm).cpu(), (b - sm).cpu()) < 0.25
+    # how far bf16 storage may move the four outputs: what the bf16-STORAGE oracle (oracle/bf16.py::MGCNOracleBf16: the
+    # reference's composition, rounded where this path stores) moves them on the same weights -- not a flat allowance
+    from oracle import bf16 as OB
+    eis = [torch.from_numpy(g3[f"edge_index/{l}"]) for l in range(4)]
+    phs = [g3[f"pool_hash/{l}"] for l in range(3)]
+    sms = [torch.from_numpy(g3[f"smposs/{l}"]) for l in range(4)]
+    state = {k: v.cpu() for k, v in net.state_dict().items() if not k.endswith("pool_hash")}
+    o32, o16 = OM.MGCNOracle(eis, phs, sms, skip=skip), OB.MGCNOracleBf16(eis, phs, sms, skip=skip)
+    o32.load_state_dict(state), o16.load_state_dict(state)
+    o32.eval(), o16.eval()
+    with torch.no_grad():
+        r32, r16 = o32(torch.from_numpy(g3["z1"]), None), o16(torch.from_numpy(g3["z1"]), None)
+    for a, b, c, sm in zip(p16, r32, r16, sms):
+        d_hip, d_ora = GU.rel_l2((a.cpu() - sm), (b - sm)), GU.rel_l2((c - sm), (b - sm))
+        assert a.dtype == torch.float32 and d_hip < 1.5 * d_ora + 2e-3, (d_hip, d_ora)
     net.train()
     out = net(D, None)
     sum((o ** 2).mean() for o in out).backward()

@@ -540,3 +540,76 @@ def test_trainer_trajectory_equals_the_oracle_loop(cpu_kernels, fixture_meshes):
     # the second step is asserted at configuration size on the device only)
     errs, dev = GU.synchronised_trajectory(tr, net, ora, oracle_iteration, dms, noise=5e-2, step_tol=(0.02, 2.0))
     assert len(errs) == 10
+
+
+def test_graph_cache_verifies_a_fingerprint_hit(cpu_kernels, fixture_meshes, monkeypatch):
+    """A level-2 hit is accepted only after the edges have been compared with the ones the cached graph was built from
+    (three wrapping sums are not the content): with the fingerprint forced to collide, another graph of the
+    same shape gets its OWN CSR."""
+    from semigcn_amd import graph
+    graph.clear_graph_cache()
+    monkeypatch.setattr(graph, "_fingerprint", lambda ei: (1, 2, 3))
+    ei = torch.from_numpy(fixture_meshes["torus"].edge_index).clone()
+    g1 = graph.graph_for(ei, 240)
+    other = ei.clone()
+    other[1, :6] = (other[1, :6] + 7) % 240            # same shape, same (forced) fingerprint, different edges
+    g2 = graph.graph_for(other, 240)
+    assert g2 is not g1
+    x = torch.randn(240, 3)
+    y1, y2 = torch.empty(240, 3), torch.empty(240, 3)
+    g1.aggregate(x, y1), g2.aggregate(x, y2)
+    assert not torch.equal(y1, y2)
+    assert graph.graph_for(other.clone(), 240) is g2                                        # verified hit: elementwise equal
+    assert graph.graph_for(other[:, torch.randperm(other.shape[1])].contiguous(), 240) is g2  # ... or equal as a multiset
+
+
+def test_trainer_epochs_step_the_scheduler_and_redraw_the_batches(cpu_kernels, fixture_meshes):
+    """Epoch-level semantics of sgcn.py:110-148: a fresh torch.randperm of ALL dummy masks per epoch, ``accumulate`` of them
+    per optimiser step, ``scheduler.step()`` at the end of the epoch (the StepLR was built and never
+    stepped)."""
+    from semigcn_amd import synth, train
+    m = fixture_meshes["torus"]
+    faces = torch.from_numpy(m.faces)
+    target = torch.from_numpy(m.vs.astype(np.float32))
+    v_keep = torch.from_numpy(m.v_mask.astype(np.float32)).view(-1, 1)
+    f_keep = v_keep[faces[:, 0]] * v_keep[faces[:, 1]] * v_keep[faces[:, 2]]
+    dms = torch.from_numpy(synth.make_dummy_masks(m.edge_index, m.num_vertices, dm_size=4, k=1, p=0.05))
+    batch = train.MeshBatch(_Data(m), faces, target, train.face_normals(target, faces), v_keep, f_keep, dms)
+    torch.manual_seed(3)
+    net = SingleScaleGCN("cpu", reorder=False)
+    tr = train.SGCNTrainer(net, batch, lr=0.01, accumulate=2)
+    tr.sched = torch.optim.lr_scheduler.StepLR(tr.opt, step_size=2, gamma=0.5)     # (the reference's period is 50 epochs)
+    seen, real = [], tr.iteration_step
+    tr.iteration_step = lambda k=None: (seen.append(k), real(k))[1]
+    steps = []
+    tr.opt.register_step_post_hook(lambda *a: steps.append(tr.iteration))
+    torch.manual_seed(17)
+    want = [torch.randperm(4).tolist() for _ in range(3)]
+    torch.manual_seed(17)
+    lrs = []
+    for _ in range(3):
+        loss = tr.train_epoch()
+        assert loss.dim() == 0 and bool(torch.isfinite(loss))
+        lrs.append(tr.opt.param_groups[0]["lr"])
+    assert seen == sum(want, []) and want[0] != want[1]                       # every mask once per epoch, order redrawn
+    assert steps == [2, 4, 6, 8, 10, 12]                                       # n_data / batch optimiser steps per epoch
+    assert lrs == [0.01, 0.005, 0.005] and tr.epoch == 3                       # StepLR(2, 0.5) stepped once per epoch
+    with pytest.raises(ValueError, match="cannot be cut"):
+        train.SGCNTrainer(net, batch, accumulate=3).train_epoch()
+
+
+def test_replay_check_does_not_spin_without_room_for_it():
+    """train.replay_matches_eager with accumulate = 1 (`(iteration + 1) % 1 == 0` held forever and the loop ran
+    optimiser steps while it span): it now declines -- the trainer goes eager -- after no iteration at all."""
+    from semigcn_amd import train
+
+    class Rep:
+        graph = object()
+
+    class Tr:
+        accumulate, iteration, _graphed, _segmented = 1, 0, Rep(), None
+
+        def iteration_step(self, k=None):
+            raise AssertionError("no iteration may run")
+    tr = Tr()
+    assert train.replay_matches_eager(tr) is False and tr._graphed is None
