@@ -60,6 +60,8 @@ def parse():
                     help="diagnostic, --gpus 1 only: run the partitioned code path on ONE rank with every collective issued "
                          "through RCCL (what a rank of an N-rank job does; not a scaling point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-distributed-estimate", action="store_true",
+                    help="skip the `distributed_estimate` of the default N=1 run (two short child runs on the 1/8 mesh)")
     ap.add_argument("--cpu-sample", default="250x200", help="torus for the CPU baseline sample")
     ap.add_argument("--cpu-full", dest="cpu_full", action="store_true", default=True,
                     help="CPU baseline (default): time ONE oracle iteration at the full mesh size as SURVEY 8(d) / BASELINE.md "
@@ -528,6 +530,48 @@ def dense_products(timer, steps: int, dt: float):
             "by_engine": by_engine, "shapes": shapes[:12] + [s for s in shapes[12:] if s["engine"] != "mfma"]}
 
 
+def distributed_estimate(args, ms_per_step_n1: float):
+    """What this code predicts for the 8-GPU strong-scaling point of the SAME mesh, measured on this one GPU (no box with more
+    than one GPU has been available to this build; the driver's SCALE run has a number to be held against): one rank of an
+    8-rank job owns V / 8 vertices, so a mesh of that size is run (a) on the partitioned code path with every collective
+    issued through RCCL on a one-rank communicator (what a rank's host and GPU do, minus the wire) and (b) unpartitioned
+    (what the GPU needs for a block of that size).  Child processes of this one -- nothing is exec'ed over a process that
+    holds the GPU."""
+    import math
+    import subprocess
+    nu, nv = map(int, args.mesh.split("x"))
+    side = max(8, int(round(math.sqrt(nu * nv / 8.0))))
+    base = [sys.executable, os.path.abspath(__file__), "--mesh", f"{side}x{side}", "--dtype", args.dtype, "--single-dtype",
+            "--no-second-order", "--no-cpu-baseline", "--no-launch-timer", "--no-distributed-estimate", "--steps", "40", "--warmup", "8"]
+    out = {"ranks": 8, "rank_mesh": f"{side}x{side}", "rank_vertices": side * side}
+
+    def run(extra):
+        try:
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            return json.loads(line[-1]) if line else {"error": (r.stderr or "")[-300:]}
+        except Exception as e:          # the estimate must never cost the bench line
+            return {"error": f"{type(e).__name__}: {e}"}
+    part = run(["--partitioned"])
+    solo = run(["--no-graph"])
+    if "ms_per_step" in part:
+        out["rank_ms_per_step"] = round(part["ms_per_step"], 3)
+        d = part.get("distributed") or {}
+        out["collectives_per_iteration"] = d.get("collectives_per_iteration")
+        out["rank_replays_hip_graph_segments"] = d.get("hip_graph_segments") is not None
+    else:
+        out["rank_error"] = part.get("error")
+    if "ms_per_step" in solo:
+        out["block_ms_per_step_unpartitioned"] = round(solo["ms_per_step"], 3)
+    else:
+        out["block_error"] = solo.get("error")
+    if "rank_ms_per_step" in out:
+        out["predicted_speedup_8_gpus_before_wire_time"] = round(ms_per_step_n1 / out["rank_ms_per_step"], 2)
+        out["note"] = ("upper bound: 57 collectives per iteration cross no link here (one-rank communicator); halo rows per rank "
+                       "and their bytes are in DESIGN.md section 5")
+    return out
+
+
 def free_port() -> int:
     import socket
     with socket.socket() as sk:
@@ -833,6 +877,10 @@ def main():
                                    "collectives_per_iteration": round(sum(coll.values()), 1), "collectives_by_kind": coll,
                                    "rank0_owned_rows": None if g is None else g.n_own,
                                    "rank0_halo_rows": None if g is None else g.n_halo}
+        if (not DIST_ON and world == 1 and args.model == "sgcn" and not args.no_distributed_estimate and not args.no_cpu_baseline
+                and mesh.num_vertices >= 500_000):
+            log("distributed estimate: two short child runs on the 1/8 mesh")
+            line["distributed_estimate"] = distributed_estimate(args, main_res["ms_per_step"])
         line["cpu_baseline"] = cpu_baseline(args.cpu_sample, mesh.num_vertices, full=args.cpu_full, recipe=args.mesh_recipe) if (
             not DIST_ON and not args.no_cpu_baseline) else None
         sys.stdout.flush()

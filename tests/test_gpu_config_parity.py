@@ -168,15 +168,7 @@ def _one_iteration_both_sides(m, *, feature_dtype, seed, skip=False, post=True, 
     def make(dtype):
         act.reset()
         if feature_dtype == torch.bfloat16:
-            V = m.num_vertices
-            blas = []
-            for i in range(13):
-                cin, cout = CHANNELS[i], CHANNELS[i + 1]
-                narrowing = post and cout < cin
-                wshape = (3 * cout, cin) if narrowing else (cout, 3 * cin)
-                a = torch.empty((V, wshape[1]), dtype=torch.bfloat16, device=DEV)
-                if not F_sg._mfma_ok(a, torch.empty(wshape, dtype=torch.bfloat16, device=DEV), wshape[0]):
-                    blas.append(i)
+            blas = _blas_layers(m.num_vertices, post)
             ora = OB.SGCNOracleBf16(skip=skip, post_when_narrowing=post, act=act, bias_bf16_layers=blas)
         else:
             ora = OM.SGCNOracle(skip=skip, act=act)
@@ -277,10 +269,18 @@ def test_c4_full_size_train_iteration_vs_oracle():
 #       input gradient and parameter gradients of the HIP block against the oracle block -- same storage points or not;
 #   (b) end to end, the HIP bf16 path is no further from the fp32 oracle than the bf16-storage oracle is (outputs, loss,
 #       direction of the gradients): bf16 storage costs what it must and nothing more.
-BF16_BLOCK_TOL = {"out": 1e-3, "dx": 2e-2, "dw": 2.5e-2}     # measured: 2.0e-4, 8.3e-3, 1.1e-2 (block 9, aggregation after the product)
+# 1.5 x the measured maxima (round 4, block path: 2.2e-4, 1.8e-3, 2.7e-3 -- blocks 6 / 7, the 512-channel layers).  Rounds 2-3
+# measured 8.3e-3 / 1.1e-2 for dx / dw: that was torch.addmm rounding the conv bias to bf16 on the BLAS-served layers, which
+# the oracle then had to be told to imitate; every engine behind sg_block_forward adds the fp32 bias.
+BF16_BLOCK_TOL = {"out": 3.3e-4, "dx": 2.7e-3, "dw": 4.1e-3}
 
 
 def _blas_layers(V, post):
+    """Blocks whose conv bias enters the product rounded to bf16: those torch.addmm serves on the per-module path (it takes
+    the bias in the operand type).  None on the block path: every engine behind sg_block_forward -- MFMA, thin, the library's
+    own hipBLASLt call -- adds the fp32 parameter in its epilogue."""
+    if F_sg.blocks_enabled():
+        return []
     blas = []
     for i in range(13):
         cin, cout = CHANNELS[i], CHANNELS[i + 1]

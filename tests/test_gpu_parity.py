@@ -723,8 +723,9 @@ def test_bn_act_widen_is_adopted_by_the_next_conv(fixture_meshes):
     (seq(xa, ei) * r).sum().backward()
     got = [xa.grad.clone()] + [p.grad.clone() for p in seq.parameters()]
     seen = []
-    orig = F_sg._adopt_wide
+    orig, blocks = F_sg._adopt_wide, F_sg.USE_BLOCK_CALLS
     F_sg._adopt_wide = lambda t, K: (seen.append(orig(t, K) is not None), None)[1]      # force the copying path
+    F_sg.USE_BLOCK_CALLS = False        # (the per-module path: a block call keeps this gradient buffer inside the library)
     try:
         for p in seq.parameters():
             p.grad = None
@@ -732,7 +733,7 @@ def test_bn_act_widen_is_adopted_by_the_next_conv(fixture_meshes):
         seq.module_1.reset_running_stats()
         (seq(xb, ei) * r).sum().backward()
     finally:
-        F_sg._adopt_wide = orig
+        F_sg._adopt_wide, F_sg.USE_BLOCK_CALLS = orig, blocks
     assert any(seen)                                      # the adoptable buffer did arrive at the conv's backward
     for a, b in zip(got, [xb.grad] + [p.grad for p in seq.parameters()]):
         assert torch.equal(a, b)
