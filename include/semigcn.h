@@ -323,6 +323,12 @@ SG_API int sg_face_mask(const int64_t* faces, int64_t F, int64_t V, const uint64
  *           with fine = 0..3F-1 (corner ids 3f+i), coarse = faces[f][i], n_fine = 3F,
  *           n_coarse = V_ext.
  * ------------------------------------------------------------------------- */
+/* sg_mesh_loss_finalize: out[0] = w_pos * sqrt(S_p / n_v + 1e-6) + k1 * S_n / n_f from the nb block partials of
+ * sg_mesh_loss_fwd (the loss of sgcn.py:130-138; w_pos, k1 = 0 / n_f = 0: one resolution's weighted position term of
+ * mgcn.py:138-143), out[1] = d loss / d S_p, out[2] = d loss / d S_n: scaled by the incoming gradient they are the `g` of
+ * the backward entry points.  One launch instead of a dozen scalar operators and their autograd nodes. */
+SG_API int sg_mesh_loss_finalize(const float* partial, int64_t nb, float n_v, float n_f, float w_pos, float k1, float* out,
+                                 void* stream);
 SG_API int64_t sg_mesh_loss_blocks(int64_t V, int64_t F);
 SG_API int sg_mesh_loss_fwd(const float* pos, const int64_t* faces, const float* target_pos, const float* v_keep,
                             const float* target_fn, const float* f_keep, int64_t V, int64_t F, float* partial,
@@ -385,6 +391,16 @@ SG_API int sg_bn_stats_finalize_tiles(const float* partial, int64_t n_tiles, int
  * (the gradients of the bounds, which the caller's autograd routes to the arg-extreme vertices); partial: float32
  * [sg_input_prep_blocks(V), 4] scratch (block sums in a fixed order: deterministic).
  * ------------------------------------------------------------------------- */
+/* sg_input_bounds: lo / hi of z1 over the vertices (util/networks.py:67: torch.min / torch.max over dim 0) in two launches:
+ * bounds [6] = lo[3], hi[3]; arg [6] = the vertex each bound was taken from (a tie goes to the lowest id); scratch
+ * partial_values float32 [sg_input_prep_blocks(V), 6], partial_index int64 [same, 6].
+ * sg_input_prep_bwd_routed: sg_input_prep_bwd with lo = bounds, hi = bounds + 3, and the gradients of the bounds (written to
+ * d_bounds [6]) ADDED to dz1 at the arg vertices in the same call -- what autograd does through torch.min / torch.max. */
+SG_API int sg_input_bounds(const float* z1, int64_t V, float* partial_values, int64_t* partial_index, float* bounds, int64_t* arg,
+                           void* stream);
+SG_API int sg_input_prep_bwd_routed(const void* gX, int64_t ldg, const float* z1, const float* dm, const int64_t* rank,
+                                    const float* bounds, const int64_t* arg, float* dz1, float* partial, float* d_bounds,
+                                    int64_t V, int dtype, void* stream);
 SG_API int64_t sg_input_prep_blocks(int64_t V);
 SG_API int sg_input_prep(const float* z1, const float* dm, const int64_t* order, const float* lo, const float* hi, void* X,
                          int64_t ldx, int64_t V, int dtype, void* stream);

@@ -105,6 +105,10 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "sg_bn_merge_tiles": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sg_multi_add": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sg_input_bounds": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sg_input_prep_bwd_routed": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int64, c_int, c_void_p]),
+    "sg_mesh_loss_finalize": (c_int, [c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "sg_input_prep_blocks": (c_int64, [c_int64]),
     "sg_input_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sg_input_prep_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -934,7 +938,46 @@ def input_prep_bwd(gX: torch.Tensor, z1: torch.Tensor, dm: Optional[torch.Tensor
     return dz1, dlh[0], dlh[1]
 
 
+def input_bounds(z1: torch.Tensor):
+    """(bounds float32 [6] = lo[3] | hi[3] of z1 over its rows, arg int64 [6] = the vertex each bound came from)."""
+    _require_device(z1, "z1")
+    V = z1.shape[0]
+    if z1.dtype != torch.float32 or z1.dim() != 2 or z1.shape[1] != 3 or not z1.is_contiguous() or V == 0:
+        raise SemigcnLibraryError(f"z1 must be contiguous float32 [V > 0, 3], got {z1.dtype} {tuple(z1.shape)}")
+    nb = _sizes("sg_input_prep_blocks", V)
+    pv = torch.empty((nb + 1, 6), dtype=torch.float32, device=z1.device)       # (last row: the result)
+    pi = torch.empty((nb + 1, 6), dtype=torch.int64, device=z1.device)
+    with _on_device(z1.device):
+        _check(load().sg_input_bounds(_ptr(z1), V, _ptr(pv), _ptr(pi), pv.data_ptr() + 24 * nb, pi.data_ptr() + 48 * nb, _stream(z1)),
+               "sg_input_bounds")
+    return pv[nb], pi[nb]
+
+
+def input_prep_bwd_routed(gX: torch.Tensor, z1: torch.Tensor, dm: Optional[torch.Tensor], rank: Optional[torch.Tensor],
+                          bounds: torch.Tensor, arg: torch.Tensor) -> torch.Tensor:
+    """dz1 [V, 3] from gX = dL/dX, the gradients of the bounds already added at the vertices the bounds came from."""
+    V = _prep_args(z1, dm, rank, bounds[:3], bounds[3:])
+    if gX.shape[0] != V or gX.device != z1.device or arg.dtype != torch.int64 or arg.numel() != 6 or not arg.is_contiguous():
+        raise SemigcnLibraryError("input_prep_bwd_routed: gX must have one row per vertex, arg six int64 values")
+    dz1 = torch.empty((V, 3), dtype=torch.float32, device=z1.device)
+    part = torch.empty((_sizes("sg_input_prep_blocks", V) + 2, 4), dtype=torch.float32, device=z1.device)
+    with _on_device(z1.device):
+        _check(load().sg_input_prep_bwd_routed(_ptr(gX), _rows2d(gX, "gX"), _ptr(z1), _ptr(dm), _ptr(rank), _ptr(bounds), _ptr(arg),
+                                               _ptr(dz1), _ptr(part), part.data_ptr() + 16 * (part.shape[0] - 2), V, dtype_code(gX),
+                                               _stream(z1)), "sg_input_prep_bwd_routed")
+    return dz1
+
+
 # ---- fused loss step ---------------------------------------------------------------------------
+def mesh_loss_finalize(partial: torch.Tensor, n_v: float, n_f: float, w_pos: float, k1: float) -> torch.Tensor:
+    """float32 [3] = (w_pos sqrt(S_p / n_v + 1e-6) + k1 S_n / n_f, d loss / d S_p, d loss / d S_n) from mesh_loss_fwd's partials."""
+    out = torch.empty((3,), dtype=torch.float32, device=partial.device)
+    with _on_device(partial.device):
+        _check(load().sg_mesh_loss_finalize(_ptr(partial), partial.shape[0], float(n_v), float(n_f), float(w_pos), float(k1), _ptr(out),
+                                            _stream(partial)), "sg_mesh_loss_finalize")
+    return out
+
+
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     _require_device(t, name)
     if t.dtype != torch.float32 or not t.is_contiguous():

@@ -600,6 +600,29 @@ SG_API int sg_input_prep_bwd(const void* gX, int64_t ldg, const float* z1, const
   return launch_input_prep_bwd(gX, ldg, z1, dm, rank, lo, hi, dz1, partial, d_lo, d_hi, V, dtype, (hipStream_t)stream);
 }
 
+SG_API int sg_input_bounds(const float* z1, int64_t V, float* partial_values, int64_t* partial_index, float* bounds, int64_t* arg,
+                           void* stream) {
+  SG_REQUIRE(V > 0 && z1 && partial_values && partial_index && bounds && arg, "sg_input_bounds: bad argument");
+  return launch_input_bounds(z1, V, partial_values, partial_index, bounds, arg, (hipStream_t)stream);
+}
+
+SG_API int sg_input_prep_bwd_routed(const void* gX, int64_t ldg, const float* z1, const float* dm, const int64_t* rank,
+                                    const float* bounds, const int64_t* arg, float* dz1, float* partial, float* d_bounds,
+                                    int64_t V, int dtype, void* stream) {
+  SG_REQUIRE(V > 0 && ldg >= 3 && gX && z1 && bounds && arg && dz1 && partial && d_bounds, "sg_input_prep_bwd_routed: bad argument");
+  SG_REQUIRE(dtype == SG_F32 || dtype == SG_BF16, "sg_input_prep_bwd_routed: unknown dtype %d", dtype);
+  int rc = launch_input_prep_bwd(gX, ldg, z1, dm, rank, bounds, bounds + 3, dz1, partial, d_bounds, d_bounds + 3, V, dtype,
+                                 (hipStream_t)stream);
+  if (rc != SG_OK) return rc;
+  return launch_bounds_route(d_bounds, d_bounds + 3, arg, dz1, (hipStream_t)stream);
+}
+
+SG_API int sg_mesh_loss_finalize(const float* partial, int64_t nb, float n_v, float n_f, float w_pos, float k1, float* out,
+                                 void* stream) {
+  SG_REQUIRE(nb > 0 && partial && out && n_v > 0.f && n_f >= 0.f, "sg_mesh_loss_finalize: bad argument");
+  return launch_mesh_loss_finalize(partial, nb, n_v, n_f, w_pos, k1, out, (hipStream_t)stream);
+}
+
 SG_API int sg_multi_add(int64_t n, const float* const* srcs, const int64_t* src_ld, const int64_t* rows, const int64_t* cols,
                         float* const* dsts, void* stream) {
   SG_REQUIRE(n >= 0 && n <= kMultiAddMax, "sg_multi_add: at most %d matrices per call", kMultiAddMax);

@@ -122,9 +122,92 @@ __global__ __launch_bounds__(256) void input_prep_bwd_finalize(const float* __re
   }
 }
 
+// ---- bounding box of z1 with the arg-extreme vertices (util/networks.py:67: torch.min / torch.max over dim 0) ----------------
+// Two launches instead of the transposed copy + four ATen reductions, and the vertex each bound came from is kept: the
+// backward pass routes the gradients of lo / hi to those vertices itself (what autograd does through torch.min / torch.max).
+// A tie goes to the lowest vertex id.
+struct Ext { float lo, hi; int64_t ilo, ihi; };
+__device__ __forceinline__ void ext_merge(Ext& a, const Ext& b) {
+  if (b.lo < a.lo || (b.lo == a.lo && b.ilo < a.ilo)) { a.lo = b.lo; a.ilo = b.ilo; }
+  if (b.hi > a.hi || (b.hi == a.hi && b.ihi < a.ihi)) { a.hi = b.hi; a.ihi = b.ihi; }
+}
+__device__ __forceinline__ Ext ext_shfl_down(const Ext& e, int off) {
+  Ext o;
+  o.lo = __shfl_down(e.lo, off, 64);
+  o.hi = __shfl_down(e.hi, off, 64);
+  o.ilo = __shfl_down((long long)e.ilo, off, 64);
+  o.ihi = __shfl_down((long long)e.ihi, off, 64);
+  return o;
+}
+// block sums of one stage: `n` candidates per column read through get(i, k); result by thread 0
+template <typename Get>
+__device__ __forceinline__ void ext_block(int64_t begin, int64_t end, Get get, float* vals /*[6]*/, int64_t* idx /*[6]*/, bool write) {
+  __shared__ Ext s_e[3][kBlock / 64];
+  constexpr int64_t kNone = INT64_MAX;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    Ext e{INFINITY, -INFINITY, kNone, kNone};
+    for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) ext_merge(e, get(i, k));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const Ext o = ext_shfl_down(e, off);
+      ext_merge(e, o);
+    }
+    if ((threadIdx.x & 63) == 0) s_e[k][threadIdx.x >> 6] = e;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && write) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      Ext e = s_e[k][0];
+      for (int w = 1; w < kBlock / 64; ++w) ext_merge(e, s_e[k][w]);
+      vals[k] = e.lo; vals[3 + k] = e.hi; idx[k] = e.ilo; idx[3 + k] = e.ihi;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void bounds_partial(const float* __restrict__ z1, int64_t V, float* __restrict__ pv,
+                                                         int64_t* __restrict__ pi) {
+  const int64_t v0 = (int64_t)blockIdx.x * kRowsPerBlock;
+  const int64_t v1 = v0 + kRowsPerBlock < V ? v0 + kRowsPerBlock : V;
+  ext_block(v0, v1, [&](int64_t v, int k) { const float x = z1[v * 3 + k]; return Ext{x, x, v, v}; },
+            pv + (int64_t)blockIdx.x * 6, pi + (int64_t)blockIdx.x * 6, true);
+}
+
+__global__ __launch_bounds__(kBlock) void bounds_finalize(const float* __restrict__ pv, const int64_t* __restrict__ pi, int64_t nb,
+                                                          float* __restrict__ bounds, int64_t* __restrict__ arg) {
+  ext_block(0, nb, [&](int64_t b, int k) { return Ext{pv[b * 6 + k], pv[b * 6 + 3 + k], pi[b * 6 + k], pi[b * 6 + 3 + k]}; },
+            bounds, arg, true);
+}
+
+// the gradients of the bounds go to the vertices the bounds came from (one thread: six adds)
+__global__ void bounds_route(const float* __restrict__ d_lo, const float* __restrict__ d_hi, const int64_t* __restrict__ arg,
+                             float* __restrict__ dz1) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    dz1[arg[k] * 3 + k] += d_lo[k];
+    dz1[arg[3 + k] * 3 + k] += d_hi[k];
+  }
+}
+
 }  // namespace
 
 int64_t input_prep_blocks(int64_t V) { return V <= 0 ? 0 : (V + kRowsPerBlock - 1) / kRowsPerBlock; }
+
+int launch_input_bounds(const float* z1, int64_t V, float* pv, int64_t* pi, float* bounds, int64_t* arg, hipStream_t stream) {
+  const int64_t nb = input_prep_blocks(V);
+  bounds_partial<<<(int)nb, kBlock, 0, stream>>>(z1, V, pv, pi);
+  SG_HIP_TRY(hipGetLastError());
+  bounds_finalize<<<1, kBlock, 0, stream>>>(pv, pi, nb, bounds, arg);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int launch_bounds_route(const float* d_lo, const float* d_hi, const int64_t* arg, float* dz1, hipStream_t stream) {
+  bounds_route<<<1, 1, 0, stream>>>(d_lo, d_hi, arg, dz1);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
 
 int launch_input_prep(const float* z1, const float* dm, const int64_t* order, const float* lo, const float* hi, void* X,
                       int64_t ldx, int64_t V, int dtype, hipStream_t stream) {

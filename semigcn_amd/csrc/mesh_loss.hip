@@ -148,7 +148,46 @@ __global__ __launch_bounds__(kBlock) void mesh_loss_bwd_vertex_add(const float* 
   grad[3 * i] += k * d.x; grad[3 * i + 1] += k * d.y; grad[3 * i + 2] += k * d.z;
 }
 
+// loss = w_pos sqrt(S_p / n_v + 1e-6) + k1 S_n / n_f from the block partials (sgcn.py:130-138 / mgcn.py:138-143 on the
+// sums of mesh_loss_fwd), with the two derivatives the backward kernels are scaled by: out = (loss, dloss/dS_p, dloss/dS_n).
+// One workgroup; the partials are added in double in a fixed order.
+__global__ __launch_bounds__(256) void mesh_loss_finalize(const float* __restrict__ partial, int64_t nb, float n_v, float n_f,
+                                                          float w_pos, float k1, float* __restrict__ out) {
+  __shared__ double s_w[2][4];
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t b = threadIdx.x; b < nb; b += 256) {
+    a0 += partial[b * 2];
+    a1 += partial[b * 2 + 1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_down(a0, off, 64);
+    a1 += __shfl_down(a1, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_w[0][threadIdx.x >> 6] = a0;
+    s_w[1][threadIdx.x >> 6] = a1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float sp = (float)((s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3]));
+    const float sn = (float)((s_w[1][0] + s_w[1][1]) + (s_w[1][2] + s_w[1][3]));
+    const float root = sqrtf(__fadd_rn(__fdiv_rn(sp, n_v), 1.0e-6f));
+    const float normal = n_f > 0.f ? __fmul_rn(k1, __fdiv_rn(sn, n_f)) : 0.f;
+    out[0] = __fadd_rn(__fmul_rn(w_pos, root), normal);
+    out[1] = w_pos * 0.5f / (root * n_v);
+    out[2] = n_f > 0.f ? k1 / n_f : 0.f;
+  }
+}
+
 }  // namespace
+
+int launch_mesh_loss_finalize(const float* partial, int64_t nb, float n_v, float n_f, float w_pos, float k1, float* out,
+                              hipStream_t stream) {
+  mesh_loss_finalize<<<1, 256, 0, stream>>>(partial, nb, n_v, n_f, w_pos, k1, out);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
 
 int launch_mesh_loss_bwd_corners(const float* pos, const int64_t* faces, const float* tfn, const float* fkeep, const float* g,
                                  int64_t F, float* corner, hipStream_t stream) {

@@ -204,6 +204,11 @@ int launch_input_prep_bwd(const void* gX, int64_t ldg, const float* z1, const fl
                           const float* hi, float* dz1, float* partial, float* d_lo, float* d_hi, int64_t V, int dtype,
                           hipStream_t stream);
 
+int launch_input_bounds(const float* z1, int64_t V, float* pv, int64_t* pi, float* bounds, int64_t* arg, hipStream_t stream);
+int launch_bounds_route(const float* d_lo, const float* d_hi, const int64_t* arg, float* dz1, hipStream_t stream);
+int launch_mesh_loss_finalize(const float* partial, int64_t nb, float n_v, float n_f, float w_pos, float k1, float* out,
+                              hipStream_t stream);
+
 // gemm_mfma.hip
 int gemm_tile_rows(int64_t N);      // rows per output tile (= rows per BatchNorm-moments record) for an N-column product
 int set_gemm_tuning(int value);

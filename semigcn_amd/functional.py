@@ -779,25 +779,37 @@ class _InputPrepFn(torch.autograd.Function):
     def forward(ctx, z1, lo, hi, dm, order, rank, dtype):
         z1c = z1.contiguous()
         dmc = None if dm is None else dm.reshape(-1).contiguous()
+        if lo is None:
+            # the bounds are z1's own (one device): two launches (sg_input_bounds), the vertices they came from kept for the
+            # backward pass, which routes the bounds' gradients there itself
+            bounds, arg = capi.input_bounds(z1c)
+            ctx.save_for_backward(z1c, bounds, arg)
+            ctx.dm, ctx.rank, ctx.routed = dmc, rank, True
+            return capi.input_prep(z1c, dmc, order, bounds[:3], bounds[3:], dtype)
         lo_c, hi_c = lo.reshape(-1).contiguous(), hi.reshape(-1).contiguous()
         ctx.save_for_backward(z1c, lo_c, hi_c)
-        ctx.dm, ctx.rank, ctx.lo_shape = dmc, rank, lo.shape
+        ctx.dm, ctx.rank, ctx.lo_shape, ctx.routed = dmc, rank, lo.shape, False
         return capi.input_prep(z1c, dmc, order, lo_c, hi_c, dtype)
 
     @staticmethod
     def backward(ctx, gX):
-        z1, lo, hi = ctx.saved_tensors
         if gX.stride(1) != 1:
             gX = gX.contiguous()
+        if ctx.routed:
+            z1, bounds, arg = ctx.saved_tensors
+            dz1 = capi.input_prep_bwd_routed(gX, z1, ctx.dm, ctx.rank, bounds, arg) if ctx.needs_input_grad[0] else None
+            return dz1, None, None, None, None, None, None
+        z1, lo, hi = ctx.saved_tensors
         dz1, d_lo, d_hi = capi.input_prep_bwd(gX, z1, ctx.dm, ctx.rank, lo, hi, need_dz1=ctx.needs_input_grad[0])
         return (dz1, d_lo.view(ctx.lo_shape) if ctx.needs_input_grad[1] else None,
                 d_hi.view(ctx.lo_shape) if ctx.needs_input_grad[2] else None, None, None, None, None)
 
 
-def input_prep(z1: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, dm: Optional[torch.Tensor],
+def input_prep(z1: torch.Tensor, lo: Optional[torch.Tensor], hi: Optional[torch.Tensor], dm: Optional[torch.Tensor],
                order: Optional[torch.Tensor], rank: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
     """The [V, 4] network input in processing order (``order`` / ``rank``: the inverse permutations, or None) and
-    feature dtype, from z1 [V, 3] fp32, the bounds ``lo`` / ``hi`` [1, 3] and the mask ``dm`` [V, 1] (or None)."""
+    feature dtype, from z1 [V, 3] fp32, the bounds ``lo`` / ``hi`` [1, 3] (None: z1's own column minima / maxima, taken by the
+    library) and the mask ``dm`` [V, 1] (or None)."""
     return _InputPrepFn.apply(z1, lo, hi, dm, order, rank, dtype)
 
 
@@ -862,6 +874,48 @@ class _MeshLossFn(torch.autograd.Function):
         else:
             grad = capi.mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, g.float().contiguous())
         return grad, None, None, None, None, None
+
+
+class _MeshLossScalarFn(torch.autograd.Function):
+    """``w_pos * sqrt(S_p / n_v + 1e-6) + k1 * S_n / n_f`` as ONE differentiable scalar (forward: the sums kernel + a one-block
+    finalize; backward: the finalize's two derivatives scaled by the incoming gradient feed the gradient kernels)."""
+
+    @staticmethod
+    def forward(ctx, pos, faces, target_pos, v_keep, target_fn, f_keep, n_v, n_f, w_pos, k1):
+        pos = pos.contiguous()
+        out = capi.mesh_loss_finalize(capi.mesh_loss_fwd(pos, faces, target_pos, v_keep, target_fn, f_keep), n_v, n_f, w_pos, k1)
+        ctx.save_for_backward(pos, faces, target_pos, v_keep, target_fn, f_keep, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, faces, target_pos, v_keep, target_fn, f_keep, out = ctx.saved_tensors
+        gs = out[1:] * g
+        if DETERMINISTIC_LOSS_BACKWARD and faces.shape[0] > 0:
+            grad = capi.mesh_loss_bwd_det(pos, faces, target_pos, v_keep, target_fn, f_keep, gs, _face_incidence(faces, pos.shape[0]))
+        else:      # (no faces: nothing is accumulated with atomics)
+            grad = capi.mesh_loss_bwd(pos, faces, target_pos, v_keep, target_fn, f_keep, gs)
+        return (grad,) + (None,) * 9
+
+
+_no_faces: dict = {}
+
+
+def mesh_loss(pos: torch.Tensor, faces: Optional[torch.Tensor], target_pos: torch.Tensor, v_keep: torch.Tensor,
+              target_fn: Optional[torch.Tensor], f_keep: Optional[torch.Tensor], n_v: float, n_f: float, w_pos: float = 1.0,
+              k1: float = 0.0) -> torch.Tensor:
+    """The loss of sgcn.py:130-138 -- ``mask_pos_rec_loss + k1 * mask_norm_rec_loss`` on the positions the network produced --
+    as one scalar; with ``faces=None`` one resolution's weighted position term of mgcn.py:138-143 (``w_pos`` = its weight)."""
+    if faces is None:
+        ent = _no_faces.get(pos.device)
+        if ent is None:
+            ent = _no_faces[pos.device] = (torch.zeros((0, 3), dtype=torch.int64, device=pos.device),
+                                           torch.zeros((0, 3), dtype=torch.float32, device=pos.device),
+                                           torch.zeros((0,), dtype=torch.float32, device=pos.device))
+        faces, target_fn, f_keep = ent
+        n_f, k1 = 0.0, 0.0
+    return _MeshLossScalarFn.apply(pos, faces, target_pos, v_keep.reshape(-1), target_fn, f_keep.reshape(-1), float(n_v), float(n_f),
+                                   float(w_pos), float(k1))
 
 
 def mesh_loss_sums(pos: torch.Tensor, faces: torch.Tensor, target_pos: torch.Tensor, v_keep: torch.Tensor,

@@ -329,19 +329,27 @@ class MGCN(nn.Module):
             mask = torch.from_numpy(dm).to(self.device)
         else:
             mask = torch.ones((z1.shape[0], 1), dtype=z1.dtype, device=self.device)
-        x = prepare_input(z1, mask.to(z1.dtype))
         heads = self.edge_inds
         part = getattr(self, "_part", None)
-        if part is not None:
-            # vertex-partitioned (dist.partition_mgcn): the input is the whole mesh (replicated, cheap: [V,4]);
-            # every level continues with this rank's rows only and the outputs are this rank's rows
-            x = x.index_select(0, part.own_ids[0])
-            heads = part.graphs
-        elif self._orders is not None:
-            x = x.index_select(0, self._orders[0][0])
-            heads = self._graphs
         fd = getattr(self, "feature_dtype", torch.float32)
-        x = x.to(fd)
+        fused_io = part is None and z1.is_cuda and z1.dtype == torch.float32 and mask.numel() == z1.shape[0]
+        if fused_io:
+            # one launch for the bounds' normalisation, the mask, the processing order and the feature dtype (as SingleScaleGCN)
+            order, rank = self._orders[0] if self._orders is not None else (None, None)
+            x = F_sg.input_prep(z1, None, None, mask.to(z1.dtype), order, rank, fd)
+            if self._orders is not None:
+                heads = self._graphs
+        else:
+            x = prepare_input(z1, mask.to(z1.dtype))
+            if part is not None:
+                # vertex-partitioned (dist.partition_mgcn): the input is the whole mesh (replicated, cheap: [V,4]);
+                # every level continues with this rank's rows only and the outputs are this rank's rows
+                x = x.index_select(0, part.own_ids[0])
+                heads = part.graphs
+            elif self._orders is not None:
+                x = x.index_select(0, self._orders[0][0])
+                heads = self._graphs
+            x = x.to(fd)
 
         res1_enc = self.encoder1(x)
         res2_enc = self.encoder2(res1_enc)
@@ -362,9 +370,11 @@ class MGCN(nn.Module):
         outs = [out0, out1, out2, out3]
         if part is not None:
             return tuple(s_own + o for s_own, o in zip(part.smposs_own, outs))
-        if self._orders is not None:
-            outs = [o.index_select(0, rank) for o, (_, rank) in zip(outs, self._orders)]
         s = self.smposs_list
+        if self._orders is not None:
+            if fused_io:      # base + rows back in caller order, one autograd node each (its backward is a gather, no atomics)
+                return tuple(F_sg.output_in_caller_order(o, sm, rank, order) for o, sm, (order, rank) in zip(outs, s, self._orders))
+            outs = [o.index_select(0, rank) for o, (_, rank) in zip(outs, self._orders)]
         return (s[0] + outs[0], s[1] + outs[1], s[2] + outs[2], s[3] + outs[3])
 
     # helpers the reference exposes (util/meshnet.py:320-341)

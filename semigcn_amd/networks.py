@@ -172,9 +172,7 @@ class SingleScaleGCN(nn.Module):
         if z1.is_cuda and z1.dtype == torch.float32 and mask.dtype == torch.float32 and mask.numel() == z1.shape[0]:
             # one launch: normalise, mask, append the mask, rows into processing order, feature dtype (csrc/input_prep.hip)
             from .functional import input_prep
-            if lo is None:
-                lo, hi = _column_min_max(z1)
-            x = input_prep(z1, lo, hi, mask, order, rank, self.feature_dtype)
+            x = input_prep(z1, lo, hi, mask, order, rank, self.feature_dtype)    # (lo is None: the library takes the bounds too)
         else:
             x = prepare_input(z1, mask, lo, hi)
             if order is not None:

@@ -501,10 +501,9 @@ class SGCNTrainer(_Epochs):
 
     def loss(self, pos: torch.Tensor) -> torch.Tensor:
         b = self.mesh
-        if pos.is_cuda and pos.dtype == torch.float32:     # fused HIP kernels (csrc/mesh_loss.hip)
-            from .functional import mesh_loss_sums
-            s = mesh_loss_sums(pos, b.faces, b.target_pos, b.v_keep, b.target_fn, b.f_keep)
-            loss = torch.sqrt(s[0] / b.n_v_keep + 1.0e-6) + self.k1 * (s[1] / b.n_f_keep)
+        if pos.is_cuda and pos.dtype == torch.float32:     # fused HIP kernels (csrc/mesh_loss.hip): one scalar
+            from .functional import mesh_loss
+            loss = mesh_loss(pos, b.faces, b.target_pos, b.v_keep, b.target_fn, b.f_keep, b.n_v_keep, b.n_f_keep, 1.0, self.k1)
             if self.k2 > 0:
                 loss = loss + self.k2 * bilateral_normal_loss(pos, face_normals(pos, b.faces), b.faces, b.f2f)[0]
             return loss
@@ -570,17 +569,17 @@ class MGCNTrainer(_Epochs):
         poss = self.model(self._data, dm)
         if poss[0].is_cuda and poss[0].dtype == torch.float32:
             # finest level: position and normal terms from the fused HIP kernels (csrc/mesh_loss.hip), as in SGCNTrainer
-            from .functional import mesh_loss_sums
-            s0 = mesh_loss_sums(poss[0], b.faces, self.model.poss_list[0], self.keeps[0], b.target_fn, b.f_keep)
-            loss = self.weights[0] * torch.sqrt(s0[0] / self.counts[0] + 1.0e-6) + self.k1 * (s0[1] / b.n_f_keep)
+            from .functional import mesh_loss
+            loss = mesh_loss(poss[0], b.faces, self.model.poss_list[0], self.keeps[0], b.target_fn, b.f_keep, self.counts[0],
+                             b.n_f_keep, self.weights[0], self.k1)
             fn = None
-            coarse = list(zip(self.weights, poss, self.model.poss_list, self.keeps, self.counts))[1:]
+            for w, p, t, keep, n in list(zip(self.weights, poss, self.model.poss_list, self.keeps, self.counts))[1:]:
+                loss = loss + mesh_loss(p, None, t, keep, None, None, n, 0.0, w)     # the coarser resolutions: position term only
         else:
             fn = face_normals(poss[0], b.faces)
             loss = self.k1 * masked_normal_l1(fn, b.target_fn, b.f_keep, b.n_f_keep)
-            coarse = list(zip(self.weights, poss, self.model.poss_list, self.keeps, self.counts))
-        for w, p, t, keep, n in coarse:
-            loss = loss + w * masked_position_rmse(p, t, keep, n)
+            for w, p, t, keep, n in zip(self.weights, poss, self.model.poss_list, self.keeps, self.counts):
+                loss = loss + w * masked_position_rmse(p, t, keep, n)
         if self.k2 > 0:
             fn = face_normals(poss[0], b.faces) if fn is None else fn
             loss = loss + self.k2 * bilateral_normal_loss(poss[0], fn, b.faces, b.f2f)[0]
