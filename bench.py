@@ -579,7 +579,22 @@ def free_port() -> int:
         return sk.getsockname()[1]
 
 
-ATTEMPT_TIMEOUT_S = float(os.environ.get("SEMIGCN_BENCH_ATTEMPT_TIMEOUT", "300"))
+def attempt_timeout_s(mesh: str) -> float:
+    """Wall-clock limit of ONE attempt of an N-rank job, from its mesh size.  Measured with eight ranks sharing one GPU and one
+    host (profiles/r04_shared_gpu_ranks.jsonl: every worker generates the mesh and its partition plan on the host, all at
+    once): 2000 x 2000 (c5, V = 4 M) reaches its first warm-up iteration after 50 s and finishes after 57 s; 1000 x 1000 after
+    7 s / 14 s.  The limit is ~5 x that: 120 s + 45 s per million vertices (c5: 300 s, the 1 M mesh: 165 s)."""
+    env = os.environ.get("SEMIGCN_BENCH_ATTEMPT_TIMEOUT")
+    if env:
+        return float(env)
+    try:
+        nu, nv = map(int, mesh.split("x"))
+    except ValueError:
+        return 300.0
+    return 120.0 + 45.0 * (nu * nv / 1.0e6)
+
+
+ATTEMPT_TIMEOUT_S = 300.0          # set from the mesh in main() / spawn_ranks() (attempt_timeout_s)
 
 
 def spawn_ranks(args) -> int:
@@ -591,6 +606,8 @@ def spawn_ranks(args) -> int:
     reason reported."""
     import signal
     import subprocess
+    global ATTEMPT_TIMEOUT_S
+    ATTEMPT_TIMEOUT_S = attempt_timeout_s(args.mesh)
     shared = os.environ.get("SEMIGCN_BENCH_SHARE_GPU") == "1"
     n_dev = torch.cuda.device_count()
     if n_dev < args.gpus and not shared:
@@ -643,6 +660,8 @@ def supervise_rank(args) -> int:
     import glob
     import subprocess
     import tempfile
+    global ATTEMPT_TIMEOUT_S
+    ATTEMPT_TIMEOUT_S = attempt_timeout_s(args.mesh)
     rank = int(os.environ.get("RANK", "0"))
     port = os.environ.get("MASTER_PORT", "0")
     mark = os.path.join(tempfile.gettempdir(), f"semigcn_bench_{os.getuid()}_{port}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}")

@@ -218,13 +218,16 @@ SG_API int sg_gather_rows(const int32_t* rows, int64_t n, const void* X, int64_t
  * local sums, out[0..1]) and, after the all-reduce of those sums, once more with them as a single block (nb = 1) for
  * c1, c2 and k of the whole mesh.
  * ------------------------------------------------------------------------- */
-/* Products with a tiny weight matrix (1 <= N, K <= 16) -- replace the `lins[k]` calls of the 4 -> 16 input layer ([3P]
+/* Products with a tiny weight matrix (sg_thin_supported(N, K): K <= 8 with N <= 32, or N, K <= 16, or K <= 32 with N <= 8 -- at
+ * most 256 entries) -- replace the `lins[k]` calls of the 4 -> 16 input layer ([3P]
  * ChebConv.forward from util/networks.py:42: K = 3 x 4 = 12 columns, no multiple of an MFMA step), `nn.Linear(16, 3)`
- * (util/networks.py:36,55) and their autograd products, the last ones of the iteration on the BLAS library:
+ * (util/networks.py:36,55), the `nn.Linear(32, 3)` heads of the MGCN (util/meshnet.py:228,236,244) and their autograd products,
+ * the last ones of the iteration on the BLAS library:
  *   sg_thin_nt:  Y[V, N] = X[V, K] * W[N, K]^T (+ bias)   X, Y float32 or bfloat16 (dtype, same for both; row strides in
  *                elements), W [N, K] (row stride ldw) and bias float32; fp32 accumulation in ascending k, bias added last.
  *   sg_thin_tn:  out[N, K] (float32, row stride ldo) = A[V, N]^T * B[V, K], A / B float32 or bfloat16; workspace: float32
  *                [sg_thin_tn_blocks(V)][256] per-block partial sums, added in block order: deterministic. */
+SG_API int sg_thin_supported(int64_t N, int64_t K);
 SG_API int64_t sg_thin_tn_blocks(int64_t V);
 SG_API int sg_thin_nt(const void* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, void* Y, int64_t ldy,
                       int64_t V, int64_t N, int64_t K, int dtype, void* stream);

@@ -96,6 +96,7 @@ _SIGNATURES = {
     "sg_gemm_tn_takes_big_tile": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
     "sg_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
                            c_void_p]),
+    "sg_thin_supported": (c_int, [c_int64, c_int64]),
     "sg_thin_tn_blocks": (c_int64, [c_int64]),
     "sg_thin_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,
                            c_void_p]),
@@ -685,13 +686,18 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return (out, mom) if moments else out
 
 
-THIN_MAX = 16      # sg_thin_nt / sg_thin_tn: weight matrices of at most 16 x 16
+THIN_ELEMS = 256      # sg_thin_nt / sg_thin_tn: weight matrices of at most 256 entries (see thin_shape)
+
+
+def thin_shape(N: int, K: int) -> bool:
+    """sg_thin_supported: K <= 8 with N <= 32, or N, K <= 16, or K <= 32 with N <= 8."""
+    return bool(_sizes("sg_thin_supported", int(N), int(K)))
 
 
 def thin_supported(A: torch.Tensor, N: int, K: int) -> bool:
-    """Shapes the thin products take: a device tensor [V, *] with unit column stride, fp32 or bf16, 1 <= N, K <= 16."""
+    """Shapes the thin products take: a device tensor [V, *] with unit column stride, fp32 or bf16, a thin weight shape."""
     return (A.is_cuda and A.dim() == 2 and A.stride(1) == 1 and A.dtype in (torch.float32, torch.bfloat16)
-            and 1 <= N <= THIN_MAX and 1 <= K <= THIN_MAX and A.shape[0] > 0)
+            and N >= 1 and K >= 1 and thin_shape(N, K) and A.shape[0] > 0)
 
 
 def thin_nt(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -723,7 +729,7 @@ def thin_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     if B.shape[0] != V or A.dtype != B.dtype or A.stride(1) != 1 or B.stride(1) != 1:
         raise SemigcnLibraryError(f"thin_tn shape mismatch: A {tuple(A.shape)} B {tuple(B.shape)}")
     out = torch.empty((N, K), dtype=torch.float32, device=A.device)
-    ws = torch.empty((_sizes("sg_thin_tn_blocks", V), THIN_MAX * THIN_MAX), dtype=torch.float32, device=A.device)
+    ws = torch.empty((_sizes("sg_thin_tn_blocks", V), THIN_ELEMS), dtype=torch.float32, device=A.device)
     with _on_device(A.device):
         _check(load().sg_thin_tn(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), V, N, K, dtype_code(A), _ptr(ws), _ptr(out),
                                  K, _stream(A)), "sg_thin_tn")

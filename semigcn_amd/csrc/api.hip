@@ -560,9 +560,11 @@ SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, in
 
 SG_API int64_t sg_thin_tn_blocks(int64_t V) { return thin_tn_blocks(V); }
 
+SG_API int sg_thin_supported(int64_t N, int64_t K) { return thin_shape(N, K) ? 1 : 0; }
+
 SG_API int sg_thin_nt(const void* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, void* Y, int64_t ldy,
                       int64_t V, int64_t N, int64_t K, int dtype, void* stream) {
-  SG_REQUIRE(V >= 0 && thin_shape(N, K), "sg_thin_nt: needs 1 <= N, K <= 16 (N=%lld K=%lld)", (long long)N, (long long)K);
+  SG_REQUIRE(V >= 0 && thin_shape(N, K), "sg_thin_nt: N x K is not a thin shape, see sg_thin_supported (N=%lld K=%lld)", (long long)N, (long long)K);
   SG_REQUIRE(V == 0 || (X && W && Y && ldx >= K && ldw >= K && ldy >= N), "sg_thin_nt: null operand or short row stride");
   SG_REQUIRE(X != Y, "sg_thin_nt: Y must not alias X");
   return launch_thin_nt(X, ldx, W, ldw, bias, Y, ldy, V, N, K, dtype, (hipStream_t)stream);
@@ -570,7 +572,7 @@ SG_API int sg_thin_nt(const void* X, int64_t ldx, const float* W, int64_t ldw, c
 
 SG_API int sg_thin_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t V, int64_t N, int64_t K, int dtype,
                       float* workspace, float* out, int64_t ldo, void* stream) {
-  SG_REQUIRE(V >= 0 && thin_shape(N, K), "sg_thin_tn: needs 1 <= N, K <= 16 (N=%lld K=%lld)", (long long)N, (long long)K);
+  SG_REQUIRE(V >= 0 && thin_shape(N, K), "sg_thin_tn: N x K is not a thin shape, see sg_thin_supported (N=%lld K=%lld)", (long long)N, (long long)K);
   SG_REQUIRE(out != nullptr && ldo >= K && workspace != nullptr, "sg_thin_tn: bad output or workspace");
   SG_REQUIRE(V == 0 || (A && B && lda >= N && ldb >= K), "sg_thin_tn: null operand or short row stride");
   return launch_thin_tn(A, lda, B, ldb, V, N, K, dtype, workspace, out, ldo, (hipStream_t)stream);

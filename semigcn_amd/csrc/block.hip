@@ -324,8 +324,16 @@ int backward(const sg_block& b, hipStream_t stream) {
   if (rc != SG_OK) return rc;
   // d bias = column sums of the conv output's gradient; through a pool they equal the column sums of dH (every cluster's
   // members share its gradient / count, an unpooled row's gradient goes to one parent)
-  rc = launch_colsum_finalize(w.colsum, col_apply_blocks(s.Vo, s.Co, b.dtype), s.Co, db, stream);
+  rc = launch_colsum_finalize(w.colsum, col_apply_blocks(s.Vo, s.Co, b.dtype), s.Co, db, stream, b.acc_bias);
   if (rc != SG_OK) return rc;
+  GradSink sink;                         // the K weight .grad accumulators: += in the kernel that finishes the reduction
+  if (sink_w) {
+    for (int k = 0; k < b.K; ++k) sink.dst[k] = b.acc_W[k];
+    sink.mode = b.order == 0 ? 1 : 2;
+    sink.Cin = (int)s.Ci;
+    sink.Cout = (int)s.Co;
+  }
+  bool sunk = false;
   void* dHc = dHp;          // gradient of the conv output [V, Cout]
   int64_t lddc = lddh;
   if (b.pool_mode) {
@@ -339,7 +347,8 @@ int backward(const sg_block& b, hipStream_t stream) {
 
   if (b.order == 0) {
     SG_REQUIRE(b.T && b.ldt >= s.KCi, "sg_block_backward: order 0 needs the saved [V, K*Cin] buffer T");
-    rc = dense_tn(dHc, lddc, b.T, b.ldt, s.V, s.Co, s.KCi, b.dtype, w.tn, b.dW, s.KCi, w.blas, kBlasWorkspace, stream);
+    rc = dense_tn(dHc, lddc, b.T, b.ldt, s.V, s.Co, s.KCi, b.dtype, w.tn, b.dW, s.KCi, w.blas, kBlasWorkspace, stream,
+                  sink_w ? &sink : nullptr, &sunk);
     if (rc != SG_OK) return rc;
     if (b.need_dx) {
       // dT = dH Wcat: block k = dL/dTx_k before the recurrence is unwound
@@ -373,25 +382,21 @@ int backward(const sg_block& b, hipStream_t stream) {
                     kBlasWorkspace, stream);
       if (rc != SG_OK) return rc;
     }
-    rc = dense_tn(w.G, s.KCo, b.X, b.ldx, s.V, s.KCo, s.Ci, b.dtype, w.tn, b.dW, s.Ci, w.blas, kBlasWorkspace, stream);
+    rc = dense_tn(w.G, s.KCo, b.X, b.ldx, s.V, s.KCo, s.Ci, b.dtype, w.tn, b.dW, s.Ci, w.blas, kBlasWorkspace, stream,
+                  sink_w ? &sink : nullptr, &sunk);
     if (rc != SG_OK) return rc;
   }
 
-  if (sink_w || b.acc_bias) {      // += into the parameters' .grad accumulators, one launch
-    const float* srcs[4];
-    float* dsts[4];
-    int64_t ld[4], rows[4], cols[4];
-    int n = 0;
-    if (b.acc_bias) {
-      srcs[n] = db; dsts[n] = b.acc_bias; ld[n] = s.Co; rows[n] = 1; cols[n] = s.Co; ++n;
+  if (sink_w && !sunk) {      // (an engine without the accumulating epilogue ran -- a single BLAS product: one add launch)
+    const float* srcs[3];
+    float* dsts[3];
+    int64_t ld[3], rows[3], cols[3];
+    for (int k = 0; k < b.K; ++k) {
+      srcs[k] = b.order == 0 ? b.dW + k * s.Ci : b.dW + k * s.Co * s.Ci;
+      ld[k] = b.order == 0 ? s.KCi : s.Ci;
+      dsts[k] = b.acc_W[k]; rows[k] = s.Co; cols[k] = s.Ci;
     }
-    if (sink_w)
-      for (int k = 0; k < b.K; ++k) {
-        srcs[n] = b.order == 0 ? b.dW + k * s.Ci : b.dW + k * s.Co * s.Ci;
-        ld[n] = b.order == 0 ? s.KCi : s.Ci;
-        dsts[n] = b.acc_W[k]; rows[n] = s.Co; cols[n] = s.Ci; ++n;
-      }
-    rc = launch_multi_add(n, srcs, ld, rows, cols, dsts, stream);
+    rc = launch_multi_add(b.K, srcs, ld, rows, cols, dsts, stream);
     if (rc != SG_OK) return rc;
   }
   return SG_OK;

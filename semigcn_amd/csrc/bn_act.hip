@@ -362,13 +362,16 @@ __device__ inline double block_sum_256(double v, double* s_w /*[4]*/) {
 
 // out[c] = sum over the nb workgroup partials of col_apply_rows<.., COLSUM>; one workgroup per channel
 __global__ __launch_bounds__(256) void colsum_finalize(const float* __restrict__ partial, int64_t nb, int C,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, float* __restrict__ acc) {
   __shared__ double s_w[4];
   const int c = blockIdx.x;
   double s0 = 0.0;
   for (int64_t b = threadIdx.x; b < nb; b += 256) s0 += partial[b * C + c];
   s0 = block_sum_256(s0, s_w);
-  if (threadIdx.x == 0) out[c] = (float)s0;
+  if (threadIdx.x == 0) {
+    out[c] = (float)s0;
+    if (acc) acc[c] += (float)s0;       // (the conv bias' .grad accumulator: no add launch of its own)
+  }
 }
 
 // stats[0][c] = mean, stats[1][c] = M2 over all V rows, from the per-block partials (Chan et al.,
@@ -740,9 +743,9 @@ int64_t col_apply_blocks(int64_t V, int64_t C, int dtype) {
   return nbr < 1 ? 1 : nbr;
 }
 
-int launch_colsum_finalize(const float* partial, int64_t nb, int64_t C, float* out, hipStream_t stream) {
+int launch_colsum_finalize(const float* partial, int64_t nb, int64_t C, float* out, hipStream_t stream, float* acc) {
   if (C == 0) return SG_OK;
-  colsum_finalize<<<(int)C, 256, 0, stream>>>(partial, nb, (int)C, out);
+  colsum_finalize<<<(int)C, 256, 0, stream>>>(partial, nb, (int)C, out, acc);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

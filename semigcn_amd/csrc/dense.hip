@@ -191,12 +191,13 @@ constexpr int64_t kMfmaMaxWeightElems = 100000;
 
 // sum of n_slabs [N, Kp] slab partials (contiguous, slab stride N * Kp) in slab order -> out (row stride ldo); any shape
 __global__ __launch_bounds__(256) void slab_sum(const float* __restrict__ W, int n_slabs, int64_t elems, int Kp,
-                                                float* __restrict__ out, int64_t ldo) {
+                                                float* __restrict__ out, int64_t ldo, const GradSink sink) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= elems) return;
   float acc = 0.f;
   for (int t = 0; t < n_slabs; ++t) acc += W[(int64_t)t * elems + e];
   out[(e / Kp) * ldo + e % Kp] = acc;
+  if (sink.mode) *sink_ptr(sink, e / Kp, e % Kp) += acc;
 }
 
 }  // namespace
@@ -264,17 +265,21 @@ int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void
 }
 
 int dense_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype, float* ws,
-             float* out, int64_t ldo, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream) {
+             float* out, int64_t ldo, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream, const GradSink* sink, bool* sunk) {
   // out[N, Kp] (float32) = A[M, N]^T B[M, Kp]
+  if (sunk) *sunk = false;
   if (N == 0 || Kp == 0) return SG_OK;
   SG_REQUIRE(M > 0, "dense_tn: no rows");
   if (thin_shape(N, Kp)) {
     TraceScope ts(2, dtype, 2, M, N, Kp, stream);
-    return launch_thin_tn(A, lda, B, ldb, M, N, Kp, dtype, ws, out, ldo, stream);
+    if (sunk) *sunk = sink != nullptr;
+    return launch_thin_tn(A, lda, B, ldb, M, N, Kp, dtype, ws, out, ldo, stream, sink);
   }
   if (dense_tn_own(dtype, M, N, Kp, lda, ldb) && a16(A) && a16(B) && a16(out) && ldo % 4 == 0) {
     TraceScope ts(2, dtype, 1, M, N, Kp, stream);
-    return launch_gemm_tn(A, lda, B, ldb, M, N, Kp, dtype, ws, out, ldo, stream);
+    const bool can = sink != nullptr && sink->Cin % 4 == 0;
+    if (sunk) *sunk = can;
+    return launch_gemm_tn(A, lda, B, ldb, M, N, Kp, dtype, ws, out, ldo, stream, can ? sink : nullptr);
   }
   TraceScope ts(2, dtype, 3, M, N, Kp, stream);
   const int64_t S = blas_tn_slabs(dtype, M);
@@ -292,7 +297,8 @@ int dense_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, 
     if (rc != SG_OK) return rc;
     ++n_slabs;
   }
-  slab_sum<<<(int)((elems + 255) / 256), 256, 0, stream>>>(ws, n_slabs, elems, (int)Kp, out, ldo);
+  slab_sum<<<(int)((elems + 255) / 256), 256, 0, stream>>>(ws, n_slabs, elems, (int)Kp, out, ldo, sink ? *sink : GradSink{});
+  if (sunk) *sunk = sink != nullptr;
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

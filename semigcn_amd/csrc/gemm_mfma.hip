@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_tn_bf16(const TnArgs g) {
 // (thread y adds slabs y, y + 16, ..), then the 16 group sums in order -- a fixed summation tree, so the result is
 // deterministic, and a small output with ~500 slabs is not one thread walking 500 dependent loads.
 __global__ __launch_bounds__(1024) void tn_reduce(const float* __restrict__ W, int n_slabs, int64_t elems, int Kp,
-                                                  float* __restrict__ out, int64_t ldo) {
+                                                  float* __restrict__ out, int64_t ldo, const GradSink sink) {
   __shared__ f32x4 s_part[16][64];
   const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
   const int64_t e = ((int64_t)blockIdx.x * 64 + x) * 4;      // Kp % 8 == 0: a float4 stays inside one row
@@ -510,6 +510,11 @@ __global__ __launch_bounds__(1024) void tn_reduce(const float* __restrict__ W, i
     for (int k = 1; k < 16; ++k) acc += s_part[k][x];
     const int64_t n = e / Kp, kk = e - n * Kp;
     *(f32x4*)(out + n * ldo + kk) = acc;
+    if (sink.mode) {                                          // Cin % 4 == 0: the four values lie in one accumulator row
+      float* const d = sink_ptr(sink, n, kk);                 // (scalar: a .grad view of a flat buffer is only 4-byte aligned)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] += acc[q];
+    }
   }
 }
 
@@ -537,7 +542,9 @@ int64_t gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
 }
 
 int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
-                   float* workspace, float* out, int64_t ldo, hipStream_t stream) {
+                   float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink_) {
+  const GradSink sink = sink_ ? *sink_ : GradSink{};
+  SG_REQUIRE(sink.mode == 0 || sink.Cin % 4 == 0, "sg_gemm_tn: a gradient sink needs Cin to be a multiple of 4");
   if (dtype != SG_BF16) {
     set_error("sg_gemm_tn: bf16 operands only (dtype %d)", dtype);
     return SG_ERR_UNSUPPORTED;
@@ -567,7 +574,7 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
       SG_HIP_TRY(hipGetLastError());
       ++slabs;
     }
-    tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo);
+    tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo, sink);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
   }
@@ -586,7 +593,7 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
   gemm_tn_bf16<<<g.n_blocks, kThreads, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   const int64_t elems = N * Kp;
-  tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo);
+  tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo, sink);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

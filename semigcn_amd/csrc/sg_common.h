@@ -95,13 +95,28 @@ static_assert(kRecW + 4 * kRingSlots <= kRecBytes && kRecSd % 16 == 0, "tile rec
 int build_tiles(Csr* c, hipStream_t stream);
 // Fills Csr::idx_w (and tile_uniq_w when the CSR carries tiles) for the source scale vector `scale` [n_cols].
 int pack_source_scale(Csr* c, const float* scale, hipStream_t stream);
+// Where a weight gradient goes besides its own [N, Kp] buffer: the K per-matrix .grad accumulators of a ChebConv
+// ([Cout, Cin] each, contiguous), += in the kernel that finishes the reduction over the vertices -- no separate add launch.
+// mode 1: the gradient is dWcat [Cout, K*Cin] (column block k -> dst[k]); mode 2: dWstack [K*Cout, Cin] (row block k -> dst[k]).
+struct GradSink {
+  float* dst[3] = {nullptr, nullptr, nullptr};
+  int mode = 0, Cin = 0, Cout = 0;
+};
+__device__ __forceinline__ float* sink_ptr(const GradSink& s, int64_t n, int64_t kk) {
+  if (s.mode == 1) {
+    const int64_t k = kk / s.Cin;
+    return s.dst[k] + n * s.Cin + (kk - k * s.Cin);
+  }
+  const int64_t k = n / s.Cout;
+  return s.dst[k] + (n - k * s.Cout) * s.Cin + kk;
+}
 // Products with a tiny weight matrix (thin_gemm.hip)
 bool thin_shape(int64_t N, int64_t K);
 int64_t thin_tn_blocks(int64_t V);
 int launch_thin_nt(const void* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t V,
                    int64_t N, int64_t K, int dtype, hipStream_t stream);
 int launch_thin_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t V, int64_t N, int64_t K, int dtype,
-                   float* workspace, float* out, int64_t ldo, hipStream_t stream);
+                   float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink = nullptr);
 // Tile records for spmm_ring (when enabled): rows scaled by scale_dst (nullable), sources by scale_src, output rows row_id (nullable).
 int build_ring_records(Csr* c, const float* scale_src, const float* scale_dst, const int32_t* row_id, hipStream_t stream);
 bool ring_enabled();
@@ -187,7 +202,7 @@ int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_
                      const float* c2, float slope, void* Y, int64_t ldy, int64_t V, int64_t C, int dtype,
                      hipStream_t stream, float* colsum = nullptr);
 int64_t col_apply_blocks(int64_t V, int64_t C, int dtype);
-int launch_colsum_finalize(const float* partial, int64_t nb, int64_t C, float* out, hipStream_t stream);
+int launch_colsum_finalize(const float* partial, int64_t nb, int64_t C, float* out, hipStream_t stream, float* acc = nullptr);
 
 int launch_bn_stats_finalize_tiles(const float* partial, int64_t nb, int64_t rpb, int64_t V, int64_t C, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
@@ -227,7 +242,7 @@ int launch_gemm_tn_256(const void* A, int64_t lda, const void* B, int64_t ldb, i
 bool gemm_tn_takes_big_tile(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 int64_t gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp);
 int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
-                   float* workspace, float* out, int64_t ldo, hipStream_t stream);
+                   float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink = nullptr);
 
 // mesh_loss.hip
 int64_t mesh_loss_blocks(int64_t V, int64_t F);
@@ -277,8 +292,10 @@ int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64
 int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void* Bt, int64_t ldbt, const float* Bt32, void* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream);
 // out[N, Kp] (float32) = A[M, N]^T B[M, Kp]; ws: dense_tn_workspace() floats
+// sink (nullable): also += the result into the K weight accumulators; *sunk tells whether the engine that ran could do it
 int dense_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype, float* ws,
-             float* out, int64_t ldo, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream);
+             float* out, int64_t ldo, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream, const GradSink* sink = nullptr,
+             bool* sunk = nullptr);
 
 }  // namespace sg
 

@@ -1,4 +1,5 @@
-// Dense products with a tiny weight matrix (K, N <= 16): the 4 -> 16 input layer of the SGCN (`lins[k]` on the 12-wide
+// Dense products with a tiny weight matrix (N x K <= 256 entries: K <= 8 with N <= 32, K, N <= 16, or K <= 32 with N <= 8 --
+// the last two shapes are the 32 -> 3 heads of the MGCN, util/meshnet.py:228,236,244, and their gradients): the 4 -> 16 input layer of the SGCN (`lins[k]` on the 12-wide
 // [Tx0|Tx1|Tx2] of 4-channel features, util/networks.py:42 via [3P] ChebConv.forward), its input and weight gradients,
 // and the 16 -> 3 output layer (`nn.Linear(16, 3)`, util/networks.py:36,55) with its autograd.  K = 12 is no multiple of
 // the 16- / 32-deep MFMA steps and the work is a few FLOPs per byte: one thread per row, the weights in LDS, fp32
@@ -12,8 +13,10 @@
 namespace sg {
 namespace {
 
-constexpr int kThinMax = 16;
+constexpr int kThinMax = 32;           // largest N or K
+constexpr int kThinElems = 256;        // N x (K rounded up to 8 / 16 / 32) <= this: one thread per entry of the weight gradient
 constexpr int kThinBlock = 256;
+__host__ __device__ inline int thin_pitch(int K) { return K <= 8 ? 8 : (K <= 16 ? 16 : 32); }
 
 template <typename T> __device__ __forceinline__ float thin_load(const T* p);
 template <> __device__ __forceinline__ float thin_load<float>(const float* p) { return *p; }
@@ -65,26 +68,28 @@ template <typename T>
 __global__ __launch_bounds__(kThinBlock) void thin_nt(const T* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw,
                                                       const float* __restrict__ bias, T* __restrict__ Y, int64_t ldy, int64_t V,
                                                       int N, int K) {
-  __shared__ float s_w[kThinMax * kThinMax];
+  __shared__ float s_w[kThinElems];
   __shared__ float s_b[kThinMax];
-  __shared__ float s_x[kThinBlock * (kThinMax + 1)];
-  __shared__ float s_y[kThinBlock * (kThinMax + 1)];
+  __shared__ float s_io[kThinBlock * (kThinMax + 1 + 8 + 1)];      // x rows (pitch K + 1) | y rows (pitch N + 1): N, K not both > 16
+  const int px = K + 1, py = N + 1;
+  float* const s_x = s_io;
+  float* const s_y = s_io + kThinBlock * px;
   for (int i = threadIdx.x; i < N * K; i += kThinBlock) s_w[i] = W[(int64_t)(i / K) * ldw + i % K];
   if (threadIdx.x < N) s_b[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
   const int64_t row0 = (int64_t)blockIdx.x * kThinBlock;
   const int rows = (int)(V - row0 < kThinBlock ? V - row0 : kThinBlock);
-  thin_stage_rows<T>(X + row0 * ldx, ldx, rows, K, s_x, kThinMax + 1);
+  thin_stage_rows<T>(X + row0 * ldx, ldx, rows, K, s_x, px);
   __syncthreads();
   if ((int)threadIdx.x < rows) {
     float x[kThinMax];
 #pragma unroll
-    for (int k = 0; k < kThinMax; ++k) x[k] = k < K ? s_x[threadIdx.x * (kThinMax + 1) + k] : 0.f;
+    for (int k = 0; k < kThinMax; ++k) x[k] = k < K ? s_x[threadIdx.x * px + k] : 0.f;
     for (int n = 0; n < N; ++n) {
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < kThinMax; ++k)
         if (k < K) acc = fmaf(x[k], s_w[n * K + k], acc);
-      s_y[threadIdx.x * (kThinMax + 1) + n] = acc + s_b[n];
+      s_y[threadIdx.x * py + n] = acc + s_b[n];
     }
   }
   __syncthreads();
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(kThinBlock) void thin_nt(const T* __restrict__ X, i
     const int per_row = N / V8;
     for (int i = threadIdx.x; i < rows * per_row; i += kThinBlock) {
       const int r = i / per_row, c = (i - r * per_row) * V8;
-      const float* q = s_y + r * (kThinMax + 1) + c;
+      const float* q = s_y + r * py + c;
       if constexpr (sizeof(T) == 4) {
         *(float2*)(Y0 + (int64_t)r * ldy + c) = make_float2(q[0], q[1]);
       } else {
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(kThinBlock) void thin_nt(const T* __restrict__ X, i
   } else {
     for (int i = threadIdx.x; i < rows * N; i += kThinBlock) {
       const int r = i / N, n = i - r * N;
-      thin_store<T>(Y0 + (int64_t)r * ldy + n, s_y[r * (kThinMax + 1) + n]);
+      thin_store<T>(Y0 + (int64_t)r * ldy + n, s_y[r * py + n]);
     }
   }
 }
@@ -121,7 +126,8 @@ __global__ __launch_bounds__(kThinBlock) void thin_tn_partial(const T* __restric
                                                               float* __restrict__ part) {
   __shared__ float s_a[kThinChunk * kThinMax];
   __shared__ float s_b[kThinChunk * kThinMax];
-  const int n = threadIdx.x / kThinMax, k = threadIdx.x % kThinMax;
+  const int P = thin_pitch(K);
+  const int n = threadIdx.x / P, k = threadIdx.x % P;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   r1 = r1 > V ? V : r1;
@@ -145,29 +151,33 @@ __global__ __launch_bounds__(kThinBlock) void thin_tn_partial(const T* __restric
       acc += (a0 + a1) + (a2 + a3);
     }
   }
-  part[(int64_t)blockIdx.x * (kThinMax * kThinMax) + threadIdx.x] = acc;
+  part[(int64_t)blockIdx.x * kThinElems + threadIdx.x] = acc;
 }
 
 // one block per output element: 256 threads add the blocks' partials (thread t: blocks t, t + 256, ..), then a fixed tree
 __global__ __launch_bounds__(kThinBlock) void thin_tn_reduce(const float* __restrict__ part, int nblocks, int N, int K,
-                                                             float* __restrict__ out, int64_t ldo) {
+                                                             float* __restrict__ out, int64_t ldo, const GradSink sink) {
   __shared__ float s_p[kThinBlock];
-  const int slot = blockIdx.x, n = slot / kThinMax, k = slot % kThinMax;
+  const int P = thin_pitch(K);
+  const int slot = blockIdx.x, n = slot / P, k = slot % P;
   if (n >= N || k >= K) return;
   float acc = 0.f;
-  for (int b = threadIdx.x; b < nblocks; b += kThinBlock) acc += part[(int64_t)b * (kThinMax * kThinMax) + slot];
+  for (int b = threadIdx.x; b < nblocks; b += kThinBlock) acc += part[(int64_t)b * kThinElems + slot];
   s_p[threadIdx.x] = acc;
   __syncthreads();
   for (int off = kThinBlock / 2; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) s_p[threadIdx.x] += s_p[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[(int64_t)n * ldo + k] = s_p[0];
+  if (threadIdx.x == 0) {
+    out[(int64_t)n * ldo + k] = s_p[0];
+    if (sink.mode) *sink_ptr(sink, n, k) += s_p[0];
+  }
 }
 
 }  // namespace
 
-bool thin_shape(int64_t N, int64_t K) { return N >= 1 && K >= 1 && N <= kThinMax && K <= kThinMax; }
+bool thin_shape(int64_t N, int64_t K) { return N >= 1 && K >= 1 && K <= kThinMax && N * thin_pitch((int)K) <= kThinElems; }
 
 int64_t thin_tn_blocks(int64_t V) {
   int64_t nb = (V + kThinTnRows - 1) / kThinTnRows;
@@ -192,7 +202,7 @@ int launch_thin_nt(const void* X, int64_t ldx, const float* W, int64_t ldw, cons
 }
 
 int launch_thin_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t V, int64_t N, int64_t K, int dtype,
-                   float* workspace, float* out, int64_t ldo, hipStream_t stream) {
+                   float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink) {
   const int64_t nb = thin_tn_blocks(V);
   const int64_t rpb = (V + nb - 1) / nb;
   if (dtype == SG_F32)
@@ -204,7 +214,7 @@ int launch_thin_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
     return SG_ERR_UNSUPPORTED;
   }
   SG_HIP_TRY(hipGetLastError());
-  thin_tn_reduce<<<kThinMax * kThinMax, kThinBlock, 0, stream>>>(workspace, (int)nb, (int)N, (int)K, out, ldo);
+  thin_tn_reduce<<<kThinElems, kThinBlock, 0, stream>>>(workspace, (int)nb, (int)N, (int)K, out, ldo, sink ? *sink : GradSink{});
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

@@ -1053,7 +1053,7 @@ class BlockPlan:
         ent = self._packs.get(dtype)
         if ent is None or ent[1].device != dev:
             n = self.K * self.Cin * self.Cout
-            thin = self.order == 0 and self.Cout <= capi.THIN_MAX and self.K * self.Cin <= capi.THIN_MAX
+            thin = self.order == 0 and capi.thin_shape(self.Cout, self.K * self.Cin)
             ent = [None, torch.empty(n, dtype=dtype, device=dev),
                    torch.empty(n, dtype=dtype, device=dev) if dtype == torch.bfloat16 else None,
                    torch.empty(n, dtype=torch.float32, device=dev) if thin else None,

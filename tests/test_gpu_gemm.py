@@ -311,12 +311,15 @@ def test_big_tile_weight_gradient_random_data_and_strides():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("V,N,K", [(1, 1, 1), (257, 16, 12), (70001, 12, 16), (100000, 3, 16), (4099, 16, 3), (5000, 16, 16), (333, 7, 5)])
+@pytest.mark.parametrize("V,N,K", [(1, 1, 1), (257, 16, 12), (70001, 12, 16), (100000, 3, 16), (4099, 16, 3), (5000, 16, 16), (333, 7, 5),
+                                   (50000, 3, 32), (18001, 32, 3), (777, 8, 32), (777, 32, 8), (300, 8, 17), (300, 5, 29)])
 def test_thin_products_match_float64(V, N, K, dtype):
-    """sg_thin_nt / sg_thin_tn (weight matrices of at most 16 x 16: the 4 -> 16 input layer, the 16 -> 3 output layer and
-    their autograd) against float64: fp32 accumulation error only, on strided operands, with and without bias; the
+    """sg_thin_nt / sg_thin_tn (weight matrices of at most 256 entries -- K <= 8 with N <= 32, N, K <= 16, K <= 32 with N <= 8:
+    the 4 -> 16 input layer, the 16 -> 3 output layer, the 32 -> 3 heads of the MGCN and their autograd) against float64: fp32 accumulation error only, on strided operands, with and without bias; the
     weight gradient deterministic run to run."""
     from semigcn_amd import capi
+    assert capi.thin_shape(N, K) and not capi.thin_shape(17, 17) and not capi.thin_shape(9, 32) and not capi.thin_shape(33, 8) \
+        and not capi.thin_shape(4, 33)
     g = torch.Generator(device=DEV).manual_seed(V + 31 * N + K)
     wide = torch.randn(V, K + 5, device=DEV, generator=g).to(dtype)
     x = wide[:, 2:2 + K]                                           # row stride K + 5, unit column stride
