@@ -79,9 +79,13 @@ def parse():
     ap.add_argument("--graph", action="store_true", default=None,
                     help="replay each iteration from hipGraphs: one graph on 1 GPU (pays off on launch-bound meshes <= ~200 K "
                          "vertices and MGCN), a tape of graph segments with the collectives between them on a partition "
-                         "(segments.py; the DEFAULT for --gpus N > 1 / --partitioned with the SGCN, where a rank is host-bound); "
-                         "needs --warmup >= 4")
-    ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager execution also on a partition")
+                         "(segments.py, over the per-module path; the default of rounds 2-3 for a partitioned SGCN, now "
+                         "slower than the eager phase-by-phase blocks); needs --warmup >= 4")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager execution (the default)")
+    ap.add_argument("--no-phases", action="store_true",
+                    help="partitioned SGCN: every module on its own (halo exchange inside each convolution, an all-gather per "
+                         "BatchNorm: 57 collectives) instead of the blocks run phase by phase below the C ABI with the "
+                         "statistics riding in the halo exchange (dist.part_chain: 44 collectives; the default)")
     ap.add_argument("--graph-collectives", action="store_true",
                     help="experimental, partitioned SGCN over RCCL only: ONE hipGraph per iteration with the RCCL calls "
                          "captured inside it instead of graph segments between eager collectives (exercised on a one-rank "
@@ -269,7 +273,8 @@ def build_trainer(args, dtype, device, world, rank, mesh):
     if DIST_ON and args.model == "sgcn":
         from semigcn_amd import dist as sgdist
         job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh,
-                                           capture=("whole" if args.graph and args.graph_collectives else args.graph))
+                                           capture=("whole" if args.graph and args.graph_collectives else args.graph),
+                                           phases=not args.no_phases)
         return job.trainer, job.workload, AGG_PER_ITER * mesh.num_edges
     batch = build_mesh_batch(mesh, device, n_masks=5)
     torch.manual_seed(314)                               # sgcn.py:19-25,76
@@ -357,19 +362,18 @@ def timed_run(trainer, args, device, world, with_timer: bool):
             torch.cuda.synchronize(device)
             timed_run.replay_check = "replayed loss == eager loss" if ok else "MISMATCH: the run continues eagerly"
             log(f"hipGraph replay check: {timed_run.replay_check}")
-        stall = args.stall_after_warmup
-        if stall and (stall < 0 or getattr(trainer, "_segmented", None) is not None) and int(os.environ.get("RANK", "0")) == world - 1:
-            log(f"TEST HOOK: the last rank stalls for {abs(stall):.0f} s")       # (--stall-after-warmup: supervisor self-test)
-            time.sleep(abs(stall))
-    elif args.stall_after_warmup < 0 and int(os.environ.get("RANK", "0")) == world - 1:
-        time.sleep(abs(args.stall_after_warmup))
+    # (--stall-after-warmup, the supervisor's self-test: > 0 stalls the first attempt only, < 0 every attempt)
+    stall = args.stall_after_warmup
+    if stall and (stall < 0 or os.environ.get("SEMIGCN_BENCH_ATTEMPT", "1") == "1") and int(os.environ.get("RANK", "0")) == world - 1:
+        log(f"TEST HOOK: the last rank stalls for {abs(stall):.0f} s")
+        time.sleep(abs(stall))
     # a rank that replays hipGraph segments issues its kernels from the graphs: per-launch event pairs are impossible inside
     # them, so its launches are timed in a short EAGER pass after the timed region (same kernels, same buffers)
     replays = getattr(trainer, "_segmented", None) is not None
     from semigcn_amd import functional as F_sg
-    # single GPU: the blocks run below the C ABI (functional.cheb_chain), timed by the library's own trace; the partitioned
-    # path still issues every launch from Python and keeps the Python-side timers
-    traced = with_timer and not replays and not DIST_ON and F_sg.blocks_enabled()
+    # the blocks run below the C ABI (functional.cheb_chain; dist.part_chain on a partition), timed by the library's own
+    # trace; the per-module partitioned path issues every launch from Python and keeps the Python-side timers
+    traced = with_timer and not replays and F_sg.blocks_enabled() and (not DIST_ON or getattr(trainer, "phases", False))
     timer = capi.LaunchTimer() if (with_timer and not replays and not traced) else None
     sync()
     capi.set_launch_timer(timer)
@@ -558,7 +562,7 @@ def distributed_estimate(args, ms_per_step_n1: float):
         out["rank_ms_per_step"] = round(part["ms_per_step"], 3)
         d = part.get("distributed") or {}
         out["collectives_per_iteration"] = d.get("collectives_per_iteration")
-        out["rank_replays_hip_graph_segments"] = d.get("hip_graph_segments") is not None
+        out["rank_path"] = "per-module" if d.get("per_module_path") else "blocks phase by phase below the C ABI (eager)"
     else:
         out["rank_error"] = part.get("error")
     if "ms_per_step" in solo:
@@ -567,8 +571,8 @@ def distributed_estimate(args, ms_per_step_n1: float):
         out["block_error"] = solo.get("error")
     if "rank_ms_per_step" in out:
         out["predicted_speedup_8_gpus_before_wire_time"] = round(ms_per_step_n1 / out["rank_ms_per_step"], 2)
-        out["note"] = ("upper bound: 57 collectives per iteration cross no link here (one-rank communicator); halo rows per rank "
-                       "and their bytes are in DESIGN.md section 5")
+        out["note"] = (f"upper bound: the {out.get('collectives_per_iteration')} collectives per iteration cross no link here "
+                       "(one-rank communicator); halo rows per rank and their bytes are in DESIGN.md section 5")
     return out
 
 
@@ -652,10 +656,11 @@ def _terminate(proc) -> None:
 def supervise_rank(args) -> int:
     """One rank of an N > 1 job as its launcher (the driver's `torch.distributed.run`, or ``spawn_ranks``) started it.  This
     process never touches the GPU: it runs the actual work in a CHILD (`bench.py ... --worker`, same rank environment) and
-    waits for it with a wall-clock limit.  A partitioned SGCN rank replays hipGraph segments by default (semigcn_amd/
-    segments.py), a path no box available to this build could exercise between two real devices; if ANY rank's worker fails
+    waits for it with a wall-clock limit.  A partitioned SGCN rank runs its blocks phase by phase below the C ABI by default
+    (dist.part_chain), a path exercised between real devices only by the driver's own SCALE run; if ANY rank's worker fails
     or overruns the limit, every supervisor kills its worker (they agree through marker files in a directory named after the
-    job's rendezvous port -- one node) and starts a FRESH one with `--no-graph`, on a fresh store prefix.  A second failure
+    job's rendezvous port -- one node) and starts a FRESH one on the per-module path of rounds 1-3 (`--no-phases --no-graph`),
+    on a fresh store prefix.  A second failure
     exits non-zero with the reason.  Nothing is ever exec'ed over a process that has initialised the GPU."""
     import glob
     import subprocess
@@ -681,7 +686,7 @@ def supervise_rank(args) -> int:
             env["TORCHELASTIC_RESTART_COUNT"] = str(int(env.get("TORCHELASTIC_RESTART_COUNT", "0")) + 1)
             if env.get("TORCHELASTIC_USE_AGENT_STORE") != "True":
                 env["MASTER_PORT"] = str(int(port) + 1)
-        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"] + (["--no-graph"] if attempt == 2 else [])
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"] + (["--no-graph", "--no-phases"] if attempt == 2 else [])
         t0 = time.perf_counter()
         proc = subprocess.Popen(cmd, env=env)
         why = None
@@ -699,7 +704,7 @@ def supervise_rank(args) -> int:
                 break
             if time.perf_counter() - t0 > ATTEMPT_TIMEOUT_S:
                 why = (f"rank {rank}'s worker did not finish attempt {attempt} within {ATTEMPT_TIMEOUT_S:.0f} s "
-                       f"({'hipGraph segment replay' if attempt == 1 else 'eager'})")
+                       f"({'blocks phase by phase' if attempt == 1 else 'per-module path'})")
                 _terminate(proc)
                 break
         if why is None:
@@ -710,7 +715,7 @@ def supervise_rank(args) -> int:
         except FileExistsError:
             pass
         reasons.append(why)
-        print(f"bench.py supervisor (rank {rank}): {why}" + ("; starting a fresh worker without hipGraph replay" if attempt == 1 else ""),
+        print(f"bench.py supervisor (rank {rank}): {why}" + ("; starting a fresh worker on the per-module path" if attempt == 1 else ""),
               file=sys.stderr, flush=True)
         # every supervisor must have seen the marker and killed its worker before the fresh set meets
         time.sleep(3.0)
@@ -791,19 +796,15 @@ def main():
     log(f"mesh generated V={mesh.num_vertices} E={mesh.num_edges}")
     dtypes = {"fp32": torch.float32, "bf16": torch.bfloat16}
     if args.graph is None:
-        # default: eager on one GPU; on a partition segment replay where a rank is host-bound -- up to ~300 K rows per rank
-        # (measured on the one-rank proxy: 125 K rows 7.2 ms replayed against 8.9-11.3 eager, 250 K rows 11.0 against
-        # 10.7-13.4, 500 K rows 18.3 against 17.8: above that the GPU is the bound and the graph launches only add bubbles)
-        rows_per_rank = mesh.num_vertices // max(world, 1)
-        args.graph = bool(DIST_ON and args.model == "sgcn" and args.warmup >= 4 and rows_per_rank <= 300_000
-                          and args.dtype == "bf16")          # (fp32 features: GPU-bound on the fp32 products at any size)
+        # default: EAGER everywhere.  A partitioned SGCN rank used to replay hipGraph segments between its collectives
+        # (rounds 2-3: 125 K rows per rank 6.8 ms replayed against 8.9-11.3 ms eager); with the blocks run phase by phase
+        # below the C ABI (dist.part_chain, 44 collectives) the eager rank measures 5.97 ms on the same proxy, needs no
+        # capture, and is the path the gloo / RCCL self-tests exercise.  --graph still replays segments (per-module path).
+        args.graph = False
         # one GPU: EAGER at every size.  The reference's own mesh sizes (c1: 5 K, c2 / c3: 50 K vertices) used to be bound by
         # ~300 launches with their Python glue and were replayed from a hipGraph by default (rounds 2-3); with runs of
         # blocks below the C ABI (sg_block_chain_*) the eager iteration is within ~1.2x of the replayed one, needs no
         # environment flag, and MGCN's dropout draws stay fresh.  --graph still replays (SGCN checked against an eager pass).
-        if DIST_ON and not args.graph:
-            log(f"partitioned run without hipGraph segments ({rows_per_rank} rows per rank, {args.dtype}; the default needs the SGCN, "
-                "bf16 features, --warmup >= 4 and <= 300000 rows per rank): eager")
     if args.graph and (args.warmup < 4 or (DIST_ON and args.model != "sgcn")):
         raise SystemExit("--graph: --warmup must be >= 4 (3 eager iterations + the capture); partitioned runs: SGCN only")
     # byte accounting assumes the finest mesh only; inside a whole-iteration hipGraph launches cannot be timed, a partitioned
@@ -890,6 +891,7 @@ def main():
                                    "single_rank_diagnostic": bool(args.partitioned and world == 1),
                                    "attempt": int(os.environ.get("SEMIGCN_BENCH_ATTEMPT", "1")),
                                    "first_attempt_failure": os.environ.get("SEMIGCN_BENCH_FIRST_FAILURE"),
+                                   "per_module_path": not getattr(trainer, "phases", False),
                                    "hip_graph_segments": (lambda sg_: None if sg_ is None or sg_.segments is None else
                                                           {"graphs": sg_.segments[0], "eager_actions": sg_.segments[1]})(
                                        getattr(trainer, "_segmented", None)),

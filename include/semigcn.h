@@ -491,7 +491,36 @@ typedef struct sg_block {
   float* acc_beta;
   /* scratch */
   void* ws; int64_t ws_bytes;
+  /* ---- one block of a VERTEX PARTITION (no reference counterpart), run phase by phase between the rank's
+   * collectives by sg_block_run; all zero / NULL for a block on one device.  The rank owns V rows of every [V, C] tensor;
+   * its buffers T / X / H / Y / G have V_ext rows: [owned | per peer: that peer's rows of the two-ring halo, then 5 pad rows].
+   * A block's halo exchange carries the rows of H (the conv output, BEFORE BatchNorm) and, in the pad rows of every peer's
+   * segment, this rank's BatchNorm statistics of H: the all-gather of the statistics rides in the exchange, and each rank
+   * applies BatchNorm + activation to the halo rows it received itself (SG_PHASE_BN). */
+  int32_t phase;               /* bit mask of sg_block_phase */
+  int32_t world;               /* ranks */
+  const sg_graph* graph_wide;  /* L^ on the owned AND the ring-1 rows: V_ext rows, V_ext columns (`graph`: V rows, V_ext columns) */
+  int64_t V_ext;
+  int64_t ldh;                 /* row stride of H (= Cout: H is also the receive buffer of its halo rows and statistics) */
+  float* local;                /* float32 [2 Cout + 1]: this rank's (mean, M2, row count) of H's owned rows */
+  const int64_t* stats_rows;   /* device int64 [world]: first pad row of peer q's segment in H (its statistics); -1 for this rank */
+  float* gathered;             /* float32 [world, 2 Cout + 1]: every rank's statistics (SG_PHASE_BN fills it from H unless ...) */
+  int32_t gathered_ready;      /* ... != 0: the caller filled it (an all-gather: the last block has no exchange behind it) */
+  int32_t reserved3_;
+  float* count;                /* float32 [1] on the device: the mesh's row count (written by SG_PHASE_BN, read by the backward phases) */
+  const int32_t* send_index;   /* device int32 [n_send]: the owned row every send row is a copy of; -1 - j: pad row j of a segment */
+  int64_t n_send;
+  void* send;                  /* [n_send, Cout] after SG_PHASE_CONV; [n_send, 2 Cin] (order 0) / [n_send, Cout] (order 1) after SG_PHASE_BWD_A */
+  const void* recv;            /* SG_PHASE_BWD_B: the halo rows of the gradient blocks as received, [V_ext - V, width of `send`] */
+  void* G;                     /* [V_ext, K * Cin] (order 0) / [V_ext, K * Cout] (order 1): lives from SG_PHASE_BWD_A to SG_PHASE_BWD_B */
 } sg_block;
+enum sg_block_phase {
+  SG_PHASE_CONV = 1,        /* the conv on [owned | halo] input rows -> H (owned rows), `local`, `send` */
+  SG_PHASE_BN = 2,          /* statistics of the whole mesh from `gathered` -> stats, count; Y = act(BN(H)) on V_out rows (V_ext: all) */
+  SG_PHASE_BWD_REDUCE = 4,  /* dvec rows 0, 1 = this rank's (sum dz, sum dz xhat) (+= into acc_beta / acc_gamma) -- all-reduce them */
+  SG_PHASE_BWD_A = 8,       /* from the all-reduced dvec rows 0, 1: dH, d bias; dW (+= acc_W); the input-gradient blocks -> G, `send` */
+  SG_PHASE_BWD_B = 16       /* `recv` -> G's halo rows; the recurrence unwound -> dX (owned rows) */
+};
 SG_API int64_t sg_block_sizeof(void);   /* sizeof(sg_block) of the library (a binding checks its mirror against it) */
 SG_API int64_t sg_block_workspace(const sg_block* blk, int backward);
 SG_API int sg_block_forward(const sg_block* blk, void* stream);
@@ -501,6 +530,9 @@ SG_API int sg_block_backward(const sg_block* blk, void* stream);
  * backward blks[n-1] .. blks[0].  The caller wires the descriptors: blks[i+1].X = blks[i].Y (written straight into the
  * next block's T when that one aggregates first), blks[i].dY = blks[i+1].dX; the blocks run one after the other on `stream`,
  * so they may share one scratch area sized for the largest of them. */
+/* sg_block_run: the phases of n partition blocks in array order (blks[i].phase), one call between two collectives.
+ * sg_block_workspace(blk, 2): scratch a partition block needs for any of its phases. */
+SG_API int sg_block_run(const sg_block* blks, int64_t n, void* stream);
 SG_API int sg_block_chain_forward(const sg_block* blks, int64_t n, void* stream);
 SG_API int sg_block_chain_backward(const sg_block* blks, int64_t n, void* stream);
 

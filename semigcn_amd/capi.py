@@ -45,7 +45,14 @@ class sg_block(ctypes.Structure):
                 ("Y", c_void_p), ("ldy", c_int64),
                 ("dY", c_void_p), ("lddy", c_int64), ("dX", c_void_p), ("lddx", c_int64), ("dW", c_void_p), ("dvec", c_void_p),
                 ("acc_W", c_void_p * 3), ("acc_bias", c_void_p), ("acc_gamma", c_void_p), ("acc_beta", c_void_p),
-                ("ws", c_void_p), ("ws_bytes", c_int64)]
+                ("ws", c_void_p), ("ws_bytes", c_int64),
+                ("phase", c_int32), ("world", c_int32), ("graph_wide", c_void_p), ("V_ext", c_int64), ("ldh", c_int64),
+                ("local", c_void_p), ("stats_rows", c_void_p), ("gathered", c_void_p), ("gathered_ready", c_int32),
+                ("reserved3_", c_int32), ("count", c_void_p), ("send_index", c_void_p), ("n_send", c_int64), ("send", c_void_p),
+                ("recv", c_void_p), ("G", c_void_p)]
+
+
+PHASE_CONV, PHASE_BN, PHASE_BWD_REDUCE, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4, 8, 16
 
 
 class sg_trace_record(ctypes.Structure):
@@ -135,6 +142,7 @@ _SIGNATURES = {
     "sg_block_workspace": (c_int64, [POINTER(sg_block), c_int]),
     "sg_block_forward": (c_int, [POINTER(sg_block), c_void_p]),
     "sg_block_backward": (c_int, [POINTER(sg_block), c_void_p]),
+    "sg_block_run": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
     "sg_block_chain_forward": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
     "sg_block_chain_backward": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
     "sg_trace_begin": (c_int, [c_int64, c_int]),
@@ -1068,7 +1076,7 @@ def face_mask_bits(faces: torch.Tensor, vbits: torch.Tensor) -> torch.Tensor:
 # ---- one [ChebConv -> pool? -> BatchNorm -> activation] block per foreign call ---------------------------------------
 def block_workspace(blk: sg_block, backward: bool) -> int:
     """Bytes of scratch sg_block_forward / sg_block_backward need for this block (depends on its shape fields only)."""
-    n = load().sg_block_workspace(byref(blk), 1 if backward else 0)
+    n = load().sg_block_workspace(byref(blk), int(backward))       # 0 forward, 1 backward, 2: a partition block (all phases)
     if n < 0:
         _check(int(n), "sg_block_workspace")
     return int(n)
@@ -1090,6 +1098,13 @@ def block_chain_forward(blks, n: int, stream: int) -> None:
         rc = _lib.sg_block_chain_forward(blks, n, stream)
     if rc:
         _check(rc, "sg_block_chain_forward")
+
+
+def block_run(blks, n: int, stream: int) -> None:
+    """The phases (``blks[i].phase``) of n partition blocks in array order: what a rank does between two collectives."""
+    rc = _lib.sg_block_run(blks, n, stream)
+    if rc:
+        _check(rc, "sg_block_run")
 
 
 def block_chain_backward(blks, n: int, stream: int) -> None:

@@ -402,6 +402,270 @@ int backward(const sg_block& b, hipStream_t stream) {
   return SG_OK;
 }
 
+// =====================================================================================================================
+// One block of a VERTEX PARTITION, phase by phase (sg_block_run; SURVEY 8(e): the reference is single-device).
+//
+// The rank owns V rows; every feature buffer has V_ext rows, [owned | per peer: its halo rows, kPadRows pad rows].  The halo
+// exchange that follows SG_PHASE_CONV moves rows of H -- the conv output BEFORE BatchNorm -- and, in the pad rows of every
+// peer's segment, this rank's BatchNorm statistics of H: the all-gather of the statistics rides in the exchange, and
+// SG_PHASE_BN applies BatchNorm + activation on all V_ext rows, halo rows included (they are forward-only copies: the
+// backward pass is owner-computes on exchanged GRADIENT rows, the global L^ being symmetric).
+constexpr int kPadRows = 5;      // (2 C + 1) floats fit into 5 rows of C bf16 (or fp32) values for every C >= 2
+
+// dst[r] = src[idx[r]] (width elements of esz bytes); idx[r] = -1 - j: pad row j, bytes [j, j + 1) * width * esz of `blob`
+// (blob_bytes long, zero beyond; blob == nullptr: zeros)
+__global__ __launch_bounds__(256) void pack_rows(const char* __restrict__ src, int64_t ld_bytes, const int32_t* __restrict__ idx,
+                                                 int64_t n, int row_bytes, const char* __restrict__ blob, int blob_bytes,
+                                                 char* __restrict__ dst) {
+  const int per_row = row_bytes / 4;                      // 4-byte words (row_bytes % 4 == 0: C % 2 == 0 for bf16)
+  for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < n * per_row; w += (int64_t)gridDim.x * 256) {
+    const int64_t r = w / per_row;
+    const int c = (int)(w - r * per_row) * 4;
+    const int i = idx[r];
+    uint32_t v = 0;
+    if (i >= 0) {
+      v = *(const uint32_t*)(src + (int64_t)i * ld_bytes + c);
+    } else if (blob) {
+      const int off = (-1 - i) * row_bytes + c;
+      if (off + 4 <= blob_bytes) v = *(const uint32_t*)(blob + off);
+    }
+    *(uint32_t*)(dst + r * row_bytes + c) = v;
+  }
+}
+
+// gathered[q] = rank q's (mean[C], M2[C], rows): this rank's from `local`, a peer's from the pad rows of its segment in H
+__global__ void gather_stats(const char* __restrict__ H, int64_t ld_bytes, const int64_t* __restrict__ stats_rows,
+                             const float* __restrict__ local, int world, int n, float* __restrict__ gathered) {
+  const int q = blockIdx.x;
+  const int64_t row = stats_rows[q];
+  const float* src = row < 0 ? local : (const float*)(H + row * ld_bytes);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) gathered[(int64_t)q * n + i] = src[i];
+}
+
+int part_check(const sg_block& b) {
+  SG_REQUIRE(b.graph && b.graph_wide, "sg_block_run: a partition block needs graph and graph_wide");
+  SG_REQUIRE(b.dtype == SG_F32 || b.dtype == SG_BF16, "sg_block_run: unknown dtype %d", b.dtype);
+  SG_REQUIRE(b.K == 3 && (b.order == 0 || b.order == 1), "sg_block_run: K = 3 only (the reference's), order 0 / 1");
+  SG_REQUIRE(b.V > 1 && b.V_ext >= b.V && b.Cin > 0 && b.Cout > 0 && b.world >= 1, "sg_block_run: bad shape");
+  SG_REQUIRE(b.graph->fwd.n_rows == b.V && b.graph->fwd.n_cols == b.V_ext && b.graph_wide->fwd.n_rows == b.V_ext &&
+                 b.graph_wide->fwd.n_cols == b.V_ext,
+             "sg_block_run: graph must be V x V_ext and graph_wide V_ext x V_ext");
+  SG_REQUIRE(b.pool == nullptr && b.pool_mode == 0, "sg_block_run: no pool inside a partition block");
+  SG_REQUIRE(b.ldh == b.Cout, "sg_block_run: H must be a contiguous [V_ext, Cout] buffer (ldh = Cout)");
+  SG_REQUIRE((b.Cout * esize(b.dtype)) % 4 == 0 && kPadRows * b.Cout * esize(b.dtype) >= (2 * b.Cout + 1) * 4,
+             "sg_block_run: Cout = %lld cannot carry the statistics in its pad rows", (long long)b.Cout);
+  if (col_apply_blocks(b.V, b.Cout, b.dtype) == 0) {
+    set_error("sg_block_run: Cout = %lld is not served", (long long)b.Cout);
+    return SG_ERR_UNSUPPORTED;
+  }
+  return SG_OK;
+}
+
+struct PartWs {
+  float* moments;   // tile / block moments of the conv output
+  void* Z;          // order 1 forward: [V_ext, K*Cout]
+  float* part;      // BatchNorm backward partials [nb, 2, Cout]
+  float* co;        // [5, Cout]
+  float* colsum;
+  void* dH;         // order 0: [V, Cout]
+  float* tn;
+  void* blas;
+};
+void carve_part(const sg_block& b, Carver& c, PartWs* w) {
+  const int64_t e = esize(b.dtype), KCi = b.K * b.Cin, KCo = b.K * b.Cout;
+  const int64_t nb = col_blocks(b.V), R = gemm_tile_rows(b.Cout), tiles = (b.V + R - 1) / R;
+  w->moments = (float*)c.take((tiles > nb ? tiles : nb) * 2 * b.Cout * 4);
+  w->Z = b.order == 1 ? c.take(b.V_ext * KCo * e) : nullptr;
+  w->part = (float*)c.take(nb * 2 * b.Cout * 4);
+  w->co = (float*)c.take(5 * b.Cout * 4);
+  w->colsum = (float*)c.take(col_apply_blocks(b.V, b.Cout, b.dtype) * b.Cout * 4);
+  w->dH = b.order == 0 ? c.take(b.V * b.Cout * e) : nullptr;
+  const int64_t tn = b.order == 0 ? dense_tn_workspace(b.dtype, b.V, b.Cout, KCi) : dense_tn_workspace(b.dtype, b.V, KCo, b.Cin);
+  w->tn = (float*)c.take(tn * 4);
+  w->blas = c.take((int64_t)kBlasWorkspace);
+}
+
+int pack_to(const sg_block& b, const void* src, int64_t ld, int64_t width, const float* blob, int64_t blob_floats, hipStream_t stream) {
+  if (b.n_send == 0) return SG_OK;
+  SG_REQUIRE(b.send && b.send_index, "sg_block_run: no send buffer / index");
+  const int64_t e = esize(b.dtype);
+  const int64_t words = b.n_send * (width * e / 4);
+  int64_t blocks = (words + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  pack_rows<<<(int)blocks, 256, 0, stream>>>((const char*)src, ld * e, b.send_index, b.n_send, (int)(width * e), (const char*)blob,
+                                            (int)(blob_floats * 4), (char*)b.send);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+int part_run(const sg_block& b, hipStream_t stream) {
+  int rc = part_check(b);
+  if (rc != SG_OK) return rc;
+  const int64_t e = esize(b.dtype), Ci = b.Cin, Co = b.Cout, KCi = b.K * Ci, KCo = b.K * Co, V = b.V, Ve = b.V_ext;
+  SG_REQUIRE(b.H != nullptr, "sg_block_run: H is null");
+  Carver c(b.ws, b.ws_bytes);
+  PartWs w;
+  carve_part(b, c, &w);
+  SG_REQUIRE(b.ws != nullptr && !c.overflow, "sg_block_run: scratch too small (%lld bytes given, %lld needed)",
+             (long long)b.ws_bytes, (long long)c.at);
+  const bool thin = b.order == 0 && thin_shape(Co, KCi);
+  if (thin) SG_REQUIRE(b.wpack32 && b.wpack32_t, "sg_block_run: a tiny weight matrix needs wpack32 / wpack32_t");
+  const float *mean = b.stats, *invstd = b.stats + Co, *scale = b.stats + 2 * Co, *shift = b.stats + 3 * Co;
+  auto agg = [&](const sg_graph* g, const void* X, int64_t ldx, const void* X0, int64_t ld0, const void* X1, int64_t ld1, void* Y,
+                 int64_t ldy, int64_t C, float a, float be, float ga) {
+    return sg_spmm(g, 0, X, ldx, X0, ld0, X1, ld1, Y, ldy, C, b.dtype, a, be, ga, (void*)stream);
+  };
+
+  if (b.phase & SG_PHASE_CONV) {
+    SG_REQUIRE(b.local && b.wpack, "sg_block_run (conv): null pointer");
+    if (b.refresh_weights && (rc = pack(b, stream)) != SG_OK) return rc;
+    bool tile_moments = false;
+    if (b.order == 0) {
+      SG_REQUIRE(b.T && b.ldt >= KCi, "sg_block_run (conv): order 0 needs the [V_ext, K*Cin] buffer T");
+      // Tx1 on the owned and ring-1 rows (one exchange serves both aggregations), Tx2 on the owned rows
+      if ((rc = agg(b.graph_wide, b.T, b.ldt, nullptr, 0, nullptr, 0, col(b.T, Ci, e), b.ldt, Ci, 1.f, 0.f, 0.f)) != SG_OK) return rc;
+      if ((rc = agg(b.graph, col(b.T, Ci, e), b.ldt, b.T, b.ldt, nullptr, 0, col(b.T, 2 * Ci, e), b.ldt, Ci, 2.f, -1.f, 0.f)) != SG_OK) return rc;
+      rc = dense_nt(b.T, b.ldt, b.wpack, b.wpack32, KCi, b.bias, b.H, b.ldh, V, Co, KCi, b.dtype, b.training ? w.moments : nullptr,
+                    &tile_moments, w.blas, kBlasWorkspace, stream);
+      if (rc != SG_OK) return rc;
+    } else {
+      SG_REQUIRE(b.X && b.ldx >= Ci, "sg_block_run (conv): order 1 needs the [V_ext, Cin] input X");
+      if (b.bias) SG_REQUIRE(b.bias_k != nullptr, "sg_block_run (conv): order 1 with a bias needs bias_k");
+      // the product on ALL V_ext rows (the halo rows' share is a few per cent): no exchange between product and aggregation
+      rc = dense_nt(b.X, b.ldx, b.wpack, nullptr, Ci, b.bias ? b.bias_k : nullptr, w.Z, KCo, Ve, KCo, Ci, b.dtype, nullptr, nullptr,
+                    w.blas, kBlasWorkspace, stream);
+      if (rc != SG_OK) return rc;
+      char* z0 = (char*)w.Z;
+      char* z1 = col(w.Z, Co, e);
+      char* z2 = col(w.Z, 2 * Co, e);
+      if ((rc = agg(b.graph_wide, z2, KCo, z1, KCo, nullptr, 0, z1, KCo, Co, 2.f, 1.f, 0.f)) != SG_OK) return rc;
+      if ((rc = agg(b.graph, z1, KCo, z0, KCo, z2, KCo, b.H, b.ldh, Co, 1.f, 1.f, -1.f)) != SG_OK) return rc;
+    }
+    if (b.training) {      // this rank's (mean, M2, rows) of its owned rows
+      if (tile_moments) {
+        const int64_t R = gemm_tile_rows(Co);
+        rc = launch_bn_merge_tiles(w.moments, (V + R - 1) / R, R, V, Co, b.local, b.local + 2 * Co, stream);
+      } else {
+        const int64_t nb = col_blocks(V);
+        rc = launch_col_reduce(0, b.H, b.ldh, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, w.moments, nb, V, Co, b.dtype, stream);
+        if (rc != SG_OK) return rc;
+        rc = launch_bn_merge_tiles(w.moments, nb, (V + nb - 1) / nb, V, Co, b.local, b.local + 2 * Co, stream);
+      }
+      if (rc != SG_OK) return rc;
+    }
+    if (b.n_send > 0 && (rc = pack_to(b, b.H, b.ldh, Co, b.training ? b.local : nullptr, 2 * Co + 1, stream)) != SG_OK) return rc;
+  }
+
+  if (b.phase & SG_PHASE_BN) {
+    SG_REQUIRE(b.stats && b.gamma && b.beta && b.Y && b.ldy >= Co && b.V_out >= V && b.V_out <= Ve, "sg_block_run (bn): bad argument");
+    if (b.training) {
+      SG_REQUIRE(b.gathered && b.count && (b.gathered_ready || (b.stats_rows && b.local)), "sg_block_run (bn): no statistics");
+      if (!b.gathered_ready) {
+        gather_stats<<<b.world, 128, 0, stream>>>((const char*)b.H, b.ldh * e, b.stats_rows, b.local, b.world, (int)(2 * Co + 1), b.gathered);
+        SG_HIP_TRY(hipGetLastError());
+      }
+      rc = launch_bn_finalize_ranks(b.gathered, b.world, Co, b.gamma, b.beta, b.running_mean, b.running_var, b.momentum, b.eps,
+                                    b.stats, b.count, b.batches_tracked, stream);
+      if (rc != SG_OK) return rc;
+    } else {
+      SG_REQUIRE(b.running_mean && b.running_var, "sg_block_run (bn): eval mode needs the running statistics");
+      bn_eval_coeffs<<<(int)((Co + 127) / 128), 128, 0, stream>>>(b.running_mean, b.running_var, b.gamma, b.beta, b.eps, (int)Co, b.stats);
+      SG_HIP_TRY(hipGetLastError());
+    }
+    rc = launch_col_apply(0, b.H, b.ldh, nullptr, 0, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, b.slope, b.Y, b.ldy,
+                          b.V_out, Co, b.dtype, stream);
+    if (rc != SG_OK) return rc;
+  }
+
+  if (b.phase & (SG_PHASE_BWD_REDUCE | SG_PHASE_BWD_A | SG_PHASE_BWD_B))
+    SG_REQUIRE(b.training, "sg_block_run: the backward phases of a partition block are for training mode");
+
+  if (b.phase & SG_PHASE_BWD_REDUCE) {
+    SG_REQUIRE(b.dY && b.lddy >= Co && b.dvec && b.stats, "sg_block_run (bwd reduce): null pointer");
+    const int64_t nb = col_blocks(V);
+    rc = launch_col_reduce(1, b.dY, b.lddy, b.H, b.ldh, scale, shift, mean, invstd, b.slope, w.part, nb, V, Co, b.dtype, stream);
+    if (rc != SG_OK) return rc;
+    // rows 0, 1 of dvec: this rank's sums (the caller all-reduces them in place); += into the BatchNorm .grad accumulators
+    rc = launch_bn_bwd_coeffs(w.part, nb, Co, 1.0, b.gamma, invstd, b.dvec, b.acc_gamma, b.acc_beta, nullptr, stream);
+    if (rc != SG_OK) return rc;
+  }
+
+  if (b.phase & SG_PHASE_BWD_A) {
+    SG_REQUIRE(b.dY && b.dvec && b.dW && b.G && b.count && b.wpack, "sg_block_run (bwd a): null pointer");
+    const bool sink_w = b.acc_W[0] != nullptr;
+    // c1, c2, k of the whole mesh from the all-reduced sums and the device-resident row count
+    rc = launch_bn_bwd_coeffs(b.dvec, 1, Co, 0.0, b.gamma, invstd, w.co, nullptr, nullptr, b.count, stream);
+    if (rc != SG_OK) return rc;
+    void* dH = b.order == 0 ? w.dH : b.G;
+    const int64_t lddh = b.order == 0 ? Co : KCo;
+    rc = launch_col_apply(1, b.dY, b.lddy, b.H, b.ldh, scale, shift, mean, invstd, w.co + 4 * Co, w.co + 2 * Co, w.co + 3 * Co, b.slope,
+                          dH, lddh, V, Co, b.dtype, stream, w.colsum);
+    if (rc != SG_OK) return rc;
+    rc = launch_colsum_finalize(w.colsum, col_apply_blocks(V, Co, b.dtype), Co, b.dvec + 5 * Co, stream, b.acc_bias);
+    if (rc != SG_OK) return rc;
+    if (b.order == 0) {
+      GradSink sink;
+      if (sink_w) {
+        for (int k = 0; k < b.K; ++k) sink.dst[k] = b.acc_W[k];
+        sink.mode = 1; sink.Cin = (int)Ci; sink.Cout = (int)Co;
+      }
+      bool sunk = false;
+      rc = dense_tn(dH, lddh, b.T, b.ldt, V, Co, KCi, b.dtype, w.tn, b.dW, KCi, w.blas, kBlasWorkspace, stream, sink_w ? &sink : nullptr, &sunk);
+      if (rc != SG_OK) return rc;
+      if (sink_w && !sunk) {
+        const float* srcs[3]; float* dsts[3]; int64_t ld[3], rows[3], cols[3];
+        for (int k = 0; k < b.K; ++k) { srcs[k] = b.dW + k * Ci; ld[k] = KCi; dsts[k] = b.acc_W[k]; rows[k] = Co; cols[k] = Ci; }
+        if ((rc = launch_multi_add(b.K, srcs, ld, rows, cols, dsts, stream)) != SG_OK) return rc;
+      }
+      // the K gradient blocks of the owned rows; blocks 1, 2 of the boundary rows go to the peers
+      rc = dense_nn(dH, lddh, b.wpack, KCi, b.wpack_t, Co, b.wpack32_t, b.G, KCi, V, KCi, Co, b.dtype, w.blas, kBlasWorkspace, stream);
+      if (rc != SG_OK) return rc;
+      if ((rc = pack_to(b, col(b.G, Ci, e), KCi, 2 * Ci, nullptr, 0, stream)) != SG_OK) return rc;
+    } else {
+      if ((rc = pack_to(b, b.G, KCo, Co, nullptr, 0, stream)) != SG_OK) return rc;     // dH is block 0 of G
+    }
+  }
+
+  if (b.phase & SG_PHASE_BWD_B) {
+    SG_REQUIRE(b.G && (!b.need_dx || (b.dX && b.lddx >= Ci)) && (Ve == V || b.recv), "sg_block_run (bwd b): null pointer");
+    const bool sink_w = b.acc_W[0] != nullptr;
+    if (b.order == 0) {
+      if (Ve > V && (rc = copy_rows(b.recv, 2 * Ci, (char*)b.G + (V * KCi + Ci) * e, KCi, Ve - V, 2 * Ci, b.dtype, stream)) != SG_OK) return rc;
+      char* g0 = (char*)b.G;
+      char* g1 = col(b.G, Ci, e);
+      char* g2 = col(b.G, 2 * Ci, e);
+      if ((rc = agg(b.graph_wide, g2, KCi, g1, KCi, nullptr, 0, g1, KCi, Ci, 2.f, 1.f, 0.f)) != SG_OK) return rc;
+      if (b.need_dx && (rc = agg(b.graph, g1, KCi, g0, KCi, g2, KCi, b.dX, b.lddx, Ci, 1.f, 1.f, -1.f)) != SG_OK) return rc;
+    } else {
+      SG_REQUIRE(b.X && b.dW, "sg_block_run (bwd b): order 1 needs the saved input X and dW");
+      if (Ve > V && (rc = copy_rows(b.recv, Co, (char*)b.G + V * KCo * e, KCo, Ve - V, Co, b.dtype, stream)) != SG_OK) return rc;
+      char* g0 = (char*)b.G;
+      char* g1 = col(b.G, Co, e);
+      char* g2 = col(b.G, 2 * Co, e);
+      if ((rc = agg(b.graph_wide, g0, KCo, nullptr, 0, nullptr, 0, g1, KCo, Co, 1.f, 0.f, 0.f)) != SG_OK) return rc;
+      if ((rc = agg(b.graph, g1, KCo, g0, KCo, nullptr, 0, g2, KCo, Co, 2.f, -1.f, 0.f)) != SG_OK) return rc;
+      if (b.need_dx) {
+        rc = dense_nn(b.G, KCo, b.wpack, Ci, b.wpack_t, KCo, nullptr, b.dX, b.lddx, V, Ci, KCo, b.dtype, w.blas, kBlasWorkspace, stream);
+        if (rc != SG_OK) return rc;
+      }
+      GradSink sink;
+      if (sink_w) {
+        for (int k = 0; k < b.K; ++k) sink.dst[k] = b.acc_W[k];
+        sink.mode = 2; sink.Cin = (int)Ci; sink.Cout = (int)Co;
+      }
+      bool sunk = false;
+      rc = dense_tn(b.G, KCo, b.X, b.ldx, V, KCo, Ci, b.dtype, w.tn, b.dW, Ci, w.blas, kBlasWorkspace, stream, sink_w ? &sink : nullptr, &sunk);
+      if (rc != SG_OK) return rc;
+      if (sink_w && !sunk) {
+        const float* srcs[3]; float* dsts[3]; int64_t ld[3], rows[3], cols[3];
+        for (int k = 0; k < b.K; ++k) { srcs[k] = b.dW + k * Co * Ci; ld[k] = Ci; dsts[k] = b.acc_W[k]; rows[k] = Co; cols[k] = Ci; }
+        if ((rc = launch_multi_add(b.K, srcs, ld, rows, cols, dsts, stream)) != SG_OK) return rc;
+      }
+    }
+  }
+  return SG_OK;
+}
+
 }  // namespace
 }  // namespace sg
 
@@ -409,12 +673,30 @@ using namespace sg;
 
 extern "C" {
 
+SG_API int sg_block_run(const sg_block* blks, int64_t n, void* stream) {
+  SG_REQUIRE(n >= 0 && (n == 0 || blks != nullptr), "sg_block_run: bad argument");
+  for (int64_t i = 0; i < n; ++i) {
+    SG_REQUIRE(blks[i].phase != 0, "sg_block_run: block %lld has no phase", (long long)i);
+    const int rc = part_run(blks[i], (hipStream_t)stream);
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
+}
+
 SG_API int64_t sg_block_sizeof(void) { return (int64_t)sizeof(sg_block); }
 
 SG_API int64_t sg_block_workspace(const sg_block* blk, int backward_pass) {
   if (!blk) {
     set_error("sg_block_workspace: null block");
     return SG_ERR_INVALID;
+  }
+  if (backward_pass == 2) {          // a partition block: one size for all of its phases
+    const int rc = part_check(*blk);
+    if (rc != SG_OK) return rc;
+    Carver c(nullptr, 0);
+    PartWs w;
+    carve_part(*blk, c, &w);
+    return c.at;
   }
   Shape s;
   const int rc = shape_of(*blk, &s);

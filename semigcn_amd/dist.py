@@ -357,6 +357,8 @@ class DistMeshGraph(_RowExchange):
         is_row = torch.zeros(self.n_ext, dtype=torch.bool, device=dev)
         is_row[:self.n_own] = True
         is_row[ext_of[torch.nonzero(r1).flatten()]] = True
+        # (kept for FoldedLayout: the same two operators on the folded row numbering)
+        self._fold_src = (dst, src, e_own, e_wide, dis, halo, [None] * world)
         self._split = []
         dst_w, src_w = ext_of[dst[e_wide]], ext_of[src[e_wide]]
         owned_row = torch.zeros(self.n_ext, dtype=torch.bool, device=dev)
@@ -382,6 +384,7 @@ class DistMeshGraph(_RowExchange):
                 continue
             _, q1, q2 = rings_of(bounds[q], bounds[q + 1])
             rows = torch.nonzero((q1 | q2)[start:end]).flatten()
+            self._fold_src[6][q] = rows
             send_rows.append(rows)
             send_splits.append(int(rows.numel()))
         self.send_splits = send_splits
@@ -393,6 +396,14 @@ class DistMeshGraph(_RowExchange):
     def extended_index(self, rows: torch.Tensor) -> torch.Tensor:
         """Position of global ``rows`` (owned or in the halo) inside this rank's ``[owned | halo]`` buffer."""
         return self._ext_of[rows]
+
+    def folded(self) -> "FoldedLayout":
+        """The layout of the phase-by-phase block path (``part_chain``): ``[owned | per peer: its halo rows, PAD_ROWS pad
+        rows]`` -- the pad rows carry the peer's BatchNorm statistics, so an exchange lands in place, statistics included."""
+        f = self.__dict__.get("_folded")
+        if f is None:
+            f = self.__dict__["_folded"] = FoldedLayout(self)
+        return f
 
     # MeshGraph-compatible surface -----------------------------------------------------
     @property
@@ -466,6 +477,299 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
     if not dist.is_initialized() or _solo(dist.get_world_size(group)):
         return x
     return _AllReduceSum.apply(x, group)
+
+
+PAD_ROWS = 5        # csrc/block.hip kPadRows: (2 C + 1) floats fit into 5 rows of C bf16 / fp32 values
+
+
+class FoldedLayout:
+    """One rank's operators and exchange plan on the folded row numbering ``[owned | per peer q != rank, ascending: q's rows
+    of the two-ring halo (ascending global id), PAD_ROWS pad rows]``.  The pad rows of a peer's segment carry that peer's
+    BatchNorm statistics of the exchanged tensor: the statistics all-gather rides in the halo exchange (57 -> 44 collectives
+    per iteration), and a receive lands in place -- rows ``[n_own:]`` of the ``[n_ext, C]`` buffer ARE the receive buffer."""
+
+    def __init__(self, g: "DistMeshGraph"):
+        dst, src, e_own, e_wide, dis, halo, send_per_peer = g._fold_src
+        dev, W, rank, n = g.device, g.world, g.rank, g.n_own
+        self.graph, self.world, self.rank, self.group, self.n_own = g, W, rank, g.group, n
+        V = g.num_vertices_global
+        ext_of = torch.full((V,), -1, dtype=torch.long, device=dev)
+        ext_of[g.start:g.end] = torch.arange(n, device=dev)
+        b = torch.tensor(g.bounds, device=dev, dtype=torch.long)
+        owner = torch.bucketize(halo, b[1:], right=True)
+        at, ext_src, stats_rows = n, [torch.arange(g.start, g.end, device=dev)], []
+        send_index, self.send_splits, self.recv_splits = [], [], []
+        pad = torch.full((PAD_ROWS,), -1, dtype=torch.long, device=dev)
+        for q in range(W):
+            if q == rank:
+                stats_rows.append(-1)
+                self.send_splits.append(0)
+                self.recv_splits.append(0)
+                continue
+            mine = halo[owner == q]
+            ext_of[mine] = at + torch.arange(mine.numel(), device=dev)
+            ext_src += [mine, pad]
+            stats_rows.append(at + int(mine.numel()))
+            at += int(mine.numel()) + PAD_ROWS
+            self.recv_splits.append(int(mine.numel()) + PAD_ROWS)
+            rows = send_per_peer[q] if send_per_peer[q] is not None else torch.zeros(0, dtype=torch.long, device=dev)
+            send_index += [rows, -1 - torch.arange(PAD_ROWS, device=dev)]
+            self.send_splits.append(int(rows.numel()) + PAD_ROWS)
+        self.n_ext = at
+        self.ext_src = torch.cat(ext_src)                          # global (processing-order) vertex per row, -1: pad row
+        self.send_index = (torch.cat(send_index) if send_index else torch.zeros(0, dtype=torch.long, device=dev)).to(torch.int32)
+        self.n_send = int(self.send_index.numel())
+        self.stats_rows = torch.tensor(stats_rows, dtype=torch.int64, device=dev)
+        dis_ext = torch.where(self.ext_src >= 0, dis[self.ext_src.clamp(min=0)], torch.zeros((), device=dev))
+        self.handle = capi.GraphHandle.from_partition(dst[e_own] - g.start, ext_of[src[e_own]], n, self.n_ext, dis_ext)
+        self.handle_wide = capi.GraphHandle.from_partition(ext_of[dst[e_wide]], ext_of[src[e_wide]], self.n_ext, self.n_ext, dis_ext)
+
+    def halo_of(self, full: torch.Tensor) -> torch.Tensor:
+        """Rows ``[n_own:]`` of the folded buffer of a mesh-wide [V, C] tensor in processing order (zeros in the pad rows)."""
+        idx = self.ext_src[self.n_own:]
+        out = full.index_select(0, idx.clamp(min=0))
+        out[idx < 0] = 0
+        return out
+
+    def exchange(self, recv: torch.Tensor, send: torch.Tensor) -> None:
+        """One all-to-all: ``send`` [n_send, C] (peer segments with their pad rows) -> ``recv`` = rows [n_own:] of a buffer."""
+        if _solo(self.world):
+            return
+        _all_to_all_rows(recv, send, self.recv_splits, self.send_splits, self.group)
+
+
+class PartChain:
+    """The 13 [ChebConv -> BatchNorm -> LeakyReLU] blocks of SingleScaleGCN (util/networks.py:83-101) on one rank of a vertex
+    partition, run phase by phase BELOW the C ABI (sg_block_run, csrc/block.hip) with the rank's collectives between the
+    calls: per block forward ONE all-to-all (rows of the conv output + this rank's BatchNorm statistics in the pad rows;
+    the block behind applies BatchNorm + activation to owned and received rows alike), backward one all-reduce (the two
+    BatchNorm sums) and one all-to-all (gradient rows).  One autograd node for the whole run."""
+
+    def __init__(self, plans, layout: FoldedLayout):
+        from . import functional as F_sg
+        self.plans, self.lay = list(plans), layout
+        n = len(self.plans)
+        mk = lambda k: (capi.sg_block * k)()
+        # descriptor arrays, one per call between two collectives
+        self.f_seg = [mk(1)] + [mk(2) for _ in range(n - 1)]        # [conv 0] ; [bn i-1, conv i]
+        self.f_tail = mk(1)                                          # [bn n-1]
+        self.b_head = mk(1)                                          # [reduce n-1]
+        self.b_a = [mk(1) for _ in range(n)]                         # [bn-apply + conv first half] of block i
+        self.b_b = [mk(1)] + [mk(2) for _ in range(n - 1)]           # [conv second half i, reduce i-1]
+        self._ws = {}
+        self._F = F_sg
+
+    def descriptors(self, i):
+        """Every descriptor that describes block i (they all get the same static fields)."""
+        n = len(self.plans)
+        out = [self.f_seg[i][0 if i == 0 else 1], self.b_a[i][0], self.b_b[i][0]]
+        out.append(self.f_seg[i + 1][0] if i + 1 < n else self.f_tail[0])
+        out.append(self.b_b[i + 1][1] if i + 1 < n else self.b_head[0])
+        return out
+
+
+class _PartChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pc: PartChain, x_own: torch.Tensor, x_halo: torch.Tensor, *params):
+        F_sg, lay, plans = pc._F, pc.lay, pc.plans
+        n, dev, dtype = len(plans), x_own.device, x_own.dtype
+        code, e = capi._DTYPES[dtype], (4 if dtype == torch.float32 else 2)
+        V, Ve, W = lay.n_own, lay.n_ext, lay.world
+        stream = capi._stream(x_own)
+        capturing = False
+        bufs = []
+        for i, p in enumerate(plans):
+            p.fingerprint()
+            inp = torch.empty((Ve, p.K * p.Cin if p.order == 0 else p.Cin), dtype=dtype, device=dev)
+            H = torch.empty((Ve, p.Cout), dtype=dtype, device=dev)
+            small = torch.empty(4 * p.Cout + (2 * p.Cout + 1) * (W + 1) + 1, dtype=torch.float32, device=dev)
+            send = torch.empty((lay.n_send, p.Cout), dtype=dtype, device=dev)
+            bufs.append((inp, H, small, send))
+        # the network input on all rows: owned rows from the autograd side, halo rows computed from the halo copies of z1 / dm
+        t0 = bufs[0][0]
+        t0[:V, :plans[0].Cin].copy_(x_own)
+        if Ve > V:
+            t0[V:, :plans[0].Cin].copy_(x_halo)
+        wsb = pc._ws.get(code)
+        if wsb is None:
+            probe = capi.sg_block()
+            wsb = 0
+            for p in plans:
+                p.init_descriptor(probe)
+                probe.graph, probe.graph_wide = lay.handle._h, lay.handle_wide._h
+                probe.dtype, probe.V, probe.V_out, probe.V_ext, probe.world, probe.ldh = code, V, V, Ve, W, p.Cout
+                wsb = max(wsb, capi.block_workspace(probe, 2))
+            pc._ws[code] = wsb
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        training = []
+        for i, p in enumerate(plans):
+            inp, H, small, send = bufs[i]
+            C = p.Cout
+            s0 = small.data_ptr()
+            stats, local, gathered, count = s0, s0 + 16 * C, s0 + 16 * C + 4 * (2 * C + 1), s0 + 16 * C + 4 * (2 * C + 1) * (W + 1)
+            t = 1 if p.bn.training else 0
+            training.append(t)
+            for blk in pc.descriptors(i):
+                p.init_descriptor(blk)
+                blk.graph, blk.graph_wide = lay.handle._h, lay.handle_wide._h
+                blk.dtype, blk.V, blk.V_ext, blk.world, blk.training = code, V, Ve, W, t
+                blk.V_out = Ve if i + 1 < n else V
+                p.bind(blk, dtype, dev)
+                if p.order == 0:
+                    blk.T, blk.ldt, blk.X, blk.ldx = inp.data_ptr(), p.K * p.Cin, inp.data_ptr(), p.K * p.Cin
+                else:
+                    blk.T, blk.ldt, blk.X, blk.ldx = None, 0, inp.data_ptr(), p.Cin
+                blk.H, blk.ldh, blk.stats, blk.local, blk.gathered, blk.count = H.data_ptr(), C, stats, local, gathered, count
+                blk.gathered_ready = 0
+                blk.stats_rows = lay.stats_rows.data_ptr()
+                blk.send_index, blk.n_send, blk.send = lay.send_index.data_ptr(), (lay.n_send if i + 1 < n else 0), send.data_ptr()
+                if i + 1 < n:
+                    q = plans[i + 1]
+                    blk.Y, blk.ldy = bufs[i + 1][0].data_ptr(), (q.K * q.Cin if q.order == 0 else q.Cin)
+                blk.ws, blk.ws_bytes = ws.data_ptr(), wsb
+            pc.f_seg[i][0 if i == 0 else 1].refresh_weights = p.stale(dtype, capturing)
+        y = torch.empty((V, plans[-1].Cout), dtype=dtype, device=dev)
+        pc.f_tail[0].Y, pc.f_tail[0].ldy = y.data_ptr(), plans[-1].Cout
+        for i in range(n):
+            if i == 0:
+                pc.f_seg[0][0].phase = capi.PHASE_CONV
+            else:
+                pc.f_seg[i][0].phase, pc.f_seg[i][1].phase = capi.PHASE_BN, capi.PHASE_CONV
+            capi.block_run(pc.f_seg[i], 1 if i == 0 else 2, stream)
+            if i + 1 < n:
+                lay.exchange(bufs[i][1][V:], bufs[i][3])          # rows of H_i + this rank's statistics -> the peers, in place
+        # the last BatchNorm has no exchange behind it: a plain all-gather of the statistics
+        p, (inp, H, small, send) = plans[-1], bufs[-1]
+        C = p.Cout
+        local = small[4 * C:4 * C + 2 * C + 1].view(1, -1)
+        gathered = small[4 * C + 2 * C + 1:4 * C + (2 * C + 1) * (W + 1)].view(W, 2 * C + 1)
+        if training[-1]:
+            if _solo(W):
+                gathered.copy_(local)
+            else:
+                _all_gather_rows(gathered, local, lay.group)
+        pc.f_tail[0].phase, pc.f_tail[0].gathered_ready = capi.PHASE_BN, 1
+        capi.block_run(pc.f_tail, 1, stream)
+        del ws
+        F_sg.block_calls[0] += n
+        ctx.pc, ctx.bufs, ctx.training, ctx.params = pc, bufs, training, params
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        pc, bufs = ctx.pc, ctx.bufs
+        F_sg, lay, plans = pc._F, pc.lay, pc.plans
+        n, dev, dtype = len(plans), dy.device, dy.dtype
+        code = capi._DTYPES[dtype]
+        V, Ve, W = lay.n_own, lay.n_ext, lay.world
+        stream = capi._stream(dy)
+        dy = dy.contiguous()
+        wsb = pc._ws[code]
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        sinking = bool(F_sg._sink_depth)
+        grads_out = []
+        Gs, dvecs, dWs, gsend, grecv, dxs = [], [], [], [], [], []
+        for i, p in enumerate(plans):
+            width = 2 * p.Cin if p.order == 0 else p.Cout
+            Gs.append(torch.empty((Ve, p.K * (p.Cin if p.order == 0 else p.Cout)), dtype=dtype, device=dev))
+            dvecs.append(torch.empty((6, p.Cout), dtype=torch.float32, device=dev))
+            dWs.append(torch.empty(p.Cout * p.K * p.Cin, dtype=torch.float32, device=dev))
+            gsend.append(torch.empty((lay.n_send, width), dtype=dtype, device=dev))
+            grecv.append(torch.empty((Ve - V, width), dtype=dtype, device=dev))
+            dxs.append(torch.empty((V, p.Cin), dtype=dtype, device=dev))
+        sunk = []
+        for i, p in enumerate(plans):
+            aw = [F_sg._grad_acc(w, dev) if sinking else None for w in p.weights]
+            sw = all(a is not None for a in aw)
+            ab = F_sg._grad_acc(p.cbias, dev) if sinking else None
+            ag, at = (F_sg._grad_acc(p.gamma, dev), F_sg._grad_acc(p.beta, dev)) if sinking else (None, None)
+            sb = ag is not None and at is not None
+            sunk.append((sw, ab is not None, sb))
+            dyi = dy if i == n - 1 else dxs[i + 1]
+            for blk in pc.descriptors(i):          # (static fields are those of the forward pass)
+                blk.training = ctx.training[i]
+                blk.dY, blk.lddy = dyi.data_ptr(), p.Cout
+                blk.dX, blk.lddx, blk.need_dx = dxs[i].data_ptr(), p.Cin, 1
+                blk.dW, blk.dvec, blk.G = dWs[i].data_ptr(), dvecs[i].data_ptr(), Gs[i].data_ptr()
+                blk.send, blk.recv, blk.n_send = gsend[i].data_ptr(), grecv[i].data_ptr(), lay.n_send
+                for k in range(3):
+                    blk.acc_W[k] = aw[k] if (sw and k < p.K) else None
+                blk.acc_bias = ab
+                blk.acc_gamma, blk.acc_beta = (ag, at) if sb else (None, None)
+                blk.refresh_weights = 0
+                blk.ws, blk.ws_bytes = ws.data_ptr(), wsb
+        # BatchNorm n-1: this rank's sums -> all-reduce; then per block: [dH, dW, gradient blocks] -> all-to-all ->
+        # [recurrence unwound -> dX ; sums of the BatchNorm in front] -> all-reduce
+        pc.b_head[0].phase = capi.PHASE_BWD_REDUCE
+        capi.block_run(pc.b_head, 1, stream)
+        bn_local = [None] * n
+        for i in range(n - 1, -1, -1):
+            p = plans[i]
+            if not sunk[i][2]:
+                bn_local[i] = dvecs[i][:2].clone()      # this rank's partial (sum dz, sum dz xhat): the gradients autograd gets
+            if not _solo(W):
+                _all_reduce(dvecs[i].view(-1)[:2 * p.Cout], dist.ReduceOp.SUM, lay.group)
+            pc.b_a[i][0].phase = capi.PHASE_BWD_A
+            capi.block_run(pc.b_a[i], 1, stream)
+            lay.exchange(grecv[i], gsend[i])
+            pc.b_b[i][0].phase = capi.PHASE_BWD_B
+            if i > 0:
+                pc.b_b[i][1].phase = capi.PHASE_BWD_REDUCE
+            capi.block_run(pc.b_b[i], 1 if i == 0 else 2, stream)
+        del ws
+        F_sg.block_calls[1] += n
+        for i, p in enumerate(plans):
+            K, Cin, Cout = p.K, p.Cin, p.Cout
+            sw, sbias, sbn = sunk[i]
+            dvec = dvecs[i]
+            grads_out.append(None if (p.cbias is None or sbias) else dvec[5].to(p.cbias.dtype))
+            if sw:
+                grads_out.extend([None] * K)
+            elif p.order == 0:
+                dWm = dWs[i].view(Cout, K * Cin)
+                grads_out.extend(dWm[:, k * Cin:(k + 1) * Cin] for k in range(K))
+            else:
+                dWm = dWs[i].view(K * Cout, Cin)
+                grads_out.extend(dWm[k * Cout:(k + 1) * Cout] for k in range(K))
+            grads_out.extend((None, None) if sbn else (bn_local[i][1].to(p.gamma.dtype), bn_local[i][0].to(p.gamma.dtype)))
+        return (None, dxs[0], None, *grads_out)
+
+
+def part_chain(sequentials, graph: "DistMeshGraph", x_own: torch.Tensor, x_halo: torch.Tensor):
+    """Blocks that START every Sequential of ``sequentials`` (each [ChebConv, BatchNorm1d, LeakyReLU (, ...)]) on this rank's
+    rows, phase by phase below the C ABI; returns (activation of the last block on the owned rows, index of the first entry
+    of the last Sequential that was NOT run), or None when the run cannot take this path (then the caller's per-module path
+    does)."""
+    from . import functional as F_sg
+    if not (x_own.is_cuda and F_sg.blocks_enabled() and dist.is_initialized()):
+        return None
+    plans = []
+    for seq in sequentials:
+        lead = seq._leading_blocks() if hasattr(seq, "_leading_blocks") else None
+        if lead is None or len(lead[0]) != 1:
+            return None
+        plans.append(lead[0][0])
+        tail = lead[1]
+    cin = x_own.shape[1]
+    for p in plans:
+        p.fingerprint()
+        bn = p.bn
+        vec = 4 if x_own.dtype == torch.float32 else 8
+        if p.K != 3 or p.pool is not None or p.Cin != cin or p.Cout % vec or not bn.training or not getattr(bn, "sg_mesh_wide", False) \
+                or not (bn.affine and bn.track_running_stats and bn.momentum is not None) \
+                or not all(F_sg._f32_dev(w, x_own.device) for w in p.weights) or p.Cout * (2 if vec == 8 else 4) * PAD_ROWS < (2 * p.Cout + 1) * 4:
+            return None
+        cin = p.Cout
+    lay = graph.folded()
+    key = tuple(id(p) for p in plans)
+    pc = graph.__dict__.setdefault("_part_chains", {}).get(key)
+    if pc is None:
+        pc = graph.__dict__["_part_chains"][key] = PartChain(plans, lay)
+    params = []
+    for p in plans:
+        params.extend(p.param_tuple)
+    return _PartChainFn.apply(pc, x_own, x_halo, *params), tail
 
 
 # --------------------------------------------------------------------------------------
@@ -770,6 +1074,11 @@ class PartitionedMesh:
     n_v_keep: float             # GLOBAL counts
     n_f_keep: float
     edge_index = None           # SingleScaleGCN reads .graph instead
+    # the halo rows' copies of the network's inputs in the folded layout (graph.folded()): with them the first block needs no
+    # exchange -- every rank prepares the input rows of its halo itself.  Set by partition_mesh; halo_inputs per iteration.
+    z1_halo: Optional[torch.Tensor] = None          # [n_ext - n, 3] (constant: the gradient of z1 is owner-computes)
+    dm_halo: Optional[torch.Tensor] = None          # [n_ext - n, M]  v_keep * dummy mask of the halo vertices
+    halo_inputs: Optional[tuple] = None             # (z1_halo, this iteration's mask column [n_ext - n, 1])
 
 
 def partition_mesh(mesh, rank: int, world: int, device, group=None, n_masks: int = 5, seed: int = 317) -> PartitionedMesh:
@@ -791,21 +1100,30 @@ def partition_mesh(mesh, rank: int, world: int, device, group=None, n_masks: int
     fa = torch.from_numpy(mesh.faces).to(device)
     f_keep_all = v_keep_all[fa[:, 0]] * v_keep_all[fa[:, 1]] * v_keep_all[fa[:, 2]]
     dm_all = torch.from_numpy(synth.make_dummy_masks(mesh.edge_index, V, dm_size=n_masks, k=4, p=0.014, seed=seed)).to(device)
-    z1 = torch.from_numpy(mesh.z1).to(device)[own].clone().requires_grad_(True)
-    return PartitionedMesh(g, z1, pos_all[own].clone(), faces_ext, vs_all[own].clone(), tfn_all[f_mine].clone(),
+    z1_all = torch.from_numpy(mesh.z1).to(device)
+    z1 = z1_all[own].clone().requires_grad_(True)
+    part = PartitionedMesh(g, z1, pos_all[own].clone(), faces_ext, vs_all[own].clone(), tfn_all[f_mine].clone(),
                            v_keep_all[own].view(-1, 1).clone(), f_keep_all[f_mine].view(-1, 1).clone(),
                            dm_all[own].clone(), float(v_keep_all.sum()), float(f_keep_all.sum()))
+    if z1_all.is_cuda:      # the phase-by-phase block path (part_chain) prepares the halo rows of the input itself
+        lay = g.folded()
+        part.z1_halo = lay.halo_of(z1_all[order]).contiguous()
+        part.dm_halo = lay.halo_of((v_keep_all.view(-1, 1) * dm_all)[order]).contiguous()
+    return part
 
 
 class DistSGCNTrainer:
     """SGCNTrainer (semigcn_amd.train, the loop of sgcn.py:118-147) on a vertex partition."""
 
     def __init__(self, model: nn.Module, part: PartitionedMesh, group=None, lr: float = 0.01, k1: float = 4.0,
-                 accumulate: int = 5, capture: bool = False):
-        """``capture=True``: after three eager iterations the iteration is recorded as hipGraph segments with the
-        collectives between them and replayed from that tape (segments.py, train._SegmentedIteration): the host work of a
-        rank drops from ~450 launches with their Python / autograd glue to ~60 graph launches + the 57 collectives."""
+                 accumulate: int = 5, capture: bool = False, phases: bool = True):
+        """``phases`` (the default): the 13 blocks run phase by phase below the C ABI with the BatchNorm statistics riding
+        in the halo exchange (part_chain: ~50 foreign calls and 44 collectives per iteration).  ``phases=False``: every
+        module on its own, the exchange inside each convolution and an all-gather per BatchNorm (57 collectives).
+        ``capture=True`` (the per-module path only): after three eager iterations the iteration is recorded as hipGraph
+        segments with the collectives between them and replayed from that tape (segments.py, train._SegmentedIteration)."""
         self.model, self.part, self.group, self.k1, self.accumulate = model, part, group, k1, accumulate
+        self.phases = bool(phases) and not capture
         convert_batchnorm(model, group)
         self.params = [p for p in model.parameters()]
         self.opt = torch.optim.Adam(self.params, lr=lr)
@@ -855,6 +1173,10 @@ class DistSGCNTrainer:
         p = self.part
         k = self.iteration % p.dummy_masks.shape[1] if mask_index is None else mask_index
         dm = p.v_keep * p.dummy_masks[:, k:k + 1]
+        if p.dm_halo is not None and self.phases:
+            p.halo_inputs = (p.z1_halo, p.dm_halo[:, k:k + 1].contiguous())
+        else:
+            p.halo_inputs = None
         loss = self._segmented(dm) if self._segmented is not None else self._forward_backward(dm)
         self.loss_sum += loss
         self.iteration += 1
@@ -875,7 +1197,8 @@ class _Job:
 
 
 def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permute: bool = False,
-                          dtype=torch.float32, group=None, mesh=None, capture: bool = False) -> _Job:
+                          dtype=torch.float32, group=None, mesh=None, capture: bool = False,
+                          phases: bool = True) -> _Job:
     """bench.py's N > 1 leg: the SAME nu x nv mesh as the 1-GPU run, cut into ``world`` blocks
     (strong scaling)."""
     from . import synth
@@ -887,14 +1210,16 @@ def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permu
     model = SingleScaleGCN(device).to(device)
     if dtype != torch.float32:
         model.set_feature_dtype(dtype)
-    trainer = DistSGCNTrainer(model, part, group, capture=capture)
+    trainer = DistSGCNTrainer(model, part, group, capture=capture, phases=phases)
     halo = torch.tensor([part.graph.n_halo], device=device)
     if world > 1:
         _all_reduce(halo, dist.ReduceOp.MAX, group)
     workload = (f"SGCN train iteration on a closed torus mesh {nu}x{nv} (V={mesh.num_vertices} E={mesh.num_edges}), "
                 f"{'fp32' if dtype == torch.float32 else 'bf16'} features, Morton-ordered and vertex-partitioned into "
                 f"{world} blocks (<= {int(halo)} halo rows per rank), "
-                f"halo exchange + mesh-wide BatchNorm + gradient all-reduce over RCCL"
+                + ("blocks run phase by phase below the C ABI, BatchNorm statistics carried by the halo exchange, "
+                   if trainer.phases else "halo exchange + an all-gather per BatchNorm, ")
+                + "gradient all-reduce over RCCL"
                 + (", iteration replayed from hipGraph segments between the collectives" if capture else ""))
     return _Job(trainer, mesh.num_vertices, mesh.num_edges, workload)
 

@@ -179,6 +179,18 @@ class SingleScaleGCN(nn.Module):
                 x = x.index_select(0, order)
             x = x.to(self.feature_dtype)
 
+        halo_in = getattr(data, "halo_inputs", None)
+        if not self.skip and halo_in is not None and getattr(graph, "sg_partitioned", False) and x.is_cuda and self.training:
+            # one rank of a vertex partition: the blocks phase by phase below the C ABI, the collectives between the calls;
+            # the halo rows of the network input are prepared here from the halo copies of z1 / dm (no exchange for block 0)
+            from .dist import part_chain
+            from .functional import input_prep
+            with torch.no_grad():
+                x_halo = input_prep(halo_in[0], lo.detach(), hi.detach(), halo_in[1], None, None, self.feature_dtype)
+            res = part_chain(self.blocks, graph, x, x_halo)
+            if res is not None:
+                x = self.blocks[-1](res[0], graph, _start=res[1])
+                return x_pos + x
         if not self.skip:
             # the loop over the 13 blocks (:83-101); on the device their whole kernel chain is ONE call below the C ABI
             x = run_sequentials([(block, graph) for block in self.blocks], x)

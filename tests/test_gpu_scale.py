@@ -202,12 +202,24 @@ def _run_selftest(world, backend, **env):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_partitioned_sgcn_and_mgcn_equal_single_rank_on_device(world):
-    """tools/dist_selftest.py: partitioned SGCN and MGCN (sg_graph_create_rect, sg_gather_rows, sg_bn_finalize_ranks,
-    DistPool) == the plain single-device models: positions <= 1e-5, loss <= 2e-6 (asserted inside the ranks)."""
+    """tools/dist_selftest.py: partitioned SGCN (the 13 blocks phase by phase below the C ABI, sg_block_run, BatchNorm
+    statistics in the pad rows of the halo exchange: 44 collectives, asserted inside the ranks) and MGCN
+    (sg_graph_create_rect, sg_gather_rows, sg_bn_finalize_ranks, DistPool) == the plain single-device models: positions
+    <= 1e-5, loss <= 2e-6 (asserted inside the ranks)."""
     r = _run_selftest(world, "gloo")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "dist_selftest OK" in r.stdout
+    assert "dist_selftest OK" in r.stdout and "path=phases collectives=44" in r.stdout
     print(r.stdout[-1500:])
+
+
+@pytest.mark.parametrize("path,n_coll", [("modules", 57), ("phases-sunk", 44)])
+def test_partitioned_sgcn_other_paths_two_ranks(path, n_coll):
+    """The same check on the per-module path of rounds 1-3 (halo exchange inside each convolution, an all-gather per
+    BatchNorm: 57 collectives; bench.py's fallback) and on the phase path with the parameter gradients added into the
+    .grad accumulators by the library (what the trainers run)."""
+    r = _run_selftest(2, "gloo", SEMIGCN_SELFTEST_PATH=path, SEMIGCN_SELFTEST_SKIP_MGCN="1")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "dist_selftest OK" in r.stdout and f"path={path} collectives={n_coll}" in r.stdout
 
 
 def test_eight_ranks_on_a_200k_vertex_mesh_equal_single_rank():
@@ -216,21 +228,29 @@ def test_eight_ranks_on_a_200k_vertex_mesh_equal_single_rank():
     model (asserted inside the ranks: positions <= 1e-5, loss <= 2e-6)."""
     r = _run_selftest(8, "gloo", SEMIGCN_SELFTEST_MESH="500x400", SEMIGCN_SELFTEST_SKIP_MGCN="1")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "dist_selftest OK" in r.stdout
+    assert "dist_selftest OK" in r.stdout and "path=phases collectives=44" in r.stdout
     assert sum("pos rel-L2" in ln for ln in r.stdout.splitlines()) == 8
     print(r.stdout[-1800:])
 
 
-def test_one_rank_over_rccl_with_every_collective_issued():
+@pytest.mark.parametrize("path", ["phases", "modules"])
+def test_one_rank_over_rccl_with_every_collective_issued(path):
     """The RCCL code path on a one-GPU box: ONE rank, backend "nccl", and SEMIGCN_DIST_FORCE_COLLECTIVES=1 so that the
     rank issues every collective of the partitioned iteration through the real library (communicator set-up, asynchronous
     all-to-all + stream wait, statistics all-gather, min/max / loss / gradient all-reduces) although each is the identity
-    for a single rank; results must still equal the plain single-device model (asserted inside the rank)."""
-    r = _run_selftest(1, "nccl", SEMIGCN_DIST_FORCE_COLLECTIVES="1")
+    for a single rank; results must still equal the plain single-device model (asserted inside the rank).  Both paths:
+    the blocks phase by phase (27 all-to-all with the statistics inside, 1 all-gather, 16 all-reduces = 44) and the
+    per-module one (28 all-to-all, 13 all-gathers, 16 all-reduces = 57)."""
+    r = _run_selftest(1, "nccl", SEMIGCN_DIST_FORCE_COLLECTIVES="1", SEMIGCN_SELFTEST_PATH=path,
+                      SEMIGCN_SELFTEST_SKIP_MGCN="1" if path == "phases" else "0")       # (the MGCN rides with "modules")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "dist_selftest OK" in r.stdout
     counts = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("collectives ")][-1].split(" ", 1)[1])
-    assert counts["backend"] == "nccl" and counts["all_to_all"] >= 28 and counts["all_gather"] >= 13 and counts["all_reduce"] >= 10
+    assert counts["backend"] == "nccl"
+    if path == "phases":           # (the gradient all-reduce after the backward pass is counted too)
+        assert (counts["all_to_all"], counts["all_gather"], counts["all_reduce"]) == (27, 1, 17), counts
+    else:
+        assert counts["all_to_all"] >= 28 and counts["all_gather"] >= 13 and counts["all_reduce"] >= 10
     print(r.stdout[-800:])
 
 
@@ -291,9 +311,12 @@ def test_bench_gpus_2_starts_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert line["distributed"]["world_size"] == 2 and line["distributed"]["collectives_per_iteration"] > 0
-    # with enough warm-up and bf16 features the ranks replay hipGraph segments between their collectives (the default for
-    # host-bound ranks: <= 300 K rows each)
-    r = subprocess.run(base[:5] + ["6", "--warmup", "5"] + base[8:-1] + ["bf16"], env=_child_env(SEMIGCN_BENCH_SHARE_GPU="1"),
+    # the default: the blocks phase by phase below the C ABI, 44 collectives + the gradient all-reduce every 5th iteration
+    d = line["distributed"]
+    assert d["per_module_path"] is False and d["hip_graph_segments"] is None and 44 <= d["collectives_per_iteration"] <= 45
+    assert line["roofline"] is not None
+    # --graph: the per-module path replayed from hipGraph segments between its collectives (the default of rounds 2-3)
+    r = subprocess.run(base[:5] + ["6", "--warmup", "5"] + base[8:-1] + ["bf16", "--graph"], env=_child_env(SEMIGCN_BENCH_SHARE_GPU="1"),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads(r.stdout.strip())
@@ -302,10 +325,10 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert "eager iterations after the timed region" in line["roofline"]["measured_over"]
 
 
-def test_bench_supervisor_retries_without_replay_after_a_stall():
-    """an N > 1 run whose hipGraph-replay attempt hangs (injected: the last rank sleeps after its
-    warm-up) is killed at the attempt's wall-clock limit and re-run ONCE from fresh worker processes with --no-graph;
-    the line says so.  A run that stalls in both attempts exits non-zero with the reason."""
+def test_bench_supervisor_retries_on_the_per_module_path_after_a_stall():
+    """an N > 1 run whose first attempt hangs (injected: the last rank sleeps after its warm-up) is
+    killed at the attempt's wall-clock limit and re-run ONCE from fresh worker processes on the per-module path
+    (--no-phases --no-graph); the line says so.  A run that stalls in both attempts exits non-zero with the reason."""
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "5",
             "--mesh", "96x64", "--no-cpu-baseline", "--dtype", "bf16"]
     env = _child_env(SEMIGCN_BENCH_SHARE_GPU="1", SEMIGCN_BENCH_ATTEMPT_TIMEOUT="60")
@@ -315,7 +338,8 @@ def test_bench_supervisor_retries_without_replay_after_a_stall():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])["distributed"]
     assert d["attempt"] == 2 and "within 60 s" in d["first_attempt_failure"] and d["hip_graph_segments"] is None
-    assert "starting a fresh worker without hipGraph replay" in r.stderr
+    assert d["per_module_path"] is True and 57 <= d["collectives_per_iteration"] <= 58
+    assert "starting a fresh worker on the per-module path" in r.stderr
     env["SEMIGCN_BENCH_ATTEMPT_TIMEOUT"] = "30"
     r = subprocess.run(base + ["--stall-after-warmup", "-600"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and "both attempts failed" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

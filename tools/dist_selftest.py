@@ -43,9 +43,29 @@ def main():
     tr = sgdist.DistSGCNTrainer(model, part, accumulate=1000)
     model.train()
     dm = part.v_keep * part.dummy_masks[:, :1]
+    # SEMIGCN_SELFTEST_PATH: "modules" = every module on its own with the exchange inside each conv and an all-gather per
+    # BatchNorm (57 collectives per iteration); "phases" (default) = the blocks phase by phase below the C ABI with the
+    # statistics riding in the halo exchange (dist.part_chain: 44); "phases-sunk": the same with the parameter gradients
+    # added into the .grad accumulators by the library (what the trainers do)
+    path = os.environ.get("SEMIGCN_SELFTEST_PATH", "phases")
+    part.halo_inputs = None if path == "modules" else (part.z1_halo, part.dm_halo[:, :1].contiguous())
+    from semigcn_amd import functional as F_sg
+    c0, b0 = dict(sgdist.collective_counts), list(F_sg.block_calls)
     pos = model(part, dm)
     loss = tr.loss(pos)
-    loss.backward()
+    if path == "phases-sunk":
+        tr.grads.zero()
+        with F_sg.sink_param_grads():
+            loss.backward()
+    else:
+        loss.backward()
+    n_coll = sum(sgdist.collective_counts.values()) - sum(c0.values())
+    blocks = [F_sg.block_calls[0] - b0[0], F_sg.block_calls[1] - b0[1]]
+    if path != "modules":
+        assert blocks == [13, 13], blocks
+        assert n_coll == 44 or not (world > 1 or sgdist.FORCE_COLLECTIVES), n_coll
+    elif world > 1 or sgdist.FORCE_COLLECTIVES:
+        assert n_coll == 57, n_coll
     sgdist.all_reduce_gradients(tr.params)
 
     # single-GPU reference on the whole mesh (plain BatchNorm, no partition)
@@ -71,7 +91,7 @@ def main():
             continue
         scale = max(float(q.grad.norm()), 1e-3 * gmax * q.grad.numel() ** 0.5)
         worst = max(worst, float((p.grad - q.grad).norm()) / scale)
-    print(f"[rank {rank}/{world}] own={g.n_own} halo={g.n_halo} send={g.n_send}  pos rel-L2 {e_pos:.2e}  "
+    print(f"[rank {rank}/{world}] path={path} collectives={n_coll} own={g.n_own} halo={g.n_halo} send={g.n_send}  pos rel-L2 {e_pos:.2e}  "
           f"loss rel {e_loss:.2e}  worst param-grad rel-L2 {worst:.2e}", flush=True)
     assert e_pos < 1e-5 and e_loss < 2e-6 and worst < 3e-2
     if os.environ.get("SEMIGCN_SELFTEST_SKIP_MGCN") != "1":
