@@ -40,7 +40,7 @@ def main():
         model.to(dev)
         if dtype != torch.float32:
             model.set_feature_dtype(dtype)
-        tr = sgdist.DistSGCNTrainer(model, part, capture=capture)
+        tr = sgdist.DistSGCNTrainer(model, part, capture=capture, phases=False)     # segments replay the per-module path
         losses = []
         for _ in range(9):
             _ = part.v_keep * 2.0                  # an unrelated eager kernel between iterations ...
