@@ -14,7 +14,8 @@ for w in "--mesh 100x50 --dtype fp32" "--mesh 250x200 --dtype fp32" "--mesh 250x
   python tools/host_call_census.py $w 2>/dev/null >> $O/host_call_census.jsonl
 done
 for i in 1 2; do
-  for m in "--no-graph" "--partitioned --no-graph" "--partitioned" "--graph"; do
+  # unpartitioned block of a rank's size; the rank: blocks phase by phase (default) / per-module eager / per-module replayed
+  for m in "--no-graph" "--partitioned" "--partitioned --no-phases" "--partitioned --no-phases --graph" "--graph"; do
     python bench.py --mesh 354x354 --dtype bf16 --single-dtype --no-second-order --no-cpu-baseline --no-launch-timer --steps 60 --warmup 10 $m 2>/dev/null >> $O/rank_proxy_125k.jsonl
   done
 done
