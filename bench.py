@@ -82,6 +82,9 @@ def parse():
                          "(segments.py, over the per-module path; the default of rounds 2-3 for a partitioned SGCN, now "
                          "slower than the eager phase-by-phase blocks); needs --warmup >= 4")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager execution (the default)")
+    ap.add_argument("--no-planes", action="store_true",
+                    help="A/B switch: the narrow bf16 layers keep their recurrence buffers as column blocks of one [V, K*C] buffer "
+                         "instead of K dense [V, C] planes (include/semigcn.h, sg_block_planar)")
     ap.add_argument("--no-phases", action="store_true",
                     help="partitioned SGCN: every module on its own (halo exchange inside each convolution, an all-gather per "
                          "BatchNorm: 57 collectives) instead of the blocks run phase by phase below the C ABI with the "
@@ -790,6 +793,10 @@ def main():
 
     from semigcn_amd import capi, synth
     capi.load()
+    if args.no_planes:
+        from semigcn_amd import functional as F_sg
+        F_sg.USE_PLANES = False
+        capi.tuning_set(capi.TUNE_BLOCK_PLANES, 0)
     log("library loaded")
     nu, nv = map(int, args.mesh.split("x"))
     mesh = make_mesh(nu, nv, args.mesh_recipe, permute=args.permute)

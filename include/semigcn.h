@@ -523,6 +523,15 @@ enum sg_block_phase {
 };
 SG_API int64_t sg_block_sizeof(void);   /* sizeof(sg_block) of the library (a binding checks its mirror against it) */
 SG_API int64_t sg_block_workspace(const sg_block* blk, int backward);
+/* Narrow layers keep the K column blocks of their recurrence buffers as K dense [V, C] PLANES instead of column blocks of one
+ * [V, K*C] buffer (an aggregation that gathers 32-byte rows from a 96-byte pitch uses a quarter of every line it pulls):
+ * bf16 features, C = 8 .. 64 a power of two, every product of the layer on the library's 128-row matrix-core kernels.
+ * For a layer that aggregates after the product the buffers are the library's own scratch and nothing changes for the
+ * caller.  For a layer that aggregates first (order 0) the buffer is the caller's T: sg_block_planar(blk) answers 1 when the
+ * shape (dtype, V, Cin, Cout, K, order of blk) qualifies, and the caller chooses the layout by passing T as [K][V][Cin]
+ * with ldt = Cin (X = T, ldx = Cin: plane 0 is the input; the block in front writes it with ldy = Cin).  ldt >= K*Cin keeps
+ * the column-block layout for any shape.  Same arithmetic, same results (tests/test_gpu_blocks.py). */
+SG_API int sg_block_planar(const sg_block* blk);
 SG_API int sg_block_forward(const sg_block* blk, void* stream);
 SG_API int sg_block_backward(const sg_block* blk, void* stream);
 /* A run of n consecutive blocks in one call -- the loop of SingleScaleGCN.forward over its 13 blocks (util/networks.py:83-101),
@@ -575,9 +584,11 @@ enum sg_tune_knob {
   SG_TUNE_GRAPH_REORDER = 6, /* sg_graph_create: process the rows in a graph-derived locality order (output rows stay
                                 where the caller expects them): 0 = when the vertex numbering has no locality (>= 25 % of
                                 the edges span more than 4096 ids, V >= 65536), 1 = never, 2 = always */
-  SG_TUNE_GEMM_TILE = 5   /* sg_gemm_nt kernel: 0 = automatic (shipped: 128 x min(N,128) tiles, the persistent 256 x 256 kernel
+  SG_TUNE_GEMM_TILE = 5,  /* sg_gemm_nt kernel: 0 = automatic (shipped: 128 x min(N,128) tiles, the persistent 256 x 256 kernel
                              for the compute-bound products), 1 = 128-row tiles only, 2 = 64 x 256 wherever N > 64 (A/B
                              switch; measured slower), 3 = the 256 x 256 kernel wherever it takes the shape */
+  SG_TUNE_BLOCK_PLANES = 7 /* sg_block_*: 1 (default) = narrow layers keep their recurrence buffers as planes
+                              (sg_block_planar), 0 = column blocks everywhere (A/B switch) */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

@@ -140,6 +140,7 @@ _SIGNATURES = {
                                c_void_p]),
     "sg_block_sizeof": (c_int64, []),
     "sg_block_workspace": (c_int64, [POINTER(sg_block), c_int]),
+    "sg_block_planar": (c_int, [POINTER(sg_block)]),
     "sg_block_forward": (c_int, [POINTER(sg_block), c_void_p]),
     "sg_block_backward": (c_int, [POINTER(sg_block), c_void_p]),
     "sg_block_run": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
@@ -488,6 +489,7 @@ class PoolHandle:
 
 
 TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB, TUNE_TILED_MIN_ROW_BYTES, TUNE_GEMM_TILE, TUNE_GRAPH_REORDER = 0, 1, 2, 3, 4, 5, 6
+TUNE_BLOCK_PLANES = 7
 
 
 def tuning_set(knob: int, value: int) -> None:
@@ -1074,6 +1076,14 @@ def face_mask_bits(faces: torch.Tensor, vbits: torch.Tensor) -> torch.Tensor:
 
 
 # ---- one [ChebConv -> pool? -> BatchNorm -> activation] block per foreign call ---------------------------------------
+def block_planar(blk: sg_block) -> bool:
+    """Does the library take this block's T as K planes [K][V][Cin] (ldt = Cin)?  (sg_block_planar: narrow bf16 layers)"""
+    r = int(load().sg_block_planar(byref(blk)))
+    if r < 0:
+        _check(r, "sg_block_planar")
+    return r == 1
+
+
 def block_workspace(blk: sg_block, backward: bool) -> int:
     """Bytes of scratch sg_block_forward / sg_block_backward need for this block (depends on its shape fields only)."""
     n = load().sg_block_workspace(byref(blk), int(backward))       # 0 forward, 1 backward, 2: a partition block (all phases)

@@ -12,6 +12,8 @@
 namespace sg {
 namespace {
 
+bool g_block_planes = true;      // SG_TUNE_BLOCK_PLANES (A/B switch; sg_block_planar then answers 0)
+
 inline int64_t esize(int dtype) { return dtype == SG_F32 ? 4 : 2; }
 inline int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
@@ -101,6 +103,10 @@ struct Shape {
   int64_t V, Vo, Ci, Co, KCi, KCo, e;
   int K;
   bool thin, blas_fwd, blas_dx, blas_dw;
+  // narrow rows as planes (sg_common.h Planes): the K column blocks of the recurrence buffers -- T and dT of a layer that
+  // aggregates first (Cin wide), Z and G of one that aggregates after the product (Cout wide) -- as K dense [V, C] tensors
+  bool planes_ok;        // the shape qualifies (order 0: the caller chooses it by passing ldt == Cin)
+  Planes pl;             // of 2^log2 = C columns, V * C elements apart
   int64_t nb;            // sg_col_blocks(V_out)
   int64_t mom_floats;    // the larger of the tile-moment / block-moment buffers
   int64_t tn_floats;
@@ -149,6 +155,24 @@ int shape_of(const sg_block& b, Shape* s) {
     if (thin_shape(s->KCo, s->Ci)) {      // (never a layer of the reference: order 1 has K*Cout >= 2 and Cin > Cout)
       set_error("sg_block: order 1 with a %lld x %lld weight stack is not served", (long long)s->KCo, (long long)s->Ci);
       return SG_ERR_UNSUPPORTED;
+    }
+  }
+  {
+    const int64_t C = b.order == 0 ? s->Ci : s->Co;
+    int lg = 0;
+    while ((1 << lg) < C) ++lg;
+    bool ok = b.dtype == SG_BF16 && b.K > 1 && (1 << lg) == C && C >= 8 && C <= 64 && g_block_planes;
+    if (ok && b.order == 0)
+      ok = dense_planes_ok_nt(b.dtype, s->V, s->Co, s->KCi) && dense_planes_ok_nt(b.dtype, s->V, s->KCi, s->Co) &&
+           dense_planes_ok_tn(b.dtype, s->V, s->Co, s->KCi);
+    else if (ok)
+      ok = dense_planes_ok_nt(b.dtype, s->V, s->KCo, s->Ci) && dense_planes_ok_nt(b.dtype, s->V, s->Ci, s->KCo) &&
+           dense_planes_ok_tn(b.dtype, s->V, s->KCo, s->Ci);
+    s->planes_ok = ok;
+    s->pl = Planes{};
+    if (ok) {
+      s->pl.log2 = lg;
+      s->pl.stride = s->V * C;
     }
   }
   s->nb = col_blocks(s->Vo);
@@ -214,6 +238,20 @@ int pack(const sg_block& b, hipStream_t stream) {
   return SG_OK;
 }
 
+// The layout of the caller's T of a layer that aggregates first: ldt >= K*Cin = K column blocks of one [V, K*Cin] buffer;
+// ldt == Cin (K > 1) = K planes [K][V][Cin], for the shapes sg_block_planar() answers 1 for.
+int t_layout(const sg_block& b, const Shape& s, const char* who, Planes* pt) {
+  *pt = Planes{};
+  SG_REQUIRE(b.T != nullptr, "%s: order 0 needs the [V, K*Cin] buffer T", who);
+  if (b.K > 1 && b.ldt == s.Ci) {
+    SG_REQUIRE(s.planes_ok, "%s: T given as K planes (ldt == Cin) for a shape that does not take them (sg_block_planar)", who);
+    *pt = s.pl;
+    return SG_OK;
+  }
+  SG_REQUIRE(b.ldt >= s.KCi, "%s: row stride of T shorter than K*Cin", who);
+  return SG_OK;
+}
+
 int forward(const sg_block& b, hipStream_t stream) {
   Shape s;
   int rc = shape_of(b, &s);
@@ -234,29 +272,33 @@ int forward(const sg_block& b, hipStream_t stream) {
   void* const Hc = b.pool_mode ? w.Hc : b.H;
   bool tile_moments = false;
   if (b.order == 0) {
-    SG_REQUIRE(b.T && b.ldt >= s.KCi, "sg_block_forward: order 0 needs the [V, K*Cin] buffer T");
+    Planes pt;
+    if ((rc = t_layout(b, s, "sg_block_forward", &pt)) != SG_OK) return rc;
+    auto t = [&](int k) { return pt.on() ? col(b.T, k * pt.stride, s.e) : col(b.T, k * s.Ci, s.e); };
     if (b.X != b.T && (rc = copy_rows(b.X, b.ldx, b.T, b.ldt, s.V, s.Ci, b.dtype, stream)) != SG_OK) return rc;
     for (int k = 1; k < b.K; ++k) {     // Tx1 = L^ Tx0;  Txk = 2 L^ Tx(k-1) - Tx(k-2)
-      rc = spmm(b, false, col(b.T, (k - 1) * s.Ci, s.e), b.ldt, k >= 2 ? col(b.T, (k - 2) * s.Ci, s.e) : nullptr, b.ldt, nullptr, 0,
-                col(b.T, k * s.Ci, s.e), b.ldt, s.Ci, k == 1 ? 1.f : 2.f, -1.f, 0.f, stream);
+      rc = spmm(b, false, t(k - 1), b.ldt, k >= 2 ? t(k - 2) : nullptr, b.ldt, nullptr, 0, t(k), b.ldt, s.Ci, k == 1 ? 1.f : 2.f,
+                -1.f, 0.f, stream);
       if (rc != SG_OK) return rc;
     }
     const bool want = b.training && b.pool_mode == 0;      // (pooled rows have other statistics than the tiles of Hc)
     rc = dense_nt(b.T, b.ldt, b.wpack, b.wpack32, s.KCi, b.bias, Hc, s.Co, s.V, s.Co, s.KCi, b.dtype, want ? w.moments : nullptr,
-                  &tile_moments, w.blas, kBlasWorkspace, stream);
+                  &tile_moments, w.blas, kBlasWorkspace, stream, pt);
     if (rc != SG_OK) return rc;
   } else {
     // Z = X Wstack^T (+ bias on Z_0); Clenshaw in place: b_k = Z_k + 2 L^ b_(k+1) - b_(k+2); out = Z_0 + L^ b_1 - b_2
-    rc = dense_nt(b.X, b.ldx, b.wpack, nullptr, s.Ci, b.bias ? b.bias_k : nullptr, w.Z, s.KCo, s.V, s.KCo, s.Ci, b.dtype, nullptr,
-                  nullptr, w.blas, kBlasWorkspace, stream);
+    const Planes pz = s.planes_ok ? s.pl : Planes{};
+    const int64_t ldz = pz.on() ? s.Co : s.KCo;
+    rc = dense_nt(b.X, b.ldx, b.wpack, nullptr, s.Ci, b.bias ? b.bias_k : nullptr, w.Z, ldz, s.V, s.KCo, s.Ci, b.dtype, nullptr,
+                  nullptr, w.blas, kBlasWorkspace, stream, Planes{}, pz);
     if (rc != SG_OK) return rc;
-    auto z = [&](int k) { return col(w.Z, k * s.Co, s.e); };
+    auto z = [&](int k) { return pz.on() ? col(w.Z, k * pz.stride, s.e) : col(w.Z, k * s.Co, s.e); };
     for (int k = b.K - 2; k >= 1; --k) {
-      rc = spmm(b, false, z(k + 1), s.KCo, z(k), s.KCo, k + 2 <= b.K - 1 ? z(k + 2) : nullptr, s.KCo, z(k), s.KCo, s.Co, 2.f, 1.f,
-                -1.f, stream);
+      rc = spmm(b, false, z(k + 1), ldz, z(k), ldz, k + 2 <= b.K - 1 ? z(k + 2) : nullptr, ldz, z(k), ldz, s.Co, 2.f, 1.f, -1.f,
+                stream);
       if (rc != SG_OK) return rc;
     }
-    rc = spmm(b, false, z(1), s.KCo, z(0), s.KCo, b.K >= 3 ? z(2) : nullptr, s.KCo, Hc, s.Co, s.Co, 1.f, 1.f, -1.f, stream);
+    rc = spmm(b, false, z(1), ldz, z(0), ldz, b.K >= 3 ? z(2) : nullptr, ldz, Hc, s.Co, s.Co, 1.f, 1.f, -1.f, stream);
     if (rc != SG_OK) return rc;
   }
   if (b.pool_mode == 1) rc = sg_pool_mean(b.pool, Hc, s.Co, b.H, s.Co, s.Co, b.dtype, (void*)stream);
@@ -313,11 +355,13 @@ int backward(const sg_block& b, hipStream_t stream) {
                             b.acc_beta, nullptr, stream);
   if (rc != SG_OK) return rc;
   // where dH goes: order 1 runs its recurrence on the gradient, dH is block 0 of G; a pool sits in between in either order
+  const Planes pg = (b.order == 1 && s.planes_ok) ? s.pl : Planes{};       // order 1: G [V, K*Cout] as planes
+  const int64_t ldg = pg.on() ? s.Co : s.KCo;
   void* dHp = w.dHp;
   int64_t lddh = s.Co;
   if (b.order == 1 && b.pool_mode == 0) {
     dHp = w.G;
-    lddh = s.KCo;
+    lddh = ldg;
   }
   rc = launch_col_apply(1, b.dY, b.lddy, b.H, s.Co, scale, shift, mean, invstd, co + 4 * s.Co, co + 2 * s.Co, co + 3 * s.Co, b.slope,
                         dHp, lddh, s.Vo, s.Co, b.dtype, stream, w.colsum);
@@ -338,7 +382,7 @@ int backward(const sg_block& b, hipStream_t stream) {
   int64_t lddc = lddh;
   if (b.pool_mode) {
     dHc = b.order == 0 ? w.dHc : w.G;
-    lddc = b.order == 0 ? s.Co : s.KCo;
+    lddc = b.order == 0 ? s.Co : ldg;
     if (b.pool_mode == 1) rc = sg_pool_mean_bwd(b.pool, dHp, s.Co, dHc, lddc, s.Co, b.dtype, (void*)stream);
     else rc = sg_unpool_bwd(b.pool, dHp, s.Co, dHc, lddc, s.Co, b.dtype, (void*)stream);
     if (rc != SG_OK) return rc;
@@ -346,19 +390,20 @@ int backward(const sg_block& b, hipStream_t stream) {
   const bool tr = !b.graph->symmetric;
 
   if (b.order == 0) {
-    SG_REQUIRE(b.T && b.ldt >= s.KCi, "sg_block_backward: order 0 needs the saved [V, K*Cin] buffer T");
+    Planes pt;
+    if ((rc = t_layout(b, s, "sg_block_backward", &pt)) != SG_OK) return rc;
     rc = dense_tn(dHc, lddc, b.T, b.ldt, s.V, s.Co, s.KCi, b.dtype, w.tn, b.dW, s.KCi, w.blas, kBlasWorkspace, stream,
-                  sink_w ? &sink : nullptr, &sunk);
+                  sink_w ? &sink : nullptr, &sunk, Planes{}, pt);
     if (rc != SG_OK) return rc;
     if (b.need_dx) {
-      // dT = dH Wcat: block k = dL/dTx_k before the recurrence is unwound
+      // dT = dH Wcat: block k = dL/dTx_k before the recurrence is unwound (planes when T is)
       void* const dT = b.K == 1 ? b.dX : w.G;
-      const int64_t ldt = b.K == 1 ? b.lddx : s.KCi;
+      const int64_t ldt = b.K == 1 ? b.lddx : (pt.on() ? s.Ci : s.KCi);
       rc = dense_nn(dHc, lddc, b.wpack, s.KCi, b.wpack_t, s.Co, b.wpack32_t, dT, ldt, s.V, s.KCi, s.Co, b.dtype, w.blas,
-                    kBlasWorkspace, stream);
+                    kBlasWorkspace, stream, Planes{}, pt);
       if (rc != SG_OK) return rc;
       if (b.K > 1) {
-        auto g = [&](int k) { return col(dT, k * s.Ci, s.e); };
+        auto g = [&](int k) { return pt.on() ? col(dT, k * pt.stride, s.e) : col(dT, k * s.Ci, s.e); };
         for (int k = b.K - 2; k >= 1; --k) {     // g_k += 2 L^T g_(k+1) - g_(k+2), in place
           rc = spmm(b, tr, g(k + 1), ldt, g(k), ldt, k + 2 <= b.K - 1 ? g(k + 2) : nullptr, ldt, g(k), ldt, s.Ci, 2.f, 1.f, -1.f, stream);
           if (rc != SG_OK) return rc;
@@ -369,21 +414,21 @@ int backward(const sg_block& b, hipStream_t stream) {
     }
   } else {
     SG_REQUIRE(b.X && b.ldx >= s.Ci, "sg_block_backward: order 1 needs the saved input X");
-    auto g = [&](int k) { return col(w.G, k * s.Co, s.e); };
+    auto g = [&](int k) { return pg.on() ? col(w.G, k * pg.stride, s.e) : col(w.G, k * s.Co, s.e); };
     // G = [T_0 | T_1 | ..](L^T) dH: the forward Chebyshev recurrence applied to the gradient
-    rc = spmm(b, tr, g(0), s.KCo, nullptr, 0, nullptr, 0, g(1), s.KCo, s.Co, 1.f, 0.f, 0.f, stream);
+    rc = spmm(b, tr, g(0), ldg, nullptr, 0, nullptr, 0, g(1), ldg, s.Co, 1.f, 0.f, 0.f, stream);
     if (rc != SG_OK) return rc;
     for (int k = 2; k < b.K; ++k) {
-      rc = spmm(b, tr, g(k - 1), s.KCo, g(k - 2), s.KCo, nullptr, 0, g(k), s.KCo, s.Co, 2.f, -1.f, 0.f, stream);
+      rc = spmm(b, tr, g(k - 1), ldg, g(k - 2), ldg, nullptr, 0, g(k), ldg, s.Co, 2.f, -1.f, 0.f, stream);
       if (rc != SG_OK) return rc;
     }
     if (b.need_dx) {
-      rc = dense_nn(w.G, s.KCo, b.wpack, s.Ci, b.wpack_t, s.KCo, nullptr, b.dX, b.lddx, s.V, s.Ci, s.KCo, b.dtype, w.blas,
-                    kBlasWorkspace, stream);
+      rc = dense_nn(w.G, ldg, b.wpack, s.Ci, b.wpack_t, s.KCo, nullptr, b.dX, b.lddx, s.V, s.Ci, s.KCo, b.dtype, w.blas,
+                    kBlasWorkspace, stream, pg);
       if (rc != SG_OK) return rc;
     }
-    rc = dense_tn(w.G, s.KCo, b.X, b.ldx, s.V, s.KCo, s.Ci, b.dtype, w.tn, b.dW, s.Ci, w.blas, kBlasWorkspace, stream,
-                  sink_w ? &sink : nullptr, &sunk);
+    rc = dense_tn(w.G, ldg, b.X, b.ldx, s.V, s.KCo, s.Ci, b.dtype, w.tn, b.dW, s.Ci, w.blas, kBlasWorkspace, stream,
+                  sink_w ? &sink : nullptr, &sunk, pg);
     if (rc != SG_OK) return rc;
   }
 
@@ -667,6 +712,12 @@ int part_run(const sg_block& b, hipStream_t stream) {
 }
 
 }  // namespace
+
+int set_block_planes(int value) {
+  g_block_planes = value != 0;
+  return SG_OK;
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -684,6 +735,17 @@ SG_API int sg_block_run(const sg_block* blks, int64_t n, void* stream) {
 }
 
 SG_API int64_t sg_block_sizeof(void) { return (int64_t)sizeof(sg_block); }
+
+SG_API int sg_block_planar(const sg_block* blk) {
+  if (!blk) {
+    set_error("sg_block_planar: null block");
+    return SG_ERR_INVALID;
+  }
+  Shape s;
+  const int rc = shape_of(*blk, &s);
+  if (rc != SG_OK) return rc;
+  return (blk->order == 0 && s.planes_ok) ? 1 : 0;
+}
 
 SG_API int64_t sg_block_workspace(const sg_block* blk, int backward_pass) {
   if (!blk) {

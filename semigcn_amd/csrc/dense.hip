@@ -227,11 +227,28 @@ int64_t dense_tn_workspace(int dtype, int64_t M, int64_t N, int64_t Kp) {      /
   return S > 1 ? (S + 1) * N * Kp : 0;
 }
 
+// operands kept as planes (sg_common.h Planes) are read and written by the 128-row MFMA kernels only
+bool dense_planes_ok_nt(int dtype, int64_t M, int64_t N, int64_t K) {
+  return !thin_shape(N, K) && dense_nt_own(dtype, M, N, K, 8, 8, 8) && !gemm_nt_takes_big_tile(M, N, K, K, K, N) &&
+         gemm_tile_rows(N) == 128;
+}
+bool dense_planes_ok_tn(int dtype, int64_t M, int64_t N, int64_t Kp) {
+  return !thin_shape(N, Kp) && dense_tn_own(dtype, M, N, Kp, 8, 8) && !gemm_tn_takes_big_tile(M, N, Kp, N, Kp);
+}
+
 int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64_t ldb, const float* bias, void* C, int64_t ldc,
              int64_t M, int64_t N, int64_t K, int dtype, float* moments, bool* moments_done, void* blas_ws, size_t blas_ws_bytes,
-             hipStream_t stream) {
+             hipStream_t stream, Planes pa, Planes pc) {
   if (moments_done) *moments_done = false;
   if (M == 0 || N == 0) return SG_OK;
+  if (pa.on() || pc.on()) {
+    SG_REQUIRE(dense_planes_ok_nt(dtype, M, N, K) && a16(A) && a16(Bp) && a16(C),
+               "dense_nt: an operand kept as planes for a product the 128-row kernel does not serve (M=%lld N=%lld K=%lld)",
+               (long long)M, (long long)N, (long long)K);
+    if (moments_done) *moments_done = moments != nullptr;
+    TraceScope ts(1, dtype, 1, M, N, K, stream);
+    return launch_gemm_nt(A, lda, Bp, ldb, bias, C, ldc, M, N, K, dtype, moments, stream, pa, pc);
+  }
   if (thin_shape(N, K) && B32) {
     TraceScope ts(1, dtype, 2, M, N, K, stream);
     return launch_thin_nt(A, lda, B32, ldb, bias, C, ldc, M, N, K, dtype, stream);
@@ -249,9 +266,17 @@ int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64
 }
 
 int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void* Bt, int64_t ldbt, const float* Bt32, void* C,
-             int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream) {
+             int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream,
+             Planes pa, Planes pc) {
   // C[M, N] = A[M, K] B[K, N]; Bt = B^T [N, K] where a transposed copy exists (the MFMA / thin kernels read that one)
   if (M == 0 || N == 0) return SG_OK;
+  if (pa.on() || pc.on()) {
+    SG_REQUIRE(Bt && dense_planes_ok_nt(dtype, M, N, K) && a16(A) && a16(Bt) && a16(C),
+               "dense_nn: an operand kept as planes for a product the 128-row kernel does not serve (M=%lld N=%lld K=%lld)",
+               (long long)M, (long long)N, (long long)K);
+    TraceScope ts(1, dtype, 1, M, N, K, stream);
+    return launch_gemm_nt(A, lda, Bt, ldbt, nullptr, C, ldc, M, N, K, dtype, nullptr, stream, pa, pc);
+  }
   if (thin_shape(N, K) && Bt32) {
     TraceScope ts(1, dtype, 2, M, N, K, stream);
     return launch_thin_nt(A, lda, Bt32, ldbt, nullptr, C, ldc, M, N, K, dtype, stream);
@@ -265,11 +290,21 @@ int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void
 }
 
 int dense_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype, float* ws,
-             float* out, int64_t ldo, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream, const GradSink* sink, bool* sunk) {
+             float* out, int64_t ldo, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream, const GradSink* sink, bool* sunk,
+             Planes pa, Planes pb) {
   // out[N, Kp] (float32) = A[M, N]^T B[M, Kp]
   if (sunk) *sunk = false;
   if (N == 0 || Kp == 0) return SG_OK;
   SG_REQUIRE(M > 0, "dense_tn: no rows");
+  if (pa.on() || pb.on()) {
+    SG_REQUIRE(dense_planes_ok_tn(dtype, M, N, Kp) && a16(A) && a16(B) && a16(out) && ldo % 4 == 0,
+               "dense_tn: an operand kept as planes for a product the 128 x 128 kernel does not serve (M=%lld N=%lld Kp=%lld)",
+               (long long)M, (long long)N, (long long)Kp);
+    TraceScope ts(2, dtype, 1, M, N, Kp, stream);
+    const bool can = sink != nullptr && sink->Cin % 4 == 0;
+    if (sunk) *sunk = can;
+    return launch_gemm_tn(A, lda, B, ldb, M, N, Kp, dtype, ws, out, ldo, stream, can ? sink : nullptr, pa, pb);
+  }
   if (thin_shape(N, Kp)) {
     TraceScope ts(2, dtype, 2, M, N, Kp, stream);
     if (sunk) *sunk = sink != nullptr;

@@ -44,6 +44,8 @@ struct GemmArgs {
   float* moments;                 // nullable: [row tiles][2][N] = per-tile column (mean, M2) of the ROUNDED output
   int M, N, K;
   int n_col_tiles, n_tiles;
+  int a_plog; int64_t a_pstride;  // A / C kept as planes of 2^plog columns (sg_common.h Planes; 31: plain row-major)
+  int c_plog; int64_t c_pstride;
 };
 
 __device__ __forceinline__ int xcd_run(int b, int nblocks) {   // blocks b, b+8, .. (one XCD) get one contiguous run
@@ -105,8 +107,9 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16(const GemmArgs g) {
   auto fetch = [&](int k0) {                                   // global -> registers
     kin = k0 + s_c * 8 < g.K;                                  // K % 8 == 0: a chunk is wholly inside or outside
     const int koff = kin ? k0 + s_c * 8 : 0;
+    const int64_t aoff = plane_off(koff, g.a_plog, g.a_pstride);   // (a 16-byte chunk never straddles a plane: 2^plog % 8 == 0)
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i] + koff);
+    for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i] + aoff);
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) rb[i] = *(const u32x4*)(b_src[i] + koff);
   };
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16(const GemmArgs g) {
     const int r = q / CPR, c = q % CPR;
     const int gc = col0 + c * 8;
     if (r < rows_valid && gc < g.N)                           // N % 8 == 0: a chunk is wholly inside or outside
-      *(u32x4*)(g.C + (int64_t)(row0 + r) * g.ldc + gc) = *(const u32x4*)(ldsC + r * C_PITCH + c * 16);
+      *(u32x4*)(g.C + (int64_t)(row0 + r) * g.ldc + plane_off(gc, g.c_plog, g.c_pstride)) = *(const u32x4*)(ldsC + r * C_PITCH + c * 16);
   }
 
   if (MOMENTS && tid < BN && col0 + tid < g.N) {               // merge the WAVES_M partials of column tid, write out
@@ -315,7 +318,7 @@ int set_gemm_tuning(int value) {
 }
 
 int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
-                   int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream) {
+                   int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream, Planes pa, Planes pc) {
   if (dtype != SG_BF16) {
     set_error("sg_gemm_nt: bf16 operands only (dtype %d); fp32 products stay with the BLAS library", dtype);
     return SG_ERR_UNSUPPORTED;
@@ -327,9 +330,18 @@ int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const
     return SG_ERR_UNSUPPORTED;
   }
   SG_REQUIRE(M <= INT32_MAX && N <= INT32_MAX && K <= INT32_MAX, "sg_gemm_nt: size out of range");
-  if (moments == nullptr && gemm_nt_takes_big_tile(M, N, K, lda, ldb, ldc))
+  const bool planes = pa.on() || pc.on();
+  if (planes) {
+    SG_REQUIRE((!pa.on() || (pa.log2 >= 3 && pa.log2 < 31 && pa.stride % 8 == 0)) &&
+               (!pc.on() || (pc.log2 >= 3 && pc.log2 < 31 && pc.stride % 8 == 0)),
+               "sg_gemm_nt: planes need >= 8 columns each and a plane stride that is a multiple of 8 elements");
+    SG_REQUIRE(!wide_tile(N), "sg_gemm_nt: operands kept as planes run on the 128-row tiles only");
+  }
+  if (!planes && moments == nullptr && gemm_nt_takes_big_tile(M, N, K, lda, ldb, ldc))
     return launch_gemm_nt_256(A, lda, B, ldb, bias, C, ldc, M, N, K, stream);
   GemmArgs g;
+  g.a_plog = pa.log2; g.a_pstride = pa.stride;
+  g.c_plog = pc.log2; g.c_pstride = pc.stride;
   g.A = (const uint16_t*)A; g.lda = lda;
   g.B = (const uint16_t*)B; g.ldb = ldb;
   g.bias = bias;
@@ -379,6 +391,8 @@ struct TnArgs {
   float* W;                    // [n_slabs][N][Kp]
   int M, N, Kp;
   int tiles_n, tiles_k, n_tiles, n_blocks, slab_rows;
+  int a_plog; int64_t a_pstride;  // A / B kept as planes of 2^plog columns (sg_common.h Planes; 31: plain row-major)
+  int b_plog; int64_t b_pstride;
 };
 
 __device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -400,8 +414,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_tn_bf16(const TnArgs g) {
   // staging: chunk q = tid + 256 i -> tile row q / 16, 16-B chunk q % 16 (16 lanes = one 256-B row segment)
   const int s_c = tid & 15;
   const bool a_col = n0 + s_c * 8 < g.N, b_col = k0 + s_c * 8 < g.Kp;    // N, Kp % 8 == 0
-  const uint16_t* a_src = g.A + (a_col ? n0 + s_c * 8 : 0);
-  const uint16_t* b_src = g.B + (b_col ? k0 + s_c * 8 : 0);
+  const uint16_t* a_src = g.A + (a_col ? plane_off(n0 + s_c * 8, g.a_plog, g.a_pstride) : 0);
+  const uint16_t* b_src = g.B + (b_col ? plane_off(k0 + s_c * 8, g.b_plog, g.b_pstride) : 0);
   int dst_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -542,7 +556,7 @@ int64_t gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
 }
 
 int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
-                   float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink_) {
+                   float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink_, Planes pa, Planes pb) {
   const GradSink sink = sink_ ? *sink_ : GradSink{};
   SG_REQUIRE(sink.mode == 0 || sink.Cin % 4 == 0, "sg_gemm_tn: a gradient sink needs Cin to be a multiple of 4");
   if (dtype != SG_BF16) {
@@ -554,7 +568,12 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
     return SG_ERR_UNSUPPORTED;
   }
   SG_REQUIRE(M > 0 && M <= INT32_MAX && N <= INT32_MAX && Kp <= INT32_MAX, "sg_gemm_tn: size out of range");
-  if (gemm_tn_takes_big_tile(M, N, Kp, lda, ldb)) {
+  const bool planes = pa.on() || pb.on();
+  if (planes)
+    SG_REQUIRE((!pa.on() || (pa.log2 >= 3 && pa.log2 < 31 && pa.stride % 8 == 0)) &&
+               (!pb.on() || (pb.log2 >= 3 && pb.log2 < 31 && pb.stride % 8 == 0)),
+               "sg_gemm_tn: planes need >= 8 columns each and a plane stride that is a multiple of 8 elements");
+  if (!planes && gemm_tn_takes_big_tile(M, N, Kp, lda, ldb)) {
     const int64_t m_full = M / 64 * 64, elems = N * Kp;
     int64_t slabs = gemm_tn_256_slabs(M, N, Kp);
     const int rc = launch_gemm_tn_256(A, lda, B, ldb, M, N, Kp, workspace, stream);
@@ -570,6 +589,7 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
       t.n_tiles = t.tiles_n * t.tiles_k;
       t.slab_rows = 512;
       t.n_blocks = t.n_tiles;
+      t.a_plog = t.b_plog = 31; t.a_pstride = t.b_pstride = 0;
       gemm_tn_bf16<<<t.n_blocks, kThreads, 0, stream>>>(t);
       SG_HIP_TRY(hipGetLastError());
       ++slabs;
@@ -587,6 +607,8 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
   g.tiles_k = (int)((Kp + 127) / 128);
   g.n_tiles = g.tiles_n * g.tiles_k;
   g.slab_rows = tn_slab_rows(M, g.n_tiles);
+  g.a_plog = pa.log2; g.a_pstride = pa.stride;
+  g.b_plog = pb.log2; g.b_pstride = pb.stride;
   const int64_t slabs = small_tn_slabs(M, N, Kp);
   SG_REQUIRE(slabs * g.n_tiles <= INT32_MAX, "sg_gemm_tn: too many workgroups");
   g.n_blocks = (int)(slabs * g.n_tiles);

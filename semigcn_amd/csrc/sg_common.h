@@ -110,6 +110,19 @@ __device__ __forceinline__ float* sink_ptr(const GradSink& s, int64_t n, int64_t
   const int64_t k = n / s.Cout;
   return s.dst[k] + (n - k * s.Cout) * s.Cin + kk;
 }
+// A matrix operand kept as PLANES of 2^log2 columns: element (r, c) lives at base + (c >> log2) * stride + r * ld +
+// (c & (2^log2 - 1)) (elements; ld = the row pitch inside a plane).  The K column blocks [Tx0 | Tx1 | Tx2] of a narrow
+// ChebConv layer (16 .. 64 channels: 32 .. 128-byte rows) are stored this way -- K dense [V, C] tensors -- because an
+// aggregation that gathers 32-byte rows from a 96-byte pitch uses a quarter of every line it pulls.
+// log2 = 31: one plane, plain row-major.
+struct Planes {
+  int log2 = 31;
+  int64_t stride = 0;
+  bool on() const { return log2 != 31; }
+};
+__host__ __device__ __forceinline__ int64_t plane_off(int c, int log2, int64_t stride) {
+  return (int64_t)(c >> log2) * stride + (c & (int)((1u << log2) - 1u));
+}
 // Products with a tiny weight matrix (thin_gemm.hip)
 bool thin_shape(int64_t N, int64_t K);
 int64_t thin_tn_blocks(int64_t V);
@@ -228,7 +241,7 @@ int launch_mesh_loss_finalize(const float* partial, int64_t nb, float n_v, float
 int gemm_tile_rows(int64_t N);      // rows per output tile (= rows per BatchNorm-moments record) for an N-column product
 int set_gemm_tuning(int value);
 int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, void* C, int64_t ldc,
-                   int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream);
+                   int64_t M, int64_t N, int64_t K, int dtype, float* moments, hipStream_t stream, Planes pa = {}, Planes pc = {});
 
 bool gemm_nt_takes_big_tile(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc);
 // gemm_mfma256.hip
@@ -242,7 +255,8 @@ int launch_gemm_tn_256(const void* A, int64_t lda, const void* B, int64_t ldb, i
 bool gemm_tn_takes_big_tile(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 int64_t gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp);
 int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
-                   float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink = nullptr);
+                   float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink = nullptr, Planes pa = {},
+                   Planes pb = {});
 
 // mesh_loss.hip
 int64_t mesh_loss_blocks(int64_t V, int64_t F);
@@ -279,23 +293,31 @@ struct TraceScope {
   }
 };
 
+// block.hip
+int set_block_planes(int value);
+
 // dense.hip -- the three product shapes of a ChebConv layer behind one engine choice (thin kernels / own MFMA / BLAS library)
 constexpr size_t kBlasWorkspace = 76u << 20;     // scratch handed to the BLAS library per call (PyTorch's default for this GPU family)
 bool dense_nt_own(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc);
 bool dense_tn_own(int dtype, int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 int64_t dense_tn_workspace(int dtype, int64_t M, int64_t N, int64_t Kp);
 // C[M, N] = A[M, K] Bp[N, K]^T (+ bias): Bp in the feature dtype, B32 (nullable) the same matrix in float32 for the thin kernels
+// pa / pc: A / C kept as planes (served by the 128-row MFMA kernel only: dense_planes_ok says whether a shape gets there)
 int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64_t ldb, const float* bias, void* C, int64_t ldc,
              int64_t M, int64_t N, int64_t K, int dtype, float* moments, bool* moments_done, void* blas_ws, size_t blas_ws_bytes,
-             hipStream_t stream);
+             hipStream_t stream, Planes pa = {}, Planes pc = {});
+// do the nt product [M, K] x [N, K]^T and the tn product [M, N]^T [M, Kp] of these sizes run on the kernels that take planes?
+bool dense_planes_ok_nt(int dtype, int64_t M, int64_t N, int64_t K);
+bool dense_planes_ok_tn(int dtype, int64_t M, int64_t N, int64_t Kp);
 // C[M, N] = A[M, K] Bp[K, N]; Bt (nullable) = Bp^T [N, K] in the feature dtype, Bt32 (nullable) in float32
 int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void* Bt, int64_t ldbt, const float* Bt32, void* C,
-             int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream);
+             int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream,
+             Planes pa = {}, Planes pc = {});
 // out[N, Kp] (float32) = A[M, N]^T B[M, Kp]; ws: dense_tn_workspace() floats
 // sink (nullable): also += the result into the K weight accumulators; *sunk tells whether the engine that ran could do it
 int dense_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype, float* ws,
              float* out, int64_t ldo, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream, const GradSink* sink = nullptr,
-             bool* sunk = nullptr);
+             bool* sunk = nullptr, Planes pa = {}, Planes pb = {});
 
 }  // namespace sg
 

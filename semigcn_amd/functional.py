@@ -153,6 +153,37 @@ def _adopt_wide(x: torch.Tensor, K: int, rows: Optional[int] = None):
     return base
 
 
+#: [K, rows, C] buffers of K dense planes (``_new_planes``): what a NARROW layer that aggregates first keeps its Tx_k in
+#: (include/semigcn.h, sg_block_planar): plane 0 is handed to the caller as an ordinary contiguous [V, C] tensor.
+_plane_buffers: "weakref.WeakValueDictionary[int, torch.Tensor]" = weakref.WeakValueDictionary()
+#: C (channels per plane) the library takes as planes -- the static part of sg_block_planar's rule; a consumer that does not
+#: qualify after all (its products on another engine) reads plane 0 as the plain tensor it is
+PLANE_CHANNELS = (8, 16, 32, 64)
+USE_PLANES = True
+
+
+def _planes_wanted(C: int, K: int, dtype) -> bool:
+    return USE_PLANES and K > 1 and dtype == torch.bfloat16 and C in PLANE_CHANNELS
+
+
+def _new_planes(V: int, C: int, K: int, dtype, device) -> torch.Tensor:
+    """Plane 0 (a contiguous [V, C] tensor) of a fresh, registered [K, V, C] buffer; planes 1..K-1 are reserved for the
+    block that adopts it (``_adopt_planes``)."""
+    base = torch.empty((K, V, C), dtype=dtype, device=device)
+    _plane_buffers[base.untyped_storage().data_ptr()] = base
+    return base[0]
+
+
+def _adopt_planes(x: torch.Tensor, K: int):
+    """The registered [K, V, C] buffer whose plane 0 ``x`` is, or None."""
+    if x.dim() != 2 or not x.is_contiguous() or x.storage_offset() != 0:
+        return None
+    base = _plane_buffers.get(x.untyped_storage().data_ptr())
+    if base is None or base.shape != (K, x.shape[0], x.shape[1]) or base.dtype != x.dtype:
+        return None
+    return base
+
+
 #: column sums that the kernel which WROTE a tensor has already taken (the fused BatchNorm backward leaves the sums of
 #: its dH: the bias gradient of the ChebConv in front of it): id(tensor) -> (weakref to it, its version, fp32 [C] sums).
 #: An entry is honoured only for the very same tensor object, unmodified since; at most a handful are kept.
@@ -1094,7 +1125,7 @@ class _Layout:
     """Where everything of one run of blocks lives for one input shape: offsets into the activation arena (kept until
     backward), the gradient buffer, and the scratch sizes."""
     __slots__ = ("rows", "off_in", "off_H", "off_stats", "arena_bytes", "ws_fwd", "ws_bwd", "dx_bytes", "off_dW", "off_dvec",
-                 "grad_floats")
+                 "grad_floats", "planar", "ldt")
 
 
 class BlockChain:
@@ -1110,19 +1141,39 @@ class BlockChain:
             p.init_descriptor(self.fwd[i])
             p.init_descriptor(self.bwd[i])
         self._layouts: dict = {}
+        self._planar: dict = {}
         self._sig = [None, None]        # static part last written into fwd / bwd
         self._dyn = [None, None]        # buffer addresses last written
         self._train = [None, None]
         self._acc = None                # gradient-accumulator addresses last written into bwd
 
-    def layout(self, dtype: torch.dtype, rows, in_place: bool, handles) -> _Layout:
-        key = (dtype, rows, in_place)
+    def takes_planes(self, i: int, dtype: torch.dtype, V: int, Vo: int, graph_h, pool_h) -> bool:
+        """Does block i keep its [Tx0 | Tx1 | ..] as K planes at this size (sg_block_planar)?"""
+        p = self.plans[i]
+        if not (p.order == 0 and _planes_wanted(p.Cin, p.K, dtype)):
+            return False
+        key = (i, dtype, V, Vo)
+        ans = self._planar.get(key)
+        if ans is None:
+            probe = capi.sg_block()
+            p.init_descriptor(probe)
+            probe.graph, probe.pool = graph_h, pool_h
+            probe.dtype, probe.V, probe.V_out, probe.training = capi._DTYPES[dtype], V, Vo, 1
+            ans = self._planar[key] = capi.block_planar(probe)
+        return ans
+
+    def layout(self, dtype: torch.dtype, rows, in_place: bool, handles, planes0: bool = False) -> _Layout:
+        key = (dtype, rows, in_place, planes0, USE_PLANES)
         lay = self._layouts.get(key)
         if lay is not None:
             return lay
         e = 4 if dtype == torch.float32 else 2
         lay = _Layout()
         lay.rows = rows
+        # which blocks keep their recurrence buffer T as planes [K][V][Cin] (ldt = Cin) instead of [V, K*Cin]
+        lay.planar = [(planes0 if (i == 0 and in_place) else self.takes_planes(i, dtype, V, Vo, *handles[i]))
+                      for i, (V, Vo) in enumerate(rows)]
+        lay.ldt = [(p.Cin if pl else p.K * p.Cin) for p, pl in zip(self.plans, lay.planar)]
         lay.off_in, lay.off_H, lay.off_stats, lay.off_dW, lay.off_dvec = [], [], [], [], []
         at = gat = 0
         ws_f = ws_b = dxb = 0
@@ -1216,20 +1267,31 @@ class _ChainFn(torch.autograd.Function):
             V = Vo
         rows = tuple(rows)
         p0 = plans[0]
-        base = None                       # block 0's [V, K*Cin] buffer when its input was born inside one
+        base = None                       # block 0's [V, K*Cin] (or [K, V, Cin]) buffer when its input was born inside one
+        planes0 = False
         if p0.order == 0:
             base = _adopt_wide(x, p0.K) if p0.K > 1 else (x if x.is_contiguous() else None)
+            if base is None and p0.K > 1:
+                pb = _adopt_planes(x, p0.K)
+                if pb is not None and chain.takes_planes(0, dtype, rows[0][0], rows[0][1], graphs[0].handle._h,
+                                                         None if pools[0] is None else pools[0]._h):
+                    base, planes0 = pb, True
         if base is None and x.stride(1) != 1:
             x = x.contiguous()
-        lay = chain._layouts.get((dtype, rows, base is not None))
+        lay = chain._layouts.get((dtype, rows, base is not None, planes0, USE_PLANES))
         if lay is None:
             lay = chain.layout(dtype, rows, base is not None,
-                               [(g.handle._h, None if pl is None else pl._h) for g, pl in zip(graphs, pools)])
+                               [(g.handle._h, None if pl is None else pl._h) for g, pl in zip(graphs, pools)], planes0)
         arena = torch.empty(lay.arena_bytes, dtype=torch.uint8, device=dev)
         ws = torch.empty(lay.ws_fwd, dtype=torch.uint8, device=dev)
         pl = plans[-1]
         Vo = rows[-1][1]
-        y = _new_wide(Vo, Vo, pl.Cout, widen, dtype, dev) if widen > 1 else torch.empty((Vo, pl.Cout), dtype=dtype, device=dev)
+        if widen > 1 and _planes_wanted(pl.Cout, widen, dtype):
+            y = _new_planes(Vo, pl.Cout, widen, dtype, dev)          # (a consumer that does not take planes reads plane 0 as is)
+        elif widen > 1:
+            y = _new_wide(Vo, Vo, pl.Cout, widen, dtype, dev)
+        else:
+            y = torch.empty((Vo, pl.Cout), dtype=dtype, device=dev)
         chain.fill_static(0, lay, dtype, dev, graphs, pools)
         training = tuple(1 if p.bn.training else 0 for p in plans)
         if training != chain._train[0]:
@@ -1247,13 +1309,13 @@ class _ChainFn(torch.autograd.Function):
                 if i == 0:
                     if base is not None:
                         blk.T = blk.X = dyn[6]
-                        blk.ldt = blk.ldx = p.K * p.Cin
+                        blk.ldt = blk.ldx = lay.ldt[0]
                     else:
                         blk.X, blk.ldx = dyn[4], dyn[5]
-                        blk.T, blk.ldt = (a0 + lay.off_in[0], p.K * p.Cin) if p.order == 0 else (None, 0)
-                elif p.order == 0:          # the block in front wrote its output into the first columns of T
+                        blk.T, blk.ldt = (a0 + lay.off_in[0], lay.ldt[0]) if p.order == 0 else (None, 0)
+                elif p.order == 0:          # the block in front wrote its output into the first columns (or plane) of T
                     blk.T = blk.X = a0 + lay.off_in[i]
-                    blk.ldt = blk.ldx = p.K * p.Cin
+                    blk.ldt = blk.ldx = lay.ldt[i]
                 else:
                     blk.X, blk.ldx, blk.T, blk.ldt = a0 + lay.off_in[i], p.Cin, None, 0
                 blk.H, blk.stats = a0 + lay.off_H[i], a0 + lay.off_stats[i]
@@ -1261,7 +1323,7 @@ class _ChainFn(torch.autograd.Function):
                     blk.Y, blk.ldy = dyn[2], dyn[3]
                 else:
                     q = plans[i + 1]
-                    blk.Y, blk.ldy = a0 + lay.off_in[i + 1], (q.K * q.Cin if q.order == 0 else q.Cin)
+                    blk.Y, blk.ldy = a0 + lay.off_in[i + 1], (lay.ldt[i + 1] if q.order == 0 else q.Cin)
                 blk.ws = w0
             chain._dyn[0] = dyn
         capi.block_chain_forward(blks, n, capi._stream(x))
@@ -1304,7 +1366,7 @@ class _ChainFn(torch.autograd.Function):
             for i, p in enumerate(plans):
                 blk = blks[i]
                 if p.order == 0:
-                    blk.T, blk.ldt, blk.X, blk.ldx = (dyn[6] if (i == 0 and in_place) else a0 + lay.off_in[i]), p.K * p.Cin, None, 0
+                    blk.T, blk.ldt, blk.X, blk.ldx = (dyn[6] if (i == 0 and in_place) else a0 + lay.off_in[i]), lay.ldt[i], None, 0
                 elif i == 0:
                     blk.T, blk.ldt, blk.X, blk.ldx = None, 0, dyn[6], dyn[7]
                 else:

@@ -220,6 +220,73 @@ def test_chains_and_single_block_calls_are_the_same_arithmetic():
     assert la == lb and all(torch.equal(a, b) for a, b in zip(ga, gb))
 
 
+@pytest.mark.parametrize("chains", [True, False])
+def test_narrow_layers_as_planes_are_the_same_arithmetic(chains):
+    """sg_block_planar: the narrow bf16 layers (16 / 32 / 64 channels) keep [Tx0 | Tx1 | Tx2] (and the library its dT / Z / G
+    scratch) as K dense [V, C] planes instead of column blocks of a [V, K*C] buffer -- addresses only: two SGCN training
+    iterations with and without the planes (SG_TUNE_BLOCK_PLANES / functional.USE_PLANES) are bit-identical, in one chain
+    (the planes sit in the chain's arena) and block by block (the producer hands plane 0 of a registered [K, V, C] buffer to
+    the block that adopts it)."""
+    from semigcn_amd import train
+
+    def run(planes: bool):
+        old, oldc = F_sg.USE_PLANES, F_sg.USE_BLOCK_CHAINS
+        F_sg.USE_PLANES, F_sg.USE_BLOCK_CHAINS = planes, chains
+        capi.tuning_set(capi.TUNE_BLOCK_PLANES, 1 if planes else 0)
+        try:
+            m = synth.torus_mesh(48, 32)
+            torch.manual_seed(11)
+            net = SingleScaleGCN(DEV).to(DEV)
+            net.set_feature_dtype(torch.bfloat16)
+            tr = train.SGCNTrainer(net, _batch(m, 5))
+            losses = [float(tr.iteration_step()) for _ in range(2)]
+            used = [bool(pl) for ch in F_sg._chains.values() for lay in ch._layouts.values() for pl in lay.planar
+                    if any(p.conv is net.blocks[i].module_0 for p in ch.plans for i in range(13))]
+            return losses, [p.grad.clone() for p in net.parameters()], used
+        finally:
+            F_sg.USE_PLANES, F_sg.USE_BLOCK_CHAINS = old, oldc
+            capi.tuning_set(capi.TUNE_BLOCK_PLANES, 1)
+    la, ga, ua = run(True)
+    lb, gb, ub = run(False)
+    # 16 -> 32, 32 -> 64 and 64 -> 128 aggregate first on 16 / 32 / 64 channels: their T is planes (the decoder's narrow layers
+    # aggregate after the product: planes inside the library's scratch)
+    assert sum(ua) == 3 and not any(ub), (ua, ub)
+    assert la == lb and all(torch.equal(a, b) for a, b in zip(ga, gb))
+
+
+def test_planes_of_a_single_narrow_block_against_column_blocks():
+    """One order-0 block (16 -> 32) and one order-1 block (64 -> 16) at an odd row count, planes against column blocks: outputs,
+    input gradient, every parameter gradient and the BatchNorm buffers bit-identical; a shape whose products leave the
+    128-row kernels (16 -> 1024) answers 0 to sg_block_planar and runs on column blocks."""
+    m = synth.torus_mesh(37, 29)
+    g = MeshGraph.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), m.num_vertices)
+    for cin, cout in ((16, 32), (64, 16), (8, 64)):
+        seq = _block_module(cin, cout, seed=cin)
+        gen = torch.Generator().manual_seed(cin + cout)
+        x = torch.randn(m.num_vertices, cin, generator=gen).to(DEV).bfloat16()
+        r = torch.randn(m.num_vertices, cout, generator=gen).to(DEV)
+        state = {k: v.clone() for k, v in seq.state_dict().items()}
+        got = _run(seq, g, x, r)
+        capi.tuning_set(capi.TUNE_BLOCK_PLANES, 0)
+        F_sg.USE_PLANES = False
+        try:
+            seq.load_state_dict(state)
+            want = _run(seq, g, x, r)
+        finally:
+            capi.tuning_set(capi.TUNE_BLOCK_PLANES, 1)
+            F_sg.USE_PLANES = True
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (cin, cout, i)
+    blk = capi.sg_block()
+    blk.graph, blk.dtype, blk.K, blk.V, blk.V_out = g.handle._h, capi._DTYPES[torch.bfloat16], 3, m.num_vertices, m.num_vertices
+    for cin, cout, want in ((16, 32, True), (64, 128, True), (16, 1024, True), (32, 2048, False), (128, 256, False), (4, 16, False)):
+        blk.Cin, blk.Cout, blk.order = cin, cout, 0
+        assert capi.block_planar(blk) == want, (cin, cout)
+    blk.dtype = capi._DTYPES[torch.float32]
+    blk.Cin, blk.Cout = 16, 32
+    assert capi.block_planar(blk) is False
+
+
 def test_golden_sgcn_through_the_block_calls(fixture_meshes):
     """Golden g2 (outputs, BatchNorm statistics and parameter gradients of the reference's own SingleScaleGCN, frozen by
     oracle/make_golden.py) reproduced with every block served by sg_block_forward / sg_block_backward: the golden test of
