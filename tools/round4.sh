@@ -10,9 +10,12 @@ bash tools/profile_round.sh r04 $COMMIT > $O/profile_round.log 2>&1
 python bench.py --steps 20 --warmup 5 > $O/bench_default_n1.json 2> $O/bench_default_n1.err
 bash tools/config_table.sh $O/configs_n1.jsonl > $O/config_table.log 2>&1
 bash tools/block_ab.sh $O/block_ab.jsonl > $O/block_ab.txt 2>&1
+rm -f $O/planes_ab.jsonl; bash tools/planes_ab.sh $O/planes_ab.jsonl > /dev/null 2>&1
+: > $O/host_call_census.jsonl
 for w in "--mesh 100x50 --dtype fp32" "--mesh 250x200 --dtype fp32" "--mesh 250x200 --dtype bf16" "--mesh 250x200 --dtype fp32 --model mgcn"; do
   python tools/host_call_census.py $w 2>/dev/null >> $O/host_call_census.jsonl
 done
+rm -f $O/rank_proxy_125k.jsonl $O/host_call_census.jsonl.old
 for i in 1 2; do
   # unpartitioned block of a rank's size; the rank: blocks phase by phase (default) / per-module eager / per-module replayed
   for m in "--no-graph" "--partitioned" "--partitioned --no-phases" "--partitioned --no-phases --graph" "--graph"; do
