@@ -67,6 +67,35 @@ def test_argument_validation_without_gpu():
     assert lib.sg_input_prep_blocks(0) == 0 and lib.sg_input_prep_blocks(1025) == 2
 
 
+def test_block_and_trace_entry_points_without_gpu():
+    """sg_block_* / sg_trace_* (include/semigcn.h; the per-block orchestration of util/networks.py:83-101 below the C ABI):
+    the ctypes mirror of the descriptor has the library's size, and every entry point rejects a bad descriptor before it
+    touches a device."""
+    lib = capi.load()
+    assert ctypes.sizeof(capi.sg_block) == lib.sg_block_sizeof()
+    blk = capi.sg_block()
+    for fn in (lib.sg_block_forward, lib.sg_block_backward):
+        assert fn(None, None) == -1 and b"null block" in lib.sg_last_error()
+        assert fn(ctypes.byref(blk), None) == -1 and b"null graph" in lib.sg_last_error()
+    assert lib.sg_block_workspace(None, 0) == -1 and lib.sg_block_workspace(ctypes.byref(blk), 1) == -1
+    assert lib.sg_block_planar(None) == -1 and b"null block" in lib.sg_last_error()
+    assert lib.sg_block_planar(ctypes.byref(blk)) == -1 and b"null graph" in lib.sg_last_error()
+    for fn in (lib.sg_block_chain_forward, lib.sg_block_chain_backward, lib.sg_block_run):
+        assert fn(None, 0, None) == 0
+        assert fn(None, 2, None) == -1 and b"bad argument" in lib.sg_last_error()
+        assert fn(None, -1, None) == -1
+    blks = (capi.sg_block * 2)()
+    assert lib.sg_block_chain_forward(blks, 2, None) == -1 and b"null graph" in lib.sg_last_error()
+    assert lib.sg_block_run(blks, 2, None) == -1 and b"no phase" in lib.sg_last_error()
+    # the launch trace: switched on and off without a device, nothing recorded
+    assert lib.sg_trace_begin(-1, 7) == -1 and b"capacity" in lib.sg_last_error()
+    assert lib.sg_trace_begin(0, 7) == 0 and lib.sg_trace_read(None, 0) == 0 and lib.sg_trace_end() == 0
+    assert lib.sg_trace_read(None, 4) == -1
+    # which weight shapes the thin-product kernels take (<= 256 entries, <= 32 columns / rows)
+    assert lib.sg_thin_supported(16, 12) == 1 and lib.sg_thin_supported(3, 16) == 1 and lib.sg_thin_supported(32, 48) == 0
+    assert lib.sg_tuning_set(capi.TUNE_BLOCK_PLANES, 1) == 0
+
+
 def test_no_cpu_fallback():
     ei = torch.tensor([[0, 1], [1, 0]])
     with pytest.raises(capi.SemigcnLibraryError, match="HIP device only"):
