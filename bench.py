@@ -559,10 +559,15 @@ def distributed_estimate(args, ms_per_step_n1: float):
             return json.loads(line[-1]) if line else {"error": (r.stderr or "")[-300:]}
         except Exception as e:          # the estimate must never cost the bench line
             return {"error": f"{type(e).__name__}: {e}"}
-    part = run(["--partitioned"])
+    # (a rank is bound by its host: the figure moves with whatever else the box's cores are doing, so the rank's run is
+    # repeated and the faster of the two stands -- both are reported)
+    parts = [run(["--partitioned"]) for _ in range(2)]
     solo = run(["--no-graph"])
+    good = [p for p in parts if "ms_per_step" in p]
+    part = min(good, key=lambda p: p["ms_per_step"]) if good else parts[0]
     if "ms_per_step" in part:
         out["rank_ms_per_step"] = round(part["ms_per_step"], 3)
+        out["rank_ms_per_step_runs"] = [round(p["ms_per_step"], 3) for p in good]
         d = part.get("distributed") or {}
         out["collectives_per_iteration"] = d.get("collectives_per_iteration")
         out["rank_path"] = "per-module" if d.get("per_module_path") else "blocks phase by phase below the C ABI (eager)"

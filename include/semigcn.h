@@ -586,7 +586,8 @@ enum sg_tune_knob {
                                 the edges span more than 4096 ids, V >= 65536), 1 = never, 2 = always */
   SG_TUNE_GEMM_TILE = 5,  /* sg_gemm_nt kernel: 0 = automatic (shipped: 128 x min(N,128) tiles, the persistent 256 x 256 kernel
                              for the compute-bound products), 1 = 128-row tiles only, 2 = 64 x 256 wherever N > 64 (A/B
-                             switch; measured slower), 3 = the 256 x 256 kernel wherever it takes the shape */
+                             switch; measured slower), 3 = the 256 x 256 kernel wherever it takes the shape, 4 = no 128 x 192 tiles for
+                             N = 192 (A/B switch), 5 = 128 x 192 tiles also for N = 384 (A/B switch; measured slower) */
   SG_TUNE_BLOCK_PLANES = 7 /* sg_block_*: 1 (default) = narrow layers keep their recurrence buffers as planes
                               (sg_block_planar), 0 = column blocks everywhere (A/B switch) */
 };

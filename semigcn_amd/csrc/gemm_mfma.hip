@@ -55,7 +55,7 @@ __device__ __forceinline__ int xcd_run(int b, int nblocks) {   // blocks b, b+8,
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool MOMENTS>
-__global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16(const GemmArgs g) {
+__global__ __launch_bounds__(kThreads, (WAVES_N * NT > 8 && WAVES_M * MT >= 8) ? 2 : 3) void gemm_nt_bf16(const GemmArgs g) {
   static_assert(WAVES_M * WAVES_N == 4, "four wavefronts per workgroup");
   constexpr int BM = WAVES_M * MT * 16, BN = WAVES_N * NT * 16;
   constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes;
@@ -302,6 +302,9 @@ constexpr int64_t kBigMinRows = 16384;
 // r02_mfma_gemm_bench.json): the column tiles of a row tile already share A through L2 (XCD-contiguous tile order),
 // and the narrower row tile re-streams B twice as often.  Kept behind the knob for A/B runs only.
 bool wide_tile(int64_t N) { return g_gemm_tile == 2 && N > 64; }
+// (measured at V = 1 M, profiles/r04_gemm192_bench.json: N = 192 0.199 -> 0.174 ms at K = 128, 0.143 -> 0.115 at K = 64; N = 384 as
+// two such tiles at two workgroups per CU is SLOWER than three 128-column tiles at three: 0.393 -> 0.442 ms; 4: A/B switch, off)
+bool tile_192(int64_t N) { return g_gemm_tile != 1 && g_gemm_tile != 4 && (N == 192 || (g_gemm_tile == 5 && N == 384)); }
 
 }  // namespace
 
@@ -350,6 +353,9 @@ int launch_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.n_col_tiles = g.n_tiles = 0;
   if (wide_tile(N)) return launch<1, 4, 4, 4>(g, stream);  // 64 x 256, wavefront tile 64 x 64
+  // N = 192 (the products around the 64 <-> 128-channel layers: [V,128]x[128,192]): ONE 128 x 192 tile per row tile, wavefront
+  // tile 64 x 96 -- no half-empty second column tile, A staged once
+  if (tile_192(N) && !moments) return launch<2, 2, 4, 6>(g, stream);
   if (N > 64) return launch<2, 2, 4, 4>(g, stream);     // 128 x 128, wavefront tile 64 x 64
   if (N > 32) return launch<4, 1, 2, 4>(g, stream);     // 128 x 64,  wavefront tile 32 x 64
   if (N > 16) return launch<4, 1, 2, 2>(g, stream);     // 128 x 32

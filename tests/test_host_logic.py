@@ -401,6 +401,28 @@ def test_wide_buffer_adoption_needs_a_registered_buffer(cpu_kernels):
     assert F_sg._adopt_wide(wide.clone(), 3) is None
 
 
+def test_plane_buffer_adoption_needs_a_registered_buffer():
+    """functional._new_planes / _adopt_planes (the narrow layers' [K, V, C] recurrence buffers, include/semigcn.h
+    sg_block_planar): plane 0 is an ordinary contiguous tensor for everybody but the block that adopts it, and only the
+    registered buffer of the right shape and dtype is adopted."""
+    from semigcn_amd import functional as F_sg
+    x = F_sg._new_planes(40, 16, 3, torch.bfloat16, "cpu")
+    assert x.shape == (40, 16) and x.is_contiguous() and x.storage_offset() == 0
+    base = F_sg._adopt_planes(x, 3)
+    assert base is not None and base.shape == (3, 40, 16) and base[0].data_ptr() == x.data_ptr()
+    assert F_sg._adopt_planes(x, 2) is None                      # another K
+    assert F_sg._adopt_planes(x.clone(), 3) is None              # a copy owns no neighbouring planes
+    assert F_sg._adopt_planes(x[:20], 3) is None                 # fewer rows than the planes were made for
+    assert F_sg._adopt_planes(base[1], 3) is None                # not plane 0
+    assert F_sg._adopt_planes(torch.zeros(3, 40, 16, dtype=torch.bfloat16)[0], 3) is None      # looks alike, not registered
+    assert F_sg._adopt_wide(x, 3) is None                        # and the column-block registry does not know it
+    # the rule a producer applies: bf16, 8 .. 64 channels a power of two, K > 1
+    assert F_sg._planes_wanted(16, 3, torch.bfloat16) and F_sg._planes_wanted(64, 3, torch.bfloat16)
+    assert not F_sg._planes_wanted(16, 3, torch.float32) and not F_sg._planes_wanted(128, 3, torch.bfloat16)
+    assert not F_sg._planes_wanted(16, 1, torch.bfloat16) and not F_sg._planes_wanted(4, 3, torch.bfloat16)
+    del base, x
+
+
 def test_weight_cache_invalidation(cpu_kernels):
     """writes through .data do not bump the version counter; invalidate_weight_cache / load_state_dict do."""
     from semigcn_amd import nn as sgnn, synth
