@@ -543,12 +543,60 @@ class PartChain:
     partition, run phase by phase BELOW the C ABI (sg_block_run, csrc/block.hip) with the rank's collectives between the
     calls: per block forward ONE all-to-all (rows of the conv output + this rank's BatchNorm statistics in the pad rows;
     the block behind applies BatchNorm + activation to owned and received rows alike), backward one all-reduce (the two
-    BatchNorm sums) and one all-to-all (gradient rows).  One autograd node for the whole run."""
+    BatchNorm sums) and one all-to-all (gradient rows).  One autograd node for the whole run.
+
+    A rank is bound by its host, so nothing is set up twice: the chain keeps SETS of buffers with their descriptor arrays
+    filled in (``_PartBuffers``); a forward takes a free set (a training loop has one: taken by the forward pass, handed
+    back at the end of the backward pass) and writes into its descriptors only what changed since that set's last use."""
 
     def __init__(self, plans, layout: FoldedLayout):
         from . import functional as F_sg
         self.plans, self.lay = list(plans), layout
-        n = len(self.plans)
+        self._ws = {}
+        self._free = {}                 # dtype -> [_PartBuffers, ..] not in use
+        self._F = F_sg
+
+    def workspace(self, dtype) -> int:
+        code = capi._DTYPES[dtype]
+        wsb = self._ws.get(code)
+        if wsb is None:
+            lay = self.lay
+            probe = capi.sg_block()
+            wsb = 0
+            for p in self.plans:
+                p.init_descriptor(probe)
+                probe.graph, probe.graph_wide = lay.handle._h, lay.handle_wide._h
+                probe.dtype, probe.V, probe.V_out, probe.V_ext, probe.world, probe.ldh = code, lay.n_own, lay.n_own, lay.n_ext, lay.world, p.Cout
+                wsb = max(wsb, capi.block_workspace(probe, 2))
+            self._ws[code] = wsb
+        return wsb
+
+    def take(self, dtype, dev) -> "_PartBuffers":
+        free = self._free.setdefault(dtype, [])
+        return free.pop() if free else _PartBuffers(self, dtype, dev)
+
+    def give_back(self, b: "_PartBuffers") -> None:
+        free = self._free.setdefault(b.dtype, [])
+        if len(free) < 2:
+            free.append(b)
+
+
+def _up256(n: int) -> int:
+    return (n + 255) & ~255
+
+
+class _PartBuffers:
+    """One set of everything a forward + backward pass of a PartChain touches: the activation arena, the gradient arena
+    (allocated at the first backward pass), the scratch, the tensor views the collectives take, and the descriptor arrays
+    -- one array per foreign call between two collectives -- with every field that does not change from call to call
+    already in place."""
+
+    def __init__(self, pc: PartChain, dtype, dev):
+        self.pc, self.dtype, self.dev = pc, dtype, dev
+        plans, lay = pc.plans, pc.lay
+        n = len(plans)
+        V, Ve, W = lay.n_own, lay.n_ext, lay.world
+        e = 4 if dtype == torch.float32 else 2
         mk = lambda k: (capi.sg_block * k)()
         # descriptor arrays, one per call between two collectives
         self.f_seg = [mk(1)] + [mk(2) for _ in range(n - 1)]        # [conv 0] ; [bn i-1, conv i]
@@ -556,16 +604,150 @@ class PartChain:
         self.b_head = mk(1)                                          # [reduce n-1]
         self.b_a = [mk(1) for _ in range(n)]                         # [bn-apply + conv first half] of block i
         self.b_b = [mk(1)] + [mk(2) for _ in range(n - 1)]           # [conv second half i, reduce i-1]
-        self._ws = {}
-        self._F = F_sg
+        # ---- forward arena: per block its input [Ve, K*Cin | Cin], conv output H [Ve, Cout], the small fp32 vectors, send rows
+        at, offs = 0, []
+        for p in plans:
+            o_in = at
+            at += _up256(Ve * (p.K * p.Cin if p.order == 0 else p.Cin) * e)
+            o_h = at
+            at += _up256(Ve * p.Cout * e)
+            o_small = at
+            at += _up256((4 * p.Cout + (2 * p.Cout + 1) * (W + 1) + 1) * 4)
+            o_send = at
+            at += _up256(lay.n_send * p.Cout * e)
+            offs.append((o_in, o_h, o_small, o_send))
+        self.fwd = torch.empty(max(at, 256), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(max(pc.workspace(dtype), 256), dtype=torch.uint8, device=dev)
+
+        def view(arena, off, rows, cols, dt):
+            es = 4 if dt == torch.float32 else 2
+            return arena[off:off + rows * cols * es].view(dt).view(rows, cols)
+        self.inp = [view(self.fwd, o[0], Ve, (p.K * p.Cin if p.order == 0 else p.Cin), dtype) for p, o in zip(plans, offs)]
+        self.H = [view(self.fwd, o[1], Ve, p.Cout, dtype) for p, o in zip(plans, offs)]
+        self.small = [self.fwd[o[2]:o[2] + (4 * p.Cout + (2 * p.Cout + 1) * (W + 1) + 1) * 4].view(torch.float32) for p, o in zip(plans, offs)]
+        self.send = [view(self.fwd, o[3], lay.n_send, p.Cout, dtype) for p, o in zip(plans, offs)]
+        self.recv = [h[V:] for h in self.H]                         # rows [V:] of H ARE the receive buffer of the exchange
+        self.in_own, self.in_halo = self.inp[0][:V, :plans[0].Cin], self.inp[0][V:, :plans[0].Cin]
+        C = plans[-1].Cout
+        self.last_local = self.small[-1][4 * C:4 * C + 2 * C + 1].view(1, -1)
+        self.last_gathered = self.small[-1][4 * C + 2 * C + 1:4 * C + (2 * C + 1) * (W + 1)].view(W, 2 * C + 1)
+        self.bwd = None
+        self.marks = None               # fingerprints of the plans the descriptors were bound to
+        self.training = None
+        self.accs = None
+        self.y_ptr = self.dy_ptr = None
+        self._fill_forward()
 
     def descriptors(self, i):
         """Every descriptor that describes block i (they all get the same static fields)."""
-        n = len(self.plans)
+        n = len(self.pc.plans)
         out = [self.f_seg[i][0 if i == 0 else 1], self.b_a[i][0], self.b_b[i][0]]
         out.append(self.f_seg[i + 1][0] if i + 1 < n else self.f_tail[0])
         out.append(self.b_b[i + 1][1] if i + 1 < n else self.b_head[0])
         return out
+
+    def _fill_forward(self) -> None:
+        pc, lay, dtype = self.pc, self.pc.lay, self.dtype
+        plans, n = pc.plans, len(pc.plans)
+        code = capi._DTYPES[dtype]
+        V, Ve, W = lay.n_own, lay.n_ext, lay.world
+        wsb = pc.workspace(dtype)
+        for i, p in enumerate(plans):
+            C = p.Cout
+            s0 = self.small[i].data_ptr()
+            stats, local, gathered, count = s0, s0 + 16 * C, s0 + 16 * C + 4 * (2 * C + 1), s0 + 16 * C + 4 * (2 * C + 1) * (W + 1)
+            inp = self.inp[i].data_ptr()
+            for blk in self.descriptors(i):
+                p.init_descriptor(blk)
+                blk.graph, blk.graph_wide = lay.handle._h, lay.handle_wide._h
+                blk.dtype, blk.V, blk.V_ext, blk.world = code, V, Ve, W
+                blk.V_out = Ve if i + 1 < n else V
+                if p.order == 0:
+                    blk.T, blk.ldt, blk.X, blk.ldx = inp, p.K * p.Cin, inp, p.K * p.Cin
+                else:
+                    blk.T, blk.ldt, blk.X, blk.ldx = None, 0, inp, p.Cin
+                blk.H, blk.ldh, blk.stats, blk.local, blk.gathered, blk.count = self.H[i].data_ptr(), C, stats, local, gathered, count
+                blk.gathered_ready = 0
+                blk.stats_rows = lay.stats_rows.data_ptr()
+                blk.send_index, blk.n_send, blk.send = lay.send_index.data_ptr(), (lay.n_send if i + 1 < n else 0), self.send[i].data_ptr()
+                if i + 1 < n:
+                    q = plans[i + 1]
+                    blk.Y, blk.ldy = self.inp[i + 1].data_ptr(), (q.K * q.Cin if q.order == 0 else q.Cin)
+                blk.ws, blk.ws_bytes = self.ws.data_ptr(), wsb
+        # the phase of every descriptor is a property of its place in the arrays
+        self.f_seg[0][0].phase = capi.PHASE_CONV
+        for i in range(1, n):
+            self.f_seg[i][0].phase, self.f_seg[i][1].phase = capi.PHASE_BN, capi.PHASE_CONV
+        self.f_tail[0].phase, self.f_tail[0].gathered_ready = capi.PHASE_BN, 1
+        self.f_tail[0].ldy = plans[-1].Cout
+
+    def bind(self) -> None:
+        """Parameter addresses and packed-weight buffers, again whenever a plan's fingerprint moved."""
+        marks = tuple(p.fingerprint() for p in self.pc.plans)
+        if marks == self.marks:
+            return
+        for i, p in enumerate(self.pc.plans):
+            for blk in self.descriptors(i):
+                p.bind(blk, self.dtype, self.dev)
+        self.marks = marks
+
+    def set_training(self, training) -> None:
+        if training == self.training:
+            return
+        for i, t in enumerate(training):
+            for blk in self.descriptors(i):
+                blk.training = t
+        self.training = training
+
+    def backward_buffers(self) -> None:
+        """The gradient arena and the backward halves of the descriptors, at the first backward pass of this set."""
+        if self.bwd is not None:
+            return
+        pc, lay, dtype, dev = self.pc, self.pc.lay, self.dtype, self.dev
+        plans, n = pc.plans, len(pc.plans)
+        V, Ve = lay.n_own, lay.n_ext
+        e = 4 if dtype == torch.float32 else 2
+        at, offs = 0, []
+        for p in plans:
+            width = 2 * p.Cin if p.order == 0 else p.Cout
+            o = []
+            for nbytes in (Ve * p.K * (p.Cin if p.order == 0 else p.Cout) * e, 6 * p.Cout * 4, p.Cout * p.K * p.Cin * 4,
+                           lay.n_send * width * e, (Ve - V) * width * e, V * p.Cin * e):
+                o.append(at)
+                at += _up256(nbytes)
+            offs.append(o)
+        self.bwd = torch.empty(max(at, 256), dtype=torch.uint8, device=dev)
+
+        def view(off, rows, cols, dt):
+            es = 4 if dt == torch.float32 else 2
+            return self.bwd[off:off + rows * cols * es].view(dt).view(rows, cols)
+        self.G, self.dvec, self.dW, self.gsend, self.grecv, self.dx = [], [], [], [], [], []
+        for p, o in zip(plans, offs):
+            width = 2 * p.Cin if p.order == 0 else p.Cout
+            self.G.append(view(o[0], Ve, p.K * (p.Cin if p.order == 0 else p.Cout), dtype))
+            self.dvec.append(view(o[1], 6, p.Cout, torch.float32))
+            self.dW.append(self.bwd[o[2]:o[2] + p.Cout * p.K * p.Cin * 4].view(torch.float32))
+            self.gsend.append(view(o[3], lay.n_send, width, dtype))
+            self.grecv.append(view(o[4], Ve - V, width, dtype))
+            self.dx.append(view(o[5], V, p.Cin, dtype))
+        self.sums = [d.view(-1)[:2 * p.Cout] for d, p in zip(self.dvec, plans)]       # what the all-reduce of a block carries
+        for i, p in enumerate(plans):
+            d = self.descriptors(i)
+            for blk in (d[1], d[2], d[4]):          # the descriptors of the backward calls: BWD_A, BWD_B, BWD_REDUCE of block i
+                if i + 1 < n:
+                    blk.dY, blk.lddy = self.dx[i + 1].data_ptr(), p.Cout
+                else:
+                    blk.lddy = p.Cout
+                blk.dX, blk.lddx, blk.need_dx = self.dx[i].data_ptr(), p.Cin, 1
+                blk.dW, blk.dvec, blk.G = self.dW[i].data_ptr(), self.dvec[i].data_ptr(), self.G[i].data_ptr()
+                # (send / recv / n_send serve the gradient-row exchange here, the rows of H in the forward descriptors)
+                blk.send, blk.recv, blk.n_send = self.gsend[i].data_ptr(), self.grecv[i].data_ptr(), lay.n_send
+        self.b_head[0].phase = capi.PHASE_BWD_REDUCE
+        for i in range(n):
+            self.b_a[i][0].phase = capi.PHASE_BWD_A
+            self.b_b[i][0].phase = capi.PHASE_BWD_B
+            if i > 0:
+                self.b_b[i][1].phase = capi.PHASE_BWD_REDUCE
 
 
 class _PartChainFn(torch.autograd.Function):
@@ -573,167 +755,106 @@ class _PartChainFn(torch.autograd.Function):
     def forward(ctx, pc: PartChain, x_own: torch.Tensor, x_halo: torch.Tensor, *params):
         F_sg, lay, plans = pc._F, pc.lay, pc.plans
         n, dev, dtype = len(plans), x_own.device, x_own.dtype
-        code, e = capi._DTYPES[dtype], (4 if dtype == torch.float32 else 2)
         V, Ve, W = lay.n_own, lay.n_ext, lay.world
         stream = capi._stream(x_own)
-        capturing = False
-        bufs = []
-        for i, p in enumerate(plans):
-            p.fingerprint()
-            inp = torch.empty((Ve, p.K * p.Cin if p.order == 0 else p.Cin), dtype=dtype, device=dev)
-            H = torch.empty((Ve, p.Cout), dtype=dtype, device=dev)
-            small = torch.empty(4 * p.Cout + (2 * p.Cout + 1) * (W + 1) + 1, dtype=torch.float32, device=dev)
-            send = torch.empty((lay.n_send, p.Cout), dtype=dtype, device=dev)
-            bufs.append((inp, H, small, send))
+        b = pc.take(dtype, dev)
+        b.bind()
+        training = tuple(1 if p.bn.training else 0 for p in plans)
+        b.set_training(training)
         # the network input on all rows: owned rows from the autograd side, halo rows computed from the halo copies of z1 / dm
-        t0 = bufs[0][0]
-        t0[:V, :plans[0].Cin].copy_(x_own)
+        b.in_own.copy_(x_own)
         if Ve > V:
-            t0[V:, :plans[0].Cin].copy_(x_halo)
-        wsb = pc._ws.get(code)
-        if wsb is None:
-            probe = capi.sg_block()
-            wsb = 0
-            for p in plans:
-                p.init_descriptor(probe)
-                probe.graph, probe.graph_wide = lay.handle._h, lay.handle_wide._h
-                probe.dtype, probe.V, probe.V_out, probe.V_ext, probe.world, probe.ldh = code, V, V, Ve, W, p.Cout
-                wsb = max(wsb, capi.block_workspace(probe, 2))
-            pc._ws[code] = wsb
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        training = []
+            b.in_halo.copy_(x_halo)
         for i, p in enumerate(plans):
-            inp, H, small, send = bufs[i]
-            C = p.Cout
-            s0 = small.data_ptr()
-            stats, local, gathered, count = s0, s0 + 16 * C, s0 + 16 * C + 4 * (2 * C + 1), s0 + 16 * C + 4 * (2 * C + 1) * (W + 1)
-            t = 1 if p.bn.training else 0
-            training.append(t)
-            for blk in pc.descriptors(i):
-                p.init_descriptor(blk)
-                blk.graph, blk.graph_wide = lay.handle._h, lay.handle_wide._h
-                blk.dtype, blk.V, blk.V_ext, blk.world, blk.training = code, V, Ve, W, t
-                blk.V_out = Ve if i + 1 < n else V
-                p.bind(blk, dtype, dev)
-                if p.order == 0:
-                    blk.T, blk.ldt, blk.X, blk.ldx = inp.data_ptr(), p.K * p.Cin, inp.data_ptr(), p.K * p.Cin
-                else:
-                    blk.T, blk.ldt, blk.X, blk.ldx = None, 0, inp.data_ptr(), p.Cin
-                blk.H, blk.ldh, blk.stats, blk.local, blk.gathered, blk.count = H.data_ptr(), C, stats, local, gathered, count
-                blk.gathered_ready = 0
-                blk.stats_rows = lay.stats_rows.data_ptr()
-                blk.send_index, blk.n_send, blk.send = lay.send_index.data_ptr(), (lay.n_send if i + 1 < n else 0), send.data_ptr()
-                if i + 1 < n:
-                    q = plans[i + 1]
-                    blk.Y, blk.ldy = bufs[i + 1][0].data_ptr(), (q.K * q.Cin if q.order == 0 else q.Cin)
-                blk.ws, blk.ws_bytes = ws.data_ptr(), wsb
-            pc.f_seg[i][0 if i == 0 else 1].refresh_weights = p.stale(dtype, capturing)
+            b.f_seg[i][0 if i == 0 else 1].refresh_weights = p.stale(dtype, False)
         y = torch.empty((V, plans[-1].Cout), dtype=dtype, device=dev)
-        pc.f_tail[0].Y, pc.f_tail[0].ldy = y.data_ptr(), plans[-1].Cout
+        b.f_tail[0].Y = y.data_ptr()
         for i in range(n):
-            if i == 0:
-                pc.f_seg[0][0].phase = capi.PHASE_CONV
-            else:
-                pc.f_seg[i][0].phase, pc.f_seg[i][1].phase = capi.PHASE_BN, capi.PHASE_CONV
-            capi.block_run(pc.f_seg[i], 1 if i == 0 else 2, stream)
+            capi.block_run(b.f_seg[i], 1 if i == 0 else 2, stream)
             if i + 1 < n:
-                lay.exchange(bufs[i][1][V:], bufs[i][3])          # rows of H_i + this rank's statistics -> the peers, in place
+                lay.exchange(b.recv[i], b.send[i])                # rows of H_i + this rank's statistics -> the peers, in place
         # the last BatchNorm has no exchange behind it: a plain all-gather of the statistics
-        p, (inp, H, small, send) = plans[-1], bufs[-1]
-        C = p.Cout
-        local = small[4 * C:4 * C + 2 * C + 1].view(1, -1)
-        gathered = small[4 * C + 2 * C + 1:4 * C + (2 * C + 1) * (W + 1)].view(W, 2 * C + 1)
         if training[-1]:
             if _solo(W):
-                gathered.copy_(local)
+                b.last_gathered.copy_(b.last_local)
             else:
-                _all_gather_rows(gathered, local, lay.group)
-        pc.f_tail[0].phase, pc.f_tail[0].gathered_ready = capi.PHASE_BN, 1
-        capi.block_run(pc.f_tail, 1, stream)
-        del ws
+                _all_gather_rows(b.last_gathered, b.last_local, lay.group)
+        capi.block_run(b.f_tail, 1, stream)
         F_sg.block_calls[0] += n
-        ctx.pc, ctx.bufs, ctx.training, ctx.params = pc, bufs, training, params
+        ctx.pc, ctx.params = pc, params
+        if any(ctx.needs_input_grad):
+            ctx.b = b                  # the set stays with this pass until its backward pass has run
+        else:
+            ctx.b = None
+            pc.give_back(b)
         ctx.save_for_backward(y)
         return y
 
     @staticmethod
     def backward(ctx, dy: torch.Tensor):
-        pc, bufs = ctx.pc, ctx.bufs
+        pc, b = ctx.pc, ctx.b
+        if b is None:
+            raise RuntimeError("part_chain: a second backward pass through the same forward (its buffers went back to the chain)")
         F_sg, lay, plans = pc._F, pc.lay, pc.plans
-        n, dev, dtype = len(plans), dy.device, dy.dtype
-        code = capi._DTYPES[dtype]
-        V, Ve, W = lay.n_own, lay.n_ext, lay.world
+        n, dev = len(plans), dy.device
+        W = lay.world
         stream = capi._stream(dy)
         dy = dy.contiguous()
-        wsb = pc._ws[code]
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        b.backward_buffers()
         sinking = bool(F_sg._sink_depth)
-        grads_out = []
-        Gs, dvecs, dWs, gsend, grecv, dxs = [], [], [], [], [], []
-        for i, p in enumerate(plans):
-            width = 2 * p.Cin if p.order == 0 else p.Cout
-            Gs.append(torch.empty((Ve, p.K * (p.Cin if p.order == 0 else p.Cout)), dtype=dtype, device=dev))
-            dvecs.append(torch.empty((6, p.Cout), dtype=torch.float32, device=dev))
-            dWs.append(torch.empty(p.Cout * p.K * p.Cin, dtype=torch.float32, device=dev))
-            gsend.append(torch.empty((lay.n_send, width), dtype=dtype, device=dev))
-            grecv.append(torch.empty((Ve - V, width), dtype=dtype, device=dev))
-            dxs.append(torch.empty((V, p.Cin), dtype=dtype, device=dev))
-        sunk = []
-        for i, p in enumerate(plans):
-            aw = [F_sg._grad_acc(w, dev) if sinking else None for w in p.weights]
+        sunk, accs = [], []
+        for p in plans:
+            aw = tuple(F_sg._grad_acc(w, dev) if sinking else None for w in p.weights)
             sw = all(a is not None for a in aw)
             ab = F_sg._grad_acc(p.cbias, dev) if sinking else None
             ag, at = (F_sg._grad_acc(p.gamma, dev), F_sg._grad_acc(p.beta, dev)) if sinking else (None, None)
             sb = ag is not None and at is not None
             sunk.append((sw, ab is not None, sb))
-            dyi = dy if i == n - 1 else dxs[i + 1]
-            for blk in pc.descriptors(i):          # (static fields are those of the forward pass)
-                blk.training = ctx.training[i]
-                blk.dY, blk.lddy = dyi.data_ptr(), p.Cout
-                blk.dX, blk.lddx, blk.need_dx = dxs[i].data_ptr(), p.Cin, 1
-                blk.dW, blk.dvec, blk.G = dWs[i].data_ptr(), dvecs[i].data_ptr(), Gs[i].data_ptr()
-                blk.send, blk.recv, blk.n_send = gsend[i].data_ptr(), grecv[i].data_ptr(), lay.n_send
-                for k in range(3):
-                    blk.acc_W[k] = aw[k] if (sw and k < p.K) else None
-                blk.acc_bias = ab
-                blk.acc_gamma, blk.acc_beta = (ag, at) if sb else (None, None)
-                blk.refresh_weights = 0
-                blk.ws, blk.ws_bytes = ws.data_ptr(), wsb
+            accs.append((aw if sw else None, ab, (ag, at) if sb else None))
+        if accs != b.accs:
+            for i, p in enumerate(plans):
+                aw, ab, gb = accs[i]
+                for blk in b.descriptors(i):
+                    for k in range(3):
+                        blk.acc_W[k] = aw[k] if (aw is not None and k < p.K) else None
+                    blk.acc_bias = ab
+                    blk.acc_gamma, blk.acc_beta = gb if gb is not None else (None, None)
+            b.accs = accs
+        if dy.data_ptr() != b.dy_ptr:
+            for blk in b.descriptors(n - 1):
+                blk.dY = dy.data_ptr()
+            b.dy_ptr = dy.data_ptr()
         # BatchNorm n-1: this rank's sums -> all-reduce; then per block: [dH, dW, gradient blocks] -> all-to-all ->
         # [recurrence unwound -> dX ; sums of the BatchNorm in front] -> all-reduce
-        pc.b_head[0].phase = capi.PHASE_BWD_REDUCE
-        capi.block_run(pc.b_head, 1, stream)
+        capi.block_run(b.b_head, 1, stream)
         bn_local = [None] * n
         for i in range(n - 1, -1, -1):
-            p = plans[i]
             if not sunk[i][2]:
-                bn_local[i] = dvecs[i][:2].clone()      # this rank's partial (sum dz, sum dz xhat): the gradients autograd gets
+                bn_local[i] = b.dvec[i][:2].clone()     # this rank's partial (sum dz, sum dz xhat): the gradients autograd gets
             if not _solo(W):
-                _all_reduce(dvecs[i].view(-1)[:2 * p.Cout], dist.ReduceOp.SUM, lay.group)
-            pc.b_a[i][0].phase = capi.PHASE_BWD_A
-            capi.block_run(pc.b_a[i], 1, stream)
-            lay.exchange(grecv[i], gsend[i])
-            pc.b_b[i][0].phase = capi.PHASE_BWD_B
-            if i > 0:
-                pc.b_b[i][1].phase = capi.PHASE_BWD_REDUCE
-            capi.block_run(pc.b_b[i], 1 if i == 0 else 2, stream)
-        del ws
+                _all_reduce(b.sums[i], dist.ReduceOp.SUM, lay.group)
+            capi.block_run(b.b_a[i], 1, stream)
+            lay.exchange(b.grecv[i], b.gsend[i])
+            capi.block_run(b.b_b[i], 1 if i == 0 else 2, stream)
         F_sg.block_calls[1] += n
+        grads_out = []
         for i, p in enumerate(plans):
             K, Cin, Cout = p.K, p.Cin, p.Cout
             sw, sbias, sbn = sunk[i]
-            dvec = dvecs[i]
-            grads_out.append(None if (p.cbias is None or sbias) else dvec[5].to(p.cbias.dtype))
+            grads_out.append(None if (p.cbias is None or sbias) else b.dvec[i][5].clone().to(p.cbias.dtype))
             if sw:
                 grads_out.extend([None] * K)
             elif p.order == 0:
-                dWm = dWs[i].view(Cout, K * Cin)
+                dWm = b.dW[i].view(Cout, K * Cin).clone()
                 grads_out.extend(dWm[:, k * Cin:(k + 1) * Cin] for k in range(K))
             else:
-                dWm = dWs[i].view(K * Cout, Cin)
+                dWm = b.dW[i].view(K * Cout, Cin).clone()
                 grads_out.extend(dWm[k * Cout:(k + 1) * Cout] for k in range(K))
             grads_out.extend((None, None) if sbn else (bn_local[i][1].to(p.gamma.dtype), bn_local[i][0].to(p.gamma.dtype)))
-        return (None, dxs[0], None, *grads_out)
+        dx0 = b.dx[0].clone()                                    # (the set goes back to the chain: its buffers are reused)
+        ctx.b = None
+        pc.give_back(b)
+        return (None, dx0, None, *grads_out)
 
 
 def part_chain(sequentials, graph: "DistMeshGraph", x_own: torch.Tensor, x_halo: torch.Tensor):
