@@ -1419,6 +1419,9 @@ int launch_rows_epi(const SpmmArgs& a, hipStream_t stream) {
     // measured on the 1 M-vertex mesh (tools/agg_bench.py): wide rows want a thin sweep front
     const int row_bytes = a.C * (int)sizeof(typename Vt<T>::elem);
     ch = row_bytes >= 2048 ? 4 : row_bytes >= 1024 ? (sizeof(typename Vt<T>::elem) == 4 ? 4 : 8) : row_bytes >= 512 ? 8 : 16;
+    // (round 4, dense 64-byte bf16 rows -- the planes of a 32-channel layer: 32 rows per chunk, 0.040 / 0.049 / 0.050 ms ->
+    // 0.037 / 0.044 / 0.044 ms with 0 / 1 / 2 epilogue operands; 32- and 128-byte rows measured level or slower)
+    if (sizeof(typename Vt<T>::elem) == 2 && row_bytes == 64) ch = 32;
     while (ch > RPW && (int64_t)a.n_rows / ch < 4096) ch >>= 1;
   }
   if (ch < RPW) ch = RPW;

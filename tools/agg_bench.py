@@ -102,6 +102,7 @@ def main():
                     print(f"{dt:5s} C={C:4d} epi={nepi} {name:28s} median {med:8.4f} ms  min {mn:8.4f} ms  "
                           f"{rec['GBs']:8.1f} GB/s  {100 * rec['frac']:5.1f}% of 8 TB/s", flush=True)
     if a.json:
+        os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
         json.dump({"mesh": a.mesh, "permute": a.permute, "order": a.order, "reorder_knob": a.reorder,
                    "locality_view": bool(g.handle.reordered), "V": V, "E": E, "results": out}, open(a.json, "w"), indent=1)
 
