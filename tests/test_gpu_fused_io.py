@@ -64,7 +64,8 @@ def test_mesh_loss_scalar_equals_the_composition(fixture_meshes):
         pb = pos0.clone().requires_grad_(True)
         lb = F_sg.mesh_loss(pb, faces, target, v_keep, tfn, f_keep, n_v, n_f, w, k1)
         (3.0 * lb).backward()
-        assert lb.dim() == 0 and abs(float(la) - float(lb)) <= 2e-7 * abs(float(la))
+        fa, fb = float(la.detach()), float(lb.detach())
+        assert lb.dim() == 0 and abs(fa - fb) <= 2e-7 * abs(fa)
         assert GU.rel_l2(pb.grad.cpu(), pa.grad.cpu()) < 1e-6
     # one resolution's position term (mgcn.py:138-143): no faces
     pa = pos0.clone().requires_grad_(True)
