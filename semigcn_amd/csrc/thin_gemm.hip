@@ -63,33 +63,34 @@ __device__ __forceinline__ void thin_stage_rows(const T* __restrict__ src, int64
 }
 
 // One block = 256 consecutive rows.  Rows pass through LDS in both directions so that consecutive lanes touch consecutive
-// addresses (a row is 6 - 64 bytes: one thread per row straight from global memory runs at ~1 TB/s).
-template <typename T>
+// addresses (a row is 6 - 64 bytes: one thread per row straight from global memory runs at ~1 TB/s).  P = K rounded up to
+// 8 / 16 / 32: a thread keeps its row in P registers; the weights are read with wave-uniform addresses straight from
+// global memory (scalar loads through the constant cache -- the first version staged them in LDS and issued one LDS read
+// per multiply) and the LDS is sized at the launch (5 - 7 blocks per CU instead of 3): [V,12] x [12,16] bf16 0.076 -> 0.048 ms at
+// V = 1 M, [V,16] x [16,3] fp32 0.049 -> 0.021 (tools/thin_bench.py).  Same fma chain per output: bit-identical to that version.
+template <typename T, int P>
 __global__ __launch_bounds__(kThinBlock) void thin_nt(const T* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw,
                                                       const float* __restrict__ bias, T* __restrict__ Y, int64_t ldy, int64_t V,
                                                       int N, int K) {
-  __shared__ float s_w[kThinElems];
-  __shared__ float s_b[kThinMax];
-  __shared__ float s_io[kThinBlock * (kThinMax + 1 + 8 + 1)];      // x rows (pitch K + 1) | y rows (pitch N + 1): N, K not both > 16
+  extern __shared__ float s_io[];      // x rows (pitch K + 1) | y rows (pitch N + 1): sized at the launch, so that 5 - 7 blocks share a CU
   const int px = K + 1, py = N + 1;
   float* const s_x = s_io;
   float* const s_y = s_io + kThinBlock * px;
-  for (int i = threadIdx.x; i < N * K; i += kThinBlock) s_w[i] = W[(int64_t)(i / K) * ldw + i % K];
-  if (threadIdx.x < N) s_b[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
   const int64_t row0 = (int64_t)blockIdx.x * kThinBlock;
   const int rows = (int)(V - row0 < kThinBlock ? V - row0 : kThinBlock);
   thin_stage_rows<T>(X + row0 * ldx, ldx, rows, K, s_x, px);
   __syncthreads();
   if ((int)threadIdx.x < rows) {
-    float x[kThinMax];
+    float x[P];
 #pragma unroll
-    for (int k = 0; k < kThinMax; ++k) x[k] = k < K ? s_x[threadIdx.x * px + k] : 0.f;
+    for (int k = 0; k < P; ++k) x[k] = k < K ? s_x[threadIdx.x * px + k] : 0.f;
     for (int n = 0; n < N; ++n) {
+      const float* __restrict__ wn = W + (int64_t)n * ldw;       // wave-uniform: scalar loads
       float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < kThinMax; ++k)
-        if (k < K) acc = fmaf(x[k], s_w[n * K + k], acc);
-      s_y[threadIdx.x * py + n] = acc + s_b[n];
+      for (int k = 0; k < P; ++k)
+        if (k < K) acc = fmaf(x[k], wn[k], acc);
+      s_y[threadIdx.x * py + n] = acc + (bias ? bias[n] : 0.f);
     }
   }
   __syncthreads();
@@ -124,8 +125,9 @@ template <typename T>
 __global__ __launch_bounds__(kThinBlock) void thin_tn_partial(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
                                                               int64_t V, int N, int K, int64_t rows_per_block,
                                                               float* __restrict__ part) {
-  __shared__ float s_a[kThinChunk * kThinMax];
-  __shared__ float s_b[kThinChunk * kThinMax];
+  extern __shared__ float s_io[];                  // [chunk][N] | [chunk][K], sized at the launch
+  float* const s_a = s_io;
+  float* const s_b = s_io + kThinChunk * N;
   const int P = thin_pitch(K);
   const int n = threadIdx.x / P, k = threadIdx.x % P;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -189,14 +191,18 @@ int launch_thin_nt(const void* X, int64_t ldx, const float* W, int64_t ldw, cons
   if (V == 0) return SG_OK;
   SG_REQUIRE(V < ((int64_t)1 << 31) * kThinBlock, "sg_thin_nt: too many rows");
   const int64_t nb = (V + kThinBlock - 1) / kThinBlock;
-  if (dtype == SG_F32)
-    thin_nt<float><<<(int)nb, kThinBlock, 0, stream>>>((const float*)X, ldx, W, ldw, bias, (float*)Y, ldy, V, (int)N, (int)K);
-  else if (dtype == SG_BF16)
-    thin_nt<uint16_t><<<(int)nb, kThinBlock, 0, stream>>>((const uint16_t*)X, ldx, W, ldw, bias, (uint16_t*)Y, ldy, V, (int)N, (int)K);
-  else {
+  const int P = thin_pitch((int)K);
+  const size_t lds = (size_t)kThinBlock * (size_t)(K + 1 + N + 1) * sizeof(float);
+#define SG_THIN_NT(TT, PP) thin_nt<TT, PP><<<(int)nb, kThinBlock, lds, stream>>>((const TT*)X, ldx, W, ldw, bias, (TT*)Y, ldy, V, (int)N, (int)K)
+  if (dtype == SG_F32) {
+    if (P == 8) SG_THIN_NT(float, 8); else if (P == 16) SG_THIN_NT(float, 16); else SG_THIN_NT(float, 32);
+  } else if (dtype == SG_BF16) {
+    if (P == 8) SG_THIN_NT(uint16_t, 8); else if (P == 16) SG_THIN_NT(uint16_t, 16); else SG_THIN_NT(uint16_t, 32);
+  } else {
     set_error("sg_thin_nt: unsupported dtype %d", dtype);
     return SG_ERR_UNSUPPORTED;
   }
+#undef SG_THIN_NT
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
@@ -205,10 +211,11 @@ int launch_thin_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
                    float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink) {
   const int64_t nb = thin_tn_blocks(V);
   const int64_t rpb = (V + nb - 1) / nb;
+  const size_t lds = (size_t)kThinChunk * (size_t)(N + K) * sizeof(float);
   if (dtype == SG_F32)
-    thin_tn_partial<float><<<(int)nb, kThinBlock, 0, stream>>>((const float*)A, lda, (const float*)B, ldb, V, (int)N, (int)K, rpb, workspace);
+    thin_tn_partial<float><<<(int)nb, kThinBlock, lds, stream>>>((const float*)A, lda, (const float*)B, ldb, V, (int)N, (int)K, rpb, workspace);
   else if (dtype == SG_BF16)
-    thin_tn_partial<uint16_t><<<(int)nb, kThinBlock, 0, stream>>>((const uint16_t*)A, lda, (const uint16_t*)B, ldb, V, (int)N, (int)K, rpb, workspace);
+    thin_tn_partial<uint16_t><<<(int)nb, kThinBlock, lds, stream>>>((const uint16_t*)A, lda, (const uint16_t*)B, ldb, V, (int)N, (int)K, rpb, workspace);
   else {
     set_error("sg_thin_tn: unsupported dtype %d", dtype);
     return SG_ERR_UNSUPPORTED;
