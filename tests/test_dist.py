@@ -326,3 +326,106 @@ def test_partitioned_mgcn_matches_unpartitioned(world):
             assert rel_l2(p["bn"][k], v) < 1e-5, k
     for n in parts[0]["grads"]:
         assert torch.equal(parts[0]["grads"][n], parts[1]["grads"][n]), n
+
+
+# --------------------------------------------------------------------------------------
+# the folded layout of the phase-by-phase block path (dist.FoldedLayout; sg_block_run needs a device, its exchange plan does not)
+# --------------------------------------------------------------------------------------
+def _folded_layouts(world, nu=48, nv=32):
+    _install_doubles()
+    from semigcn_amd import dist as sgdist, reorder, synth
+    mesh = synth.torus_mesh(nu, nv, permute=True)
+    V = mesh.num_vertices
+    order, rank_of = reorder.morton_order(torch.from_numpy(mesh.x_pos))
+    ei = reorder.permute_edge_index(torch.from_numpy(mesh.edge_index), rank_of)
+    gs = [sgdist.DistMeshGraph(ei, V, r, world) for r in range(world)]
+    return sgdist, ei, V, gs, [g.folded() for g in gs]
+
+
+def test_folded_layout_plan_is_consistent():
+    """[owned | per peer: its halo rows, PAD_ROWS pad rows]: what rank r packs for peer q (send_index) is, row for row, what q
+    keeps in r's segment of its buffer; the pad rows sit where stats_rows says; the two operators on the folded numbering
+    reproduce the global operator on the owned rows (one hop) and on the owned + ring-1 rows (the wide one)."""
+    world = 4
+    sgdist, ei, V, gs, lays = _folded_layouts(world)
+    P = sgdist.PAD_ROWS
+    for r, (g, lay) in enumerate(zip(gs, lays)):
+        assert lay.n_own == g.n_own and lay.send_splits[r] == 0 and lay.recv_splits[r] == 0
+        assert lay.n_ext == g.n_own + sum(lay.recv_splits) and lay.n_send == sum(lay.send_splits)
+        assert torch.equal(lay.ext_src[:g.n_own], torch.arange(g.start, g.end))
+        at_recv = g.n_own
+        for q in range(world):
+            if q == r:
+                assert int(lay.stats_rows[q]) == -1
+                continue
+            n_rows = lay.recv_splits[q] - P
+            seg = lay.ext_src[at_recv:at_recv + lay.recv_splits[q]]
+            assert n_rows >= 0 and bool((seg[:n_rows] >= gs[q].start).all()) and bool((seg[:n_rows] < gs[q].end).all())
+            assert (n_rows < 2 or bool((seg[1:n_rows] > seg[:n_rows - 1]).all())) and bool((seg[n_rows:] == -1).all())
+            assert int(lay.stats_rows[q]) == at_recv + n_rows
+            # what q sends to r
+            lq = lays[q]
+            at_send = sum(lq.send_splits[:r])
+            sent = lq.send_index[at_send:at_send + lq.send_splits[r]].long()
+            assert lq.send_splits[r] == lay.recv_splits[q]
+            assert torch.equal(sent[:n_rows] + gs[q].start, seg[:n_rows]), (r, q)
+            assert torch.equal(sent[n_rows:], -1 - torch.arange(P)), (r, q)
+            at_recv += lay.recv_splits[q]
+    # operators: one hop on the owned rows; the wide one on every row whose neighbours all lie in the buffer (owned + ring 1)
+    x = torch.randn(V, 6)
+    full = sgdist.DistMeshGraph(ei, V, 0, 1)
+    y_full = full.handle.spmm(x, torch.empty(V, 6))
+    for g, lay in zip(gs, lays):
+        idx = lay.ext_src
+        x_ext = x[idx.clamp(min=0)] * (idx >= 0).view(-1, 1)
+        y = lay.handle.spmm(x_ext, torch.empty(lay.n_own, 6))
+        assert torch.allclose(y, y_full[g.start:g.end], atol=1e-6)
+        yw = lay.handle_wide.spmm(x_ext, torch.zeros(lay.n_ext, 6))
+        assert torch.allclose(yw[:lay.n_own], y_full[g.start:g.end], atol=1e-6)
+        ring1 = torch.unique(ei[1][(ei[0] >= g.start) & (ei[0] < g.end)])          # sources of the owned rows
+        ring1 = ring1[(ring1 < g.start) | (ring1 >= g.end)]
+        pos = {int(v): i for i, v in enumerate(idx.tolist()) if v >= 0}
+        rows = torch.tensor([pos[int(v)] for v in ring1.tolist()])
+        assert rows.numel() > 0 and torch.allclose(yw[rows], y_full[ring1], atol=1e-6)
+        # two hops with ONE exchange: Tx2 = 2 L (L x) - x on the owned rows from the wide first hop
+        t2 = 2.0 * lay.handle.spmm(yw, torch.empty(lay.n_own, 6)) - x[g.start:g.end]
+        want = 2.0 * full.handle.spmm(y_full, torch.empty(V, 6)) - x
+        assert torch.allclose(t2, want[g.start:g.end], atol=1e-5)
+
+
+def _folded_exchange_rank(rank, world, port, out_dir):
+    _install_doubles()
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sgdist, ei, V, gs, lays = _folded_layouts(world, 24, 16)
+    g, lay = gs[rank], lays[rank]
+    C, P = 6, sgdist.PAD_ROWS
+    x = torch.randn(V, C, generator=torch.Generator().manual_seed(9))
+    blob = lambda q: torch.arange(2 * C + 1, dtype=torch.float32) + 100.0 * (q + 1)       # rank q's "statistics"
+    buf = torch.full((lay.n_ext, C), float("nan"))
+    buf[:lay.n_own] = x[g.start:g.end]
+    # what SG_PHASE_CONV's pack kernel does (csrc/block.hip pack_rows): rows by send_index, the blob across the pad rows
+    pad = torch.zeros(P * C)
+    pad[:2 * C + 1] = blob(rank)
+    idx = lay.send_index.long()
+    send = torch.where((idx >= 0).view(-1, 1), buf[idx.clamp(min=0)], pad.view(P, C)[(-1 - idx).clamp(min=0)])
+    lay.exchange(buf[lay.n_own:], send)
+    src = lay.ext_src
+    ok_rows = torch.equal(buf[src >= 0], x[src[src >= 0]])
+    ok_stats = all(torch.equal(buf[int(lay.stats_rows[q]):int(lay.stats_rows[q]) + P].reshape(-1)[:2 * C + 1], blob(q))
+                   for q in range(world) if q != rank)
+    torch.save({"rows": ok_rows, "stats": ok_stats, "n_halo": lay.n_ext - lay.n_own - P * (world - 1)},
+               os.path.join(out_dir, f"fold_r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_folded_exchange_lands_rows_and_statistics_in_place(world):
+    """ONE all-to-all per block on the folded layout, over gloo: the receive buffer is rows [n_own:] of the feature buffer
+    itself, every halo row arrives at its place and every peer's statistics blob in the pad rows of that peer's segment."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_folded_exchange_rank, args=(world, 29650 + world, d), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, f"fold_r{r}.pt")) for r in range(world)]
+    assert all(r["rows"] and r["stats"] and r["n_halo"] > 0 for r in res), res
