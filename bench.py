@@ -43,6 +43,12 @@ def log(msg: str):
         print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def log_all(msg: str):
+    """Start-up marks of EVERY rank (SEMIGCN_BENCH_VERBOSE=1): where an N-rank job spends its time before the first step."""
+    if os.environ.get("SEMIGCN_BENCH_VERBOSE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,7 +281,7 @@ def build_trainer(args, dtype, device, world, rank, mesh):
     nu, nv = map(int, args.mesh.split("x"))
     if DIST_ON and args.model == "sgcn":
         from semigcn_amd import dist as sgdist
-        job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh,
+        job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh, log=log_all,
                                            capture=("whole" if args.graph and args.graph_collectives else args.graph),
                                            phases=not args.no_phases)
         return job.trainer, job.workload, AGG_PER_ITER * mesh.num_edges
@@ -355,6 +361,8 @@ def timed_run(trainer, args, device, world, with_timer: bool):
         trainer.iteration_step()
         torch.cuda.synchronize(device)
         log(f"warm-up iteration {i} done")
+        if i == 0:
+            log_all("first warm-up iteration done")
     timed_run.replay_check = None
     if getattr(trainer, "_segmented", None) is not None or getattr(trainer, "_graphed", None) is not None:
         # a replaying trainer is trusted only after ONE replayed iteration has reproduced an eager one on the same inputs

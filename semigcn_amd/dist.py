@@ -1202,14 +1202,17 @@ class PartitionedMesh:
     halo_inputs: Optional[tuple] = None             # (z1_halo, this iteration's mask column [n_ext - n, 1])
 
 
-def partition_mesh(mesh, rank: int, world: int, device, group=None, n_masks: int = 5, seed: int = 317) -> PartitionedMesh:
+def partition_mesh(mesh, rank: int, world: int, device, group=None, n_masks: int = 5, seed: int = 317, log=None) -> PartitionedMesh:
     """Cut a synth.SynthMesh (every rank builds the same one) into this rank's share."""
     from . import synth, train
+    log = log or (lambda msg: None)
     V = mesh.num_vertices
     pos_all = torch.from_numpy(mesh.x_pos).to(device)
     order, rank_of = _reorder.morton_order(pos_all)
     ei = _reorder.permute_edge_index(torch.from_numpy(mesh.edge_index).to(device), rank_of)
+    log("edges in Morton order")
     g = DistMeshGraph(ei, V, rank, world, group)
+    log(f"partition plan: {g.n_own} owned + {g.n_halo} halo rows")
     own = order[g.start:g.end]                                   # old ids of my vertices, in my order
     faces = rank_of[torch.from_numpy(mesh.faces).to(device)]     # new ids
     f_mine = (faces[:, 0] >= g.start) & (faces[:, 0] < g.end)
@@ -1220,7 +1223,9 @@ def partition_mesh(mesh, rank: int, world: int, device, group=None, n_masks: int
     v_keep_all = torch.from_numpy(mesh.v_mask.astype(np.float32)).to(device)
     fa = torch.from_numpy(mesh.faces).to(device)
     f_keep_all = v_keep_all[fa[:, 0]] * v_keep_all[fa[:, 1]] * v_keep_all[fa[:, 2]]
+    log("targets and keep masks")
     dm_all = torch.from_numpy(synth.make_dummy_masks(mesh.edge_index, V, dm_size=n_masks, k=4, p=0.014, seed=seed)).to(device)
+    log("dummy masks")
     z1_all = torch.from_numpy(mesh.z1).to(device)
     z1 = z1_all[own].clone().requires_grad_(True)
     part = PartitionedMesh(g, z1, pos_all[own].clone(), faces_ext, vs_all[own].clone(), tfn_all[f_mine].clone(),
@@ -1228,6 +1233,7 @@ def partition_mesh(mesh, rank: int, world: int, device, group=None, n_masks: int
                            dm_all[own].clone(), float(v_keep_all.sum()), float(f_keep_all.sum()))
     if z1_all.is_cuda:      # the phase-by-phase block path (part_chain) prepares the halo rows of the input itself
         lay = g.folded()
+        log("folded layout")
         part.z1_halo = lay.halo_of(z1_all[order]).contiguous()
         part.dm_halo = lay.halo_of((v_keep_all.view(-1, 1) * dm_all)[order]).contiguous()
     return part
@@ -1319,14 +1325,17 @@ class _Job:
 
 def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permute: bool = False,
                           dtype=torch.float32, group=None, mesh=None, capture: bool = False,
-                          phases: bool = True) -> _Job:
+                          phases: bool = True, log=None) -> _Job:
     """bench.py's N > 1 leg: the SAME nu x nv mesh as the 1-GPU run, cut into ``world`` blocks
     (strong scaling)."""
     from . import synth
     from .networks import SingleScaleGCN
+    log = log or (lambda msg: None)
     if mesh is None:
         mesh = synth.torus_mesh(nu, nv, permute=permute)
-    part = partition_mesh(mesh, rank, world, device, group)
+    log("partitioning")
+    part = partition_mesh(mesh, rank, world, device, group, log=log)
+    log("partition done")
     torch.manual_seed(314)
     model = SingleScaleGCN(device).to(device)
     if dtype != torch.float32:
