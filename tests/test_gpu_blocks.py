@@ -30,9 +30,9 @@ def _per_module(fn):
         F_sg.USE_BLOCK_CALLS = old
 
 
-def _block_module(cin, cout, pool=None, slope=0.01, seed=0):
+def _block_module(cin, cout, pool=None, slope=0.01, seed=0, K=3):
     torch.manual_seed(seed)
-    layers = [(sgnn.ChebConv(cin, cout, K=3), "x, edge_index -> x")]
+    layers = [(sgnn.ChebConv(cin, cout, K=K), "x, edge_index -> x")]
     if pool is not None:
         layers.append((pool, "x -> x"))
     layers += [(torch.nn.BatchNorm1d(cout), "x -> x"), (torch.nn.LeakyReLU(slope) if slope else torch.nn.ReLU(), "x -> x")]
@@ -80,6 +80,33 @@ def test_block_call_equals_the_per_module_path(dtype, cin, cout, train, fixture_
     # (eval mode: the per-module path takes scale / shift and the two BatchNorm gradient sums with ATen ops)
     own_kernels = dtype == torch.bfloat16 and (cin, cout) != (4, 32) and train
     _compare(got, want, own_kernels, 2e-6 if dtype == torch.float32 else 2e-2, train)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("K,cin,cout", [(1, 32, 64), (2, 16, 32), (2, 64, 32), (1, 64, 16)])
+def test_block_call_with_fewer_chebyshev_terms(dtype, K, cin, cout):
+    """K = 1 (no aggregation at all: a per-vertex Linear + BatchNorm + activation) and K = 2 (one hop; two planes for a
+    narrow layer) through the same entry points -- the reference only instantiates K = 3 (util/networks.py:11), [3P]
+    ChebConv takes any K >= 1 -- against the per-module path."""
+    m = synth.torus_mesh(40, 30)
+    g = MeshGraph.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), m.num_vertices)
+    seq = _block_module(cin, cout, K=K, seed=K)
+    gen = torch.Generator().manual_seed(cin * 100 + cout + K)
+    x = torch.randn(m.num_vertices, cin, generator=gen).to(DEV).to(dtype)
+    r = torch.randn(m.num_vertices, cout, generator=gen).to(DEV)
+    state = {k: v.clone() for k, v in seq.state_dict().items()}
+    before = list(F_sg.block_calls)
+    got = _run(seq, g, x, r)
+    assert F_sg.block_calls == [before[0] + 1, before[1] + 1], "the block path did not serve this block"
+    seq.load_state_dict(state)
+    want = _per_module(lambda: _run(seq, g, x, r))
+    scale = max(float(w.abs().max()) for w in want[3:3 + K])
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        if i == 2:            # the conv bias gradient: zero in exact arithmetic behind a BatchNorm
+            assert float(a.abs().max()) <= 4e-3 * scale and float(b.abs().max()) <= 4e-3 * scale
+        else:
+            assert GU.rel_l2(a.float().cpu(), b.float().cpu()) < (2e-6 if dtype == torch.float32 else 2e-2), (i, K)
 
 
 def _compare(got, want, exact: bool, tol: float, train: bool = True):
