@@ -109,6 +109,37 @@ def test_block_call_with_fewer_chebyshev_terms(dtype, K, cin, cout):
             assert GU.rel_l2(a.float().cpu(), b.float().cpu()) < (2e-6 if dtype == torch.float32 else 2e-2), (i, K)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 16), (128, 256)])
+def test_block_call_on_an_asymmetric_graph_with_isolated_vertices(dtype, cin, cout):
+    """An edge_index that is NOT symmetric (a third of the reverse edges dropped: the backward pass aggregates over the
+    transposed CSR), with repeated edges, self-loops (dropped by [3P] ChebConv.__norm__) and a few vertices without any edge
+    (deg^-1/2 = inf -> 0): the block entry points against the per-module path, both evaluation orders, planes included."""
+    m = synth.torus_mesh(40, 30)
+    V = m.num_vertices
+    ei = torch.from_numpy(m.edge_index)
+    gen = torch.Generator().manual_seed(cin + cout)
+    keep = torch.rand(ei.shape[1], generator=gen) > 0.33
+    keep |= ei[0] < ei[1]                                           # every undirected edge keeps at least one direction
+    ei = ei[:, keep]
+    lone = torch.randperm(V, generator=gen)[:7]                     # cut seven vertices out completely
+    ei = ei[:, ~(torch.isin(ei[0], lone) | torch.isin(ei[1], lone))]
+    ei = torch.cat([ei, ei[:, :50], torch.arange(20).repeat(2, 1)], dim=1)       # repeated edges and self-loops
+    g = MeshGraph.from_edge_index(ei.to(DEV), V)
+    assert not g.symmetric
+    seq = _block_module(cin, cout, seed=3)
+    x = torch.randn(V, cin, generator=gen).to(DEV).to(dtype)
+    r = torch.randn(V, cout, generator=gen).to(DEV)
+    state = {k: v.clone() for k, v in seq.state_dict().items()}
+    before = list(F_sg.block_calls)
+    got = _run(seq, g, x, r)
+    assert F_sg.block_calls == [before[0] + 1, before[1] + 1]
+    seq.load_state_dict(state)
+    want = _per_module(lambda: _run(seq, g, x, r))
+    assert all(bool(torch.isfinite(t.float()).all()) for t in got)
+    _compare(got, want, dtype == torch.bfloat16, 2e-6, True)
+
+
 def _compare(got, want, exact: bool, tol: float, train: bool = True):
     """Entries: y, dx, d conv-bias, dW_0..2, d gamma, d beta, running_mean, running_var, num_batches_tracked.  In training
     mode the conv bias gradient is zero in exact arithmetic (BatchNorm removes the column mean): both paths return
