@@ -222,6 +222,16 @@ def test_partitioned_sgcn_other_paths_two_ranks(path, n_coll):
     assert "dist_selftest OK" in r.stdout and f"path={path} collectives={n_coll}" in r.stdout
 
 
+def test_partitioned_bf16_features_two_ranks():
+    """bf16 feature storage on a partition (what `bench.py --gpus N` runs): the statistics travel as fp32 words inside bf16
+    pad rows (5 rows of C bf16 values hold 2 C + 1 floats), halo rows and gradient rows are packed 2 bytes per value.
+    Against the single-device bf16 model: positions and loss close (asserted inside the ranks); gradients only loosely --
+    two bf16 evaluations with different summation orders diverge."""
+    r = _run_selftest(2, "gloo", SEMIGCN_SELFTEST_DTYPE="bf16", SEMIGCN_SELFTEST_SKIP_MGCN="1")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "dist_selftest OK" in r.stdout and "path=phases collectives=44" in r.stdout
+
+
 def test_eight_ranks_on_a_200k_vertex_mesh_equal_single_rank():
     """The 8-way partition the scaling run uses (Morton blocks, two-ring halos, 7 peers per rank), on a 500x400 mesh with
     the eight ranks sharing the one GPU over gloo: partitioned SGCN forward / loss / reduced gradients == the single-device

@@ -40,6 +40,11 @@ def main():
     model = SingleScaleGCN(dev)
     GU.fill_state(model, seed=77)
     model.to(dev)
+    # SEMIGCN_SELFTEST_DTYPE=bf16: bf16 feature storage on both sides (what bench.py runs); the comparison is then between two
+    # bf16 evaluations that differ in the order of their fp32 additions (tile moments per rank, halo rows computed twice)
+    bf16 = os.environ.get("SEMIGCN_SELFTEST_DTYPE") == "bf16"
+    if bf16:
+        model.set_feature_dtype(torch.bfloat16)
     tr = sgdist.DistSGCNTrainer(model, part, accumulate=1000)
     model.train()
     dm = part.v_keep * part.dummy_masks[:, :1]
@@ -72,6 +77,8 @@ def main():
     ref = SingleScaleGCN(dev)
     GU.fill_state(ref, seed=77)
     ref.to(dev).train()
+    if bf16:
+        ref.set_feature_dtype(torch.bfloat16)
     batch = bench.build_mesh_batch(mesh, dev, n_masks=2)
     rt = train.SGCNTrainer(ref, batch, accumulate=1000)
     dm_full = batch.v_keep * batch.dummy_masks[:, :1]
@@ -93,7 +100,14 @@ def main():
         worst = max(worst, float((p.grad - q.grad).norm()) / scale)
     print(f"[rank {rank}/{world}] path={path} collectives={n_coll} own={g.n_own} halo={g.n_halo} send={g.n_send}  pos rel-L2 {e_pos:.2e}  "
           f"loss rel {e_loss:.2e}  worst param-grad rel-L2 {worst:.2e}", flush=True)
-    assert e_pos < 1e-5 and e_loss < 2e-6 and worst < 3e-2
+    if bf16:
+        # measured (2 and 4 ranks, 96 x 64 torus; the per-module path reads the same): positions 1.9e-3 (the offsets are ~1e-2 of
+        # the positions), loss 2e-4 .. 4e-4, worst parameter gradient 1.6 -- two bf16 evaluations that differ only in the order
+        # of their fp32 additions do not stay together through 13 BatchNorm layers; what this run pins
+        # is that nothing GROSS is wrong with bf16 rows on a partition (statistics in bf16 pad rows, halo rows, packing)
+        assert e_pos < 4e-3 and e_loss < 5e-3 and worst < 3.0, (e_pos, e_loss, worst)
+    else:
+        assert e_pos < 1e-5 and e_loss < 2e-6 and worst < 3e-2
     if os.environ.get("SEMIGCN_SELFTEST_SKIP_MGCN") != "1":
         mgcn_selftest(rank, world, dev)
     dist.barrier()
