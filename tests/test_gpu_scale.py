@@ -205,10 +205,12 @@ def test_partitioned_sgcn_and_mgcn_equal_single_rank_on_device(world):
     """tools/dist_selftest.py: partitioned SGCN (the 13 blocks phase by phase below the C ABI, sg_block_run, BatchNorm
     statistics in the pad rows of the halo exchange: 44 collectives, asserted inside the ranks) and MGCN
     (sg_graph_create_rect, sg_gather_rows, sg_bn_finalize_ranks, DistPool) == the plain single-device models: positions
-    <= 1e-5, loss <= 2e-6 (asserted inside the ranks)."""
-    r = _run_selftest(world, "gloo")
+    <= 1e-5, loss <= 2e-6 (asserted inside the ranks); and the phase path against the per-module path on the SAME partition:
+    positions and loss <= 1e-6, reduced gradients <= 5e-3 (same arithmetic, other merge points)."""
+    r = _run_selftest(world, "gloo", SEMIGCN_SELFTEST_CROSS="1")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "dist_selftest OK" in r.stdout and "path=phases collectives=44" in r.stdout
+    assert "phases vs per-module path on the same partition" in r.stdout
     print(r.stdout[-1500:])
 
 
