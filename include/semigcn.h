@@ -378,6 +378,29 @@ SG_API int64_t sg_gemm_tn_slabs(int64_t M, int64_t N, int64_t Kp);
 SG_API int sg_gemm_tn_takes_big_tile(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype,
                       float* workspace, float* out, int64_t ldo, void* stream);
+/* ------------------------------------------------------------------------- *
+ * The same two products at the reference's OWN precision -- float32 features, float32 parameters (util/networks.py:40-53;
+ * BASELINE configs c2 / c3; [3P] ChebConv `lins[k]` and their autograd) -- on the bf16 matrix cores: every float32
+ * operand is split exactly into three bf16 pieces (x = hi + mid + lo, 3 x 8 significand bits) and a product is
+ * accumulated in float32 from the six piece products of weight >= 2^-16 (csrc/gemm_split.hip).  Error against a
+ * float64 product: that of a float32 FMA chain (<= 1.5e-7 sum |a b| at K <= 1024); small-integer operands bit for bit.
+ *   sg_gemm_nt_f32:  C[M, N] = A[M, K] op(W) (+ bias[N]); W element (n, k) at W[n * w_rs + k * w_cs] -- (ldw, 1) for the
+ *                    [N, K] weights of the forward product, (1, ldw) for a [K, N] matrix (the input gradient dOut * Wcat
+ *                    without a transposed copy).  workspace: sg_gemm_nt_f32_workspace(N, K) bytes (the split image of W,
+ *                    rebuilt by every call: microseconds).  K % 32 == 0, K >= 64, N % 4 == 0, N >= 64, M >= 256, row
+ *                    strides multiples of 4, 16-byte aligned buffers: sg_gemm_nt_f32_supported; else SG_ERR_INVALID.
+ *   sg_gemm_tn_f32:  out[N, Kp] (row stride ldo) = A[M, N]^T B[M, Kp], a reduction over all M vertices; workspace: float32
+ *                    [sg_gemm_tn_f32_slabs(M, N, Kp), N_pad, Kp_pad] slab partials (sg_gemm_tn_f32_workspace bytes), added
+ *                    in slab order: deterministic.  N, Kp, lda, ldb multiples of 4, ldo % 4 == 0, M >= 4096.
+ * ------------------------------------------------------------------------- */
+SG_API int sg_gemm_nt_f32_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
+SG_API int64_t sg_gemm_nt_f32_workspace(int64_t N, int64_t K);
+SG_API int sg_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
+                          int64_t ldc, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream);
+SG_API int sg_gemm_tn_f32_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
+SG_API int64_t sg_gemm_tn_f32_workspace(int64_t M, int64_t N, int64_t Kp);
+SG_API int sg_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp,
+                          void* workspace, int64_t workspace_bytes, float* out, int64_t ldo, void* stream);
 /* sg_bn_stats_finalize for partials cut into uniform tiles of rows_per_tile rows (the last one shorter) */
 SG_API int sg_bn_stats_finalize_tiles(const float* partial, int64_t n_tiles, int64_t rows_per_tile, int64_t V, int64_t C,
                                       const float* gamma, const float* beta, float* running_mean, float* running_var,

@@ -99,6 +99,14 @@ _SIGNATURES = {
     "sg_gemm_row_tiles": (c_int64, [c_int64, c_int64]),
     "sg_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                            c_int, c_void_p, c_void_p]),
+    "sg_gemm_nt_f32_supported": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
+    "sg_gemm_nt_f32_workspace": (c_int64, [c_int64, c_int64]),
+    "sg_gemm_nt_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                               c_int64, c_void_p, c_int64, c_void_p]),
+    "sg_gemm_tn_f32_supported": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
+    "sg_gemm_tn_f32_workspace": (c_int64, [c_int64, c_int64, c_int64]),
+    "sg_gemm_tn_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                               c_int64, c_void_p]),
     "sg_gemm_tn_slabs": (c_int64, [c_int64, c_int64, c_int64]),
     "sg_gemm_tn_takes_big_tile": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
     "sg_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
@@ -774,6 +782,61 @@ def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     with _on_device(A.device):
         _check(load().sg_gemm_tn(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), M, N, Kp, SG_BF16, _ptr(ws), _ptr(out),
                                  Kp, _stream(A)), "sg_gemm_tn")
+    return out
+
+
+def gemm_nt_f32_supported(A: torch.Tensor, N: int, ldc: Optional[int] = None) -> bool:
+    """Shapes sg_gemm_nt_f32 takes (float32 on the bf16 matrix cores, exact three-way split): see include/semigcn.h."""
+    if A.dtype != torch.float32 or not A.is_cuda or A.dim() != 2 or A.stride(1) != 1 or A.data_ptr() % 16:
+        return False
+    M, K = A.shape
+    return bool(_sizes("sg_gemm_nt_f32_supported", int(M), int(N), int(K), int(A.stride(0)), int(ldc if ldc is not None else N)))
+
+
+def gemm_nt_f32(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                w_is_kn: bool = False) -> torch.Tensor:
+    """``A @ W.T (+ bias)`` for float32 A [M, K] and W [N, K] -- or ``A @ W`` for W [K, N] with ``w_is_kn`` -- on the bf16
+    matrix cores at float32-equivalent error (csrc/gemm_split.hip)."""
+    _require_device(A, "A")
+    _require_device(W, "W")
+    M, K = A.shape
+    N = W.shape[1] if w_is_kn else W.shape[0]
+    if (W.shape[0] if w_is_kn else W.shape[1]) != K or A.dtype != torch.float32 or W.dtype != torch.float32:
+        raise SemigcnLibraryError(f"gemm_nt_f32 shape / dtype mismatch: A {tuple(A.shape)} W {tuple(W.shape)}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    rs, cs = (W.stride(1), W.stride(0)) if w_is_kn else (W.stride(0), W.stride(1))
+    nbytes = _sizes("sg_gemm_nt_f32_workspace", N, K)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)
+    with _on_device(A.device):
+        _check(load().sg_gemm_nt_f32(_ptr(A), _rows2d(A, "A"), _ptr(W), rs, cs, _ptr(bias), _ptr(out), _rows2d(out, "out"),
+                                     M, N, K, _ptr(ws), nbytes, _stream(A)), "sg_gemm_nt_f32")
+    return out
+
+
+def gemm_tn_f32_supported(A: torch.Tensor, B: torch.Tensor) -> bool:
+    if A.dtype != torch.float32 or B.dtype != torch.float32 or not A.is_cuda or A.dim() != 2 or B.dim() != 2:
+        return False
+    if A.shape[0] != B.shape[0] or A.stride(1) != 1 or B.stride(1) != 1 or A.data_ptr() % 16 or B.data_ptr() % 16:
+        return False
+    return bool(_sizes("sg_gemm_tn_f32_supported", int(A.shape[0]), int(A.shape[1]), int(B.shape[1]), int(A.stride(0)),
+                       int(B.stride(0))))
+
+
+def gemm_tn_f32(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """``A.T @ B`` for float32 A [M, N], B [M, Kp] on the bf16 matrix cores at float32-equivalent error; deterministic."""
+    _require_device(A, "A")
+    _require_device(B, "B")
+    M, N = A.shape
+    Kp = B.shape[1]
+    if B.shape[0] != M:
+        raise SemigcnLibraryError(f"gemm_tn_f32 shape mismatch: A {tuple(A.shape)} B {tuple(B.shape)}")
+    out = torch.empty((N, Kp), dtype=torch.float32, device=A.device)
+    nbytes = _sizes("sg_gemm_tn_f32_workspace", M, N, Kp)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)
+    with _on_device(A.device):
+        _check(load().sg_gemm_tn_f32(_ptr(A), _rows2d(A, "A"), _ptr(B), _rows2d(B, "B"), M, N, Kp, _ptr(ws), nbytes, _ptr(out),
+                                     Kp, _stream(A)), "sg_gemm_tn_f32")
     return out
 
 

@@ -258,6 +258,16 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
                    float* workspace, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink = nullptr, Planes pa = {},
                    Planes pb = {});
 
+// gemm_split.hip -- float32 products on the bf16 matrix cores (exact three-way split, six piece products)
+bool gemm_nt_f32s_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
+int64_t gemm_nt_f32s_workspace(int64_t N, int64_t K);
+int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
+                        int64_t ldc, int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes, hipStream_t stream);
+bool gemm_tn_f32s_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
+int64_t gemm_tn_f32s_workspace(int64_t M, int64_t N, int64_t Kp);
+int launch_gemm_tn_f32s(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, void* ws,
+                        int64_t ws_bytes, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink = nullptr);
+
 // mesh_loss.hip
 int64_t mesh_loss_blocks(int64_t V, int64_t F);
 int launch_mesh_loss_fwd(const float* pos, const int64_t* faces, const float* tpos, const float* vkeep, const float* tfn,
