@@ -611,8 +611,11 @@ enum sg_tune_knob {
                              for the compute-bound products), 1 = 128-row tiles only, 2 = 64 x 256 wherever N > 64 (A/B
                              switch; measured slower), 3 = the 256 x 256 kernel wherever it takes the shape, 4 = no 128 x 192 tiles for
                              N = 192 (A/B switch), 5 = 128 x 192 tiles also for N = 384 (A/B switch; measured slower) */
-  SG_TUNE_BLOCK_PLANES = 7 /* sg_block_*: 1 (default) = narrow layers keep their recurrence buffers as planes
+  SG_TUNE_BLOCK_PLANES = 7, /* sg_block_*: 1 (default) = narrow layers keep their recurrence buffers as planes
                               (sg_block_planar), 0 = column blocks everywhere (A/B switch) */
+  SG_TUNE_F32_ENGINE = 8   /* dense products on float32 features: 0 (default) = the split-bf16 MFMA kernels (csrc/gemm_split.hip)
+                              wherever they take the shape, the BLAS library for the rest; bit 0 = the BLAS library for all of
+                              them (A/B switch); bit 4 = sg_gemm_nt_f32 without the half-block stagger (A/B switch) */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

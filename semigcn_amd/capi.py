@@ -498,6 +498,7 @@ class PoolHandle:
 
 TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB, TUNE_TILED_MIN_ROW_BYTES, TUNE_GEMM_TILE, TUNE_GRAPH_REORDER = 0, 1, 2, 3, 4, 5, 6
 TUNE_BLOCK_PLANES = 7
+TUNE_F32_ENGINE = 8
 
 
 def tuning_set(knob: int, value: int) -> None:

@@ -22,7 +22,7 @@
 // A is NOT staged through LDS: one workgroup = 8 wavefronts x 32 rows, a wavefront owns its 32 rows x all NT columns, so
 // no other wavefront ever needs its A rows -- they go global -> VGPR (two 16-byte loads per lane and 16 x 32 fragment, 64
 // contiguous bytes per row and instruction), are split in registers (11 VALU per pair of values, v_cvt_pk_bf16_f32 does
-// the rounding and the packing) two K blocks ahead of their use, and 192 MFMAs (NT = 256) run on each K block: 0.5 VALU
+// the rounding and the packing) one K block ahead of their use, and 192 MFMAs (NT = 256) run on each K block: 0.5 VALU
 // per MFMA, inside the issue slots a 16-cycle MFMA leaves free.  The k order inside a 32-block is permuted (lane group q
 // holds k = 4q..4q+3 and 16+4q..16+4q+3) so that each A load is one dwordx4; the weight image uses the same order.
 // Persistent: a workgroup keeps its column tile and walks row tiles; the DMA ring and the A prefetch run across tile
@@ -117,7 +117,13 @@ struct SplitNt {
   int n_col_tiles, n_row_tiles, streams;
 };
 
-template <int NF>
+// STAG: wavefronts 4-7 run half a K block behind wavefronts 0-3 (two workgroup barriers per K block; the two wavefronts of a
+// SIMD are in different halves): while one issues its LDS-DMA, loads, splits A or stores a tile, its partner's MFMAs keep the
+// SIMD's matrix pipe busy.  Global barrier #b: the early group's K block s starts at #2s and has its middle at #2s + 1, the
+// late group's starts at #2s + 1.  Ring rules: a wavefront joins #2s only after ITS pieces of the DMA of block s have landed
+// (early group: at the top of s; late group: in the middle of s - 1); the DMA of block s + D overwrites the slot of block
+// s - 1, whose last readers (the late group) are done at #2s + 1 -- so every wavefront issues it right after #2s + 1.
+template <int NF, bool STAG>
 __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g) {
   constexpr int SLOT = 3 * NF * 1024;              // one K block of the column tile: 48 KB (NT = 256) / 24 KB (NT = 128)
   constexpr int RING = NF == 16 ? 3 : 4;
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool late = STAG && wave >= 4;
   const int fr = lane & 15, fq = lane >> 4;
 
   const int b = blockIdx.x;
@@ -146,7 +153,6 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
     const int col = ct * NT + tid;
     bias_s[tid] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
   }
-  // (an ordinary load + ds_write: hipcc waits for it right here, before the first DMA is counted)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
   // ---- the weight stream: K block kb of this column tile = SLOT contiguous bytes; wavefront w copies pieces w*P .. w*P+P-1
@@ -203,50 +209,105 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
   set_tile(0);
 #pragma unroll
   for (int d = 0; d < D; ++d) dma();
-  Pieces cur[2], nxt[2];
+  Pieces cur[2];
   {
     const Raw r0 = load_a();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) cur[i] = split8(r0.v[i][0], r0.v[i][1]);
+    for (int i = 0; i < 2; ++i) cur[i] = split8(r0.v[i][0], r0.v[i][1]);      // (hipcc waits for r0 here: the DMAs before it have landed)
   }
-  Raw rawc = load_a();                                    // K block 1
+  if (late) __builtin_amdgcn_s_barrier();                 // pairs with the early group's barrier #0
 
-  int since = D;                                          // K blocks since a tile was stored, capped at D
+  // counted waits (vector-memory operations of THIS wavefront younger than the DMA pieces waited for; stores of a finished
+  // tile sit in the same in-order queue).  Per K block, in program order -- early group (and no stagger): [A loads 4] .. [DMA P]
+  // .. [stores]; late group: [DMA P][A loads 4] .. [stores].
+  //   top of block s, no stagger (DMA first):  4 + (D - 1)(P + 4)     early group:  (D - 1)(P + 4)
+  //   middle of block s, late group (waits for block s + 1):  4 + (D - 1)(P + 4)
+  constexpr int kTopPlain = 4 + (D - 1) * (P + 4), kTopEarly = (D - 1) * (P + 4), kMidLate = 4 + (D - 1) * (P + 4);
+  static_assert(kTopPlain + NSTORE < 64, "vmcnt is a 6-bit field");
+#define SGS_WAIT2(base, with_stores)                                        \
+  do {                                                                       \
+    if (with_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((base) + NSTORE) : "memory"); \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(base) : "memory");        \
+  } while (0)
+
+  int since = D;                                          // completed K blocks since a tile was stored, capped at D
   int rslot = 0, ck = 0, ctile = 0;
-  constexpr int kBase = 4 + (D - 1) * (P + 4);            // vector-memory operations younger than the DMA of the block read next
-  for (int s = 0; s < total; ++s) {
-    // the DMA of this K block has landed (this wavefront's share), then everybody's; the slot read one block ago is free
-    if (since < D && exact_stores) {
-      if constexpr (NF == 16) SGS_WAIT_VM(46); else SGS_WAIT_VM(34);
-    } else {
-      if constexpr (NF == 16) SGS_WAIT_VM(14); else SGS_WAIT_VM(18);
-    }
-    static_assert(kBase == (NF == 16 ? 14 : 18) && kBase + NSTORE == (NF == 16 ? 46 : 34), "counted waits");
-    __builtin_amdgcn_s_barrier();
-    dma();                                                // K block s + D
-    __builtin_amdgcn_sched_barrier(0);                    // (the counted waits assume the DMA is the step's FIRST vector-memory work)
-    const Raw rawn = load_a();                            // A of K block s + 2
-#pragma unroll
-    for (int i = 0; i < 2; ++i) nxt[i] = split8(rawc.v[i][0], rawc.v[i][1]);      // pieces of K block s + 1
+  // One half of a K block.  The weight fragments of two column fragments (a GROUP: 6 x ds_read_b128) are read one group
+  // ahead of the 24 MFMAs that use them: all eight wavefronts run this code in step, and a group that waited for its own reads
+  // left both wavefronts of a SIMD parked on lgkmcnt together with the matrix pipe idle (0.59 busy, PMC, first version).
+  // The reads are inline asm with hand-counted `s_waitcnt lgkmcnt(6)` TIED to the fragments they make valid: hipcc's own
+  // bookkeeping waits for lgkmcnt(0) in front of the third group, i.e. for the reads it has just issued.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds + lane * 16;
+  uint32_t sbaddr = lds0;
+  bf16x8 f[2][2][3];
+#define SGS_RD1(dst, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(sbaddr), "n"(OFF))
+#define SGS_RD6(B, H, GI)                                                       \
+  SGS_RD1(f[B][0][0], (0 * NF + (H) * (NF / 2) + 2 * (GI) + 0) * 1024);         \
+  SGS_RD1(f[B][0][1], (1 * NF + (H) * (NF / 2) + 2 * (GI) + 0) * 1024);         \
+  SGS_RD1(f[B][0][2], (2 * NF + (H) * (NF / 2) + 2 * (GI) + 0) * 1024);         \
+  SGS_RD1(f[B][1][0], (0 * NF + (H) * (NF / 2) + 2 * (GI) + 1) * 1024);         \
+  SGS_RD1(f[B][1][1], (1 * NF + (H) * (NF / 2) + 2 * (GI) + 1) * 1024);         \
+  SGS_RD1(f[B][1][2], (2 * NF + (H) * (NF / 2) + 2 * (GI) + 1) * 1024)
+#define SGS_READY6(B, N)                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                       \
+               : "+v"(f[B][0][0]), "+v"(f[B][0][1]), "+v"(f[B][0][2]), "+v"(f[B][1][0]), "+v"(f[B][1][1]), "+v"(f[B][1][2])::"memory")
+#define SGS_MM(B, H, GI)                                                                  \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                         \
+    const bf16x8 bh = f[B][u][0], bm = f[B][u][1], bl = f[B][u][2];                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                       \
+      f32x4 c = acc[i][(H) * (NF / 2) + 2 * (GI) + u];                                    \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, cur[i].h, c, 0, 0, 0);              \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, cur[i].l, c, 0, 0, 0);              \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, cur[i].m, c, 0, 0, 0);              \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, cur[i].h, c, 0, 0, 0);              \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, cur[i].m, c, 0, 0, 0);              \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, cur[i].h, c, 0, 0, 0);              \
+      acc[i][(H) * (NF / 2) + 2 * (GI) + u] = c;                                          \
+    }                                                                                     \
+  }                                                                                       \
+  __builtin_amdgcn_sched_barrier(0)
+#define SGS_HALF(H)                    \
+  do {                                 \
+    SGS_RD6(0, H, 0);                  \
+    SGS_RD6(1, H, 1);                  \
+    SGS_READY6(0, 6);                  \
+    SGS_MM(0, H, 0);                   \
+    if constexpr (NF == 16) {          \
+      SGS_RD6(0, H, 2);                \
+      SGS_READY6(1, 6);                \
+      SGS_MM(1, H, 1);                 \
+      SGS_RD6(1, H, 3);                \
+      SGS_READY6(0, 6);                \
+      SGS_MM(0, H, 2);                 \
+      SGS_READY6(1, 0);                \
+      SGS_MM(1, H, 3);                 \
+    } else {                           \
+      SGS_READY6(1, 0);                \
+      SGS_MM(1, H, 1);                 \
+    }                                  \
+  } while (0)
 
-    const uint8_t* const sb = lds + rslot * SLOT + lane * 16;
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-      const bf16x8 bh = *(const bf16x8*)(sb + (0 * NF + j) * 1024);
-      const bf16x8 bm = *(const bf16x8*)(sb + (1 * NF + j) * 1024);
-      const bf16x8 bl = *(const bf16x8*)(sb + (2 * NF + j) * 1024);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f32x4 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, cur[i].h, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, cur[i].l, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, cur[i].m, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, cur[i].h, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, cur[i].m, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, cur[i].h, c, 0, 0, 0);
-        acc[i][j] = c;
+  for (int s = 0; s < total; ++s) {
+    // ---- top of the K block
+    if (!STAG) SGS_WAIT2(kTopPlain, since < D && exact_stores);
+    else if (!late) SGS_WAIT2(kTopEarly, since < D && exact_stores);
+    __builtin_amdgcn_s_barrier();
+    if (!STAG || late) {
+      dma();                                              // K block s + D
+      __builtin_amdgcn_sched_barrier(0);                  // (the counted waits assume this order of the vector-memory work)
+    }
+    const Raw rawn = load_a();                            // A of K block s + 1: a whole block of MFMAs to arrive
+    sbaddr = lds0 + rslot * SLOT;
+    SGS_HALF(0);
+    if (STAG) {
+      if (late) SGS_WAIT2(kMidLate, since < D - 1 && exact_stores);
+      __builtin_amdgcn_s_barrier();
+      if (!late) {
+        dma();
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    SGS_HALF(1);
     rslot = rslot + 1 == RING ? 0 : rslot + 1;
     since = since < D ? since + 1 : D;
 
@@ -268,25 +329,34 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
       ++ctile;
       since = 0;
     }
+    // the pieces of the next K block, in place (this block's MFMAs have been issued; beside the SIMD partner's MFMAs)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) cur[i] = nxt[i];
-    rawc = rawn;
+    for (int i = 0; i < 2; ++i) cur[i] = split8(rawn.v[i][0], rawn.v[i][1]);
   }
+  if (STAG && !late) __builtin_amdgcn_s_barrier();        // pairs with the late group's last middle barrier
   SGS_WAIT_VM(0);                                         // no LDS-DMA may be in flight when the workgroup ends
+#undef SGS_WAIT2
+#undef SGS_HALF
+#undef SGS_MM
+#undef SGS_READY6
+#undef SGS_RD6
+#undef SGS_RD1
 }
-
 
 // ---- tn: the weight gradient ---------------------------------------------------------------------------------------------------
 // out[N, Kp] = A[M, N]^T B[M, Kp] (dWcat = dOut^T [Tx0|Tx1|Tx2]; autograd of the `lins[k]` calls, util/networks.py:42,49).
 // The reduction index m is the ROW of both operands and both stream from HBM, so both are split on the way into LDS: one
 // workgroup = one 256 (n) x 128 (k') tile of the result for one slab of rows, walked in steps of 32 rows.  Per step every
-// thread loads 6 float4 (rows of A: 1 KB per wavefront instruction), splits them in registers (no redundancy: each value
-// is split once per tile it feeds) and writes the three bf16 planes [32 m][256 | 128] into LDS (ds_write_b64; 32-byte
-// segments XOR-swizzled by the row, as sg::gemm_tn_bf16); the MFMA fragments -- 8 consecutive m of one column -- are read
-// with the transposing ds_read_b64_tr_b16.  Two buffers of 72 KB; the loads of step s + 1 are issued before the MFMAs of
-// step s and stashed after them.  96 MFMAs per wavefront and step (4 x 4 fragments x 6 piece products), 132 VALU.
+// thread loads 6 float4 (rows of A: 1 KB per wavefront instruction) TWO steps ahead, splits them in registers (each value
+// once per tile it feeds) and writes the three bf16 planes [32 m][256 | 128] into the other LDS buffer (ds_write_b64;
+// 32-byte segments XOR-swizzled by the row, as sg::gemm_tn_bf16); the MFMA fragments -- 8 consecutive m of one column -- are
+// read with the transposing ds_read_b64_tr_b16.  A wavefront owns 32 n x all 128 k': its two A fragments stay in registers
+// for the step, the eight B fragments stream one ahead of the 12 MFMAs that use them (inline asm reads, hand-counted
+// lgkmcnt: hipcc's own bookkeeping waits for every read in flight).  ONE instruction stream per wavefront, nothing waits
+// for work it has just started: the six split-and-stash slices of the next step sit between the MFMA groups (pinned by empty
+// asm statements: hipcc otherwise sinks them behind the last MFMA), the step's only workgroup barrier in front of its last
+// MFMA group, followed at once by the fragment reads of the next step.  96 MFMAs per wavefront and step, 132 VALU.
 // Slab partials go to the workspace and are summed in slab order by sg::split_tn_reduce: deterministic.
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct SplitTn {
@@ -324,145 +394,213 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 1, wk = wave & 1;
+  // ---- work items: (slab, tile) pairs; the workgroups with equal blockIdx % 8 (one XCD, for speed only) walk the items of the
+  //      slabs x, x + 8, .. in order, tile fastest, so the tiles of a slab run side by side and share its rows through one L2
   const int b = blockIdx.x;
-  const int slot = b >> 3;
-  const int tile = slot % g.n_tiles;
-  const int slab = (b & 7) + 8 * (slot / g.n_tiles);
-  const int n0 = (tile / g.tiles_k) * 256, k0 = (tile % g.tiles_k) * 128;
+  const int xg = b & 7, yg = b >> 3, per_group = gridDim.x >> 3;
+  const int items = (g.slabs >> 3) * g.n_tiles;        // per group
   const int q = g.steps / g.slabs, rem = g.steps % g.slabs;
-  const int first = slab * q + (slab < rem ? slab : rem);
-  const int count = q + (slab < rem ? 1 : 0);
+  int n0 = 0, k0 = 0, first = 0, count = 0, slab = 0;
 
   // ---- staging map: A float4 f = tid + 512 i -> row (tid >> 6) + 8 i, columns 4 (tid & 63); B: row (tid >> 5) + 16 i, 4 (tid & 31)
   const int ca = tid & 63, cb = tid & 31;
-  const bool a_ok = n0 + 4 * ca < g.N, b_ok = k0 + 4 * cb < g.Kp;           // N, Kp % 4 == 0
-  const float* const a_src = g.A + (a_ok ? n0 + 4 * ca : 0);
-  const float* const b_src = g.B + (b_ok ? k0 + 4 * cb : 0);
-  int dst_a[4], dst_b[2];
+  bool a_ok = false, b_ok = false;                     // N, Kp % 4 == 0
+  const float* a_src = g.A;
+  const float* b_src = g.B;
+  auto set_item = [&](int item) {
+    const int tile = item % g.n_tiles;
+    slab = xg + 8 * (item / g.n_tiles);
+    n0 = (tile / g.tiles_k) * 256;
+    k0 = (tile % g.tiles_k) * 128;
+    first = slab * q + (slab < rem ? slab : rem);
+    count = q + (slab < rem ? 1 : 0);
+    a_ok = n0 + 4 * ca < g.N;
+    b_ok = k0 + 4 * cb < g.Kp;
+    a_src = g.A + (a_ok ? n0 + 4 * ca : 0);
+    b_src = g.B + (b_ok ? k0 + 4 * cb : 0);
+  };
+  int dst[6];                                          // byte offset of the thread's float4 q in plane 0 of its operand
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (tid >> 6) + 8 * i;
-    dst_a[i] = r * 512 + ((((ca >> 2) ^ tn_swz(r)) << 5) | ((ca & 3) << 3));
+    dst[i] = r * 512 + ((((ca >> 2) ^ tn_swz(r)) << 5) | ((ca & 3) << 3));
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (tid >> 5) + 16 * i;
-    dst_b[i] = 3 * PA + r * 256 + ((((cb >> 2) ^ tn_swz(r)) << 5) | ((cb & 3) << 3));
+    dst[4 + i] = 3 * PA + r * 256 + ((((cb >> 2) ^ tn_swz(r)) << 5) | ((cb & 3) << 3));
   }
-  f32x4 ra[4], rb[2];
-  auto fetch = [&](int step) {
+  f32x4 raw[2][6];                                     // two steps of this thread's rows in flight
+  uint32_t keep[2];                                    // bit q: float4 q of the set is inside the matrix (else it is stashed as zeros)
+  // (the loaded values are NOT touched here: a select on them would make hipcc wait for the loads right behind their issue)
+  auto fetch = [&](f32x4 (&r)[6], uint32_t& kp, int step) {
     const int m0 = (first + step) * 32;
+    kp = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int m = m0 + (tid >> 6) + 8 * i;
       const bool in = m < g.M;
       m = in ? m : g.M - 1;
-      const f32x4 v = *(const f32x4*)(a_src + (int64_t)m * g.lda);
-      ra[i] = (in && a_ok) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      r[i] = *(const f32x4*)(a_src + (int64_t)m * g.lda);
+      kp |= (in && a_ok) ? 1u << i : 0u;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int m = m0 + (tid >> 5) + 16 * i;
       const bool in = m < g.M;
       m = in ? m : g.M - 1;
-      const f32x4 v = *(const f32x4*)(b_src + (int64_t)m * g.ldb);
-      rb[i] = (in && b_ok) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      r[4 + i] = *(const f32x4*)(b_src + (int64_t)m * g.ldb);
+      kp |= (in && b_ok) ? 16u << i : 0u;
     }
   };
-  auto stash = [&](int buf) {
-    uint8_t* const base = lds + buf * BUF;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const Pieces4 s = split4(ra[i]);
-      *(u32x2*)(base + dst_a[i]) = s.h;
-      *(u32x2*)(base + PA + dst_a[i]) = s.m;
-      *(u32x2*)(base + 2 * PA + dst_a[i]) = s.l;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const Pieces4 s = split4(rb[i]);
-      *(u32x2*)(base + dst_b[i]) = s.h;
-      *(u32x2*)(base + PB + dst_b[i]) = s.m;
-      *(u32x2*)(base + 2 * PB + dst_b[i]) = s.l;
-    }
+  // one float4 of the thread -> its 3 x 8 bytes in the planes of buffer `buf` (the empty asm pins the arithmetic here)
+  auto slice = [&](const f32x4 v, uint32_t kp, int qq, int buf) {
+    Pieces4 p = split4((kp >> qq) & 1u ? v : f32x4{0.f, 0.f, 0.f, 0.f});
+    asm volatile("" : "+v"(p.h), "+v"(p.m), "+v"(p.l));
+    uint8_t* const d = lds + buf * BUF + dst[qq];
+    const int plane = qq < 4 ? PA : PB;
+    *(u32x2*)(d) = p.h;
+    *(u32x2*)(d + plane) = p.m;
+    *(u32x2*)(d + 2 * plane) = p.l;
   };
 
   // ---- transposing fragment reads: lane = 16 fg + 4 fq + fp supplies row 8 fg + 4 hh + fq, columns 4 fp .. + 3 of a 16-column
   //      segment; lane 16 fg + i receives column i of those 4 rows (hh = 0 / 1: the two halves of the lane's 8 m)
   const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
-  int row_a[2], row_b[2], swz[2];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds;
+  uint32_t adr_a[2][2], adr_b[8][2];                   // [fragment][hh]: address in plane 0 of buffer 0
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
     const int row = 8 * fg + 4 * hh + fq;
-    row_a[hh] = row * 512 + fp * 8;
-    row_b[hh] = row * 256 + fp * 8;
-    swz[hh] = tn_swz(row);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) adr_a[i][hh] = lds0 + row * 512 + fp * 8 + (((wave * 2 + i) ^ tn_swz(row)) << 5);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) adr_b[j][hh] = lds0 + 3 * PA + row * 256 + fp * 8 + ((j ^ tn_swz(row)) << 5);
   }
-  auto frag = [&](const uint8_t* plane, const int (&row_off)[2], int seg) -> bf16x8 {
-    bf16x4 h[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const uint8_t* p = plane + row_off[hh] + ((seg ^ swz[hh]) << 5);
-      h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p);
-    }
-    return bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
-  };
+  u32x2 af[2][2][3][2];                                // [set][i][plane][hh]
+  u32x2 bf[2][3][2];                                   // [buffer of the stream][plane][hh]
+#define TN_RD1(dst, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(ADDR), "n"(OFF))
+#define TN_RDB(S, J, BOFF)                                      \
+  TN_RD1(bf[S][0][0], adr_b[J][0] + (BOFF), 0);                 \
+  TN_RD1(bf[S][0][1], adr_b[J][1] + (BOFF), 0);                 \
+  TN_RD1(bf[S][1][0], adr_b[J][0] + (BOFF), PB);                \
+  TN_RD1(bf[S][1][1], adr_b[J][1] + (BOFF), PB);                \
+  TN_RD1(bf[S][2][0], adr_b[J][0] + (BOFF), 2 * PB);            \
+  TN_RD1(bf[S][2][1], adr_b[J][1] + (BOFF), 2 * PB)
+#define TN_RDA(SET, I, BOFF)                                    \
+  TN_RD1(af[SET][I][0][0], adr_a[I][0] + (BOFF), 0);            \
+  TN_RD1(af[SET][I][0][1], adr_a[I][1] + (BOFF), 0);            \
+  TN_RD1(af[SET][I][1][0], adr_a[I][0] + (BOFF), PA);           \
+  TN_RD1(af[SET][I][1][1], adr_a[I][1] + (BOFF), PA);           \
+  TN_RD1(af[SET][I][2][0], adr_a[I][0] + (BOFF), 2 * PA);       \
+  TN_RD1(af[SET][I][2][1], adr_a[I][1] + (BOFF), 2 * PA)
+#define TN_READYB(S, N)                                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                       \
+               : "+v"(bf[S][0][0]), "+v"(bf[S][0][1]), "+v"(bf[S][1][0]), "+v"(bf[S][1][1]), "+v"(bf[S][2][0]), "+v"(bf[S][2][1])::"memory")
+#define TN_READYA(SET, I)                                                                                        \
+  asm volatile("" : "+v"(af[SET][I][0][0]), "+v"(af[SET][I][0][1]), "+v"(af[SET][I][1][0]), "+v"(af[SET][I][1][1]), \
+               "+v"(af[SET][I][2][0]), "+v"(af[SET][I][2][1]))
+#define TN_OP(x) __builtin_bit_cast(bf16x8, u32x4{(x)[0][0], (x)[0][1], (x)[1][0], (x)[1][1]})
+#define TN_MM(SET, S, J)                                                       \
+  {                                                                            \
+    const bf16x8 bh = TN_OP(bf[S][0]), bm = TN_OP(bf[S][1]), bl = TN_OP(bf[S][2]); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                            \
+      const bf16x8 ah = TN_OP(af[SET][i][0]), am = TN_OP(af[SET][i][1]), al = TN_OP(af[SET][i][2]); \
+      f32x4 c = acc[i][J];                                                     \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, c, 0, 0, 0);         \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, c, 0, 0, 0);         \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am, c, 0, 0, 0);         \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah, c, 0, 0, 0);         \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am, c, 0, 0, 0);         \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, c, 0, 0, 0);         \
+      acc[i][J] = c;                                                           \
+    }                                                                          \
+  }
+  // fragment J of the step: read J + 1, multiply J, then a slice of the side work
+#define TN_J(SET, J, BOFF, SIDE)                  \
+  TN_RDB(((J) + 1) & 1, (J) + 1, BOFF);           \
+  TN_READYB((J) & 1, 6);                          \
+  TN_MM(SET, (J) & 1, J)                          \
+  SIDE;                                           \
+  __builtin_amdgcn_sched_barrier(0)
+  // one step with literal parity PAR (= s & 1): multiplies buffer PAR with A-fragment set PAR, stashes step s + 1 (raw set
+  // PAR ^ 1) into buffer PAR ^ 1, loads step s + 2 into raw set PAR
+#define TN_STEP(PAR)                                                                      \
+  do {                                                                                    \
+    constexpr uint32_t boff = (PAR) * BUF, noff = ((PAR) ^ 1) * BUF;                      \
+    fetch(raw[PAR], keep[PAR], s + 2);                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    TN_READYA(PAR, 0);                                                                    \
+    TN_READYA(PAR, 1);                                                                    \
+    TN_J(PAR, 0, boff, (void)0);                                                          \
+    TN_J(PAR, 1, boff, slice(raw[(PAR) ^ 1][0], keep[(PAR) ^ 1], 0, (PAR) ^ 1));                           \
+    TN_J(PAR, 2, boff, slice(raw[(PAR) ^ 1][1], keep[(PAR) ^ 1], 1, (PAR) ^ 1));                           \
+    TN_J(PAR, 3, boff, slice(raw[(PAR) ^ 1][2], keep[(PAR) ^ 1], 2, (PAR) ^ 1));                           \
+    TN_J(PAR, 4, boff, slice(raw[(PAR) ^ 1][3], keep[(PAR) ^ 1], 3, (PAR) ^ 1));                           \
+    TN_J(PAR, 5, boff, slice(raw[(PAR) ^ 1][4], keep[(PAR) ^ 1], 4, (PAR) ^ 1));                           \
+    TN_J(PAR, 6, boff, slice(raw[(PAR) ^ 1][5], keep[(PAR) ^ 1], 5, (PAR) ^ 1));                           \
+    TN_READYB(1, 0);      /* fragment 7, and every LDS write of this wavefront's stash */ \
+    __builtin_amdgcn_s_barrier();                                                         \
+    TN_RDA((PAR) ^ 1, 0, noff);                                                           \
+    TN_RDA((PAR) ^ 1, 1, noff);                                                           \
+    TN_RDB(0, 0, noff);                                                                   \
+    TN_MM(PAR, 1, 7)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
 
-  f32x4 acc[4][4];
+  for (int item = yg; item < items; item += per_group) {
+  set_item(item);
+  f32x4 acc[2][8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (count > 0) {
-    fetch(0);
-    stash(0);
-  }
-  for (int s = 0; s < count; ++s) {
-    const int buf = s & 1;
-    __syncthreads();                 // step s is in LDS (every wavefront's share); the other buffer's readers are done
-    const bool more = s + 1 < count;
-    if (more) fetch(s + 1);
-    const uint8_t* const base = lds + buf * BUF;
-    bf16x8 ah[4], am[4], al[4];
+    // ---- prologue: step 0 stashed into buffer 0 and visible, step 1 in raw set 1, the fragments of step 0 being read
+    fetch(raw[0], keep[0], 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ah[i] = frag(base, row_a, wn * 4 + i);
-      am[i] = frag(base + PA, row_a, wn * 4 + i);
-      al[i] = frag(base + 2 * PA, row_a, wn * 4 + i);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16x8 bh = frag(base + 3 * PA, row_b, wk * 4 + j);
-      const bf16x8 bm = frag(base + 3 * PA + PB, row_b, wk * 4 + j);
-      const bf16x8 bl = frag(base + 3 * PA + 2 * PB, row_b, wk * 4 + j);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[i], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[i], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[i], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[i], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], c, 0, 0, 0);
-        acc[i][j] = c;
+    for (int qq = 0; qq < 6; ++qq) slice(raw[0][qq], keep[0], qq, 0);
+    fetch(raw[1], keep[1], 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    TN_RDA(0, 0, 0u);
+    TN_RDA(0, 1, 0u);
+    TN_RDB(0, 0, 0u);
+    for (int s = 0; s < count; s += 2) {
+      TN_STEP(0);
+      if (s + 1 < count) {
+        ++s;
+        TN_STEP(1);
+        --s;
+      } else {
+        break;
       }
     }
-    if (more) stash(buf ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the fragment reads issued for the step after the last)
   }
+#undef TN_STEP
+#undef TN_J
+#undef TN_MM
+#undef TN_OP
+#undef TN_READYA
+#undef TN_READYB
+#undef TN_RDA
+#undef TN_RDB
+#undef TN_RD1
 
   // ---- the slab's partial tile: D = (B fragment) x (A fragment): lane holds k' = 4 (lane >> 4) .. + 3 of column n = lane & 15
   float* const W = g.W + (int64_t)slab * g.N * g.Kp;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + (wn * 4 + i) * 16 + (lane & 15);
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + (wave * 2 + i) * 16 + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kk = k0 + (wk * 4 + j) * 16 + 4 * (lane >> 4);
+    for (int j = 0; j < 8; ++j) {
+      const int kk = k0 + j * 16 + 4 * (lane >> 4);
       if (n < g.N && kk < g.Kp) *(f32x4*)(W + (int64_t)n * g.Kp + kk) = acc[i][j];
     }
   }
+  }      // items
 }
 
 // out[n][k] = the slabs' partial tiles added in slab order (64 x 16 threads: 64 consecutive float4, 16 slab groups, then the
@@ -493,6 +631,15 @@ __global__ __launch_bounds__(1024) void split_tn_reduce(const float* __restrict_
 }  // namespace
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
+// SG_TUNE_F32_ENGINE: 0 = shipped; bit 0: the BLAS library serves every fp32 product (A/B runs); bit 4: nt kernel without the
+// half-block stagger of wavefronts 4-7
+static int g_split_variant = 0;
+int set_split_tuning(int value) {
+  g_split_variant = value;
+  return SG_OK;
+}
+bool split_engine_enabled() { return !(g_split_variant & 1); }
+
 static inline int split_nf(int64_t N) { return N % 256 == 0 || N > 640 ? 16 : (N % 128 == 0 || N <= 128 ? 8 : 16); }
 
 bool gemm_nt_f32s_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
@@ -541,8 +688,12 @@ int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_r
   const int need = (g.n_row_tiles + 7) / 8 * 8;
   streams = streams > need ? need : streams;
   g.streams = streams;
-  if (nf == 16) gemm_nt_f32s<16><<<streams * g.n_col_tiles, kSplitThreads, 0, stream>>>(g);
-  else gemm_nt_f32s<8><<<streams * g.n_col_tiles, kSplitThreads, 0, stream>>>(g);
+  const bool stag = !(g_split_variant & 16);
+  const int grid = streams * g.n_col_tiles;
+  if (nf == 16 && stag) gemm_nt_f32s<16, true><<<grid, kSplitThreads, 0, stream>>>(g);
+  else if (nf == 16) gemm_nt_f32s<16, false><<<grid, kSplitThreads, 0, stream>>>(g);
+  else if (stag) gemm_nt_f32s<8, true><<<grid, kSplitThreads, 0, stream>>>(g);
+  else gemm_nt_f32s<8, false><<<grid, kSplitThreads, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
@@ -552,13 +703,20 @@ bool gemm_tn_f32s_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64
          ldb % 4 == 0 && N < (1 << 20) && Kp < (1 << 20);
 }
 
+// slabs of rows: 8 x s, s the smallest count for which the items of one XCD group (s x tiles) fill its 32 workgroups evenly,
+// halved while a slab would be shorter than 64 steps of 32 rows
 static int split_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
   const int64_t n_tiles = ((N + 255) / 256) * ((Kp + 127) / 128);
-  int64_t slabs = (256 / n_tiles) / 8 * 8;
-  slabs = slabs < 8 ? 8 : slabs;
+  int64_t g = n_tiles, r = 32;
+  while (r) {
+    const int64_t t = g % r;
+    g = r;
+    r = t;
+  }
+  int64_t s = 32 / g;
   const int64_t steps = (M + 31) / 32;
-  while (slabs > 8 && steps < 4 * slabs) slabs -= 8;
-  return (int)slabs;
+  while (s > 1 && steps < 64 * 8 * s) s = (s + 1) / 2;
+  return (int)(8 * s);
 }
 
 int64_t gemm_tn_f32s_workspace(int64_t M, int64_t N, int64_t Kp) { return (int64_t)split_tn_slabs(M, N, Kp) * N * Kp * 4; }
@@ -581,7 +739,8 @@ int launch_gemm_tn_f32s(const float* A, int64_t lda, const float* B, int64_t ldb
   g.n_tiles = (int)((N + 255) / 256) * g.tiles_k;
   g.slabs = split_tn_slabs(M, N, Kp);
   g.steps = (int)((M + 31) / 32);
-  gemm_tn_f32s<<<g.slabs * g.n_tiles, kSplitThreads, 0, stream>>>(g);
+  const int items = (g.slabs / 8) * g.n_tiles;         // per XCD group
+  gemm_tn_f32s<<<8 * (items < 32 ? items : 32), kSplitThreads, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   const int64_t elems = N * Kp;
   split_tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(g.W, g.slabs, elems, (int)Kp, out, ldo, sink);

@@ -77,7 +77,12 @@ def main():
     ap.add_argument("--out", default="gpurun_out/gemm_f32split_bench.json")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--engine", type=int, default=0, help="SG_TUNE_F32_ENGINE value (kernel variants; see include/semigcn.h)")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--only", type=int, default=-1, help="run only product number N of the sequence (0 = nt of the first layer, 1 = nn, 2 = tn, 3 = ...)")
+    ap.add_argument("--no-blas", action="store_true", help="skip the BLAS library's timing")
     a = ap.parse_args()
+    capi.tuning_set(capi.TUNE_F32_ENGINE, a.engine)
     dev = torch.device("cuda:0")
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     out = open(a.out, "w")
@@ -87,12 +92,13 @@ def main():
         out.write(json.dumps(r) + "\n")
         out.flush()
 
-    for r in check(dev):
-        emit(r)
+    if not a.no_check:
+        for r in check(dev):
+            emit(r)
     V = a.V
     # (Cin, Cout) of the SGCN's ChebConv layers (K = 3); aggregate-first layers multiply [V, 3 Cin] x [3 Cin, Cout]
     layers = [(256, 512), (256, 256), (128, 256), (64, 128)] if a.quick else [(256, 512), (256, 256), (128, 256), (64, 128), (32, 64)]
-    g = torch.Generator(device="cpu").manual_seed(1)
+    seq = 0
     for (ci, co) in layers:
         K, N = 3 * ci, co
         T = torch.randn((V, K), device=dev)
@@ -108,10 +114,15 @@ def main():
              capi.gemm_nt_f32_supported(dH, K)),
             ("tn [%d,V]x[V,%d]" % (N, K), lambda: capi.gemm_tn_f32(dH, T), lambda: torch.mm(dH.t(), T), capi.gemm_tn_f32_supported(dH, T)),
         ):
-            row = {"product": name, "V": V, "gflop": flop / 1e9}
-            t_lib = timed(lib, a.reps)
-            row["blas_ms"] = t_lib
-            row["blas_tflops"] = flop / t_lib / 1e9
+            seq += 1
+            if a.only >= 0 and a.only != seq - 1:
+                continue
+            row = {"product": name, "V": V, "gflop": flop / 1e9, "engine": a.engine}
+            t_lib = float("nan")
+            if not a.no_blas:
+                t_lib = timed(lib, a.reps)
+                row["blas_ms"] = t_lib
+                row["blas_tflops"] = flop / t_lib / 1e9
             if sup:
                 t_own = timed(own, a.reps)
                 row["own_ms"] = t_own
