@@ -574,7 +574,8 @@ SG_API int sg_block_chain_backward(const sg_block* blks, int64_t n, void* stream
  * has synchronised the device, sg_trace_read copies up to n records out (returns their number, negative on error) and
  * sg_trace_end releases the events.  Record: kind 0 = aggregation (a = C, b = epilogue operands, c = rows processed),
  * 1 = product C = A B^T / A B (a = M, b = N, c = K), 2 = weight gradient A^T B (a = M, b = N, c = Kp); engine 0 = the
- * library's aggregation kernels, 1 = own MFMA kernels, 2 = thin-product kernels, 3 = BLAS library. */
+ * library's aggregation kernels, 1 = own MFMA kernels, 2 = thin-product kernels, 3 = BLAS library, 4 = split-bf16 MFMA kernels
+ * (float32 features). */
 typedef struct sg_trace_record {
   int32_t kind, dtype, engine, reserved_;
   int64_t a, b, c;
@@ -615,7 +616,8 @@ enum sg_tune_knob {
                               (sg_block_planar), 0 = column blocks everywhere (A/B switch) */
   SG_TUNE_F32_ENGINE = 8   /* dense products on float32 features: 0 (default) = the split-bf16 MFMA kernels (csrc/gemm_split.hip)
                               wherever they take the shape, the BLAS library for the rest; bit 0 = the BLAS library for all of
-                              them (A/B switch); bit 4 = sg_gemm_nt_f32 without the half-block stagger (A/B switch) */
+                              them (A/B switch); bits 1 / 2 / 3 = only the forward / input-gradient / weight-gradient products go to the
+                              library; bit 4 = sg_gemm_nt_f32 without the half-block stagger (A/B switch) */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

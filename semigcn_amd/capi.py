@@ -219,6 +219,8 @@ def load():
         raise SemigcnLibraryError(f"struct sg_block: the library's has {lib.sg_block_sizeof()} bytes, the binding's "
                                   f"{ctypes.sizeof(sg_block)} -- rebuild the library (make -C semigcn_amd/csrc)")
     _lib = lib
+    if os.environ.get("SEMIGCN_F32_ENGINE"):               # A/B and bisecting runs: see SG_TUNE_F32_ENGINE in include/semigcn.h
+        lib.sg_tuning_set(8, int(os.environ["SEMIGCN_F32_ENGINE"]))
     return lib
 
 
@@ -1161,34 +1163,39 @@ chain_host_seconds = [0.0, 0.0]
 _PROFILE_CHAINS = os.environ.get("SEMIGCN_PROFILE_CHAINS") == "1"
 
 
-def block_chain_forward(blks, n: int, stream: int) -> None:
-    """``blks``: a ctypes array of sg_block (n of them are run, first to last)."""
-    if _PROFILE_CHAINS:
-        import time
-        t0 = time.perf_counter()
-        rc = _lib.sg_block_chain_forward(blks, n, stream)
-        chain_host_seconds[0] += time.perf_counter() - t0
-    else:
-        rc = _lib.sg_block_chain_forward(blks, n, stream)
+def block_chain_forward(blks, n: int, stream: int, device: Optional[torch.device] = None) -> None:
+    """``blks``: a ctypes array of sg_block (n of them are run, first to last).  ``device``: the device of the blocks' tensors
+    -- made current for the call when it is not (the kernels, hipMemcpy2DAsync and the BLAS handle below the ABI all go by
+    the CURRENT device; ``stream`` must be a stream of it)."""
+    with (_NO_GUARD if device is None else _on_device(device)):
+        if _PROFILE_CHAINS:
+            import time
+            t0 = time.perf_counter()
+            rc = _lib.sg_block_chain_forward(blks, n, stream)
+            chain_host_seconds[0] += time.perf_counter() - t0
+        else:
+            rc = _lib.sg_block_chain_forward(blks, n, stream)
     if rc:
         _check(rc, "sg_block_chain_forward")
 
 
-def block_run(blks, n: int, stream: int) -> None:
+def block_run(blks, n: int, stream: int, device: Optional[torch.device] = None) -> None:
     """The phases (``blks[i].phase``) of n partition blocks in array order: what a rank does between two collectives."""
-    rc = _lib.sg_block_run(blks, n, stream)
+    with (_NO_GUARD if device is None else _on_device(device)):
+        rc = _lib.sg_block_run(blks, n, stream)
     if rc:
         _check(rc, "sg_block_run")
 
 
-def block_chain_backward(blks, n: int, stream: int) -> None:
-    if _PROFILE_CHAINS:
-        import time
-        t0 = time.perf_counter()
-        rc = _lib.sg_block_chain_backward(blks, n, stream)
-        chain_host_seconds[1] += time.perf_counter() - t0
-    else:
-        rc = _lib.sg_block_chain_backward(blks, n, stream)
+def block_chain_backward(blks, n: int, stream: int, device: Optional[torch.device] = None) -> None:
+    with (_NO_GUARD if device is None else _on_device(device)):
+        if _PROFILE_CHAINS:
+            import time
+            t0 = time.perf_counter()
+            rc = _lib.sg_block_chain_backward(blks, n, stream)
+            chain_host_seconds[1] += time.perf_counter() - t0
+        else:
+            rc = _lib.sg_block_chain_backward(blks, n, stream)
     if rc:
         _check(rc, "sg_block_chain_backward")
 
@@ -1198,7 +1205,7 @@ class LaunchTrace:
     launches, which no Python-side timer can bracket any more.  ``with LaunchTrace(capacity) as t: ...`` then, after a
     device synchronize, ``t.records()`` -> list of dicts (kind "agg" / "nt" / "tn", dtype, engine, a, b, c, ms)."""
     KINDS = {0: "agg", 1: "nt", 2: "tn"}
-    ENGINES = {0: "agg", 1: "mfma", 2: "thin", 3: "blas"}
+    ENGINES = {0: "agg", 1: "mfma", 2: "thin", 3: "blas", 4: "split"}
 
     def __init__(self, capacity: int = 1 << 16, kinds=("agg", "nt", "tn")):
         self.capacity = int(capacity)

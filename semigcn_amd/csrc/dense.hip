@@ -8,8 +8,10 @@
 // Engines, in the order they are tried (the rule functional.py applied call by call before the blocks moved below the C ABI):
 //   * the thin-product kernels (thin_gemm.hip) for weight matrices of at most 16 x 16;
 //   * the library's MFMA kernels (gemm_mfma.hip / gemm_mfma256.hip) for bf16 operands whose shape they take;
-//   * the BLAS library (hipBLASLt) for everything else: fp32 features -- the reference's own precision, a plain library
-//     GEMM -- and bf16 shapes that are no multiple of an MFMA step.  hipBLASLt is bound at run time from the copy that
+//   * for fp32 features -- the reference's own precision -- the split-bf16 MFMA kernels (gemm_split.hip: every operand as
+//     three bf16 pieces, six piece products, fp32-equivalent error) wherever they take the shape;
+//   * the BLAS library (hipBLASLt) for everything else: fp32 shapes the split kernels do not take and bf16 shapes that are
+//     no multiple of an MFMA step.  hipBLASLt is bound at run time from the copy that
 //     is already loaded into the process (PyTorch ships one; /opt/rocm/lib otherwise): no link-time dependency.
 #include <dlfcn.h>
 
@@ -224,7 +226,12 @@ int64_t dense_tn_workspace(int dtype, int64_t M, int64_t N, int64_t Kp) {      /
   if (thin_shape(N, Kp)) return thin_tn_blocks(M) * 256;
   if (dense_tn_own(dtype, M, N, Kp, 8, 8)) return gemm_tn_slabs(M, N, Kp) * N * Kp;
   const int64_t S = blas_tn_slabs(dtype, M);
-  return S > 1 ? (S + 1) * N * Kp : 0;
+  int64_t need = S > 1 ? (S + 1) * N * Kp : 0;
+  if (dtype == SG_F32 && gemm_tn_f32s_supported(M, N, Kp, 4, 4)) {        // (sized for either engine: the A/B switch is a run-time knob)
+    const int64_t split = gemm_tn_f32s_workspace(M, N, Kp) / 4;
+    need = need > split ? need : split;
+  }
+  return need;
 }
 
 // operands kept as planes (sg_common.h Planes) are read and written by the 128-row MFMA kernels only
@@ -261,6 +268,12 @@ int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64
     TraceScope ts(1, dtype, 1, M, N, K, stream);
     return launch_gemm_nt(A, lda, Bp, ldb, bias, C, ldc, M, N, K, dtype, mom, stream);
   }
+  if (dtype == SG_F32 && split_engine_enabled(0) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) && blas_ws &&
+      (int64_t)blas_ws_bytes >= gemm_nt_f32s_workspace(N, K)) {
+    TraceScope ts(1, dtype, 4, M, N, K, stream);
+    return launch_gemm_nt_f32s((const float*)A, lda, (const float*)Bp, ldb, 1, bias, (float*)C, ldc, M, N, K, blas_ws,
+                               (int64_t)blas_ws_bytes, stream);
+  }
   TraceScope ts(1, dtype, 3, M, N, K, stream);
   return lt_gemm(0, 1, M, N, K, A, lda, Bp, ldb, bias, C, ldc, dtype, dtype, 1, 0, 0, 0, blas_ws, blas_ws_bytes, stream);
 }
@@ -284,6 +297,12 @@ int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void
   if (Bt && dense_nt_own(dtype, M, N, K, lda, ldbt, ldc) && a16(A) && a16(Bt) && a16(C)) {
     TraceScope ts(1, dtype, 1, M, N, K, stream);
     return launch_gemm_nt(A, lda, Bt, ldbt, nullptr, C, ldc, M, N, K, dtype, nullptr, stream);
+  }
+  if (dtype == SG_F32 && split_engine_enabled(1) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) && blas_ws &&
+      (int64_t)blas_ws_bytes >= gemm_nt_f32s_workspace(N, K)) {
+    TraceScope ts(1, dtype, 4, M, N, K, stream);      // B is [K, N]: element (n, k) at Bp[k * ldb + n]
+    return launch_gemm_nt_f32s((const float*)A, lda, (const float*)Bp, 1, ldb, nullptr, (float*)C, ldc, M, N, K, blas_ws,
+                               (int64_t)blas_ws_bytes, stream);
   }
   TraceScope ts(1, dtype, 3, M, N, K, stream);
   return lt_gemm(0, 0, M, N, K, A, lda, Bp, ldb, nullptr, C, ldc, dtype, dtype, 1, 0, 0, 0, blas_ws, blas_ws_bytes, stream);
@@ -315,6 +334,14 @@ int dense_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, 
     const bool can = sink != nullptr && sink->Cin % 4 == 0;
     if (sunk) *sunk = can;
     return launch_gemm_tn(A, lda, B, ldb, M, N, Kp, dtype, ws, out, ldo, stream, can ? sink : nullptr);
+  }
+  if (dtype == SG_F32 && split_engine_enabled(2) && gemm_tn_f32s_supported(M, N, Kp, lda, ldb) && a16(A) && a16(B) && a16(out) &&
+      a16(ws) && ldo % 4 == 0) {
+    TraceScope ts(2, dtype, 4, M, N, Kp, stream);
+    const bool can = sink != nullptr && sink->Cin % 4 == 0;
+    if (sunk) *sunk = can;
+    return launch_gemm_tn_f32s((const float*)A, lda, (const float*)B, ldb, M, N, Kp, ws, gemm_tn_f32s_workspace(M, N, Kp), out, ldo,
+                               stream, can ? sink : nullptr);
   }
   TraceScope ts(2, dtype, 3, M, N, Kp, stream);
   const int64_t S = blas_tn_slabs(dtype, M);

@@ -117,13 +117,11 @@ struct SplitNt {
   int n_col_tiles, n_row_tiles, streams;
 };
 
-// STAG: wavefronts 4-7 run half a K block behind wavefronts 0-3 (two workgroup barriers per K block; the two wavefronts of a
-// SIMD are in different halves): while one issues its LDS-DMA, loads, splits A or stores a tile, its partner's MFMAs keep the
-// SIMD's matrix pipe busy.  Global barrier #b: the early group's K block s starts at #2s and has its middle at #2s + 1, the
-// late group's starts at #2s + 1.  Ring rules: a wavefront joins #2s only after ITS pieces of the DMA of block s have landed
-// (early group: at the top of s; late group: in the middle of s - 1); the DMA of block s + D overwrites the slot of block
-// s - 1, whose last readers (the late group) are done at #2s + 1 -- so every wavefront issues it right after #2s + 1.
-template <int NF, bool STAG>
+// (A variant with wavefronts 4-7 half a K block behind wavefronts 0-3 -- two workgroup barriers per block, the DMA issued by
+// each half right after the barrier that frees the slot -- measured 1-2 % faster alone on the GPU and NOT deterministic with
+// four processes sharing it: 1-6 of 60 repetitions of a product differed, tools/split_stress2.py; the cause was not found and
+// the variant was removed)
+template <int NF>
 __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g) {
   constexpr int SLOT = 3 * NF * 1024;              // one K block of the column tile: 48 KB (NT = 256) / 24 KB (NT = 128)
   constexpr int RING = NF == 16 ? 3 : 4;
@@ -136,7 +134,6 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool late = STAG && wave >= 4;
   const int fr = lane & 15, fq = lane >> 4;
 
   const int b = blockIdx.x;
@@ -215,14 +212,11 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
 #pragma unroll
     for (int i = 0; i < 2; ++i) cur[i] = split8(r0.v[i][0], r0.v[i][1]);      // (hipcc waits for r0 here: the DMAs before it have landed)
   }
-  if (late) __builtin_amdgcn_s_barrier();                 // pairs with the early group's barrier #0
 
-  // counted waits (vector-memory operations of THIS wavefront younger than the DMA pieces waited for; stores of a finished
-  // tile sit in the same in-order queue).  Per K block, in program order -- early group (and no stagger): [A loads 4] .. [DMA P]
-  // .. [stores]; late group: [DMA P][A loads 4] .. [stores].
-  //   top of block s, no stagger (DMA first):  4 + (D - 1)(P + 4)     early group:  (D - 1)(P + 4)
-  //   middle of block s, late group (waits for block s + 1):  4 + (D - 1)(P + 4)
-  constexpr int kTopPlain = 4 + (D - 1) * (P + 4), kTopEarly = (D - 1) * (P + 4), kMidLate = 4 + (D - 1) * (P + 4);
+  // counted wait at the top of K block s (vector-memory operations of THIS wavefront younger than its pieces of the DMA of
+  // block s; the stores of a finished tile sit in the same in-order queue).  Per K block, in program order:
+  // [DMA P][A loads 4] .. [stores]; the DMA of block s was issued at the top of block s - D:  4 + (D - 1)(P + 4)
+  constexpr int kTopPlain = 4 + (D - 1) * (P + 4);
   static_assert(kTopPlain + NSTORE < 64, "vmcnt is a 6-bit field");
 #define SGS_WAIT2(base, with_stores)                                        \
   do {                                                                       \
@@ -289,24 +283,13 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
 
   for (int s = 0; s < total; ++s) {
     // ---- top of the K block
-    if (!STAG) SGS_WAIT2(kTopPlain, since < D && exact_stores);
-    else if (!late) SGS_WAIT2(kTopEarly, since < D && exact_stores);
-    __builtin_amdgcn_s_barrier();
-    if (!STAG || late) {
-      dma();                                              // K block s + D
-      __builtin_amdgcn_sched_barrier(0);                  // (the counted waits assume this order of the vector-memory work)
-    }
+    SGS_WAIT2(kTopPlain, since < D && exact_stores);
+    __builtin_amdgcn_s_barrier();                         // block s is in LDS (everybody's pieces); the slot of block s - 1 is free
+    dma();                                                // K block s + D
+    __builtin_amdgcn_sched_barrier(0);                    // (the counted waits assume this order of the vector-memory work)
     const Raw rawn = load_a();                            // A of K block s + 1: a whole block of MFMAs to arrive
     sbaddr = lds0 + rslot * SLOT;
     SGS_HALF(0);
-    if (STAG) {
-      if (late) SGS_WAIT2(kMidLate, since < D - 1 && exact_stores);
-      __builtin_amdgcn_s_barrier();
-      if (!late) {
-        dma();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
     SGS_HALF(1);
     rslot = rslot + 1 == RING ? 0 : rslot + 1;
     since = since < D ? since + 1 : D;
@@ -333,7 +316,6 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
 #pragma unroll
     for (int i = 0; i < 2; ++i) cur[i] = split8(rawn.v[i][0], rawn.v[i][1]);
   }
-  if (STAG && !late) __builtin_amdgcn_s_barrier();        // pairs with the late group's last middle barrier
   SGS_WAIT_VM(0);                                         // no LDS-DMA may be in flight when the workgroup ends
 #undef SGS_WAIT2
 #undef SGS_HALF
@@ -631,14 +613,14 @@ __global__ __launch_bounds__(1024) void split_tn_reduce(const float* __restrict_
 }  // namespace
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-// SG_TUNE_F32_ENGINE: 0 = shipped; bit 0: the BLAS library serves every fp32 product (A/B runs); bit 4: nt kernel without the
-// half-block stagger of wavefronts 4-7
+// SG_TUNE_F32_ENGINE: 0 = shipped; bit 0: the BLAS library serves every fp32 product (A/B runs); bits 1 / 2 / 3: only the
+// forward / input-gradient / weight-gradient products go to the library (bisecting aid)
 static int g_split_variant = 0;
 int set_split_tuning(int value) {
   g_split_variant = value;
   return SG_OK;
 }
-bool split_engine_enabled() { return !(g_split_variant & 1); }
+bool split_engine_enabled(int kind) { return !(g_split_variant & 1) && !(g_split_variant & (2 << kind)); }      // kind 0 nt, 1 nn, 2 tn
 
 static inline int split_nf(int64_t N) { return N % 256 == 0 || N > 640 ? 16 : (N % 128 == 0 || N <= 128 ? 8 : 16); }
 
@@ -688,12 +670,9 @@ int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_r
   const int need = (g.n_row_tiles + 7) / 8 * 8;
   streams = streams > need ? need : streams;
   g.streams = streams;
-  const bool stag = !(g_split_variant & 16);
   const int grid = streams * g.n_col_tiles;
-  if (nf == 16 && stag) gemm_nt_f32s<16, true><<<grid, kSplitThreads, 0, stream>>>(g);
-  else if (nf == 16) gemm_nt_f32s<16, false><<<grid, kSplitThreads, 0, stream>>>(g);
-  else if (stag) gemm_nt_f32s<8, true><<<grid, kSplitThreads, 0, stream>>>(g);
-  else gemm_nt_f32s<8, false><<<grid, kSplitThreads, 0, stream>>>(g);
+  if (nf == 16) gemm_nt_f32s<16><<<grid, kSplitThreads, 0, stream>>>(g);
+  else gemm_nt_f32s<8><<<grid, kSplitThreads, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

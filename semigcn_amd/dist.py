@@ -770,7 +770,7 @@ class _PartChainFn(torch.autograd.Function):
         y = torch.empty((V, plans[-1].Cout), dtype=dtype, device=dev)
         b.f_tail[0].Y = y.data_ptr()
         for i in range(n):
-            capi.block_run(b.f_seg[i], 1 if i == 0 else 2, stream)
+            capi.block_run(b.f_seg[i], 1 if i == 0 else 2, stream, dev)
             if i + 1 < n:
                 lay.exchange(b.recv[i], b.send[i])                # rows of H_i + this rank's statistics -> the peers, in place
         # the last BatchNorm has no exchange behind it: a plain all-gather of the statistics
@@ -779,7 +779,7 @@ class _PartChainFn(torch.autograd.Function):
                 b.last_gathered.copy_(b.last_local)
             else:
                 _all_gather_rows(b.last_gathered, b.last_local, lay.group)
-        capi.block_run(b.f_tail, 1, stream)
+        capi.block_run(b.f_tail, 1, stream, dev)
         F_sg.block_calls[0] += n
         ctx.pc, ctx.params = pc, params
         if any(ctx.needs_input_grad):
@@ -826,16 +826,16 @@ class _PartChainFn(torch.autograd.Function):
             b.dy_ptr = dy.data_ptr()
         # BatchNorm n-1: this rank's sums -> all-reduce; then per block: [dH, dW, gradient blocks] -> all-to-all ->
         # [recurrence unwound -> dX ; sums of the BatchNorm in front] -> all-reduce
-        capi.block_run(b.b_head, 1, stream)
+        capi.block_run(b.b_head, 1, stream, dev)
         bn_local = [None] * n
         for i in range(n - 1, -1, -1):
             if not sunk[i][2]:
                 bn_local[i] = b.dvec[i][:2].clone()     # this rank's partial (sum dz, sum dz xhat): the gradients autograd gets
             if not _solo(W):
                 _all_reduce(b.sums[i], dist.ReduceOp.SUM, lay.group)
-            capi.block_run(b.b_a[i], 1, stream)
+            capi.block_run(b.b_a[i], 1, stream, dev)
             lay.exchange(b.grecv[i], b.gsend[i])
-            capi.block_run(b.b_b[i], 1 if i == 0 else 2, stream)
+            capi.block_run(b.b_b[i], 1 if i == 0 else 2, stream, dev)
         F_sg.block_calls[1] += n
         grads_out = []
         for i, p in enumerate(plans):

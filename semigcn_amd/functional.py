@@ -91,11 +91,29 @@ def _tn_thin(dout: torch.Tensor, T: torch.Tensor) -> bool:
             and dout.shape[0] == T.shape[0] and _thin_ok(dout, dout.shape[1], T.shape[1]))
 
 
+#: float32 features: the dense products on the split-bf16 MFMA kernels (csrc/gemm_split.hip) where they take the shape;
+#: SEMIGCN_F32_BLAS=1 leaves them with the BLAS library (A/B switch; the block path has SG_TUNE_F32_ENGINE)
+USE_SPLIT_F32 = os.environ.get("SEMIGCN_F32_BLAS") != "1"
+
+
+def _tn_split(dout: torch.Tensor, T: torch.Tensor) -> bool:
+    return (USE_SPLIT_F32 and dout.is_cuda and dout.dtype == torch.float32 and T.dtype == torch.float32
+            and not _tn_thin(dout, T) and capi.gemm_tn_f32_supported(dout, T))
+
+
+def _nt_split(a: torch.Tensor, n: int, out: Optional[torch.Tensor]) -> bool:
+    if not (USE_SPLIT_F32 and a.is_cuda and a.dtype == torch.float32 and a.dim() == 2):
+        return False
+    if out is not None and (out.dtype != torch.float32 or out.stride(1) != 1 or out.data_ptr() % 16):
+        return False
+    return capi.gemm_nt_f32_supported(a, n, None if out is None else out.stride(0))
+
+
 def weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     if _gemm_timer is None or not dout.is_cuda:
         return _weight_grad(dout, T)
     own = _tn_own(dout, T)
-    engine = "mfma" if own else ("thin" if _tn_thin(dout, T) else "blas")
+    engine = "mfma" if own else ("thin" if _tn_thin(dout, T) else ("split" if _tn_split(dout, T) else "blas"))
     with _timed(("tn", dout.shape[0], dout.shape[1], T.shape[1], str(dout.dtype).replace("torch.", ""), engine)):
         return _weight_grad(dout, T)
 
@@ -111,6 +129,8 @@ def _weight_grad(dout: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
         return capi.gemm_tn(dout, T)       # own MFMA kernels (transposing LDS reads, slab partials summed in order)
     if _tn_thin(dout, T):
         return capi.thin_tn(dout, T)       # a tiny weight matrix: per-block partial sums, added in block order
+    if _tn_split(dout, T):
+        return capi.gemm_tn_f32(dout, T)   # float32 on the bf16 matrix cores (exact three-way split), slab partials in order
     S = min(128 if dout.dtype == torch.float32 else 64, V // 4096)
     if S <= 1 or not (dout.is_contiguous() and T.is_contiguous()):
         return _mm_f32_out(dout.t(), T)
@@ -363,7 +383,8 @@ def dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = No
         return _dense_nt(a, b, bias, out, moments)
     ldc = b.shape[0] if out is None else out.stride(0)
     own = _mfma_ok(a, b, ldc) and (out is None or (out.stride(1) == 1 and out.data_ptr() % 16 == 0))
-    engine = "mfma" if own else ("thin" if _thin_ok(a, b.shape[0], a.shape[1], out) else "blas")
+    engine = "mfma" if own else ("thin" if _thin_ok(a, b.shape[0], a.shape[1], out) else
+                                 ("split" if _nt_split(a, b.shape[0], out) and b.dtype == torch.float32 else "blas"))
     with _timed(("nt", a.shape[0], b.shape[0], a.shape[1], str(a.dtype).replace("torch.", ""), engine)):
         return _dense_nt(a, b, bias, out, moments)
 
@@ -384,6 +405,8 @@ def _dense_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = N
     if _thin_ok(a, b.shape[0], a.shape[1], out):        # a tiny weight matrix (K = 12 is no MFMA step): one thread per row
         bias32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float()).contiguous()
         return capi.thin_nt(a, b, bias32, out=out)
+    if b.dtype == torch.float32 and b.dim() == 2 and _nt_split(a, b.shape[0], out):
+        return capi.gemm_nt_f32(a, b, None if bias is None else bias.float().contiguous(), out=out)
     if bias is not None:
         return torch.addmm(bias.to(a.dtype), a, b.t()) if out is None else torch.addmm(bias.to(a.dtype), a, b.t(), out=out)
     return a @ b.t() if out is None else torch.mm(a, b.t(), out=out)
@@ -393,14 +416,20 @@ def dense_nn(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
     """``a @ w`` on the BLAS library (the input-gradient product where no transposed weight copy is kept: fp32 features);
     a tiny ``w`` (<= 16 x 16) on the thin-product kernel."""
     thin = a.is_cuda and a.dim() == 2 and w.dim() == 2 and _thin_ok(a, w.shape[1], a.shape[1], out)
+    split = (not thin) and w.dim() == 2 and w.dtype == torch.float32 and _nt_split(a, w.shape[1], out)
+
+    def run():
+        if thin:
+            return capi.thin_nt(a, w.t(), None, out=out)
+        if split:
+            return capi.gemm_nt_f32(a, w, None, out=out, w_is_kn=True)
+        return a @ w if out is None else torch.mm(a, w, out=out)
+
     if _gemm_timer is None or not a.is_cuda:
-        if thin:
-            return capi.thin_nt(a, w.t(), None, out=out)
-        return a @ w if out is None else torch.mm(a, w, out=out)
-    with _timed(("nt", a.shape[0], w.shape[1], a.shape[1], str(a.dtype).replace("torch.", ""), "thin" if thin else "blas")):
-        if thin:
-            return capi.thin_nt(a, w.t(), None, out=out)
-        return a @ w if out is None else torch.mm(a, w, out=out)
+        return run()
+    with _timed(("nt", a.shape[0], w.shape[1], a.shape[1], str(a.dtype).replace("torch.", ""),
+                 "thin" if thin else ("split" if split else "blas"))):
+        return run()
 
 
 class _ChebConvFn(torch.autograd.Function):
@@ -1326,7 +1355,7 @@ class _ChainFn(torch.autograd.Function):
                     blk.Y, blk.ldy = a0 + lay.off_in[i + 1], (lay.ldt[i + 1] if q.order == 0 else q.Cin)
                 blk.ws = w0
             chain._dyn[0] = dyn
-        capi.block_chain_forward(blks, n, capi._stream(x))
+        capi.block_chain_forward(blks, n, capi._stream(x), x.device)
         del ws
         block_calls[0] += n
         chain_calls[0] += 1
@@ -1408,7 +1437,7 @@ class _ChainFn(torch.autograd.Function):
                 blk.acc_bias = ab
                 blk.acc_gamma, blk.acc_beta = gb if gb is not None else (None, None)
             chain._acc = accs
-        capi.block_chain_backward(blks, n, capi._stream(dy))
+        capi.block_chain_backward(blks, n, capi._stream(dy), dy.device)
         del ws
         block_calls[1] += n
         chain_calls[1] += 1

@@ -29,6 +29,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+#: faces whose predicted normal is within this distance of the target normal in some component are left out of the loss on both
+#: sides of a gradient comparison (the L1 normal term has a kink there: see _one_iteration_both_sides)
+KINK_TAU = 1e-4
+
+
 # --------------------------------------------------------------------------------------
 def _batch(m, n_masks, device=DEV):
     V = m.num_vertices
@@ -150,6 +155,25 @@ def _one_iteration_both_sides(m, *, feature_dtype, seed, skip=False, post=True, 
     data = batch.data
     dm = batch.v_keep * batch.dummy_masks[:, :1]
     rank = net._layout(data)[2]
+    # The normal term of the loss is an L1 norm (sgcn.py:131 -> util/loss.py, mask_norm_rec_loss): its gradient is
+    # sign(fn_pred - fn_target), discontinuous where a component crosses zero -- the loss has kinks exactly like the
+    # network's LeakyReLUs, and a face within rounding of one sends a gradient of either sign to its three vertices depending
+    # on the last bits of the forward (measured, c2 mesh: 3 of 300 K components change sign between two fp32-equivalent dense
+    # engines, and those 9 vertices then carry 8e-3 of the whole |dz1| -- the comparison would measure the dice, not the
+    # arithmetic).  So both sides evaluate the loss on the faces that are NOT within KINK_TAU of such a kink in the path's own
+    # forward (a preliminary pass; ~0.1 % of the faces drop out; parameters and BatchNorm buffers are restored after it).
+    with torch.no_grad():
+        pos0 = net(data, dm).double()
+    net.load_state_dict(state0)
+    fn0 = train.face_normals(pos0, batch.faces)
+    near = ((fn0 - batch.target_fn.double()).abs() < KINK_TAU).any(1) & (batch.f_keep.view(-1) > 0)
+    kink_faces = int(near.sum())
+    assert kink_faces <= 0.02 * batch.n_f_keep, (kink_faces, batch.n_f_keep)
+    batch.f_keep = batch.f_keep.clone()
+    batch.f_keep[near] = 0.0
+    batch.n_f_keep = int(batch.f_keep.sum().item())
+    near_host = near.cpu().numpy()
+    del pos0, fn0
     with GU.FusedActivationMasks(rank) as rec:
         pos = net(data, dm)
     loss = tr.loss(pos)
@@ -175,8 +199,10 @@ def _one_iteration_both_sides(m, *, feature_dtype, seed, skip=False, post=True, 
         ora.load_state_dict(state0)
         return ora
     side = _OracleSide(m, batch)
+    side.f_mask = side.f_mask & ~near_host          # the same face set on the oracle's side
+    assert int(side.f_mask.sum()) == batch.n_f_keep
     xp = side.x_pos.double()
-    res = {}
+    res = {"kink_faces": kink_faces}
     if fp32_oracle:
         o32 = _oracle_run(make(torch.float32), side, m, torch.float32, threads)
         res["hip_vs_oracle"] = _errors(hip, o32, xp)
@@ -357,6 +383,83 @@ def test_bf16_blocks_teacher_forced_vs_bf16_storage_oracle(post, monkeypatch):
     print("worst", worst)
     for k, (e, i) in worst.items():
         assert e < BF16_BLOCK_TOL[k], (k, i, e)
+
+
+@pytest.mark.skipif(os.environ.get("SEMIGCN_SKIP_FULL_SIZE_ORACLE") == "1", reason="switched off by the environment")
+def test_c4_bf16_blocks_teacher_forced_full_size():
+    """BASELINE configs[3] in ITS OWN storage type at ITS OWN size: blocks 4-7 of the SGCN (128 -> 256 -> 256 -> 512 -> 256
+    channels: the launches the headline is timed on -- spmm_ring at V = 1 M, gemm_nt_256 / gemm_tn_256, BatchNorm tile
+    moments merged over 7 813 tiles) one block at a time on the 1000 x 1000 mesh against the bf16-STORAGE oracle's block
+    (oracle/bf16.py: ChebConv with fp32 sums and bf16 rounding at the stored rows), both fed the same stored input rows and
+    the same stored output gradient.  The oracle's BatchNorm is evaluated in float64: ATen's fp32 CPU BatchNorm is the noisy
+    side at a million rows (1e-4, see test_c4_full_size_train_iteration_vs_oracle).  Bounds: BF16_BLOCK_TOL, the bounds of
+    the 5 K-vertex test; the running statistics against the float64 moments of the oracle's conv output."""
+    import psutil
+    if psutil.virtual_memory().available < 80e9:
+        pytest.skip("the oracle's [E + 2V, C] message tensors need ~40 GB of host memory at V = 1 M")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    m = synth.torus_mesh(1000, 1000, edge_flips=0.15)
+    V = m.num_vertices
+    net = SingleScaleGCN(DEV, reorder=False)
+    GU.fill_state(net, seed=63)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(DEV).train()
+    net.set_feature_dtype(torch.bfloat16)
+    ora = OB.SGCNOracleBf16(post_when_narrowing=True, bias_bf16_layers=_blas_layers(V, True))
+    ora.load_state_dict(state0)
+    ora.train()
+    ei = torch.from_numpy(m.edge_index)
+
+    class D:
+        z1 = torch.from_numpy(m.z1).to(DEV)
+        x_pos = torch.from_numpy(m.x_pos).to(DEV)
+        edge_index = torch.from_numpy(m.edge_index).to(DEV)
+    graph = net.graph(D)
+    gen = torch.Generator().manual_seed(64)
+    worst = {"out": (0.0, None), "dx": (0.0, None), "dw": (0.0, None), "bn": (0.0, None)}
+    for i in (4, 5, 6, 7):
+        cin, cout = CHANNELS[i], CHANNELS[i + 1]
+        # stored rows: what a BatchNorm + LeakyReLU in front leaves, and a gradient of the size a mean loss sends back
+        x = OB.rb(torch.nn.functional.leaky_relu(torch.randn((V, cin), generator=gen)))
+        dy = OB.rb(torch.randn((V, cout), generator=gen) * (1.0 / V))
+        conv, bn = ora.blocks[i].module_0, ora.blocks[i].module_1
+        xo = x.clone().requires_grad_(True)
+        h = conv(xo, ei)                                         # fp32 sums, bf16-stored rows
+        h64 = h.double()
+        mean, var = h64.mean(0), h64.var(0, unbiased=False)
+        y64 = (h64 - mean) * torch.rsqrt(var + bn.eps) * bn.weight.double() + bn.bias.double()
+        yo = ora.act(y64.float())
+        yo.backward(dy)
+        og = {n: p.grad.clone() for n, p in ora.blocks[i].named_parameters() if p.grad is not None}
+        ora.zero_grad(set_to_none=True)
+        rm_ref = ((1 - bn.momentum) * state0[f"blocks.{i}.module_1.running_mean"].double() + bn.momentum * mean).detach()
+        rv_ref = ((1 - bn.momentum) * state0[f"blocks.{i}.module_1.running_var"].double()
+                  + bn.momentum * var * (V / (V - 1.0))).detach()
+        del h64, y64
+
+        net.zero_grad(set_to_none=True)
+        blk = net.blocks[i]
+        xh = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+        yh = blk(xh, graph)
+        yh.backward(dy.to(DEV).to(yh.dtype))
+        e_out = GU.rel_l2(yh.detach().float().cpu(), yo.detach())
+        e_dx = GU.rel_l2(xh.grad.float().cpu(), xo.grad)
+        e_dw = 0.0
+        for n, p in blk.named_parameters():
+            if n == "module_0.bias":                             # in front of a BatchNorm: zero in exact arithmetic
+                continue
+            e_dw = max(e_dw, GU.rel_l2(p.grad.float().cpu(), og[n]))
+        hbn = blk.module_1
+        e_bn = max(GU.rel_l2(hbn.running_mean.cpu().double(), rm_ref), GU.rel_l2(hbn.running_var.cpu().double(), rv_ref))
+        print(f"block {i:2d} {cin:3d}->{cout:3d} V={V}  out {e_out:.2e}  dx {e_dx:.2e}  dw {e_dw:.2e}  bn {e_bn:.2e}")
+        for k, e in (("out", e_out), ("dx", e_dx), ("dw", e_dw), ("bn", e_bn)):
+            if e > worst[k][0]:
+                worst[k] = (e, i)
+        del xo, h, yo, xh, yh
+    print("worst", worst)
+    for k in ("out", "dx", "dw"):
+        assert worst[k][0] < BF16_BLOCK_TOL[k], (k, worst[k])
+    assert worst["bn"][0] < 1e-4, worst["bn"]
 
 
 def _cos(a, b):
