@@ -586,8 +586,11 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
 }
 
 // out[n][k] = the slabs' partial tiles added in slab order (64 x 16 threads: 64 consecutive float4, 16 slab groups, then the
-// group sums in order: a fixed tree); += into the layer's weight .grad accumulators when a sink is given
-__global__ __launch_bounds__(1024) void split_tn_reduce(const float* __restrict__ W, int n_slabs, int64_t elems, int Kp,
+// group sums in order: a fixed tree); += into the layer's weight .grad accumulators when a sink is given.  TR: the partials
+// are [Kp][N] (the product was computed with its operands exchanged because that tiles with less padding): element (r, c)
+// of a partial goes to out[c][r].
+template <bool TR>
+__global__ __launch_bounds__(1024) void split_tn_reduce(const float* __restrict__ W, int n_slabs, int64_t elems, int cols,
                                                         float* __restrict__ out, int64_t ldo, const GradSink sink) {
   __shared__ f32x4 s_part[16][64];
   const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
@@ -600,12 +603,20 @@ __global__ __launch_bounds__(1024) void split_tn_reduce(const float* __restrict_
   if (y == 0 && e < elems) {
 #pragma unroll
     for (int k = 1; k < 16; ++k) acc += s_part[k][x];
-    const int64_t n = e / Kp, kk = e - n * Kp;
-    *(f32x4*)(out + n * ldo + kk) = acc;
-    if (sink.mode) {
-      float* const d = sink_ptr(sink, n, kk);
+    const int64_t r = e / cols, c = e - r * cols;          // cols % 4 == 0: the four values lie in one row of the partial
+    if (!TR) {
+      *(f32x4*)(out + r * ldo + c) = acc;
+      if (sink.mode) {
+        float* const d = sink_ptr(sink, r, c);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) d[q] += acc[q];
+        for (int q = 0; q < 4; ++q) d[q] += acc[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        out[(c + q) * ldo + r] = acc[q];
+        if (sink.mode) *sink_ptr(sink, c + q, r) += acc[q];
+      }
     }
   }
 }
@@ -685,7 +696,9 @@ bool gemm_tn_f32s_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64
 // slabs of rows: 8 x s, s the smallest count for which the items of one XCD group (s x tiles) fill its 32 workgroups evenly,
 // halved while a slab would be shorter than 64 steps of 32 rows
 static int split_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
-  const int64_t n_tiles = ((N + 255) / 256) * ((Kp + 127) / 128);
+  int64_t n_tiles = ((N + 255) / 256) * ((Kp + 127) / 128);
+  const int64_t n_tiles_t = ((Kp + 255) / 256) * ((N + 127) / 128);
+  if (n_tiles_t * 256 * 128 < n_tiles * 256 * 128) n_tiles = n_tiles_t;         // (the orientation launch_gemm_tn_f32s takes)
   int64_t g = n_tiles, r = 32;
   while (r) {
     const int64_t t = g % r;
@@ -700,6 +713,8 @@ static int split_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
 
 int64_t gemm_tn_f32s_workspace(int64_t M, int64_t N, int64_t Kp) { return (int64_t)split_tn_slabs(M, N, Kp) * N * Kp * 4; }
 
+static inline int64_t split_tn_padded(int64_t N, int64_t Kp) { return ((N + 255) / 256 * 256) * ((Kp + 127) / 128 * 128); }
+
 int launch_gemm_tn_f32s(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, void* ws,
                         int64_t ws_bytes, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink_) {
   SG_REQUIRE(gemm_tn_f32s_supported(M, N, Kp, lda, ldb) && ldo % 4 == 0, "sg_gemm_tn_f32: unsupported shape (M=%lld N=%lld Kp=%lld)",
@@ -709,20 +724,25 @@ int launch_gemm_tn_f32s(const float* A, int64_t lda, const float* B, int64_t ldb
              (long long)ws_bytes, (long long)gemm_tn_f32s_workspace(M, N, Kp));
   const GradSink sink = sink_ ? *sink_ : GradSink{};
   SG_REQUIRE(sink.mode == 0 || sink.Cin % 4 == 0, "sg_gemm_tn_f32: a gradient sink needs Cin to be a multiple of 4");
+  // the tile is 256 (rows of the result) x 128 (columns): compute the transposed result where that pads less (384 x 256 as
+  // 256 x 384: 2 x 2 tiles with a quarter empty -> 1 x 3 full ones)
+  const bool tr = split_tn_padded(Kp, N) < split_tn_padded(N, Kp);
   SplitTn g;
-  g.A = A; g.lda = lda;
-  g.B = B; g.ldb = ldb;
+  g.A = tr ? B : A; g.lda = tr ? ldb : lda;
+  g.B = tr ? A : B; g.ldb = tr ? lda : ldb;
   g.W = (float*)ws;
-  g.M = (int)M; g.N = (int)N; g.Kp = (int)Kp;
-  g.tiles_k = (int)((Kp + 127) / 128);
-  g.n_tiles = (int)((N + 255) / 256) * g.tiles_k;
+  g.M = (int)M; g.N = (int)(tr ? Kp : N); g.Kp = (int)(tr ? N : Kp);
+  g.tiles_k = (g.Kp + 127) / 128;
+  g.n_tiles = ((g.N + 255) / 256) * g.tiles_k;
   g.slabs = split_tn_slabs(M, N, Kp);
   g.steps = (int)((M + 31) / 32);
   const int items = (g.slabs / 8) * g.n_tiles;         // per XCD group
   gemm_tn_f32s<<<8 * (items < 32 ? items : 32), kSplitThreads, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   const int64_t elems = N * Kp;
-  split_tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(g.W, g.slabs, elems, (int)Kp, out, ldo, sink);
+  const int blocks = (int)((elems / 4 + 63) / 64);
+  if (tr) split_tn_reduce<true><<<blocks, 1024, 0, stream>>>(g.W, g.slabs, elems, g.Kp, out, ldo, sink);
+  else split_tn_reduce<false><<<blocks, 1024, 0, stream>>>(g.W, g.slabs, elems, g.Kp, out, ldo, sink);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
