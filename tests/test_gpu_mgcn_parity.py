@@ -17,7 +17,7 @@ import torch
 
 import golden_util as GU
 from oracle import bf16 as OB, models as OM
-from semigcn_amd import functional as F_sg, meshprep, synth, train
+from semigcn_amd import functional as F_sg, meshprep, nn as sgnn, synth, train
 from semigcn_amd.meshnet import MGCN
 from test_gpu_config_parity import _assert_fp32_parity, _assert_pattern_only_overridden_at_kinks, _batch, _errors
 
@@ -192,7 +192,12 @@ def test_c3_mgcn_train_iteration_vs_oracle():
 # (b) bf16 feature storage: stages teacher-forced against the bf16-storage oracle; end to end no further from fp32 than
 #     the storage oracle itself
 # --------------------------------------------------------------------------------------
-MGCN_BF16_STAGE_TOL = {"out": 1.2e-2, "dx": 0.13}      # measured (five blocks deep, no forcing inside a stage): 7.8e-3, 8.7e-2 (encoder3)
+MGCN_BF16_STAGE_TOL = {"out": 1.2e-2}      # a whole stage, five blocks deep with no forcing inside it (measured 7.8e-3, encoder3)
+# every block of a stage forced on its own (the oracle's stored input rows and output gradient), 1.5 x the measured maxima
+# (out 4.4e-4 encoder3/3; dx 1.3e-2 encoder3/2 -- 27 of the 30 blocks are below 3e-3, the three above are blocks on the two
+# coarsest levels, 1 K - 3 K vertices, where one LeakyReLU sign that bf16 rounding flips weighs 1e-2 of the gradient);
+# a stage's input gradient used to be bounded at 0.13 over five unforced blocks (measured 8.7e-2)
+MGCN_BF16_BLOCK_TOL = {"out": 6.6e-4, "dx": 2e-2}
 
 
 def _blas_convs(net):
@@ -227,7 +232,8 @@ def test_mgcn_bf16_stages_teacher_forced_vs_bf16_storage_oracle():
         h.remove()
     level_in = {"encoder1": 0, "encoder2": 1, "encoder3": 2, "decoder3": 3, "decoder2": 2, "decoder1": 1}
     level_out = {"encoder1": 1, "encoder2": 2, "encoder3": 3, "decoder3": 2, "decoder2": 1, "decoder1": 0}
-    worst = {"out": (0.0, None), "dx": (0.0, None)}
+    worst = {"out": (0.0, None)}
+    worst_block = {"out": (0.0, None), "dx": (0.0, None)}
     for name in stages + ["decoder1"]:
         stage = net.decoder1[0] if name == "decoder1" else getattr(net, name)
         xin, yout = caps[name]
@@ -247,12 +253,49 @@ def test_mgcn_bf16_stages_teacher_forced_vs_bf16_storage_oracle():
         e_out = GU.rel_l2(y.detach().float().index_select(0, oo[1]).cpu(), yout.detach())
         e_dx = GU.rel_l2(x.grad.float().index_select(0, net._orders[level_in[name]][1]).cpu(), gin)
         print(f"{name}: out {e_out:.2e}  dx {e_dx:.2e}")
-        for k, e in (("out", e_out), ("dx", e_dx)):
-            if e > worst[k][0]:
-                worst[k] = (e, name)
-    print("worst", worst)
-    for k, (e, name) in worst.items():
-        assert e < MGCN_BF16_STAGE_TOL[k], (k, name, e)
+        if e_out > worst["out"][0]:
+            worst["out"] = (e_out, name)
+        # ---- every block of the stage on its own: [conv (pool | unpool)? BatchNorm LeakyReLU] on the oracle block's stored
+        #      input rows and the gradient the oracle sent to its output
+        down = name.startswith("encoder")
+        blocks = ([("model1", 0, 3), ("model1", 3, 7)] if down else [("model1", 0, 4)]) + \
+                 [("model2", a, a + 3) for a in range(0, 9 if down else 12, 3)]
+        got = []
+
+        def grab_b(mod, inp, out):
+            out.retain_grad()
+            got.append(out)
+        bh = [getattr(getattr(ostage, sn), f"module_{b - 1}").register_forward_hook(grab_b) for sn, a, b in blocks]
+        for d in ora.dropouts():
+            d.calls = 0
+        xo2 = xin.detach().clone().requires_grad_(True)
+        ostage(xo2).backward(yout.grad)
+        for h in bh:
+            h.remove()
+        assert len(got) == 5
+        g1, g2 = stage._graphs
+        for b, (sn, a0, a1) in enumerate(blocks):
+            xb = xo2 if b == 0 else got[b - 1]
+            yb = got[b]
+            lin = level_in[name] if (b == 0 or (down and b == 1)) else level_out[name]
+            lout = level_in[name] if (down and b == 0) else level_out[name]
+            seq = getattr(stage, sn)
+            mods = [seq[i] for i in range(a0, a1)]
+            tmp = sgnn.Sequential("x, edge_index", [(mm, "x, edge_index -> x" if isinstance(mm, sgnn.ChebConv) else "x -> x")
+                                                    for mm in mods])
+            xh = xb.detach().to(DEV).index_select(0, net._orders[lin][0]).to(torch.bfloat16).requires_grad_(True)
+            yh = tmp(xh, g1 if sn == "model1" else g2)
+            yh.backward(yb.grad.to(DEV).index_select(0, net._orders[lout][0]).to(yh.dtype))
+            eb_out = GU.rel_l2(yh.detach().float().index_select(0, net._orders[lout][1]).cpu(), yb.detach())
+            eb_dx = GU.rel_l2(xh.grad.float().index_select(0, net._orders[lin][1]).cpu(), xb.grad)
+            print(f"   {name} block {b} ({sn}[{a0}:{a1}]): out {eb_out:.2e}  dx {eb_dx:.2e}")
+            for k, e in (("out", eb_out), ("dx", eb_dx)):
+                if e > worst_block[k][0]:
+                    worst_block[k] = (e, f"{name}/{b}")
+    print("worst stage", worst, "worst block", worst_block)
+    assert worst["out"][0] < MGCN_BF16_STAGE_TOL["out"], worst
+    for k, (e, where) in worst_block.items():
+        assert e < MGCN_BF16_BLOCK_TOL[k], (k, where, e)
 
 
 def test_mgcn_bf16_end_to_end_no_further_from_fp32_than_the_storage_oracle():
