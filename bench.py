@@ -23,7 +23,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# hipGraph replays (--graph; the default for partitioned SGCN runs) are exact only with the runtime's graph "packet capture"
+# hipGraph replays (--graph, one GPU) are exact only with the runtime's graph "packet capture"
 # off, and the runtime reads the flag once, at its initialisation: it has to be in the environment before the first HIP call
 # (semigcn_amd.train.GRAPH_ENV).  It changes nothing for eager execution.
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
@@ -39,14 +39,36 @@ _T0 = time.perf_counter()
 
 
 def log(msg: str):
+    if os.environ.get("SEMIGCN_BENCH_MARK"):             # a supervised worker: every rank keeps its marks (see log_all)
+        log_all(msg)
+        if os.environ.get("SEMIGCN_BENCH_VERBOSE") == "1":
+            return
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+_MARKS = []
+
+
 def log_all(msg: str):
-    """Start-up marks of EVERY rank (SEMIGCN_BENCH_VERBOSE=1): where an N-rank job spends its time before the first step."""
+    """Start-up marks of EVERY rank: where an N-rank job spends its time before the first step.  Kept in memory (rank 0's go
+    into the JSON line), appended to a per-rank file in the supervisor's marker directory as they happen (what a stalled
+    attempt leaves behind for the post-mortem, next to its faulthandler dump), printed with SEMIGCN_BENCH_VERBOSE=1."""
+    t = time.perf_counter() - _T0
+    _MARKS.append((round(t, 2), msg))
+    d = os.environ.get("SEMIGCN_BENCH_MARK")
+    if d:
+        try:
+            with open(os.path.join(d, f"marks_attempt{os.environ.get('SEMIGCN_BENCH_ATTEMPT', '1')}_rank{os.environ.get('RANK', '0')}.txt"), "a") as f:
+                f.write(f"{t:8.2f} {msg}\n")
+        except OSError:
+            pass
     if os.environ.get("SEMIGCN_BENCH_VERBOSE") == "1":
-        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{t:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def startup_marks():
+    return {m: t for t, m in _MARKS}
 
 
 def parse():
@@ -81,12 +103,12 @@ def parse():
                     help="skip the extra run in the other vertex order (SURVEY 8(d): report grid AND random order)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stall-after-warmup", type=float, default=0.0, help=argparse.SUPPRESS)
+    ap.add_argument("--stall-attempts", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--no-launch-timer", action="store_true")
     ap.add_argument("--graph", action="store_true", default=None,
-                    help="replay each iteration from hipGraphs: one graph on 1 GPU (pays off on launch-bound meshes <= ~200 K "
-                         "vertices and MGCN), a tape of graph segments with the collectives between them on a partition "
-                         "(segments.py, over the per-module path; the default of rounds 2-3 for a partitioned SGCN, now "
-                         "slower than the eager phase-by-phase blocks); needs --warmup >= 4")
+                    help="ONE GPU only: replay each iteration from a hipGraph (pays off on launch-bound meshes <= ~200 K vertices "
+                         "and MGCN); needs --warmup >= 4.  A partitioned rank is always eager (its two replay modes of rounds "
+                         "2-4 were retired: DESIGN.md section 8)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager execution (the default)")
     ap.add_argument("--no-planes", action="store_true",
                     help="A/B switch: the narrow bf16 layers keep their recurrence buffers as column blocks of one [V, K*C] buffer "
@@ -95,10 +117,6 @@ def parse():
                     help="partitioned SGCN: every module on its own (halo exchange inside each convolution, an all-gather per "
                          "BatchNorm: 57 collectives) instead of the blocks run phase by phase below the C ABI with the "
                          "statistics riding in the halo exchange (dist.part_chain: 44 collectives; the default)")
-    ap.add_argument("--graph-collectives", action="store_true",
-                    help="experimental, partitioned SGCN over RCCL only: ONE hipGraph per iteration with the RCCL calls "
-                         "captured inside it instead of graph segments between eager collectives (exercised on a one-rank "
-                         "communicator only; never the default)")
     ap.add_argument("--model", default="sgcn", choices=["sgcn", "mgcn"],
                     help="mgcn: BASELINE config c3 (3 pool levels, hierarchy from meshprep.DeviceMesh); not the headline metric")
     return ap.parse_args()
@@ -282,7 +300,6 @@ def build_trainer(args, dtype, device, world, rank, mesh):
     if DIST_ON and args.model == "sgcn":
         from semigcn_amd import dist as sgdist
         job = sgdist.build_partitioned_job(nu, nv, world, rank, device, permute=args.permute, dtype=dtype, mesh=mesh, log=log_all,
-                                           capture=("whole" if args.graph and args.graph_collectives else args.graph),
                                            phases=not args.no_phases)
         return job.trainer, job.workload, AGG_PER_ITER * mesh.num_edges
     batch = build_mesh_batch(mesh, device, n_masks=5)
@@ -364,23 +381,22 @@ def timed_run(trainer, args, device, world, with_timer: bool):
         if i == 0:
             log_all("first warm-up iteration done")
     timed_run.replay_check = None
-    if getattr(trainer, "_segmented", None) is not None or getattr(trainer, "_graphed", None) is not None:
+    if getattr(trainer, "_graphed", None) is not None:
         # a replaying trainer is trusted only after ONE replayed iteration has reproduced an eager one on the same inputs
         # (train.replay_matches_eager; MGCN draws dropout masks, so its two passes cannot be compared)
-        if args.model == "sgcn" and not (args.graph and args.graph_collectives):
+        if args.model == "sgcn":
             from semigcn_amd import train as sgtrain
             ok = sgtrain.replay_matches_eager(trainer)
             torch.cuda.synchronize(device)
             timed_run.replay_check = "replayed loss == eager loss" if ok else "MISMATCH: the run continues eagerly"
             log(f"hipGraph replay check: {timed_run.replay_check}")
-    # (--stall-after-warmup, the supervisor's self-test: > 0 stalls the first attempt only, < 0 every attempt)
+    # (--stall-after-warmup, the supervisor's self-test: > 0 stalls the first --stall-attempts attempts, < 0 every attempt)
     stall = args.stall_after_warmup
-    if stall and (stall < 0 or os.environ.get("SEMIGCN_BENCH_ATTEMPT", "1") == "1") and int(os.environ.get("RANK", "0")) == world - 1:
+    if stall and (stall < 0 or int(os.environ.get("SEMIGCN_BENCH_ATTEMPT", "1")) <= args.stall_attempts) \
+            and int(os.environ.get("RANK", "0")) == world - 1:
         log(f"TEST HOOK: the last rank stalls for {abs(stall):.0f} s")
         time.sleep(abs(stall))
-    # a rank that replays hipGraph segments issues its kernels from the graphs: per-launch event pairs are impossible inside
-    # them, so its launches are timed in a short EAGER pass after the timed region (same kernels, same buffers)
-    replays = getattr(trainer, "_segmented", None) is not None
+    replays = False
     from semigcn_amd import functional as F_sg
     # the blocks run below the C ABI (functional.cheb_chain; dist.part_chain on a partition), timed by the library's own
     # trace; the per-module partitioned path issues every launch from Python and keeps the Python-side timers
@@ -393,11 +409,14 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     if DIST_ON:
         from semigcn_amd import dist as sgdist
         c0 = dict(sgdist.collective_counts)
+    bc0 = list(F_sg.block_calls)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.iteration_step()
     sync()
     dt = time.perf_counter() - t0
+    # blocks that really ran below the C ABI (forward, backward) per iteration: what `per_module_path` claims, measured
+    timed_run.block_calls = [round((F_sg.block_calls[i] - bc0[i]) / args.steps, 2) for i in range(2)]
     capi.set_launch_timer(None)
     if traced:
         timer.stop()
@@ -407,11 +426,6 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     timed_run.gemm_timer, timed_run.gemm_steps = None, 0
     if with_timer:
         from semigcn_amd import functional as F_sg
-        seg = getattr(trainer, "_segmented", None)
-        if replays:
-            trainer._segmented = None                      # eager iterations of the same trainer
-            timer = capi.LaunchTimer()
-            capi.set_launch_timer(timer)
         # the dense products get their own short pass AFTER the timed region (an event pair per product inside it would
         # cost the headline ~0.7 %; the aggregation kernel's pairs stay inside it on one GPU, as the contract asks)
         timed_run.gemm_steps = max(1, min(args.steps, 5))
@@ -428,10 +442,6 @@ def timed_run(trainer, args, device, world, with_timer: bool):
         if traced:
             timed_run.gemm_timer.stop()
         F_sg.set_gemm_timer(None)
-        if replays:
-            capi.set_launch_timer(None)
-            trainer._segmented = seg
-            timed_run.timer_dt, timed_run.timer_steps = timed_run.gemm_dt, timed_run.gemm_steps
     if DIST_ON:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -493,9 +503,7 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
                 "all_aggregations_GBs": round(total_B / total_t, 1),
                 "all_aggregations_frac": round(total_B / total_t / HBM_PEAK_GBS, 4),
                 "aggregation_share_of_step": round(total_t / (getattr(timed_run, "timer_dt", dt) * 1e3), 4),
-                "measured_over": ("the timed region" if getattr(timed_run, "timer_steps", args.steps) == args.steps and not getattr(
-                    trainer, "_segmented", None) else f"{timed_run.timer_steps} eager iterations after the timed region "
-                    "(the timed iterations replay hipGraph segments)")}
+                "measured_over": "the timed region"}
     dense = dense_products(getattr(timed_run, "gemm_timer", None), getattr(timed_run, "gemm_steps", 0),
                            getattr(timed_run, "gemm_dt", 0.0))
     return {"value": value, "ms_per_step": dt / args.steps * 1e3, "dense_products": dense,
@@ -621,8 +629,8 @@ def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  Runs BEFORE this process has
     made any HIP call (torch.cuda.device_count() does not initialise the GPU on this image); the ranks are child
     processes of `python -m torch.distributed.run`, nothing is exec'ed over a process that touched the GPU.  Every rank
-    supervises its own worker (``supervise_rank``: wall-clock limit per attempt, ONE fresh retry without hipGraph replay);
-    this launcher adds the outer limit -- two attempts plus slack -- after which the whole process group is killed and the
+    supervises its own worker (``supervise_rank``: wall-clock limit per attempt, fresh retries: the phase path once more, then
+    the per-module path); this launcher adds the outer limit -- three attempts plus slack -- after which the whole process group is killed and the
     reason reported."""
     import signal
     import subprocess
@@ -641,14 +649,14 @@ def spawn_ranks(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    limit = 2 * ATTEMPT_TIMEOUT_S + 180
+    limit = 3 * ATTEMPT_TIMEOUT_S + 180
     log(f"--gpus {args.gpus} without a launcher: starting {args.gpus} ranks with torch.distributed.run on port {port} "
         f"(outer limit {limit:.0f} s)")
     proc = subprocess.Popen(cmd, env=env, start_new_session=True)
     try:
         return proc.wait(timeout=limit)
     except subprocess.TimeoutExpired:
-        print(f"bench.py: the {args.gpus}-rank job did not finish within {limit:.0f} s (two attempts of "
+        print(f"bench.py: the {args.gpus}-rank job did not finish within {limit:.0f} s (three attempts of "
               f"{ATTEMPT_TIMEOUT_S:.0f} s each); killing its process group", file=sys.stderr, flush=True)
         try:
             os.killpg(proc.pid, signal.SIGKILL)
@@ -672,12 +680,16 @@ def _terminate(proc) -> None:
 def supervise_rank(args) -> int:
     """One rank of an N > 1 job as its launcher (the driver's `torch.distributed.run`, or ``spawn_ranks``) started it.  This
     process never touches the GPU: it runs the actual work in a CHILD (`bench.py ... --worker`, same rank environment) and
-    waits for it with a wall-clock limit.  A partitioned SGCN rank runs its blocks phase by phase below the C ABI by default
-    (dist.part_chain), a path exercised between real devices only by the driver's own SCALE run; if ANY rank's worker fails
+    waits for it with a wall-clock limit.  A partitioned SGCN rank runs its blocks phase by phase below the C ABI
+    (dist.part_chain), a path exercised between real devices only by the driver's own SCALE run.  If ANY rank's worker fails
     or overruns the limit, every supervisor kills its worker (they agree through marker files in a directory named after the
-    job's rendezvous port -- one node) and starts a FRESH one on the per-module path of rounds 1-3 (`--no-phases --no-graph`),
-    on a fresh store prefix.  A second failure
-    exits non-zero with the reason.  Nothing is ever exec'ed over a process that has initialised the GPU."""
+    job's rendezvous port -- one node) and starts a FRESH one, on a fresh store prefix:
+      attempt 2: the SAME phase path again (a start-up hiccup must not turn the first real SCALE number into a measurement of
+                 the slow path);
+      attempt 3: the per-module path of rounds 1-3 (`--no-phases`: every collective issued from Python, 57 per iteration).
+    A third failure exits non-zero with the reasons.  Every worker leaves its start-up marks and, if it is still alive shortly
+    before the limit, a faulthandler dump of all its threads in the marker directory; the supervisor prints both for its rank
+    when an attempt fails.  Nothing is ever exec'ed over a process that has initialised the GPU."""
     import glob
     import subprocess
     import tempfile
@@ -691,18 +703,20 @@ def supervise_rank(args) -> int:
         for f in glob.glob(os.path.join(mark, "*")):
             os.remove(f)
     reasons = []
-    for attempt in (1, 2):
+    n_attempts = 3
+    for attempt in range(1, n_attempts + 1):
         env = dict(os.environ)
         env["SEMIGCN_BENCH_ATTEMPT"], env["SEMIGCN_BENCH_MARK"] = str(attempt), mark
-        if attempt == 2:
-            if reasons:
-                env["SEMIGCN_BENCH_FIRST_FAILURE"] = reasons[0][:400]
-            # a store prefix / port of its own: the first attempt's keys (and, without an agent store, its listening socket)
+        if attempt > 1:
+            env["SEMIGCN_BENCH_FIRST_FAILURE"] = " | ".join(reasons)[:600]
+            # a store prefix / port of its own: the earlier attempts' keys (and, without an agent store, their listening socket)
             # must not be met again
-            env["TORCHELASTIC_RESTART_COUNT"] = str(int(env.get("TORCHELASTIC_RESTART_COUNT", "0")) + 1)
+            env["TORCHELASTIC_RESTART_COUNT"] = str(int(env.get("TORCHELASTIC_RESTART_COUNT", "0")) + attempt - 1)
             if env.get("TORCHELASTIC_USE_AGENT_STORE") != "True":
-                env["MASTER_PORT"] = str(int(port) + 1)
-        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"] + (["--no-graph", "--no-phases"] if attempt == 2 else [])
+                env["MASTER_PORT"] = str(int(port) + attempt - 1)
+        per_module = attempt == n_attempts
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"] + (["--no-phases"] if per_module else [])
+        path = "per-module path" if (per_module or args.no_phases) else "blocks phase by phase"
         t0 = time.perf_counter()
         proc = subprocess.Popen(cmd, env=env)
         why = None
@@ -710,7 +724,7 @@ def supervise_rank(args) -> int:
             try:
                 rc = proc.wait(timeout=1.0)
                 if rc != 0 and not os.path.exists(os.path.join(mark, f"done{attempt}")):
-                    why = f"rank {rank}'s worker exited with code {rc} in attempt {attempt}"
+                    why = f"rank {rank}'s worker exited with code {rc} in attempt {attempt} ({path})"
                 break
             except subprocess.TimeoutExpired:
                 pass
@@ -719,8 +733,7 @@ def supervise_rank(args) -> int:
                 _terminate(proc)
                 break
             if time.perf_counter() - t0 > ATTEMPT_TIMEOUT_S:
-                why = (f"rank {rank}'s worker did not finish attempt {attempt} within {ATTEMPT_TIMEOUT_S:.0f} s "
-                       f"({'blocks phase by phase' if attempt == 1 else 'per-module path'})")
+                why = f"rank {rank}'s worker did not finish attempt {attempt} within {ATTEMPT_TIMEOUT_S:.0f} s ({path})"
                 _terminate(proc)
                 break
         if why is None:
@@ -731,11 +744,16 @@ def supervise_rank(args) -> int:
         except FileExistsError:
             pass
         reasons.append(why)
-        print(f"bench.py supervisor (rank {rank}): {why}" + ("; starting a fresh worker on the per-module path" if attempt == 1 else ""),
-              file=sys.stderr, flush=True)
+        nxt = ("" if attempt == n_attempts else
+               "; starting a fresh worker on " + ("the SAME phase path" if attempt + 1 < n_attempts else "the per-module path"))
+        print(f"bench.py supervisor (rank {rank}): {why}{nxt}", file=sys.stderr, flush=True)
+        for kind in ("marks", "traceback"):    # the post-mortem of THIS rank's worker
+            fn = os.path.join(mark, f"{kind}_attempt{attempt}_rank{rank}.txt")
+            if os.path.exists(fn) and os.path.getsize(fn):
+                print(f"bench.py supervisor (rank {rank}): {kind} of attempt {attempt}:\n" + open(fn).read()[-3000:], file=sys.stderr, flush=True)
         # every supervisor must have seen the marker and killed its worker before the fresh set meets
         time.sleep(3.0)
-    print(f"bench.py: both attempts failed on rank {rank}: {' | '.join(reasons)}", file=sys.stderr, flush=True)
+    print(f"bench.py: all {n_attempts} attempts failed on rank {rank}: {' | '.join(reasons)}", file=sys.stderr, flush=True)
     return 3
 
 
@@ -786,6 +804,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("SEMIGCN_BENCH_MARK"):
+        # a supervised worker: if it is still running shortly before its supervisor's limit, every thread's Python stack goes
+        # into the marker directory -- what a stalled start-up was doing (the 1-in-8 stall of round 4 left nothing behind)
+        import faulthandler
+        try:
+            tb = open(os.path.join(os.environ["SEMIGCN_BENCH_MARK"], f"traceback_attempt{os.environ.get('SEMIGCN_BENCH_ATTEMPT', '1')}"
+                                                                      f"_rank{rank}.txt"), "w")
+            faulthandler.enable(file=tb, all_threads=True)
+            faulthandler.dump_traceback_later(max(10.0, attempt_timeout_s(args.mesh) - 8.0), repeat=False, file=tb, exit=False)
+        except OSError:
+            pass
+    log_all("worker started")
     if DIST_ON:
         import torch.distributed as dist
         store = None
@@ -799,10 +829,12 @@ def main():
                                  is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=300),
                                  wait_for_workers=False)
             store = dist.PrefixStore(f"semigcn/attempt{attempt}", base)
+        log_all("process group: init")
         if shared:
             dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", store=store, device_id=device, rank=rank, world_size=world)
+        log_all("process group: ready")
 
     from semigcn_amd import capi, synth
     capi.load()
@@ -816,20 +848,19 @@ def main():
     log(f"mesh generated V={mesh.num_vertices} E={mesh.num_edges}")
     dtypes = {"fp32": torch.float32, "bf16": torch.bfloat16}
     if args.graph is None:
-        # default: EAGER everywhere.  A partitioned SGCN rank used to replay hipGraph segments between its collectives
-        # (rounds 2-3: 125 K rows per rank 6.8 ms replayed against 8.9-11.3 ms eager); with the blocks run phase by phase
-        # below the C ABI (dist.part_chain, 44 collectives) the eager rank measures 5.97 ms on the same proxy, needs no
-        # capture, and is the path the gloo / RCCL self-tests exercise.  --graph still replays segments (per-module path).
+        # default: EAGER everywhere.  A partitioned rank is ALWAYS eager: the blocks run phase by phase below the C ABI
+        # (dist.part_chain, 44 collectives); its hipGraph replay modes of rounds 2-4 were retired.
         args.graph = False
         # one GPU: EAGER at every size.  The reference's own mesh sizes (c1: 5 K, c2 / c3: 50 K vertices) used to be bound by
         # ~300 launches with their Python glue and were replayed from a hipGraph by default (rounds 2-3); with runs of
         # blocks below the C ABI (sg_block_chain_*) the eager iteration is within ~1.2x of the replayed one, needs no
         # environment flag, and MGCN's dropout draws stay fresh.  --graph still replays (SGCN checked against an eager pass).
-    if args.graph and (args.warmup < 4 or (DIST_ON and args.model != "sgcn")):
-        raise SystemExit("--graph: --warmup must be >= 4 (3 eager iterations + the capture); partitioned runs: SGCN only")
-    # byte accounting assumes the finest mesh only; inside a whole-iteration hipGraph launches cannot be timed, a partitioned
-    # rank that replays segments times them in a short EAGER pass after the timed region (timed_run)
-    with_timer = not args.no_launch_timer and args.model == "sgcn" and (not args.graph or DIST_ON)
+    if args.graph and DIST_ON:
+        raise SystemExit("--graph: one GPU only (a partitioned rank runs eagerly; its replay modes were retired in round 5)")
+    if args.graph and args.warmup < 4:
+        raise SystemExit("--graph: --warmup must be >= 4 (3 eager iterations + the capture)")
+    # byte accounting assumes the finest mesh only; inside a whole-iteration hipGraph launches cannot be timed
+    with_timer = not args.no_launch_timer and args.model == "sgcn" and not args.graph
 
     trainer, workload, agg_edges = build_trainer(args, dtypes[args.dtype], device, world, rank, mesh)
     log("model built; warm-up")
@@ -912,9 +943,8 @@ def main():
                                    "attempt": int(os.environ.get("SEMIGCN_BENCH_ATTEMPT", "1")),
                                    "first_attempt_failure": os.environ.get("SEMIGCN_BENCH_FIRST_FAILURE"),
                                    "per_module_path": not getattr(trainer, "phases", False),
-                                   "hip_graph_segments": (lambda sg_: None if sg_ is None or sg_.segments is None else
-                                                          {"graphs": sg_.segments[0], "eager_actions": sg_.segments[1]})(
-                                       getattr(trainer, "_segmented", None)),
+                                   "block_calls_per_iteration": getattr(timed_run, "block_calls", None),
+                                   "startup_marks_s": startup_marks(),
                                    "collectives_per_iteration": round(sum(coll.values()), 1), "collectives_by_kind": coll,
                                    "rank0_owned_rows": None if g is None else g.n_own,
                                    "rank0_halo_rows": None if g is None else g.n_halo}

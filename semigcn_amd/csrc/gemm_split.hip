@@ -336,8 +336,8 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
 // for the step, the eight B fragments stream one ahead of the 12 MFMAs that use them (inline asm reads, hand-counted
 // lgkmcnt: hipcc's own bookkeeping waits for every read in flight).  ONE instruction stream per wavefront, nothing waits
 // for work it has just started: the six split-and-stash slices of the next step sit between the MFMA groups (pinned by empty
-// asm statements: hipcc otherwise sinks them behind the last MFMA), the step's only workgroup barrier in front of its last
-// MFMA group, followed at once by the fragment reads of the next step.  96 MFMAs per wavefront and step, 132 VALU.
+// asm statements: hipcc otherwise sinks them behind the last MFMA), the step's only workgroup barrier behind its last
+// MFMA group.  96 MFMAs per wavefront and step, 132 VALU.
 // Slab partials go to the workspace and are summed in slab order by sg::split_tn_reduce: deterministic.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -450,44 +450,47 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
   //      segment; lane 16 fg + i receives column i of those 4 rows (hh = 0 / 1: the two halves of the lane's 8 m)
   const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds;
-  uint32_t adr_a[2][2], adr_b[8][2];                   // [fragment][hh]: address in plane 0 of buffer 0
+  uint32_t adr_a[2][2], base_b[2];                     // [fragment][hh]: address in plane 0 of buffer 0; B: without the segment
+  uint32_t swz_b[2];
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
     const int row = 8 * fg + 4 * hh + fq;
 #pragma unroll
     for (int i = 0; i < 2; ++i) adr_a[i][hh] = lds0 + row * 512 + fp * 8 + (((wave * 2 + i) ^ tn_swz(row)) << 5);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) adr_b[j][hh] = lds0 + 3 * PA + row * 256 + fp * 8 + ((j ^ tn_swz(row)) << 5);
+    base_b[hh] = lds0 + 3 * PA + row * 256 + fp * 8;
+    swz_b[hh] = (uint32_t)tn_swz(row);
   }
-  u32x2 af[2][2][3][2];                                // [set][i][plane][hh]
+  // (the 16 B addresses are two VALU each where they are used, not 16 registers: the kernel sits at the 256-register limit)
+#define TN_ADRB(J, H) (base_b[H] + ((((uint32_t)(J)) ^ swz_b[H]) << 5))
+  u32x2 af[2][3][2];                                   // [i][plane][hh]
   u32x2 bf[2][3][2];                                   // [buffer of the stream][plane][hh]
 #define TN_RD1(dst, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(ADDR), "n"(OFF))
 #define TN_RDB(S, J, BOFF)                                      \
-  TN_RD1(bf[S][0][0], adr_b[J][0] + (BOFF), 0);                 \
-  TN_RD1(bf[S][0][1], adr_b[J][1] + (BOFF), 0);                 \
-  TN_RD1(bf[S][1][0], adr_b[J][0] + (BOFF), PB);                \
-  TN_RD1(bf[S][1][1], adr_b[J][1] + (BOFF), PB);                \
-  TN_RD1(bf[S][2][0], adr_b[J][0] + (BOFF), 2 * PB);            \
-  TN_RD1(bf[S][2][1], adr_b[J][1] + (BOFF), 2 * PB)
-#define TN_RDA(SET, I, BOFF)                                    \
-  TN_RD1(af[SET][I][0][0], adr_a[I][0] + (BOFF), 0);            \
-  TN_RD1(af[SET][I][0][1], adr_a[I][1] + (BOFF), 0);            \
-  TN_RD1(af[SET][I][1][0], adr_a[I][0] + (BOFF), PA);           \
-  TN_RD1(af[SET][I][1][1], adr_a[I][1] + (BOFF), PA);           \
-  TN_RD1(af[SET][I][2][0], adr_a[I][0] + (BOFF), 2 * PA);       \
-  TN_RD1(af[SET][I][2][1], adr_a[I][1] + (BOFF), 2 * PA)
+  TN_RD1(bf[S][0][0], TN_ADRB(J, 0) + (BOFF), 0);               \
+  TN_RD1(bf[S][0][1], TN_ADRB(J, 1) + (BOFF), 0);               \
+  TN_RD1(bf[S][1][0], TN_ADRB(J, 0) + (BOFF), PB);              \
+  TN_RD1(bf[S][1][1], TN_ADRB(J, 1) + (BOFF), PB);              \
+  TN_RD1(bf[S][2][0], TN_ADRB(J, 0) + (BOFF), 2 * PB);          \
+  TN_RD1(bf[S][2][1], TN_ADRB(J, 1) + (BOFF), 2 * PB)
+#define TN_RDA(I, BOFF)                                         \
+  TN_RD1(af[I][0][0], adr_a[I][0] + (BOFF), 0);                 \
+  TN_RD1(af[I][0][1], adr_a[I][1] + (BOFF), 0);                 \
+  TN_RD1(af[I][1][0], adr_a[I][0] + (BOFF), PA);                \
+  TN_RD1(af[I][1][1], adr_a[I][1] + (BOFF), PA);                \
+  TN_RD1(af[I][2][0], adr_a[I][0] + (BOFF), 2 * PA);            \
+  TN_RD1(af[I][2][1], adr_a[I][1] + (BOFF), 2 * PA)
 #define TN_READYB(S, N)                                                                                          \
   asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                       \
                : "+v"(bf[S][0][0]), "+v"(bf[S][0][1]), "+v"(bf[S][1][0]), "+v"(bf[S][1][1]), "+v"(bf[S][2][0]), "+v"(bf[S][2][1])::"memory")
-#define TN_READYA(SET, I)                                                                                        \
-  asm volatile("" : "+v"(af[SET][I][0][0]), "+v"(af[SET][I][0][1]), "+v"(af[SET][I][1][0]), "+v"(af[SET][I][1][1]), \
-               "+v"(af[SET][I][2][0]), "+v"(af[SET][I][2][1]))
+#define TN_READYA(I)                                                                                             \
+  asm volatile("" : "+v"(af[I][0][0]), "+v"(af[I][0][1]), "+v"(af[I][1][0]), "+v"(af[I][1][1]), "+v"(af[I][2][0]), "+v"(af[I][2][1]))
+#define TN_TIE6(x) "+v"((x)[0][0]), "+v"((x)[0][1]), "+v"((x)[1][0]), "+v"((x)[1][1]), "+v"((x)[2][0]), "+v"((x)[2][1])
 #define TN_OP(x) __builtin_bit_cast(bf16x8, u32x4{(x)[0][0], (x)[0][1], (x)[1][0], (x)[1][1]})
-#define TN_MM(SET, S, J)                                                       \
+#define TN_MM(S, J)                                                            \
   {                                                                            \
     const bf16x8 bh = TN_OP(bf[S][0]), bm = TN_OP(bf[S][1]), bl = TN_OP(bf[S][2]); \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                            \
-      const bf16x8 ah = TN_OP(af[SET][i][0]), am = TN_OP(af[SET][i][1]), al = TN_OP(af[SET][i][2]); \
+      const bf16x8 ah = TN_OP(af[i][0]), am = TN_OP(af[i][1]), al = TN_OP(af[i][2]);             \
       f32x4 c = acc[i][J];                                                     \
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, c, 0, 0, 0);         \
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, c, 0, 0, 0);         \
@@ -499,34 +502,39 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
     }                                                                          \
   }
   // fragment J of the step: read J + 1, multiply J, then a slice of the side work
-#define TN_J(SET, J, BOFF, SIDE)                  \
+#define TN_J(J, BOFF, SIDE)                       \
   TN_RDB(((J) + 1) & 1, (J) + 1, BOFF);           \
   TN_READYB((J) & 1, 6);                          \
-  TN_MM(SET, (J) & 1, J)                          \
+  TN_MM((J) & 1, J)                               \
   SIDE;                                           \
   __builtin_amdgcn_sched_barrier(0)
-  // one step with literal parity PAR (= s & 1): multiplies buffer PAR with A-fragment set PAR, stashes step s + 1 (raw set
-  // PAR ^ 1) into buffer PAR ^ 1, loads step s + 2 into raw set PAR
+  // one step with literal parity PAR (= s & 1): multiplies buffer PAR, stashes step s + 1 (raw set PAR ^ 1) into buffer
+  // PAR ^ 1, loads step s + 2 into raw set PAR.  The step's own A fragments and first B fragment are read at its top -- NOT
+  // ahead, behind the previous step's barrier: behind the LAST step nothing would use such a read, and to hipcc a read whose
+  // result nothing uses is a register that is free again right behind the asm statement; it put the addresses of the
+  // partial-tile stores there, and the data, landing late, overwrote them (seen only with several processes sharing the GPU:
+  // longer LDS latencies; a branch around the read-ahead, a peeled last step and registers tied to a later wait all made
+  // hipcc spill asm outputs).  Every asm read here is consumed inside the step that issues it.
 #define TN_STEP(PAR)                                                                      \
   do {                                                                                    \
-    constexpr uint32_t boff = (PAR) * BUF, noff = ((PAR) ^ 1) * BUF;                      \
-    fetch(raw[PAR], keep[PAR], s + 2);                                                               \
+    constexpr uint32_t boff = (PAR) * BUF;                                                \
+    fetch(raw[PAR], keep[PAR], s + 2);                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                    \
-    TN_READYA(PAR, 0);                                                                    \
-    TN_READYA(PAR, 1);                                                                    \
-    TN_J(PAR, 0, boff, (void)0);                                                          \
-    TN_J(PAR, 1, boff, slice(raw[(PAR) ^ 1][0], keep[(PAR) ^ 1], 0, (PAR) ^ 1));                           \
-    TN_J(PAR, 2, boff, slice(raw[(PAR) ^ 1][1], keep[(PAR) ^ 1], 1, (PAR) ^ 1));                           \
-    TN_J(PAR, 3, boff, slice(raw[(PAR) ^ 1][2], keep[(PAR) ^ 1], 2, (PAR) ^ 1));                           \
-    TN_J(PAR, 4, boff, slice(raw[(PAR) ^ 1][3], keep[(PAR) ^ 1], 3, (PAR) ^ 1));                           \
-    TN_J(PAR, 5, boff, slice(raw[(PAR) ^ 1][4], keep[(PAR) ^ 1], 4, (PAR) ^ 1));                           \
-    TN_J(PAR, 6, boff, slice(raw[(PAR) ^ 1][5], keep[(PAR) ^ 1], 5, (PAR) ^ 1));                           \
+    TN_RDA(0, boff);                                                                      \
+    TN_RDA(1, boff);                                                                      \
+    TN_RDB(0, 0, boff);                                                                   \
+    TN_READYA(0);                                                                         \
+    TN_READYA(1);                                                                         \
+    TN_J(0, boff, (void)0);                                                               \
+    TN_J(1, boff, slice(raw[(PAR) ^ 1][0], keep[(PAR) ^ 1], 0, (PAR) ^ 1));               \
+    TN_J(2, boff, slice(raw[(PAR) ^ 1][1], keep[(PAR) ^ 1], 1, (PAR) ^ 1));               \
+    TN_J(3, boff, slice(raw[(PAR) ^ 1][2], keep[(PAR) ^ 1], 2, (PAR) ^ 1));               \
+    TN_J(4, boff, slice(raw[(PAR) ^ 1][3], keep[(PAR) ^ 1], 3, (PAR) ^ 1));               \
+    TN_J(5, boff, slice(raw[(PAR) ^ 1][4], keep[(PAR) ^ 1], 4, (PAR) ^ 1));               \
+    TN_J(6, boff, slice(raw[(PAR) ^ 1][5], keep[(PAR) ^ 1], 5, (PAR) ^ 1));               \
     TN_READYB(1, 0);      /* fragment 7, and every LDS write of this wavefront's stash */ \
-    __builtin_amdgcn_s_barrier();                                                         \
-    TN_RDA((PAR) ^ 1, 0, noff);                                                           \
-    TN_RDA((PAR) ^ 1, 1, noff);                                                           \
-    TN_RDB(0, 0, noff);                                                                   \
-    TN_MM(PAR, 1, 7)                                                                      \
+    TN_MM(1, 7)                                                                           \
+    __builtin_amdgcn_s_barrier();      /* step s + 1 is in LDS; buffer PAR is free */     \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
 
@@ -539,16 +547,13 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (count > 0) {
-    // ---- prologue: step 0 stashed into buffer 0 and visible, step 1 in raw set 1, the fragments of step 0 being read
+    // ---- prologue: step 0 stashed into buffer 0 and visible, step 1 in raw set 1
     fetch(raw[0], keep[0], 0);
 #pragma unroll
     for (int qq = 0; qq < 6; ++qq) slice(raw[0][qq], keep[0], qq, 0);
     fetch(raw[1], keep[1], 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    TN_RDA(0, 0, 0u);
-    TN_RDA(0, 1, 0u);
-    TN_RDB(0, 0, 0u);
     for (int s = 0; s < count; s += 2) {
       TN_STEP(0);
       if (s + 1 < count) {
@@ -559,17 +564,18 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
         break;
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the fragment reads issued for the step after the last)
   }
 #undef TN_STEP
 #undef TN_J
 #undef TN_MM
 #undef TN_OP
+#undef TN_TIE6
 #undef TN_READYA
 #undef TN_READYB
 #undef TN_RDA
 #undef TN_RDB
 #undef TN_RD1
+#undef TN_ADRB
 
   // ---- the slab's partial tile: D = (B fragment) x (A fragment): lane holds k' = 4 (lane >> 4) .. + 3 of column n = lane & 15
   float* const W = g.W + (int64_t)slab * g.N * g.Kp;

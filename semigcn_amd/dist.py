@@ -36,7 +36,6 @@ import torch.nn as nn
 
 from . import capi
 from . import reorder as _reorder
-from . import segments as _seg
 
 
 # --------------------------------------------------------------------------------------
@@ -132,8 +131,9 @@ def _pg_all_to_all(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_spl
     return dist.all_to_all_single(recv, send, recv_splits, send_splits, group=group, async_op=True)
 
 
-# Every collective is an EAGER action in the sense of segments.py: issued through ``_seg.eager`` so that an iteration that
-# is being recorded cuts its hipGraph segment around it and replays the same call on the same (static) tensors.
+# (Rounds 2-4 could record a partitioned iteration as hipGraph segments with these calls between them, or as ONE graph with the
+# RCCL calls captured inside; both modes were retired in round 5 -- the eager phase path is faster than either on the rank
+# proxy and is the one path a first multi-GPU lease has to debug.  DESIGN.md section 8.)
 def _all_reduce(t: torch.Tensor, op, group) -> None:
     def run():
         collective_counts["all_reduce"] += 1
@@ -143,7 +143,7 @@ def _all_reduce(t: torch.Tensor, op, group) -> None:
             t.copy_(h)
         else:
             _pg_all_reduce(t, op, group)
-    _seg.eager(run)
+    run()
 
 
 def _all_gather_rows(out: torch.Tensor, inp: torch.Tensor, group) -> None:
@@ -155,7 +155,7 @@ def _all_gather_rows(out: torch.Tensor, inp: torch.Tensor, group) -> None:
             out.copy_(ho)
         else:
             _pg_all_gather(out, inp, group)
-    _seg.eager(run)
+    run()
 
 
 def _all_to_all_rows(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits, group) -> None:
@@ -173,7 +173,7 @@ def _all_to_all_rows(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_s
             work = _pg_all_to_all(recv, send, recv_splits, send_splits, group)
             if work is not None:
                 work.wait()
-    _seg.eager(run)
+    run()
 
 
 # --------------------------------------------------------------------------------------
@@ -214,12 +214,12 @@ class _RowExchange:
         recv = torch.empty((self.n_halo, blk_ext.shape[1]), dtype=blk_ext.dtype, device=blk_ext.device)
         work = None
         if send.is_cuda and _backend(self.group) != "gloo":
-            work = {}                  # filled by the (eager, replayable) start action, drained by the wait action
+            work = {}                  # filled by the start action, drained by the wait action
 
             def start():
                 collective_counts["all_to_all"] += 1
                 work["w"] = _pg_all_to_all(recv, send, self.recv_splits, self.send_splits, self.group)
-            _seg.eager(start)
+            start()
         else:
             self._a2a(recv, send, self.recv_splits, self.send_splits)
         return work, recv, send, blk_ext
@@ -233,7 +233,7 @@ class _RowExchange:
                 w = work.pop("w", None)
                 if w is not None:
                     w.wait()           # the CURRENT stream waits for the collective; the host does not block
-            _seg.eager(wait)
+            wait()
         blk_ext[self.n_own:].copy_(recv)
 
     def exchange_reverse_add(self, grad_halo: torch.Tensor, grad_own: torch.Tensor) -> None:
@@ -866,10 +866,13 @@ def part_chain(sequentials, graph: "DistMeshGraph", x_own: torch.Tensor, x_halo:
     if not (x_own.is_cuda and F_sg.blocks_enabled() and dist.is_initialized()):
         return None
     plans = []
-    for seq in sequentials:
+    sequentials = list(sequentials)
+    for k, seq in enumerate(sequentials):
         lead = seq._leading_blocks() if hasattr(seq, "_leading_blocks") else None
         if lead is None or len(lead[0]) != 1:
             return None
+        if k + 1 < len(sequentials) and lead[1] != len(seq):
+            return None              # modules behind the block of an INNER Sequential (a Dropout, a second conv) would be skipped
         plans.append(lead[0][0])
         tail = lead[1]
     cin = x_own.shape[1]
@@ -1243,34 +1246,21 @@ class DistSGCNTrainer:
     """SGCNTrainer (semigcn_amd.train, the loop of sgcn.py:118-147) on a vertex partition."""
 
     def __init__(self, model: nn.Module, part: PartitionedMesh, group=None, lr: float = 0.01, k1: float = 4.0,
-                 accumulate: int = 5, capture: bool = False, phases: bool = True):
+                 accumulate: int = 5, phases: bool = True):
         """``phases`` (the default): the 13 blocks run phase by phase below the C ABI with the BatchNorm statistics riding
         in the halo exchange (part_chain: ~50 foreign calls and 44 collectives per iteration).  ``phases=False``: every
-        module on its own, the exchange inside each convolution and an all-gather per BatchNorm (57 collectives).
-        ``capture=True`` (the per-module path only): after three eager iterations the iteration is recorded as hipGraph
-        segments with the collectives between them and replayed from that tape (segments.py, train._SegmentedIteration)."""
+        module on its own, the exchange inside each convolution and an all-gather per BatchNorm (57 collectives): the
+        supervisor's last-resort fallback (bench.py) and the path MGCN still takes.  Both are eager."""
         self.model, self.part, self.group, self.k1, self.accumulate = model, part, group, k1, accumulate
-        self.phases = bool(phases) and not capture
+        self.phases = bool(phases)
         convert_batchnorm(model, group)
         self.params = [p for p in model.parameters()]
         self.opt = torch.optim.Adam(self.params, lr=lr)
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=50, gamma=0.5)
         self.iteration = 0
         self.loss_sum = torch.zeros((), device=part.z1.device)
-        from .train import GradBuffer, _SegmentedIteration
+        from .train import GradBuffer
         self.grads = GradBuffer(self.params)
-        self._segmented = None
-        if capture == "whole":
-            # experimental: ONE hipGraph for the whole iteration with the RCCL calls captured inside it (no segment
-            # boundaries at all).  Exercised on a one-rank communicator only -- not the default anywhere.
-            from .train import _GraphedIteration
-            if _backend(group) == "gloo":
-                raise ValueError('capture="whole" needs the nccl backend (gloo collectives are staged through the host)')
-            self._segmented = _GraphedIteration(self.params, part.v_keep, self._forward_backward)
-            self._segmented.segments = None
-        elif capture:
-            leaves = [part.z1] if isinstance(part.z1, torch.Tensor) and part.z1.requires_grad else []
-            self._segmented = _SegmentedIteration(self.params, part.v_keep, self._forward_backward, leaves)
 
     def _forward_backward(self, dm: torch.Tensor) -> torch.Tensor:
         from .functional import sink_param_grads
@@ -1304,7 +1294,7 @@ class DistSGCNTrainer:
             p.halo_inputs = (p.z1_halo, p.dm_halo[:, k:k + 1].contiguous())
         else:
             p.halo_inputs = None
-        loss = self._segmented(dm) if self._segmented is not None else self._forward_backward(dm)
+        loss = self._forward_backward(dm)
         self.loss_sum += loss
         self.iteration += 1
         if self.iteration % self.accumulate == 0:
@@ -1324,8 +1314,7 @@ class _Job:
 
 
 def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permute: bool = False,
-                          dtype=torch.float32, group=None, mesh=None, capture: bool = False,
-                          phases: bool = True, log=None) -> _Job:
+                          dtype=torch.float32, group=None, mesh=None, phases: bool = True, log=None) -> _Job:
     """bench.py's N > 1 leg: the SAME nu x nv mesh as the 1-GPU run, cut into ``world`` blocks
     (strong scaling)."""
     from . import synth
@@ -1340,7 +1329,7 @@ def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permu
     model = SingleScaleGCN(device).to(device)
     if dtype != torch.float32:
         model.set_feature_dtype(dtype)
-    trainer = DistSGCNTrainer(model, part, group, capture=capture, phases=phases)
+    trainer = DistSGCNTrainer(model, part, group, phases=phases)
     halo = torch.tensor([part.graph.n_halo], device=device)
     if world > 1:
         _all_reduce(halo, dist.ReduceOp.MAX, group)
@@ -1349,8 +1338,7 @@ def build_partitioned_job(nu: int, nv: int, world: int, rank: int, device, permu
                 f"{world} blocks (<= {int(halo)} halo rows per rank), "
                 + ("blocks run phase by phase below the C ABI, BatchNorm statistics carried by the halo exchange, "
                    if trainer.phases else "halo exchange + an all-gather per BatchNorm, ")
-                + "gradient all-reduce over RCCL"
-                + (", iteration replayed from hipGraph segments between the collectives" if capture else ""))
+                + "gradient all-reduce over RCCL")
     return _Job(trainer, mesh.num_vertices, mesh.num_edges, workload)
 
 

@@ -190,122 +190,6 @@ class _GraphedIteration:
         return self.loss.clone()
 
 
-class _SegmentedIteration:
-    """One training iteration of a PARTITIONED model recorded as a tape of hipGraph segments with the collectives between
-    them and replayed from it (semigcn_amd/segments.py).  Same contract as _GraphedIteration for ``body(mask)``; in
-    addition every collective / wait inside it must go through ``segments.eager`` (dist.py's do).  The backward pass runs
-    on the calling thread while recording (segments are begun and ended on one thread)."""
-
-    WARMUP = 3
-
-    def __init__(self, params, mask_like: torch.Tensor, body, leaves=()):
-        if not graphs_usable():
-            raise RuntimeError(f"hipGraph replay needs {GRAPH_ENV[0]}={GRAPH_ENV[1]} in the environment BEFORE the process first touches "
-                               "the GPU (see _GraphedIteration)")
-        self.params, self.leaves, self.body = [p for p in params], [t for t in leaves], body
-        self.mask = torch.zeros_like(mask_like)
-        self.rec = None
-        self.loss = None
-        self.calls = 0
-        self.stream = torch.cuda.Stream(mask_like.device)
-        _SegmentedIteration._instances += 1
-        self._uid = _SegmentedIteration._instances      # the same on every rank (the ranks build the same trainers)
-
-    _instances = 0
-
-    def __call__(self, mask: torch.Tensor) -> torch.Tensor:
-        from . import segments
-        cur = torch.cuda.current_stream()
-        self.mask.copy_(mask)
-        if self.rec is not None:
-            self.stream.wait_stream(cur)
-            self.rec.replay()
-            cur.wait_stream(self.stream)
-            return self.loss.clone()
-        self.calls += 1
-        if self.calls <= self.WARMUP:
-            self.stream.wait_stream(cur)
-            with torch.cuda.stream(self.stream), torch.autograd.set_multithreading_enabled(False):
-                loss = self.body(self.mask)
-            cur.wait_stream(self.stream)
-            return loss
-        for t in list(self.params) + list(self.leaves):      # gradients must accumulate in place inside the segments
-            if t.requires_grad and t.grad is None:
-                t.grad = torch.zeros_like(t)
-        import gc
-        gc.collect()
-        rec = segments.SegmentRecorder(self.stream)
-        self.stream.wait_stream(cur)
-        try:
-            with torch.autograd.set_multithreading_enabled(False):
-                self.loss = rec.record(lambda: self.body(self.mask))
-        except Exception as e:
-            # body() may have issued k of its ~57 collectives before failing; re-running it eagerly here would put k + N
-            # collectives on this rank's communicator against 2 N on a rank that recorded -- the sequences no longer pair
-            # up and the job hangs until a watchdog fires.  So: tell the other ranks (through the rendezvous STORE, not
-            # through a collective) and fail; the launcher starts a fresh set of ranks without replay (bench.py).
-            _publish_record_outcome(self._uid, ok=False)
-            raise RuntimeError(f"recording the iteration as hipGraph segments failed on this rank ({type(e).__name__}: {e}); "
-                               "a partially recorded iteration cannot be continued eagerly (its collectives would no longer "
-                               "pair up across ranks) -- restart without capture") from e
-        _publish_record_outcome(self._uid, ok=True)
-        failed = _ranks_that_failed_to_record(self._uid)
-        if failed:
-            raise RuntimeError(f"rank(s) {failed} could not record the iteration as hipGraph segments; every rank drops its "
-                               "tape -- restart without capture")
-        self.rec = rec
-        rec.replay()                                           # the recording pass executed no captured kernel
-        cur.wait_stream(self.stream)
-        return self.loss.clone()
-
-    @property
-    def segments(self):
-        """(graph segments, eager actions) of the recorded tape, or None before the recording."""
-        return None if self.rec is None else self.rec.counts()
-
-
-def _default_store():
-    import torch.distributed as tdist
-    if not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size() <= 1:
-        return None
-    try:
-        return tdist.distributed_c10d._get_default_store()
-    except Exception:
-        return None
-
-
-def _publish_record_outcome(uid: int, ok: bool) -> None:
-    """One key per (recorder, rank) in the job's rendezvous store: a side channel that does not depend on the order of the
-    collectives a failing rank may have left half issued."""
-    store = _default_store()
-    if store is None:
-        return
-    import torch.distributed as tdist
-    try:
-        store.set(f"semigcn/segrec/{uid}/{tdist.get_rank()}", "ok" if ok else "fail")
-    except Exception:
-        pass
-
-
-def _ranks_that_failed_to_record(uid: int, timeout_s: float = 300.0):
-    """Ranks whose recording failed (or that did not report within ``timeout_s``); [] when every rank recorded."""
-    store = _default_store()
-    if store is None:
-        return []
-    import datetime
-    import torch.distributed as tdist
-    bad = []
-    for r in range(tdist.get_world_size()):
-        key = f"semigcn/segrec/{uid}/{r}"
-        try:
-            store.wait([key], datetime.timedelta(seconds=timeout_s))
-            if store.get(key) != b"ok":
-                bad.append(r)
-        except Exception:
-            bad.append(r)
-    return bad
-
-
 def replay_matches_eager(trainer, mask_index: int = 0, rtol: float = 1e-6, grad_rtol: float = 1e-4) -> bool:
     """Trust a replaying trainer only after ONE replayed iteration has reproduced an eager one: both run on the same mask
     with the same parameters (no optimiser step lies between them; BatchNorm normalises with batch statistics in training
@@ -317,11 +201,11 @@ def replay_matches_eager(trainer, mask_index: int = 0, rtol: float = 1e-6, grad_
     models with active Dropout (MGCN: two passes draw different masks) -- bench.py does not replay those by default.
     Returns False (and leaves the trainer on its EAGER path) otherwise.  On a partition the gradient verdict is local to a
     rank; the callers all-reduce it where ranks must agree (bench.py)."""
-    rep = getattr(trainer, "_segmented", None) or getattr(trainer, "_graphed", None)
+    rep = getattr(trainer, "_graphed", None)
     if rep is None:
         return True
-    attr = "_segmented" if getattr(trainer, "_segmented", None) is not None else "_graphed"
-    while getattr(rep, "rec", None) is None and getattr(rep, "graph", None) is None:
+    attr = "_graphed"
+    while getattr(rep, "graph", None) is None:
         trainer.iteration_step(mask_index)              # still warming up / recording
     if trainer.accumulate < 3:
         # the pair of iterations below must not straddle an optimiser step (it would change the parameters between them),

@@ -464,56 +464,6 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
-def test_segment_tape_orders_graphs_and_eager_actions(monkeypatch):
-    """segments.SegmentRecorder with stand-ins for the CUDA graph objects: an eager action cuts the running segment, runs
-    once while recording and once per replay, nested eager actions run inside their parent, and the tape replays in the
-    recorded order."""
-    import contextlib
-    from semigcn_amd import segments
-    log = []
-
-    class FakeGraph:
-        count = 0
-
-        def __init__(self):
-            FakeGraph.count += 1
-            self.id = FakeGraph.count
-
-        def capture_begin(self, pool=None, capture_error_mode=None):
-            log.append(("begin", self.id))
-
-        def capture_end(self):
-            log.append(("end", self.id))
-
-        def replay(self):
-            log.append(("replay", self.id))
-
-    monkeypatch.setattr(segments.torch.cuda, "CUDAGraph", FakeGraph)
-    monkeypatch.setattr(segments.torch.cuda, "graph_pool_handle", lambda: (0, 0))
-    monkeypatch.setattr(segments.torch.cuda, "synchronize", lambda *a, **k: None)
-    monkeypatch.setattr(segments.torch.cuda, "stream", lambda s: contextlib.nullcontext())
-    assert segments.eager(lambda: 7) == 7 and not segments.recording()       # outside a recording: just runs
-
-    def body():
-        assert segments.recording()
-        a = segments.eager(lambda: log.append(("call", "A")) or "a")
-        segments.eager(lambda: (log.append(("call", "B")), segments.eager(lambda: log.append(("call", "B-inner")))))
-        return a
-
-    rec = segments.SegmentRecorder(stream=None)
-    assert rec.record(body) == "a" and not segments.recording()
-    assert rec.counts() == (3, 2)
-    assert log == [("begin", 1), ("end", 1), ("call", "A"), ("begin", 2), ("end", 2), ("call", "B"), ("call", "B-inner"),
-                   ("begin", 3), ("end", 3)]
-    del log[:]
-    rec.replay()
-    assert log == [("replay", 1), ("call", "A"), ("replay", 2), ("call", "B"), ("call", "B-inner"), ("replay", 3)]
-    # a failing body ends the open segment and leaves no recorder behind
-    with pytest.raises(ZeroDivisionError):
-        segments.SegmentRecorder(stream=None).record(lambda: 1 / 0)
-    assert not segments.recording()
-
-
 def test_trainer_trajectory_equals_the_oracle_loop(cpu_kernels, fixture_meshes):
     """train.SGCNTrainer (5 accumulated forward + loss + backward passes, Adam, in-place gradient buffer) against the
     oracle's restatement of sgcn.py:118-147 over 10 iterations / 2 Adam steps -- the host logic of the trajectory tests
