@@ -410,6 +410,7 @@ def timed_run(trainer, args, device, world, with_timer: bool):
         from semigcn_amd import dist as sgdist
         c0 = dict(sgdist.collective_counts)
     bc0 = list(F_sg.block_calls)
+    nr0 = list(sgdist.native_runs) if DIST_ON else [0, 0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.iteration_step()
@@ -417,6 +418,8 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     dt = time.perf_counter() - t0
     # blocks that really ran below the C ABI (forward, backward) per iteration: what `per_module_path` claims, measured
     timed_run.block_calls = [round((F_sg.block_calls[i] - bc0[i]) / args.steps, 2) for i in range(2)]
+    # passes (forward, backward) per iteration that ran as ONE sg_part_run call with the collectives enqueued by the library
+    timed_run.native_runs = [round((sgdist.native_runs[i] - nr0[i]) / args.steps, 2) for i in range(2)] if DIST_ON else None
     capi.set_launch_timer(None)
     if traced:
         timer.stop()
@@ -685,7 +688,8 @@ def supervise_rank(args) -> int:
     or overruns the limit, every supervisor kills its worker (they agree through marker files in a directory named after the
     job's rendezvous port -- one node) and starts a FRESH one, on a fresh store prefix:
       attempt 2: the SAME phase path again (a start-up hiccup must not turn the first real SCALE number into a measurement of
-                 the slow path);
+                 the slow path), its collectives issued one by one through torch.distributed instead of by the library's own
+                 communicator (SEMIGCN_DIST_NATIVE=0: csrc/comm.hip has met real peers only in the driver's SCALE run);
       attempt 3: the per-module path of rounds 1-3 (`--no-phases`: every collective issued from Python, 57 per iteration).
     A third failure exits non-zero with the reasons.  Every worker leaves its start-up marks and, if it is still alive shortly
     before the limit, a faulthandler dump of all its threads in the marker directory; the supervisor prints both for its rank
@@ -714,6 +718,7 @@ def supervise_rank(args) -> int:
             env["TORCHELASTIC_RESTART_COUNT"] = str(int(env.get("TORCHELASTIC_RESTART_COUNT", "0")) + attempt - 1)
             if env.get("TORCHELASTIC_USE_AGENT_STORE") != "True":
                 env["MASTER_PORT"] = str(int(port) + attempt - 1)
+            env["SEMIGCN_DIST_NATIVE"] = "0"
         per_module = attempt == n_attempts
         cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"] + (["--no-phases"] if per_module else [])
         path = "per-module path" if (per_module or args.no_phases) else "blocks phase by phase"
@@ -745,7 +750,7 @@ def supervise_rank(args) -> int:
             pass
         reasons.append(why)
         nxt = ("" if attempt == n_attempts else
-               "; starting a fresh worker on " + ("the SAME phase path" if attempt + 1 < n_attempts else "the per-module path"))
+               "; starting a fresh worker on " + ("the SAME phase path (collectives through torch.distributed)" if attempt + 1 < n_attempts else "the per-module path"))
         print(f"bench.py supervisor (rank {rank}): {why}{nxt}", file=sys.stderr, flush=True)
         for kind in ("marks", "traceback"):    # the post-mortem of THIS rank's worker
             fn = os.path.join(mark, f"{kind}_attempt{attempt}_rank{rank}.txt")
@@ -944,6 +949,7 @@ def main():
                                    "first_attempt_failure": os.environ.get("SEMIGCN_BENCH_FIRST_FAILURE"),
                                    "per_module_path": not getattr(trainer, "phases", False),
                                    "block_calls_per_iteration": getattr(timed_run, "block_calls", None),
+                                   "part_run_calls_per_iteration": getattr(timed_run, "native_runs", None),
                                    "startup_marks_s": startup_marks(),
                                    "collectives_per_iteration": round(sum(coll.values()), 1), "collectives_by_kind": coll,
                                    "rank0_owned_rows": None if g is None else g.n_own,

@@ -519,7 +519,9 @@ typedef struct sg_block {
    * its buffers T / X / H / Y / G have V_ext rows: [owned | per peer: that peer's rows of the two-ring halo, then 5 pad rows].
    * A block's halo exchange carries the rows of H (the conv output, BEFORE BatchNorm) and, in the pad rows of every peer's
    * segment, this rank's BatchNorm statistics of H: the all-gather of the statistics rides in the exchange, and each rank
-   * applies BatchNorm + activation to the halo rows it received itself (SG_PHASE_BN). */
+   * applies BatchNorm + activation to the halo rows it received itself (SG_PHASE_BN), which clears the pad rows of H once
+   * it has read them: no buffer keeps statistics bytes where feature values are expected.  Invariant the layout relies on:
+   * no column of `graph` / `graph_wide` names a pad row, and every reduction over rows stops at the V owned rows. */
   int32_t phase;               /* bit mask of sg_block_phase */
   int32_t world;               /* ranks */
   const sg_graph* graph_wide;  /* L^ on the owned AND the ring-1 rows: V_ext rows, V_ext columns (`graph`: V rows, V_ext columns) */
@@ -567,6 +569,46 @@ SG_API int sg_block_backward(const sg_block* blk, void* stream);
 SG_API int sg_block_run(const sg_block* blks, int64_t n, void* stream);
 SG_API int sg_block_chain_forward(const sg_block* blks, int64_t n, void* stream);
 SG_API int sg_block_chain_backward(const sg_block* blks, int64_t n, void* stream);
+
+/* ---- The rank's collectives below the C ABI (SURVEY.md section 8(b) `sg_halo_exchange`, section 8(e)).  No reference
+ * counterpart: the reference is one process on one device (util/networks.py:83-101 runs its 13 blocks with no exchange
+ * step); a vertex partition adds one exchange of boundary rows per block and direction, and the all-reduce / all-gather of
+ * the BatchNorm statistics that couple all vertices (util/networks.py:43).  Replaces, for the phase path, the per-collective
+ * torch.distributed calls of semigcn_amd/dist.py (_PartChainFn.forward / .backward: 13 + 1 forward, 26 backward).
+ *
+ * sg_comm wraps ONE RCCL communicator, bound at run time by dlopen from the copy of librccl.so already in the process (or
+ * /opt/rocm/lib): sg_comm_available() == 0 when none can be loaded, and every call below then answers SG_ERR_UNSUPPORTED.
+ * Rank 0 draws a 128-byte id (sg_comm_unique_id) and the host passes it to the other ranks (e.g. through torch.distributed's
+ * store); every rank then calls sg_comm_create -- collectively, with the HIP device it will use current -- with the rows it
+ * sends to / receives from each peer in ONE halo exchange (pad rows included; [world] each; a partition has 0 for itself,
+ * equal counts for itself are a copy).
+ * All collectives are enqueued on `stream`, the stream of the kernels around them: no event hand-off, no host wait.
+ *   sg_halo_exchange       all-to-all with the communicator's per-peer row counts: `send` = [sum send_rows, row_bytes] packed by
+ *                          peer, `recv` = [sum recv_rows, row_bytes] (rows [V:] of a partition block's H / its `recv`)
+ *   sg_comm_all_reduce_f32 in-place sum of n floats (a block's two BatchNorm backward sums: dvec rows 0, 1)
+ *   sg_comm_all_gather     bytes_per_rank from every rank, in rank order (the last block's BatchNorm statistics)
+ *   sg_part_run            a schedule: steps[i] is a run of partition-block phases (sg_block_run) or one of the three
+ *                          collectives; a rank's whole forward (or backward) pass over its blocks is one call.  `comm` may be
+ *                          NULL when no step is a collective. */
+typedef struct sg_comm sg_comm;
+enum sg_part_step_kind { SG_STEP_BLOCKS = 0, SG_STEP_EXCHANGE = 1, SG_STEP_ALL_REDUCE = 2, SG_STEP_ALL_GATHER = 3 };
+typedef struct sg_part_step {
+  int32_t kind;            /* sg_part_step_kind */
+  int32_t reserved_;
+  const sg_block* blocks;  /* SG_STEP_BLOCKS: n descriptors, run in array order */
+  int64_t n;               /* BLOCKS: descriptors; EXCHANGE: bytes per row; ALL_REDUCE: floats; ALL_GATHER: bytes per rank */
+  const void* send;        /* EXCHANGE, ALL_GATHER: what this rank contributes */
+  void* recv;              /* EXCHANGE, ALL_GATHER: where the peers' rows land; ALL_REDUCE: the float32 buffer (in place) */
+} sg_part_step;
+SG_API int sg_comm_available(void);
+SG_API int sg_comm_unique_id(void* id128);
+SG_API int sg_comm_create(const void* id128, int rank, int world, const int64_t* send_rows, const int64_t* recv_rows, sg_comm** out);
+SG_API int sg_comm_destroy(sg_comm* comm);
+SG_API int sg_halo_exchange(sg_comm* comm, const void* send, void* recv, int64_t row_bytes, void* stream);
+SG_API int sg_comm_all_reduce_f32(sg_comm* comm, float* buf, int64_t n, void* stream);
+SG_API int sg_comm_all_gather(sg_comm* comm, const void* in, void* out, int64_t bytes_per_rank, void* stream);
+SG_API int64_t sg_part_step_sizeof(void);
+SG_API int sg_part_run(sg_comm* comm, const sg_part_step* steps, int64_t n, void* stream);
 
 /* Per-launch timing of the kernels the library starts (benchmarking aid; off by default, costs two hipEventRecord per kernel
  * when on).  sg_trace_begin(capacity, kinds) starts recording up to `capacity` launches of the kinds in the bit mask
@@ -617,7 +659,7 @@ enum sg_tune_knob {
   SG_TUNE_F32_ENGINE = 8   /* dense products on float32 features: 0 (default) = the split-bf16 MFMA kernels (csrc/gemm_split.hip)
                               wherever they take the shape, the BLAS library for the rest; bit 0 = the BLAS library for all of
                               them (A/B switch); bits 1 / 2 / 3 = only the forward / input-gradient / weight-gradient products go to the
-                              library; bit 4 = sg_gemm_nt_f32 without the half-block stagger (A/B switch) */
+                              library (bisecting aid) */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

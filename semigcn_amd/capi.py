@@ -55,6 +55,15 @@ class sg_block(ctypes.Structure):
 PHASE_CONV, PHASE_BN, PHASE_BWD_REDUCE, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4, 8, 16
 
 
+class sg_part_step(ctypes.Structure):
+    """Mirror of ``struct sg_part_step`` (include/semigcn.h): one entry of a rank's schedule for ``sg_part_run``."""
+    _fields_ = [("kind", c_int32), ("reserved_", c_int32), ("blocks", POINTER(sg_block)), ("n", c_int64),
+                ("send", c_void_p), ("recv", c_void_p)]
+
+
+STEP_BLOCKS, STEP_EXCHANGE, STEP_ALL_REDUCE, STEP_ALL_GATHER = 0, 1, 2, 3
+
+
 class sg_trace_record(ctypes.Structure):
     _fields_ = [("kind", c_int32), ("dtype", c_int32), ("engine", c_int32), ("reserved_", c_int32),
                 ("a", c_int64), ("b", c_int64), ("c", c_int64), ("ms", c_float), ("reserved2_", c_float)]
@@ -152,6 +161,15 @@ _SIGNATURES = {
     "sg_block_forward": (c_int, [POINTER(sg_block), c_void_p]),
     "sg_block_backward": (c_int, [POINTER(sg_block), c_void_p]),
     "sg_block_run": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
+    "sg_comm_available": (c_int, []),
+    "sg_comm_unique_id": (c_int, [c_void_p]),
+    "sg_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_void_p)]),
+    "sg_comm_destroy": (c_int, [c_void_p]),
+    "sg_halo_exchange": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sg_comm_all_reduce_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "sg_comm_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sg_part_step_sizeof": (c_int64, []),
+    "sg_part_run": (c_int, [c_void_p, POINTER(sg_part_step), c_int64, c_void_p]),
     "sg_block_chain_forward": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
     "sg_block_chain_backward": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
     "sg_trace_begin": (c_int, [c_int64, c_int]),
@@ -218,6 +236,9 @@ def load():
     if lib.sg_block_sizeof() != ctypes.sizeof(sg_block):
         raise SemigcnLibraryError(f"struct sg_block: the library's has {lib.sg_block_sizeof()} bytes, the binding's "
                                   f"{ctypes.sizeof(sg_block)} -- rebuild the library (make -C semigcn_amd/csrc)")
+    if lib.sg_part_step_sizeof() != ctypes.sizeof(sg_part_step):
+        raise SemigcnLibraryError(f"struct sg_part_step: the library's has {lib.sg_part_step_sizeof()} bytes, the binding's "
+                                  f"{ctypes.sizeof(sg_part_step)} -- rebuild the library (make -C semigcn_amd/csrc)")
     _lib = lib
     if os.environ.get("SEMIGCN_F32_ENGINE"):               # A/B and bisecting runs: see SG_TUNE_F32_ENGINE in include/semigcn.h
         lib.sg_tuning_set(8, int(os.environ["SEMIGCN_F32_ENGINE"]))
@@ -1185,6 +1206,76 @@ def block_run(blks, n: int, stream: int, device: Optional[torch.device] = None) 
         rc = _lib.sg_block_run(blks, n, stream)
     if rc:
         _check(rc, "sg_block_run")
+
+
+class Comm:
+    """One RCCL communicator of the library's own (``sg_comm``, csrc/comm.hip): the rank's collectives enqueued below the C
+    ABI, on the stream of the kernels around them.  ``Comm.unique_id()`` on rank 0 -> the 128 bytes every rank passes to the
+    constructor (a collective call: all ranks, each with its device current)."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, send_rows, recv_rows, device: torch.device):
+        lib = load()
+        if len(unique_id) != 128:
+            raise SemigcnLibraryError(f"Comm: the unique id has {len(unique_id)} bytes, not 128")
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        srows = (c_int64 * world)(*[int(v) for v in send_rows])
+        rrows = (c_int64 * world)(*[int(v) for v in recv_rows])
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        h = c_void_p()
+        with _on_device(self.device):
+            _check(lib.sg_comm_create(buf, rank, world, srows, rrows, ctypes.byref(h)), "sg_comm_create")
+        self._h = h
+
+    @staticmethod
+    def available() -> bool:
+        return bool(load().sg_comm_available())
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _check(load().sg_comm_unique_id(buf), "sg_comm_unique_id")
+        return buf.raw
+
+    def halo_exchange(self, recv: torch.Tensor, send: torch.Tensor) -> None:
+        """``send`` [sum send_rows, C] packed by peer -> ``recv`` [sum recv_rows, C]; on the current stream of ``send``."""
+        _require_device(send, "send")
+        _require_device(recv, "recv")
+        if not (send.is_contiguous() and recv.is_contiguous()) or send.dtype != recv.dtype or send.shape[1:] != recv.shape[1:]:
+            raise SemigcnLibraryError("Comm.halo_exchange: contiguous [rows, C] buffers of one dtype and width")
+        rb = send.element_size()
+        for d in send.shape[1:]:
+            rb *= int(d)
+        with _on_device(self.device):
+            _check(_lib.sg_halo_exchange(self._h, send.data_ptr(), recv.data_ptr(), rb, _stream(send)), "sg_halo_exchange")
+
+    def all_reduce_(self, t: torch.Tensor) -> None:
+        _require_device(t, "t")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise SemigcnLibraryError("Comm.all_reduce_: a contiguous float32 tensor")
+        with _on_device(self.device):
+            _check(_lib.sg_comm_all_reduce_f32(self._h, t.data_ptr(), t.numel(), _stream(t)), "sg_comm_all_reduce_f32")
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        _require_device(inp, "inp")
+        _require_device(out, "out")
+        nb = inp.numel() * inp.element_size()
+        if not (inp.is_contiguous() and out.is_contiguous()) or out.numel() * out.element_size() != nb * self.world:
+            raise SemigcnLibraryError("Comm.all_gather: contiguous buffers, out = world x inp")
+        with _on_device(self.device):
+            _check(_lib.sg_comm_all_gather(self._h, inp.data_ptr(), out.data_ptr(), nb, _stream(inp)), "sg_comm_all_gather")
+
+    def close(self) -> None:
+        h, self._h = self._h, None
+        if h and _lib is not None:
+            _lib.sg_comm_destroy(h)
+
+
+def part_run(comm: Optional["Comm"], steps, n: int, stream: int, device: Optional[torch.device] = None) -> None:
+    """A rank's schedule -- runs of partition-block phases with the collectives between them -- in ONE foreign call."""
+    with (_NO_GUARD if device is None else _on_device(device)):
+        rc = _lib.sg_part_run(comm._h if comm is not None else None, steps, n, stream)
+    if rc:
+        _check(rc, "sg_part_run")
 
 
 def block_chain_backward(blks, n: int, stream: int, device: Optional[torch.device] = None) -> None:

@@ -479,12 +479,20 @@ __global__ __launch_bounds__(256) void pack_rows(const char* __restrict__ src, i
 }
 
 // gathered[q] = rank q's (mean[C], M2[C], rows): this rank's from `local`, a peer's from the pad rows of its segment in H
-__global__ void gather_stats(const char* __restrict__ H, int64_t ld_bytes, const int64_t* __restrict__ stats_rows,
+// The pad rows are then cleared (an eval-mode block and a gradient exchange send zeros there already: pack_rows): they held
+// statistics bytes that would read as arbitrary bf16 / fp32 FEATURES, NaN and Inf included, and SG_PHASE_BN applies
+// BatchNorm + activation to all V_ext rows -- no pad row is ever an aggregation source and every reduction stops at the V
+// owned rows, but a row of finite values costs nothing and cannot poison a later V_ext-wide pass.
+__global__ void gather_stats(char* __restrict__ H, int64_t ld_bytes, const int64_t* __restrict__ stats_rows,
                              const float* __restrict__ local, int world, int n, float* __restrict__ gathered) {
   const int q = blockIdx.x;
   const int64_t row = stats_rows[q];
   const float* src = row < 0 ? local : (const float*)(H + row * ld_bytes);
   for (int i = threadIdx.x; i < n; i += blockDim.x) gathered[(int64_t)q * n + i] = src[i];
+  if (row < 0) return;
+  __syncthreads();
+  uint32_t* pad = (uint32_t*)(H + row * ld_bytes);
+  for (int64_t i = threadIdx.x; i < kPadRows * ld_bytes / 4; i += blockDim.x) pad[i] = 0u;
 }
 
 int part_check(const sg_block& b) {
@@ -606,7 +614,7 @@ int part_run(const sg_block& b, hipStream_t stream) {
     if (b.training) {
       SG_REQUIRE(b.gathered && b.count && (b.gathered_ready || (b.stats_rows && b.local)), "sg_block_run (bn): no statistics");
       if (!b.gathered_ready) {
-        gather_stats<<<b.world, 128, 0, stream>>>((const char*)b.H, b.ldh * e, b.stats_rows, b.local, b.world, (int)(2 * Co + 1), b.gathered);
+        gather_stats<<<b.world, 128, 0, stream>>>((char*)b.H, b.ldh * e, b.stats_rows, b.local, b.world, (int)(2 * Co + 1), b.gathered);
         SG_HIP_TRY(hipGetLastError());
       }
       rc = launch_bn_finalize_ranks(b.gathered, b.world, Co, b.gamma, b.beta, b.running_mean, b.running_var, b.momentum, b.eps,

@@ -38,6 +38,7 @@ struct LtApi {
   decltype(&hipblasLtMatmulPreferenceDestroy) PrefDestroy = nullptr;
   decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
   decltype(&hipblasLtMatmul) Matmul = nullptr;
+  decltype(&hipblasLtGetVersion) GetVersion = nullptr;      // (optional: absent from very old builds)
   bool ok = false;
   std::string why;
 };
@@ -74,6 +75,7 @@ const LtApi& lt_api() {     // call with g_lt_mu held
             bind(so, "hipblasLtMatmulPreferenceDestroy", &g_lt.PrefDestroy) &&
             bind(so, "hipblasLtMatmulAlgoGetHeuristic", &g_lt.Heuristic) && bind(so, "hipblasLtMatmul", &g_lt.Matmul);
   if (!ok) g_lt.why = "libhipblaslt.so.1 lacks an expected entry point";
+  bind(so, "hipblasLtGetVersion", &g_lt.GetVersion);
   g_lt.ok = ok;
   return g_lt;
 }
@@ -123,7 +125,17 @@ int lt_gemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const void* A, in
   int dev = 0;
   SG_HIP_TRY(hipGetDevice(&dev));
   SG_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d out of range", dev);
-  if (!g_lt_handle[dev]) SG_LT_TRY(lt.Create(&g_lt_handle[dev]));
+  if (!g_lt_handle[dev]) {
+    SG_LT_TRY(lt.Create(&g_lt_handle[dev]));
+    // the structs and enums this file was compiled against (hipblasLtMatmulAlgo_t is passed by value into the plan cache) are
+    // those of ONE major version of the library: a process that loaded another one is refused, not miscomputed
+    int ver = 0;
+    if (lt.GetVersion && lt.GetVersion(g_lt_handle[dev], &ver) == HIPBLAS_STATUS_SUCCESS && ver / 100000 != HIPBLASLT_VERSION_MAJOR &&
+        ver / 10000 != HIPBLASLT_VERSION_MAJOR) {      // (major * 100000 + minor * 100 + patch; older builds: major * 10000)
+      set_error("the loaded libhipblaslt reports version %d; this library was built against major version %d", ver, HIPBLASLT_VERSION_MAJOR);
+      return SG_ERR_UNSUPPORTED;
+    }
+  }
   PlanKey key{dev, opA, opB, dt_in, dt_out, bias ? 1 : 0, batch, M, N, K, lda, ldb, ldc, sa, sb, sc};
   auto it = g_plans.find(key);
   if (it == g_plans.end()) {

@@ -25,6 +25,7 @@ New design -- the reference is single-process, single-device and has no counterp
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -481,6 +482,14 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
 
 PAD_ROWS = 5        # csrc/block.hip kPadRows: (2 C + 1) floats fit into 5 rows of C bf16 / fp32 values
 
+#: The phase path's collectives below the C ABI (csrc/comm.hip: the library's own RCCL communicator, a rank's forward /
+#: backward pass over its blocks as ONE foreign call each).  SEMIGCN_DIST_NATIVE=0 keeps them on torch.distributed -- what
+#: gloo groups always use, and what bench.py's supervisor falls back to.
+NATIVE_COLLECTIVES = os.environ.get("SEMIGCN_DIST_NATIVE", "1") != "0"
+_comm_seq = [0]
+#: passes (forward, backward) this rank ran as one sg_part_run call
+native_runs = [0, 0]
+
 
 class FoldedLayout:
     """One rank's operators and exchange plan on the folded row numbering ``[owned | per peer q != rank, ascending: q's rows
@@ -492,6 +501,7 @@ class FoldedLayout:
         dst, src, e_own, e_wide, dis, halo, send_per_peer = g._fold_src
         dev, W, rank, n = g.device, g.world, g.rank, g.n_own
         self.graph, self.world, self.rank, self.group, self.n_own = g, W, rank, g.group, n
+        self._comm = None
         V = g.num_vertices_global
         ext_of = torch.full((V,), -1, dtype=torch.long, device=dev)
         ext_of[g.start:g.end] = torch.arange(n, device=dev)
@@ -523,6 +533,49 @@ class FoldedLayout:
         dis_ext = torch.where(self.ext_src >= 0, dis[self.ext_src.clamp(min=0)], torch.zeros((), device=dev))
         self.handle = capi.GraphHandle.from_partition(dst[e_own] - g.start, ext_of[src[e_own]], n, self.n_ext, dis_ext)
         self.handle_wide = capi.GraphHandle.from_partition(ext_of[dst[e_wide]], ext_of[src[e_wide]], self.n_ext, self.n_ext, dis_ext)
+
+    def native_comm(self):
+        """The library's own communicator for this layout (capi.Comm), created at first use -- a collective call, so every
+        rank decides alike: RCCL groups only (gloo has no device path), switch on, librccl loadable.  The 128-byte id goes
+        from rank 0 to the others through the process group's store.  Before it is trusted, ONE exchange of a known
+        pattern is compared, bit for bit, with torch.distributed's all-to-all on the same rows (all ranks agree on the
+        verdict through an all-reduce): a first multi-GPU run checks the peer offsets it could never exercise on one GPU.
+        Returns None when the phase path keeps its collectives on torch.distributed."""
+        if self._comm is not None:
+            return self._comm or None
+        self._comm = False
+        if not NATIVE_COLLECTIVES or _solo(self.world) or _backend(self.group) != "nccl" or not capi.Comm.available():
+            return None
+        dev = self.graph.device
+        store = dist.distributed_c10d._get_default_store()
+        ranks = dist.get_process_group_ranks(_pg(self.group))
+        _comm_seq[0] += 1
+        key = "semigcn/sg_comm/%s/%d" % ("-".join(map(str, ranks)), _comm_seq[0])
+        if self.rank == 0:
+            uid = capi.Comm.unique_id()
+            store.set(key, uid)
+        else:
+            uid = bytes(store.get(key))
+        comm = capi.Comm(uid, self.rank, self.world, self.send_splits, self.recv_splits, dev)
+        # the known-answer exchange: row r of what rank p sends carries (p, r) -- against torch.distributed's own all-to-all
+        send = torch.empty((self.n_send, 4), dtype=torch.float32, device=dev)
+        send[:, 0] = float(self.rank)
+        send[:, 1] = torch.arange(self.n_send, device=dev, dtype=torch.float32)
+        send[:, 2:] = 0.5
+        got = torch.full((self.n_ext - self.n_own, 4), -1.0, device=dev)
+        want = torch.full_like(got, -2.0)
+        comm.halo_exchange(got, send)
+        _all_to_all_rows(want, send, self.recv_splits, self.send_splits, self.group)
+        collective_counts["all_to_all"] -= 1
+        bad = torch.tensor([0.0 if torch.equal(got, want) else 1.0], device=dev)
+        _pg_all_reduce(bad, dist.ReduceOp.SUM, self.group)
+        if float(bad.item()) != 0.0:
+            import warnings
+            warnings.warn("semigcn_amd.dist: the library's own halo exchange disagreed with torch.distributed's on the "
+                          "known-answer rows; the phase path keeps its collectives on torch.distributed")
+            return None
+        self._comm = comm
+        return comm
 
     def halo_of(self, full: torch.Tensor) -> torch.Tensor:
         """Rows ``[n_own:]`` of the folded buffer of a mesh-wide [V, C] tensor in processing order (zeros in the pad rows)."""
@@ -636,7 +689,43 @@ class _PartBuffers:
         self.training = None
         self.accs = None
         self.y_ptr = self.dy_ptr = None
+        self.steps = [None, None]
         self._fill_forward()
+
+    def schedule(self, backward: bool):
+        """The steps of one pass for ``capi.part_run``: the descriptor arrays of this set with the collectives between
+        them, in the order _PartChainFn issues them one by one on the torch.distributed path."""
+        if self.steps[backward] is not None:
+            return self.steps[backward]
+        plans, n = self.pc.plans, len(self.pc.plans)
+        e = 4 if self.dtype == torch.float32 else 2
+        ent = []
+        if not backward:
+            for i, p in enumerate(plans):
+                ent.append((capi.STEP_BLOCKS, self.f_seg[i], 1 if i == 0 else 2, None, None))
+                if i + 1 < n:
+                    ent.append((capi.STEP_EXCHANGE, None, p.Cout * e, self.send[i], self.recv[i]))
+            C = plans[-1].Cout
+            ent.append((capi.STEP_ALL_GATHER, None, (2 * C + 1) * 4, self.last_local, self.last_gathered))
+            ent.append((capi.STEP_BLOCKS, self.f_tail, 1, None, None))
+        else:
+            ent.append((capi.STEP_BLOCKS, self.b_head, 1, None, None))
+            for i in range(n - 1, -1, -1):
+                p = plans[i]
+                width = 2 * p.Cin if p.order == 0 else p.Cout
+                ent.append((capi.STEP_ALL_REDUCE, None, 2 * p.Cout, None, self.sums[i]))
+                ent.append((capi.STEP_BLOCKS, self.b_a[i], 1, None, None))
+                ent.append((capi.STEP_EXCHANGE, None, width * e, self.gsend[i], self.grecv[i]))
+                ent.append((capi.STEP_BLOCKS, self.b_b[i], 1 if i == 0 else 2, None, None))
+        arr = (capi.sg_part_step * len(ent))()
+        for st, (kind, blocks, cnt, send, recv) in zip(arr, ent):
+            st.kind, st.n = kind, cnt
+            if blocks is not None:
+                st.blocks = ctypes.cast(blocks, ctypes.POINTER(capi.sg_block))
+            st.send = send.data_ptr() if send is not None else None
+            st.recv = recv.data_ptr() if recv is not None else None
+        self.steps[backward] = arr
+        return arr
 
     def descriptors(self, i):
         """Every descriptor that describes block i (they all get the same static fields)."""
@@ -769,17 +858,26 @@ class _PartChainFn(torch.autograd.Function):
             b.f_seg[i][0 if i == 0 else 1].refresh_weights = p.stale(dtype, False)
         y = torch.empty((V, plans[-1].Cout), dtype=dtype, device=dev)
         b.f_tail[0].Y = y.data_ptr()
-        for i in range(n):
-            capi.block_run(b.f_seg[i], 1 if i == 0 else 2, stream, dev)
-            if i + 1 < n:
-                lay.exchange(b.recv[i], b.send[i])                # rows of H_i + this rank's statistics -> the peers, in place
-        # the last BatchNorm has no exchange behind it: a plain all-gather of the statistics
-        if training[-1]:
-            if _solo(W):
-                b.last_gathered.copy_(b.last_local)
-            else:
-                _all_gather_rows(b.last_gathered, b.last_local, lay.group)
-        capi.block_run(b.f_tail, 1, stream, dev)
+        comm = lay.native_comm() if all(training) else None
+        if comm is not None:
+            # ONE foreign call: the 14 runs of phases with the 12 exchanges and the statistics all-gather enqueued between them
+            steps = b.schedule(False)
+            capi.part_run(comm, steps, len(steps), stream, dev)
+            collective_counts["all_to_all"] += n - 1
+            collective_counts["all_gather"] += 1
+            native_runs[0] += 1
+        else:
+            for i in range(n):
+                capi.block_run(b.f_seg[i], 1 if i == 0 else 2, stream, dev)
+                if i + 1 < n:
+                    lay.exchange(b.recv[i], b.send[i])            # rows of H_i + this rank's statistics -> the peers, in place
+            # the last BatchNorm has no exchange behind it: a plain all-gather of the statistics
+            if training[-1]:
+                if _solo(W):
+                    b.last_gathered.copy_(b.last_local)
+                else:
+                    _all_gather_rows(b.last_gathered, b.last_local, lay.group)
+            capi.block_run(b.f_tail, 1, stream, dev)
         F_sg.block_calls[0] += n
         ctx.pc, ctx.params = pc, params
         if any(ctx.needs_input_grad):
@@ -826,16 +924,26 @@ class _PartChainFn(torch.autograd.Function):
             b.dy_ptr = dy.data_ptr()
         # BatchNorm n-1: this rank's sums -> all-reduce; then per block: [dH, dW, gradient blocks] -> all-to-all ->
         # [recurrence unwound -> dX ; sums of the BatchNorm in front] -> all-reduce
-        capi.block_run(b.b_head, 1, stream, dev)
         bn_local = [None] * n
-        for i in range(n - 1, -1, -1):
-            if not sunk[i][2]:
-                bn_local[i] = b.dvec[i][:2].clone()     # this rank's partial (sum dz, sum dz xhat): the gradients autograd gets
-            if not _solo(W):
-                _all_reduce(b.sums[i], dist.ReduceOp.SUM, lay.group)
-            capi.block_run(b.b_a[i], 1, stream, dev)
-            lay.exchange(b.grecv[i], b.gsend[i])
-            capi.block_run(b.b_b[i], 1 if i == 0 else 2, stream, dev)
+        # (BatchNorm gradients that autograd wants as tensors are this rank's PARTIAL sums, read between a block's reduce
+        #  phase and its all-reduce: such a pass takes the call-by-call path)
+        comm = lay.native_comm() if all(sk[2] for sk in sunk) else None
+        if comm is not None:
+            steps = b.schedule(True)
+            capi.part_run(comm, steps, len(steps), stream, dev)
+            collective_counts["all_reduce"] += n
+            collective_counts["all_to_all"] += n
+            native_runs[1] += 1
+        else:
+            capi.block_run(b.b_head, 1, stream, dev)
+            for i in range(n - 1, -1, -1):
+                if not sunk[i][2]:
+                    bn_local[i] = b.dvec[i][:2].clone()     # this rank's partial (sum dz, sum dz xhat): the gradients autograd gets
+                if not _solo(W):
+                    _all_reduce(b.sums[i], dist.ReduceOp.SUM, lay.group)
+                capi.block_run(b.b_a[i], 1, stream, dev)
+                lay.exchange(b.grecv[i], b.gsend[i])
+                capi.block_run(b.b_b[i], 1 if i == 0 else 2, stream, dev)
         F_sg.block_calls[1] += n
         grads_out = []
         for i, p in enumerate(plans):

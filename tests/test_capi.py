@@ -96,6 +96,37 @@ def test_block_and_trace_entry_points_without_gpu():
     assert lib.sg_tuning_set(capi.TUNE_BLOCK_PLANES, 1) == 0
 
 
+def test_comm_entry_points_without_gpu():
+    """sg_comm_* / sg_halo_exchange / sg_part_run (csrc/comm.hip): the schedule entry's ctypes mirror has
+    the library's size, and every entry point rejects a bad argument before RCCL or a device is touched."""
+    lib = capi.load()
+    assert ctypes.sizeof(capi.sg_part_step) == lib.sg_part_step_sizeof()
+    assert lib.sg_comm_unique_id(None) == -1 and b"null buffer" in lib.sg_last_error()
+    out = ctypes.c_void_p()
+    rows = (ctypes.c_int64 * 2)(0, 3)
+    idb = ctypes.create_string_buffer(128)
+    assert lib.sg_comm_create(None, 0, 2, rows, rows, ctypes.byref(out)) == -1 and b"no id" in lib.sg_last_error()
+    assert lib.sg_comm_create(idb, 2, 2, rows, rows, ctypes.byref(out)) == -1 and b"bad rank" in lib.sg_last_error()
+    assert lib.sg_comm_create(idb, 0, 2, None, None, ctypes.byref(out)) == -1 and b"row counts" in lib.sg_last_error()
+    neg = (ctypes.c_int64 * 2)(0, -1)
+    assert lib.sg_comm_create(idb, 0, 2, neg, rows, ctypes.byref(out)) == -1 and b"peer 1" in lib.sg_last_error()
+    assert out.value is None
+    assert lib.sg_comm_destroy(None) == 0
+    assert lib.sg_halo_exchange(None, None, None, 8, None) == -1 and b"null communicator" in lib.sg_last_error()
+    assert lib.sg_comm_all_reduce_f32(None, None, 4, None) == -1
+    assert lib.sg_comm_all_gather(None, None, None, 4, None) == -1
+    assert lib.sg_part_run(None, None, 0, None) == 0
+    assert lib.sg_part_run(None, None, 2, None) == -1 and b"bad argument" in lib.sg_last_error()
+    steps = (capi.sg_part_step * 2)()
+    steps[0].kind = capi.STEP_BLOCKS                      # an empty run of blocks: nothing to do
+    steps[1].kind = capi.STEP_EXCHANGE
+    assert lib.sg_part_run(None, steps, 1, None) == 0
+    assert lib.sg_part_run(None, steps, 2, None) == -1 and b"no communicator" in lib.sg_last_error()
+    steps[0].kind = 7
+    assert lib.sg_part_run(None, steps, 1, None) == -1 and b"kind 7" in lib.sg_last_error()
+    assert lib.sg_comm_available() in (0, 1)
+
+
 def test_no_cpu_fallback():
     ei = torch.tensor([[0, 1], [1, 0]])
     with pytest.raises(capi.SemigcnLibraryError, match="HIP device only"):

@@ -267,6 +267,69 @@ def test_one_rank_over_rccl_with_every_collective_issued(path):
     print(r.stdout[-800:])
 
 
+def test_one_rank_phase_path_collectives_below_the_c_abi_equal_the_torch_distributed_ones():
+    """csrc/comm.hip on a one-GPU box: ONE rank over RCCL with every collective issued.  With the parameter gradients sunk
+    into the .grad accumulators (what the trainers run) the forward AND the backward pass over the 13 blocks are ONE
+    sg_part_run call each -- the library's own communicator, the 12 + 13 exchanges, 13 all-reduces and the statistics
+    all-gather enqueued between the kernels -- and the rank's positions, loss and gradients are bit for bit those of the
+    same run with the collectives issued one by one through torch.distributed (SEMIGCN_DIST_NATIVE=0); the collective
+    count stays 44 + the gradient all-reduce."""
+    out = {}
+    for native in ("1", "0"):
+        r = _run_selftest(1, "nccl", SEMIGCN_DIST_FORCE_COLLECTIVES="1", SEMIGCN_SELFTEST_PATH="phases-sunk",
+                          SEMIGCN_SELFTEST_SKIP_MGCN="1", SEMIGCN_DIST_NATIVE=native)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert "dist_selftest OK" in r.stdout and "path=phases-sunk collectives=44" in r.stdout
+        line = [ln for ln in r.stdout.splitlines() if " digest " in ln][-1]
+        out[native] = (line.split(" digest ")[1].split()[0], line.split("native_part_runs=")[1].strip())
+        counts = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("collectives ")][-1].split(" ", 1)[1])
+        assert (counts["all_to_all"], counts["all_gather"], counts["all_reduce"]) == (27, 1, 17), counts
+    assert out["1"][1] == "[1, 1]" and out["0"][1] == "[0, 0]", out
+    assert out["1"][0] == out["0"][0], out
+
+
+def test_halo_exchange_entry_points_on_a_one_rank_communicator():
+    """sg_comm_* / sg_halo_exchange / sg_part_run directly: a one-rank RCCL communicator whose rank sends rows to ITSELF (a
+    send and a receive to one's own rank inside a group is a copy) drives the grouped send / receive path, the per-peer
+    offsets, the in-place all-reduce and the all-gather through the real library."""
+    import ctypes
+    from semigcn_amd import capi
+    dev = torch.device("cuda:0")
+    assert capi.Comm.available()
+    comm = capi.Comm(capi.Comm.unique_id(), 0, 1, [1000], [1000], dev)
+    for dt, C in ((torch.float32, 64), (torch.bfloat16, 256)):
+        send = torch.randn((1000, C), device=dev).to(dt)
+        recv = torch.zeros_like(send)
+        comm.halo_exchange(recv, send)
+        assert torch.equal(recv, send)
+    v = torch.arange(128, device=dev, dtype=torch.float32)
+    w = v.clone()
+    comm.all_reduce_(w)
+    assert torch.equal(w, v)
+    out = torch.zeros((1, 33), device=dev)
+    comm.all_gather(out, v[:33].contiguous())
+    assert torch.equal(out[0], v[:33])
+    # the same three as one schedule
+    send = torch.randn((1000, 32), device=dev)
+    recv = torch.zeros_like(send)
+    w.mul_(2.0)
+    steps = (capi.sg_part_step * 3)()
+    steps[0].kind, steps[0].n, steps[0].send, steps[0].recv = capi.STEP_EXCHANGE, 128, send.data_ptr(), recv.data_ptr()
+    steps[1].kind, steps[1].n, steps[1].recv = capi.STEP_ALL_REDUCE, 128, w.data_ptr()
+    steps[2].kind, steps[2].n, steps[2].send, steps[2].recv = capi.STEP_ALL_GATHER, 33 * 4, v.data_ptr(), out.data_ptr()
+    out.zero_()
+    capi.part_run(comm, steps, 3, torch.cuda.current_stream(dev).cuda_stream, dev)
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send) and torch.equal(w, 2.0 * v) and torch.equal(out[0], v[:33])
+    # a collective step without a communicator, an unknown step kind: refused, nothing enqueued
+    with pytest.raises(capi.SemigcnLibraryError, match="no communicator"):
+        capi.part_run(None, steps, 3, 0, dev)
+    steps[0].kind = 9
+    with pytest.raises(capi.SemigcnLibraryError, match="kind 9"):
+        capi.part_run(comm, steps, 1, 0, dev)
+    comm.close()
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for RCCL")
 def test_partitioned_ranks_over_rccl():
     r = _run_selftest(2, "nccl")

@@ -72,6 +72,27 @@ def main():
     elif world > 1 or sgdist.FORCE_COLLECTIVES:
         assert n_coll == 57, n_coll
     sgdist.all_reduce_gradients(tr.params)
+    # what this rank computed, bit for bit (two runs of one path on the same inputs -- e.g. the collectives below the C ABI
+    # against the same collectives through torch.distributed -- must print the same line), and how the passes were issued
+    import hashlib
+    h = hashlib.sha256()
+    h.update(pos.detach().float().cpu().numpy().tobytes())
+    h.update(loss.detach().float().cpu().numpy().tobytes())
+    for q in model.parameters():
+        if q.grad is not None:
+            h.update(q.grad.detach().float().cpu().numpy().tobytes())
+    print(f"[rank {rank}/{world}] digest {h.hexdigest()[:24]} native_part_runs={sgdist.native_runs}", flush=True)
+    if path != "modules":
+        # no buffer of the phase path keeps statistics bytes (or anything else that is not a finite feature value) in the pad
+        # rows of the peers' segments: SG_PHASE_BN clears them in H once it has read them
+        n_checked = 0
+        for pc in part.graph.__dict__.get("_part_chains", {}).values():
+            for bufs in pc._free.values():
+                for b in bufs:
+                    for t in b.inp + b.H:
+                        assert bool(torch.isfinite(t.float()).all()), "a non-finite value in a phase-path buffer"
+                        n_checked += 1
+        assert n_checked >= 26 or world == 1, n_checked
 
     if os.environ.get("SEMIGCN_SELFTEST_CROSS") == "1" and path == "phases":
         # the SAME partitioned model once more on the per-module path: the two differ in where BatchNorm's moments are merged
