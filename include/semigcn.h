@@ -392,6 +392,9 @@ SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, in
  *   sg_gemm_tn_f32:  out[N, Kp] (row stride ldo) = A[M, N]^T B[M, Kp], a reduction over all M vertices; workspace: float32
  *                    [sg_gemm_tn_f32_slabs(M, N, Kp), N_pad, Kp_pad] slab partials (sg_gemm_tn_f32_workspace bytes), added
  *                    in slab order: deterministic.  N, Kp, lda, ldb multiples of 4, ldo % 4 == 0, M >= 4096.
+ * Weight matrices of 4 .. 48 rows and columns (multiples of 4; the 16 -> 32 and 32 -> 16 layers) are HBM-bound and below the
+ * matrix-core tile: the same entry points run them as plain float32 FMA chains on the vector ALUs (csrc/gemm_mid.hip; any M,
+ * no workspace for nt, sg_gemm_tn_f32_workspace bytes of block partials for tn, same deterministic reduce).
  * ------------------------------------------------------------------------- */
 SG_API int sg_gemm_nt_f32_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
 SG_API int64_t sg_gemm_nt_f32_workspace(int64_t N, int64_t K);

@@ -561,10 +561,12 @@ SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, in
 }
 
 SG_API int sg_gemm_nt_f32_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
-  return gemm_nt_f32s_supported(M, N, K, lda, ldc) ? 1 : 0;
+  return (gemm_nt_f32s_supported(M, N, K, lda, ldc) || (M >= 0 && mid_shape(N, K) && lda % 4 == 0 && ldc % 4 == 0)) ? 1 : 0;
 }
 
-SG_API int64_t sg_gemm_nt_f32_workspace(int64_t N, int64_t K) { return N > 0 && K > 0 ? gemm_nt_f32s_workspace(N, K) : 0; }
+SG_API int64_t sg_gemm_nt_f32_workspace(int64_t N, int64_t K) {
+  return (N > 0 && K > 0 && !mid_shape(N, K)) ? gemm_nt_f32s_workspace(N, K) : 0;
+}
 
 SG_API int sg_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
                           int64_t ldc, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -572,14 +574,16 @@ SG_API int sg_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t w
   if (M == 0 || N == 0) return SG_OK;
   SG_REQUIRE(A && W && C && K > 0, "sg_gemm_nt_f32: null operand or K = 0");
   SG_REQUIRE(lda >= K && ldc >= N, "sg_gemm_nt_f32: row stride shorter than the row");
+  if (mid_shape(N, K)) return launch_mid_nt(A, lda, W, w_rs, w_cs, bias, C, ldc, M, N, K, (hipStream_t)stream);
   return launch_gemm_nt_f32s(A, lda, W, w_rs, w_cs, bias, C, ldc, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 SG_API int sg_gemm_tn_f32_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb) {
-  return gemm_tn_f32s_supported(M, N, Kp, lda, ldb) ? 1 : 0;
+  return (gemm_tn_f32s_supported(M, N, Kp, lda, ldb) || (M > 0 && mid_shape(N, Kp) && lda % 4 == 0 && ldb % 4 == 0)) ? 1 : 0;
 }
 
 SG_API int64_t sg_gemm_tn_f32_workspace(int64_t M, int64_t N, int64_t Kp) {
+  if (M > 0 && mid_shape(N, Kp)) return mid_tn_workspace(M, N, Kp) * 4;
   return M > 0 && N > 0 && Kp > 0 ? gemm_tn_f32s_workspace(M, N, Kp) : 0;
 }
 
@@ -588,6 +592,10 @@ SG_API int sg_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t l
   SG_REQUIRE(M >= 0 && N >= 0 && Kp >= 0, "sg_gemm_tn_f32: negative size");
   if (N == 0 || Kp == 0) return SG_OK;
   SG_REQUIRE(A && B && out && ldo >= Kp && lda >= N && ldb >= Kp, "sg_gemm_tn_f32: null operand or short row stride");
+  if (mid_shape(N, Kp)) {
+    SG_REQUIRE(workspace && workspace_bytes >= mid_tn_workspace(M, N, Kp) * 4, "sg_gemm_tn_f32: workspace too small");
+    return launch_mid_tn(A, lda, B, ldb, M, N, Kp, (float*)workspace, out, ldo, (hipStream_t)stream, nullptr);
+  }
   return launch_gemm_tn_f32s(A, lda, B, ldb, M, N, Kp, workspace, workspace_bytes, out, ldo, (hipStream_t)stream);
 }
 

@@ -243,6 +243,10 @@ int64_t dense_tn_workspace(int dtype, int64_t M, int64_t N, int64_t Kp) {      /
     const int64_t split = gemm_tn_f32s_workspace(M, N, Kp) / 4;
     need = need > split ? need : split;
   }
+  if (dtype == SG_F32 && mid_shape(N, Kp)) {
+    const int64_t mid = mid_tn_workspace(M, N, Kp);
+    need = need > mid ? need : mid;
+  }
   return need;
 }
 
@@ -286,6 +290,10 @@ int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64
     return launch_gemm_nt_f32s((const float*)A, lda, (const float*)Bp, ldb, 1, bias, (float*)C, ldc, M, N, K, blas_ws,
                                (int64_t)blas_ws_bytes, stream);
   }
+  if (dtype == SG_F32 && split_engine_enabled(0) && mid_shape(N, K) && lda % 4 == 0 && ldc % 4 == 0 && a16(A) && a16(C)) {
+    TraceScope ts(1, dtype, 2, M, N, K, stream);
+    return launch_mid_nt((const float*)A, lda, (const float*)Bp, ldb, 1, bias, (float*)C, ldc, M, N, K, stream);
+  }
   TraceScope ts(1, dtype, 3, M, N, K, stream);
   return lt_gemm(0, 1, M, N, K, A, lda, Bp, ldb, bias, C, ldc, dtype, dtype, 1, 0, 0, 0, blas_ws, blas_ws_bytes, stream);
 }
@@ -315,6 +323,10 @@ int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void
     TraceScope ts(1, dtype, 4, M, N, K, stream);      // B is [K, N]: element (n, k) at Bp[k * ldb + n]
     return launch_gemm_nt_f32s((const float*)A, lda, (const float*)Bp, 1, ldb, nullptr, (float*)C, ldc, M, N, K, blas_ws,
                                (int64_t)blas_ws_bytes, stream);
+  }
+  if (dtype == SG_F32 && split_engine_enabled(1) && mid_shape(N, K) && lda % 4 == 0 && ldc % 4 == 0 && a16(A) && a16(C)) {
+    TraceScope ts(1, dtype, 2, M, N, K, stream);      // B is [K, N]: element (n, k) at Bp[k * ldb + n]
+    return launch_mid_nt((const float*)A, lda, (const float*)Bp, 1, ldb, nullptr, (float*)C, ldc, M, N, K, stream);
   }
   TraceScope ts(1, dtype, 3, M, N, K, stream);
   return lt_gemm(0, 0, M, N, K, A, lda, Bp, ldb, nullptr, C, ldc, dtype, dtype, 1, 0, 0, 0, blas_ws, blas_ws_bytes, stream);
@@ -354,6 +366,13 @@ int dense_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, 
     if (sunk) *sunk = can;
     return launch_gemm_tn_f32s((const float*)A, lda, (const float*)B, ldb, M, N, Kp, ws, gemm_tn_f32s_workspace(M, N, Kp), out, ldo,
                                stream, can ? sink : nullptr);
+  }
+  if (dtype == SG_F32 && split_engine_enabled(2) && mid_shape(N, Kp) && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0 && a16(A) &&
+      a16(B) && a16(out) && a16(ws)) {
+    TraceScope ts(2, dtype, 2, M, N, Kp, stream);
+    const bool can = sink != nullptr && sink->Cin % 4 == 0;
+    if (sunk) *sunk = can;
+    return launch_mid_tn((const float*)A, lda, (const float*)B, ldb, M, N, Kp, ws, out, ldo, stream, can ? sink : nullptr);
   }
   TraceScope ts(2, dtype, 3, M, N, Kp, stream);
   const int64_t S = blas_tn_slabs(dtype, M);

@@ -699,22 +699,29 @@ bool gemm_tn_f32s_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64
          ldb % 4 == 0 && N < (1 << 20) && Kp < (1 << 20);
 }
 
-// slabs of rows: 8 x s, s the smallest count for which the items of one XCD group (s x tiles) fill its 32 workgroups evenly,
-// halved while a slab would be shorter than 64 steps of 32 rows
+// slabs of rows: 8 x s (one set of s per XCD group of 32 workgroups).  s by a small cost model, in units of one 32-row step
+// of one tile (~2.5 us): the items of a group (s x tiles) run in ceil(items / 32) rounds of (steps per slab + ~4 steps of
+// pipeline fill and partial-tile store) each, and the slab partials cost the reduce kernel a read (~10 MB per step unit).
+// A 1 M-row product of 12 tiles takes s = 8 (3 rounds of 488 steps); a 50 K-row product of ONE tile takes s = 32 (one round
+// of 7 steps) where a fixed 64-step minimum per slab left it on 16 workgroups for 98 steps (0.24 ms for a 0.6 GFLOP product).
 static int split_tn_slabs(int64_t M, int64_t N, int64_t Kp) {
   int64_t n_tiles = ((N + 255) / 256) * ((Kp + 127) / 128);
   const int64_t n_tiles_t = ((Kp + 255) / 256) * ((N + 127) / 128);
   if (n_tiles_t * 256 * 128 < n_tiles * 256 * 128) n_tiles = n_tiles_t;         // (the orientation launch_gemm_tn_f32s takes)
-  int64_t g = n_tiles, r = 32;
-  while (r) {
-    const int64_t t = g % r;
-    g = r;
-    r = t;
-  }
-  int64_t s = 32 / g;
   const int64_t steps = (M + 31) / 32;
-  while (s > 1 && steps < 64 * 8 * s) s = (s + 1) / 2;
-  return (int)(8 * s);
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 32; ++s) {
+    const int64_t per_slab = (steps + 8 * s - 1) / (8 * s);
+    if (s > 1 && (per_slab < 4 || (double)(8 * s) * N * Kp * 4 > 192e6)) break;
+    const int64_t items = s * n_tiles, rounds = (items + 31) / 32;
+    const double cost = (double)rounds * (per_slab + 4) + (double)(8 * s) * N * Kp * 4 / 10e6;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = s;
+    }
+  }
+  return 8 * best;
 }
 
 int64_t gemm_tn_f32s_workspace(int64_t M, int64_t N, int64_t Kp) { return (int64_t)split_tn_slabs(M, N, Kp) * N * Kp * 4; }
@@ -749,6 +756,18 @@ int launch_gemm_tn_f32s(const float* A, int64_t lda, const float* B, int64_t ldb
   const int blocks = (int)((elems / 4 + 63) / 64);
   if (tr) split_tn_reduce<true><<<blocks, 1024, 0, stream>>>(g.W, g.slabs, elems, g.Kp, out, ldo, sink);
   else split_tn_reduce<false><<<blocks, 1024, 0, stream>>>(g.W, g.slabs, elems, g.Kp, out, ldo, sink);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+// out = the n_slabs partials [N, Kp] of `ws` added in the fixed tree of split_tn_reduce (+= into the sink's accumulators):
+// the reduce step of the weight-gradient kernels, also used by gemm_mid.hip
+int launch_split_tn_reduce(const float* ws, int n_slabs, int64_t N, int64_t Kp, float* out, int64_t ldo, const GradSink* sink,
+                           hipStream_t stream) {
+  SG_REQUIRE(Kp % 4 == 0 && ldo % 4 == 0, "split_tn_reduce: the column count and the row stride must be multiples of 4");
+  const int64_t elems = N * Kp;
+  const int blocks = (int)((elems / 4 + 63) / 64);
+  split_tn_reduce<false><<<blocks, 1024, 0, stream>>>(ws, n_slabs, elems, (int)Kp, out, ldo, sink ? *sink : GradSink{});
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

@@ -267,6 +267,15 @@ int set_split_tuning(int value);
 bool split_engine_enabled(int kind = 0);
 bool gemm_tn_f32s_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 int64_t gemm_tn_f32s_workspace(int64_t M, int64_t N, int64_t Kp);
+int launch_split_tn_reduce(const float* ws, int n_slabs, int64_t N, int64_t Kp, float* out, int64_t ldo, const GradSink* sink,
+                           hipStream_t stream);
+// float32 products with a small weight matrix on the vector ALUs (gemm_mid.hip): N, K in 4 .. 48, multiples of 4
+bool mid_shape(int64_t N, int64_t K);
+int64_t mid_tn_workspace(int64_t M, int64_t N, int64_t Kp);      // float32 elements
+int launch_mid_nt(const float* X, int64_t ldx, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* Y, int64_t ldy,
+                  int64_t M, int64_t N, int64_t K, hipStream_t stream);
+int launch_mid_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, float* ws, float* out,
+                  int64_t ldo, hipStream_t stream, const GradSink* sink);
 int launch_gemm_tn_f32s(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, void* ws,
                         int64_t ws_bytes, float* out, int64_t ldo, hipStream_t stream, const GradSink* sink = nullptr);
 

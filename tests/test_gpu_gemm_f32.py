@@ -92,16 +92,53 @@ def test_split_tn_random_data_strides_and_error_vs_float64(M, N, Kp):
     assert e_own <= 1.25 * e_lib + 3e-8 and e_own < 6e-7, (e_own, e_lib)
 
 
+MID_SHAPES = [(50000, 32, 48), (50000, 48, 32), (1000, 16, 48), (777, 48, 48), (4099, 8, 20), (256, 4, 4), (33333, 24, 36)]
+
+
+@pytest.mark.parametrize("M,N,K", MID_SHAPES)
+def test_small_weight_products_on_the_vector_alus(M, N, K):
+    """csrc/gemm_mid.hip behind the same entry points: weight matrices of 4 .. 48 rows and columns (the 16 -> 32 and 32 -> 16
+    layers, util/networks.py:40-53) as plain float32 FMA chains.  Small integers bit for bit in all three forms (forward,
+    input gradient from the [K, N] storage, weight gradient); random data against float64 no worse than the BLAS library."""
+    g = torch.Generator(device=DEV).manual_seed(M + 5 * N + 11 * K)
+    a, w, bias = _ints((M, K), 8, g), _ints((N, K), 8, g), _ints((N,), 8, g)
+    ref = (a.double() @ w.double().t() + bias.double()).float()
+    assert capi.gemm_nt_f32_supported(a, N)
+    assert torch.equal(capi.gemm_nt_f32(a, w, bias), ref)
+    assert torch.equal(capi.gemm_nt_f32(a, w.t().contiguous(), bias, w_is_kn=True), ref)
+    wide = torch.zeros((M, N + 8), device=DEV)
+    capi.gemm_nt_f32(a, w, bias, out=wide[:, 4:4 + N])
+    assert torch.equal(wide[:, 4:4 + N], ref) and torch.all(wide[:, :4] == 0) and torch.all(wide[:, 4 + N:] == 0)
+    b = _ints((M, N), 4, g)
+    a4 = _ints((M, K), 4, g)
+    assert capi.gemm_tn_f32_supported(b, a4)
+    dw = capi.gemm_tn_f32(b, a4)
+    assert torch.equal(dw, (b.double().t() @ a4.double()).float())
+    assert torch.equal(capi.gemm_tn_f32(b, a4), dw)
+    ar, wr = torch.randn((M, K), device=DEV, generator=g), torch.randn((N, K), device=DEV, generator=g) * 0.1
+    r64 = ar.double() @ wr.double().t()
+    den = ar.double().abs() @ wr.double().abs().t()
+    e_own = ((capi.gemm_nt_f32(ar, wr).double() - r64).abs() / den).max().item()
+    e_lib = (((ar @ wr.t()).double() - r64).abs() / den).max().item()
+    assert e_own <= 1.25 * e_lib + 3e-8 and e_own < 6e-7, (e_own, e_lib)
+    br = torch.randn((M, N), device=DEV, generator=g)
+    r64 = br.double().t() @ ar.double()
+    den = br.double().abs().t() @ ar.double().abs()
+    e_own = ((capi.gemm_tn_f32(br, ar).double() - r64).abs() / den).max().item()
+    e_lib = (((br.t() @ ar).double() - r64).abs() / den).max().item()
+    assert e_own <= 1.25 * e_lib + 3e-8 and e_own < 6e-7, (e_own, e_lib)
+
+
 def test_split_products_reject_what_they_cannot_take():
-    a = torch.zeros((1000, 48), device=DEV)
-    assert not capi.gemm_nt_f32_supported(a, 64)                     # K = 48 is no multiple of 32
+    a = torch.zeros((1000, 80), device=DEV)
+    assert not capi.gemm_nt_f32_supported(a, 64)                     # K = 80 is no multiple of 32 (and no small weight matrix)
     assert not capi.gemm_nt_f32_supported(torch.zeros((100, 64), device=DEV), 64)      # fewer rows than a tile
     assert not capi.gemm_nt_f32_supported(torch.zeros((1000, 64), device=DEV, dtype=torch.bfloat16), 64)
     with pytest.raises(capi.SemigcnLibraryError, match="unsupported shape"):
-        capi.gemm_nt_f32(a, torch.zeros((64, 48), device=DEV))
+        capi.gemm_nt_f32(a, torch.zeros((64, 80), device=DEV))
     assert not capi.gemm_tn_f32_supported(torch.zeros((1000, 64), device=DEV), torch.zeros((1000, 64), device=DEV))
     lib = capi.load()
-    assert lib.sg_gemm_nt_f32(a.data_ptr(), 64, a.data_ptr(), 64, 1, None, a.data_ptr(), 64, 1000, 64, 64, None, 0, None) == -1
+    assert lib.sg_gemm_nt_f32(a.data_ptr(), 80, a.data_ptr(), 80, 1, None, a.data_ptr(), 80, 1000, 64, 64, None, 0, None) == -1
     assert b"workspace" in lib.sg_last_error()
 
 
