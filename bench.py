@@ -132,6 +132,8 @@ def aggregation_kernel_name(C: int, esize: int, n_epi: int) -> str:
     """Which kernel sg_spmm dispatches to for this shape on a mesh graph (csrc/spmm.hip, launch_typed_one)."""
     if esize == 2 and C in (128, 256):        # pipelined LDS-tile kernel (graphs that carry tile records: every mesh graph here)
         return "spmm_ring"
+    if esize == 4 and (C == 128 or (C == 256 and n_epi >= 1)):      # the same pipeline on float32 rows (256 channels: two half-row launches)
+        return "spmm_ring_f32" if C == 128 else "spmm_ring_f32 x 2 (128-channel halves)"
     row_bytes = C * esize
     shared = esize == 4 and row_bytes >= 1024 and (row_bytes >= 2048 or n_epi == 0) and 16 < C // (16 // esize) <= 128
     return "spmm_shared" if shared else "spmm_rows"

@@ -130,7 +130,12 @@ SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, 
  * (<= 16 rows and their <= 56 distinct sources staged in LDS) on the matrix cores,
  * with the fp32 weights split exactly into three bf16 pieces and the MFMA's own
  * accumulation order -- same error bound, a different last bit in ~1 % of the
- * bf16 outputs (SG_TUNE_FLAGS bit 11 restores the fma chain).
+ * bf16 outputs (SG_TUNE_FLAGS bit 11 restores the fma chain).  float32 rows of 128
+ * channels (and of 256 with at most one epilogue operand) take the same tiled
+ * pipeline with float32 operands on v_mfma_f32_16x16x4_f32: the nonzero terms of a row
+ * are still added in ascending neighbour id, the matrix core's 4-term inner sum rounds
+ * differently from an fma chain (a few ulp; SG_TUNE_FLAGS bit 13 restores the chain).
+ * The tile records are built by the first aggregation that can use them.
  * Non-finite inputs: the gathers run in fixed-size batches whose unused slots
  * are switched off by a ZERO WEIGHT on a row that is read anyway (a neighbour of
  * one of the rows the same wavefront works on, or row 0; in the tiled kernel: any
@@ -642,7 +647,7 @@ enum sg_tune_knob {
                              applied; measured slower), bit 8: 4-channel bf16 rows on the one-thread-per-element kernel instead of the
                              one-thread-per-row kernel, bit 11: NO tiled matrix-core kernel (spmm_ring) for bf16 rows of 128 / 256
                              channels (at graph creation: no tile records are built), bit 12: spmm_ring stores straight from the
-                             MFMA layout instead of full rows through LDS (A/B switches) */
+                             MFMA layout instead of full rows through LDS, bit 13: NO tiled kernel for float32 rows (A/B switches) */
   SG_TUNE_UNROLL = 2,     /* gathers a lane group issues back to back in the aggregation kernel: 8, 6 or 4
                              (fewer = fewer VGPRs = more resident wavefronts); 0 = the shipped choice per shape */
   SG_TUNE_SLAB = 3,       /* channels per column slab (one sweep of all rows per slab); 0 = off */

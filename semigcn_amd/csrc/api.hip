@@ -3,6 +3,8 @@
 
 #include <new>
 
+#include <mutex>
+
 #include "sg_common.h"
 
 namespace sg {
@@ -51,6 +53,21 @@ int check_dense(const char* what, const void* X, int64_t ld, int64_t C) {
   return SG_OK;
 }
 
+// The tile records of spmm_ring, at the first aggregation that can use them (see Csr::rec_pending).  Not while the stream is
+// being captured into a hipGraph (the build allocates and synchronises): such a call runs on the rows kernel and the records
+// wait for the next eager one -- every trainer here runs its warm-up iterations eagerly before it captures.
+std::mutex g_rec_mu;
+int build_pending_records(const Csr& c_, hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) (void)hipGetLastError();
+  if (st != hipStreamCaptureStatusNone) return SG_OK;
+  std::lock_guard<std::mutex> lock(g_rec_mu);          // (forward and backward passes run on different host threads)
+  Csr& c = const_cast<Csr&>(c_);
+  if (!c.rec_pending) return SG_OK;
+  c.rec_pending = false;
+  return build_ring_records(&c, c.pend_scale_src, c.pend_scale_dst, c.pend_row_id, stream);
+}
+
 int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64_t ldx,
             const void* X0, int64_t ldx0, const void* X1, int64_t ldx1, void* Y, int64_t ldy,
             int64_t C, int dtype, float alpha, float beta, float gamma, hipStream_t stream,
@@ -63,6 +80,9 @@ int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64
   if (X0 && (rc = check_dense("X0", X0, ldx0, C)) != SG_OK) return rc;
   if (X1 && (rc = check_dense("X1", X1, ldx1, C)) != SG_OK) return rc;
   SG_REQUIRE(X != Y, "Y must not alias X");
+  if (c.rec_pending && (dtype == SG_BF16 || (dtype == SG_F32 && ring_f32_enabled())) && (C == 128 || C == 256) &&
+      (rc = build_pending_records(c, stream)) != SG_OK)
+    return rc;
   SpmmArgs a;
   a.rowptr = c.rowptr;
   a.idx = c.idx;
@@ -162,14 +182,14 @@ SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void
     }
     if ((rc = pack_source_scale(&g->fwd, g->dis_src, stream)) != SG_OK) break;
     if (!g->symmetric && (rc = pack_source_scale(&g->bwd, g->dis_src, stream)) != SG_OK) break;
-    if (ring_enabled() && !g->symmetric && (rc = build_ring_records(&g->bwd, g->dis_src, g->dis_dst, nullptr, stream)) != SG_OK) break;
+    if (ring_enabled() && !g->symmetric) g->bwd.defer_records(g->dis_src, g->dis_dst, nullptr);
     if (g->symmetric) {      // numbering without locality (a raw scan): process the rows in a graph-derived order
       if ((rc = locality_order(g->fwd, graph_reorder_mode(), stream, &g->row_id)) != SG_OK) break;
     }
     // tile records of the forward CSR only where sg_spmm will read them: a graph that gets a locality view is always
     // applied through that view (its records are built below), so records of the plain row order would be dead weight
     // (896 bytes per 16 rows for the graph's lifetime, a sort and two stream syncs at creation)
-    if (ring_enabled() && !g->row_id && (rc = build_ring_records(&g->fwd, g->dis_src, g->dis_dst, nullptr, stream)) != SG_OK) break;
+    if (ring_enabled() && !g->row_id) g->fwd.defer_records(g->dis_src, g->dis_dst, nullptr);
     if (g->symmetric) {
       if (g->row_id) {
         if ((rc = permute_rows(g->fwd, g->row_id, stream, &g->loc)) != SG_OK) break;
@@ -181,7 +201,7 @@ SG_API int sg_graph_create(const int64_t* edge_index, int64_t E, int64_t V, void
         if ((rc = gather_floats(g->dis_dst, g->row_id, V, g->dis_dst_loc, stream)) != SG_OK) break;
         if (tiles_enabled() && (rc = build_tiles(&g->loc, stream)) != SG_OK) break;
         if ((rc = pack_source_scale(&g->loc, g->dis_src, stream)) != SG_OK) break;
-        if (ring_enabled() && (rc = build_ring_records(&g->loc, g->dis_src, g->dis_dst_loc, g->row_id, stream)) != SG_OK) break;
+        if (ring_enabled()) g->loc.defer_records(g->dis_src, g->dis_dst_loc, g->row_id);
       }
     }
     if (hipStreamSynchronize(stream) != hipSuccess) {
@@ -222,7 +242,7 @@ SG_API int sg_graph_create_rect(const int64_t* dst, const int64_t* src, int64_t 
         rc = SG_ERR_HIP;
       }
       if (rc == SG_OK) rc = pack_source_scale(&g->fwd, g->dis_src, stream);
-      if (rc == SG_OK && ring_enabled()) rc = build_ring_records(&g->fwd, g->dis_src, g->dis_dst, nullptr, stream);
+      if (rc == SG_OK && ring_enabled()) g->fwd.defer_records(g->dis_src, g->dis_dst, nullptr);
       if (rc == SG_OK && hipStreamSynchronize(stream) != hipSuccess) {
         set_error("stream sync failed in sg_graph_create_rect");
         rc = SG_ERR_HIP;
@@ -267,7 +287,7 @@ SG_API int sg_graph_create_rows(const int64_t* dst_pos, const int64_t* src, int6
       rc = SG_ERR_HIP;
     }
     if (rc == SG_OK) rc = pack_source_scale(&g->fwd, g->dis_src, stream);
-    if (rc == SG_OK && ring_enabled()) rc = build_ring_records(&g->fwd, g->dis_src, g->dis_dst, g->row_id, stream);
+    if (rc == SG_OK && ring_enabled()) g->fwd.defer_records(g->dis_src, g->dis_dst, g->row_id);
     if (rc == SG_OK && hipStreamSynchronize(stream) != hipSuccess) {
       set_error("stream sync failed in sg_graph_create_rows");
       rc = SG_ERR_HIP;

@@ -58,6 +58,19 @@ struct Csr {
   int32_t lt_nrec = 0;
   const float* rec_scale_dst = nullptr;
   const int32_t* rec_row_id = nullptr;
+  // the records are built by the FIRST aggregation that can use them (bf16 rows of 128 / 256 channels): a graph that only
+  // ever sees float32 features or narrow rows -- fp32 runs, the coarse levels of the MGCN -- never pays for them
+  // (896 bytes per 16 rows, a scan and two stream syncs).  rec_pending: what to build them for, set at graph creation.
+  bool rec_pending = false;
+  const float* pend_scale_src = nullptr;
+  const float* pend_scale_dst = nullptr;
+  const int32_t* pend_row_id = nullptr;
+  void defer_records(const float* ss, const float* sd, const int32_t* rid) {
+    rec_pending = true;
+    pend_scale_src = ss;
+    pend_scale_dst = sd;
+    pend_row_id = rid;
+  }
   const float* packed_scale = nullptr;
   void release();
 };
@@ -133,6 +146,7 @@ int launch_thin_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
 // Tile records for spmm_ring (when enabled): rows scaled by scale_dst (nullable), sources by scale_src, output rows row_id (nullable).
 int build_ring_records(Csr* c, const float* scale_src, const float* scale_dst, const int32_t* row_id, hipStream_t stream);
 bool ring_enabled();
+bool ring_f32_enabled();
 
 // Builds a Csr from (dst, src) int64 device pairs. Pairs with dst == src are dropped when
 // drop_self. If keys_out != nullptr the sorted (dst << 32 | src) keys (n entries, dropped

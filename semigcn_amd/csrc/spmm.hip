@@ -38,7 +38,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum : int { kFlagXcdMap = 1, kFlagNoTiles = 2, kFlagNoPackedScale = 4, kFlagBlockBarrier = 8, kFlagWideAddr = 16, kFlagNoExact = 32,
-             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512, kFlagNoRing = 2048, kFlagRingDirectStores = 4096 };
+             kFlagStreamEpilogue = 64, kFlagLdsTiles = 128, kFlagNoQuad = 256, kFlagThreadRows = 512, kFlagNoRing = 2048, kFlagRingDirectStores = 4096,
+             kFlagNoRingF32 = 8192 };
 
 // Every wavefront stages ITS OWN chunk in its own LDS slice, so nothing crosses wavefronts: LDS operations of
 // one wavefront complete in issue order, and a compiler-level wave barrier keeps the reads behind the writes.
@@ -1202,6 +1203,324 @@ int launch_ring(const SpmmArgs& a, hipStream_t stream) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// spmm_ring_f32: the same pipeline for FLOAT32 rows of 128 / 256 channels -- the reference's own precision
+// (util/networks.py:40-53 via [3P] ChebConv.propagate; BASELINE configs c2 / c3), where spmm_rows stood at 0.55 of the HBM peak.
+// Producers, records, ring and barriers are those of spmm_ring; what changes is the reduction:
+//   Y_tile^T (16 channels x 16 rows) += X^T (16 channels x 4 slots) * W^T (4 slots x 16 rows) on v_mfma_f32_16x16x4_f32 --
+//   float32 operands, float32 products and sums, no pieces: a lane supplies ONE source value per step (a plain ds_read_b32
+//   of the row as it lies in LDS, no transposing read) and one weight, and ends up with 4 consecutive channels of its row:
+//   the epilogue operands come in and the result goes out as float4.  The nonzero terms of a row are added in ascending
+//   source order, as spmm_rows does; the matrix core's 4-term inner sum rounds differently: equal to a few ulp, tested.
+//   * source rows are 512 B / 1 KB: the 64-byte segments of a row are XOR-swizzled by (slot & 3) -- the four slots of a
+//     step then sit in four different bank groups (ds_read_b32: conflict-free);
+//   * the weights of a tile are ONE float32 matrix [16 rows][4 k-lanes][16 steps] (row pitch 272 B: conflict-free b128 reads),
+//     4.25 KB per stage instead of three bf16 pieces;
+//   * the kernel takes 128 channels (512-byte rows, D = 3 stages of 32 - 48 KB); rows of 256 channels run as their two halves
+//     (launch_ring_f32 below: a 1 KB row leaves room for two stages only);
+//   * finished tiles leave straight from the MFMA layout (16 rows x 64 B per store, two stores per 128-byte line back to back).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRingFARow = 272;                      // bytes of one row of the float32 weight matrix: 4 x 16 floats + 16
+template <int ROWB, int NEPI, int D>
+struct RingLdsF {
+  static constexpr int NREC = 2 * D;
+  static constexpr int kSrc = kRingSlots * ROWB;
+  static constexpr int kA = kLdsRows * kRingFARow;
+  static constexpr int kEpi = kLdsRows * ROWB;
+  static constexpr int kStage = kSrc + kA + NEPI * kEpi;
+  static constexpr int oA = kSrc;
+  static constexpr int oEpi = kSrc + kA;
+  static constexpr int oRec = D * kStage;
+  static constexpr int total = oRec + NREC * kRecBytes;
+};
+
+template <int NBW, int NEPI, int D, int BPW>
+__global__ __launch_bounds__(64 * (4 * NBW / BPW) + 256) void spmm_ring_f32(const SpmmArgs a, const int nt) {
+  constexpr int CW = 4 * NBW / BPW;                 // consumer wavefronts: each owns BPW 16-channel blocks
+  constexpr int PW = 4;
+  constexpr int C = 64 * NBW;
+  constexpr int ROWB = 4 * C;
+  constexpr int G = ROWB / 16;
+  constexpr int RPW = 64 / G;
+  constexpr int SRC_MAX = (kRingSlots / RPW + PW - 1) / PW;
+  constexpr int EPI_PER_WAVE = kLdsRows / RPW / PW;
+  constexpr int FIXED = NEPI * EPI_PER_WAVE + 1;
+  static_assert(NBW == 2 || NBW == 4, "128 or 256 channels");
+  static_assert(EPI_PER_WAVE * RPW * PW == kLdsRows, "equal shares");
+  static_assert((D - 2) * (SRC_MAX + FIXED) <= 32 && D >= 2 && D <= 5, "vmcnt switch range");
+  using L = RingLdsF<ROWB, NEPI, D>;
+  static_assert(L::total <= 160 * 1024, "LDS budget");
+
+  __shared__ __attribute__((aligned(16))) uint8_t smem[L::total];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int nx = ((int)gridDim.x - xcd + 7) >> 3;
+  const int q = nt >> 3, rem = nt & 7;
+  const int tile_lo = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int tile_cnt = q + (xcd < rem ? 1 : 0);
+  const int n_my = jb < tile_cnt ? (tile_cnt - jb + nx - 1) / nx : 0;
+  if (n_my == 0) return;
+  const int t_first = tile_lo + jb;
+
+  const float* __restrict__ X = (const float*)a.X;
+
+  // weights and source slots start as zeros (only the nonzero weights are ever written and taken back)
+  for (int o = tid * 16; o < D * L::kStage; o += (CW + PW) * 64 * 16) *(u32x4*)(smem + o) = u32x4{0u, 0u, 0u, 0u};
+  SG_RING_BARRIER();
+
+  if (wave >= CW) {
+    // =============================== producers: DMA + weight matrices, D - 1 tiles ahead ===============================
+    const int pw = wave - CW, ptid = tid - CW * 64;
+    __builtin_amdgcn_s_setprio(3);
+    const int g = lane / G, gl = lane % G;
+    const float* __restrict__ X0 = (const float*)a.X0;
+    const float* __restrict__ X1 = (const float*)a.X1;
+    auto tile_of = [&](int k) { return t_first + (k < n_my ? k : n_my - 1) * nx; };
+    auto issue_meta = [&](int tile, int slot) {
+      constexpr int LPW = kRecBytes / 16 / PW;
+      if (lane < LPW)
+        ring_dma16(a.lt_rec + (int64_t)tile * kRecBytes + (pw * LPW + lane) * 16, smem + L::oRec + slot * kRecBytes + pw * LPW * 16);
+    };
+    int f_nu, f_src[SRC_MAX], f_erow[EPI_PER_WAVE];
+    auto fetch = [&](int slot) {
+      const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
+      f_nu = *(const int32_t*)(rec + kRecNu);
+#pragma unroll
+      for (int j = 0; j < SRC_MAX; ++j) {
+        const int sl = (pw + PW * j) * RPW + g;
+        f_src[j] = ((const int32_t*)(rec + kRecSrc))[sl < kRingSlots ? sl : kRingSlots - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < EPI_PER_WAVE; ++j) f_erow[j] = ((const int32_t*)(rec + kRecRow))[(pw + PW * j) * RPW + g];
+    };
+    uint32_t a_slots = 0xffffffffu;                 // 6 bits per stage: the slot this thread's weight went to (63: none)
+    auto issue_tile = [&](int slot, int st) -> int {
+      const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
+      uint8_t* stage = smem + st * L::kStage;
+      const int nu = __builtin_amdgcn_readfirstlane(f_nu);
+      const int n_inst = (nu + RPW - 1) / RPW;
+      int issued = 0;
+#pragma unroll
+      for (int j = 0; j < SRC_MAX; ++j) {
+        const int i = pw + PW * j;
+        if (i < n_inst) {                           // wave-uniform
+          const int sl = i * RPW + g;
+          const int chunk = gl ^ ((sl & 3) << 2);   // 64-byte segments XOR-swizzled by the slot
+          ring_dma16(X + (int64_t)f_src[j] * a.ldx + chunk * 4, stage + i * (RPW * ROWB));
+          ++issued;
+        }
+      }
+      if (NEPI >= 1) {
+#pragma unroll
+        for (int j = 0; j < EPI_PER_WAVE; ++j) {
+          const int i = pw + PW * j;
+          const int lr = i * RPW + g;
+          const int chunk = gl ^ (lr & 15);         // 16-byte chunks XOR-swizzled by the row
+          ring_dma16(X0 + (int64_t)f_erow[j] * a.ldx0 + chunk * 4, stage + L::oEpi + i * (RPW * ROWB));
+          if (NEPI >= 2) ring_dma16(X1 + (int64_t)f_erow[j] * a.ldx1 + chunk * 4, stage + L::oEpi + L::kEpi + i * (RPW * ROWB));
+        }
+        issued += NEPI * EPI_PER_WAVE;
+      }
+      // the slots behind the list up to the end of their group of four steps: zeros (a stale row of an earlier tile must not
+      // meet a zero weight as Inf / NaN far from where it came from)
+      int kend = (nu + 15) & ~15;
+      kend = kend > kRingSlots ? kRingSlots : kend;
+      for (int o = n_inst * RPW * ROWB + ptid * 16; o < kend * ROWB; o += PW * 64 * 16) *(u32x4*)(stage + o) = u32x4{0u, 0u, 0u, 0u};
+      // weight matrix: thread (row, u) owns the u-th neighbour of the row
+      const int ar = ptid >> 4, au = ptid & 15;
+      const int deg = rec[kRecDeg + ar];
+      const int sl_new = rec[kRecSlot + ptid] & 63;
+      const float w = ((const float*)(rec + kRecW))[sl_new < kRingSlots ? sl_new : 0];
+      uint8_t* Ab = stage + L::oA + ar * kRingFARow;
+      const int old = (a_slots >> (6 * st)) & 63;
+      if (old != 63) *(float*)(Ab + (old & 3) * 64 + (old >> 2) * 4) = 0.f;
+      int sl = 63;
+      if (au < deg) {
+        sl = sl_new;
+        *(float*)(Ab + (sl & 3) * 64 + (sl >> 2) * 4) = w;
+      }
+      a_slots = (a_slots & ~(63u << (6 * st))) | ((uint32_t)sl << (6 * st));
+      return issued;
+    };
+
+    for (int k = 0; k < 2 * D - 1; ++k) issue_meta(tile_of(k), k);
+    ring_wait_vm<0>();
+    SG_RING_BARRIER();                              // (P0)
+    int inflight[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) inflight[k] = 0;
+    for (int k = 0; k < D - 1; ++k) {
+      fetch(k);
+      (void)issue_tile(k, k);
+    }
+    fetch(D - 1);
+    asm volatile("" ::: "memory");
+    int st = 0, rs = 0;
+    for (int i = 0; i < n_my; ++i) {
+      if (i == 0) {
+        ring_wait_vm<0>();
+      } else {
+        int allowed = 0;
+#pragma unroll
+        for (int k = 0; k < D - 2; ++k) allowed += inflight[k];
+        ring_wait_vm_n(allowed);
+      }
+      SG_RING_BARRIER();                            // tile i is ready for the consumers; they are done with tile i - 1
+      const int st_n = st == 0 ? D - 1 : st - 1;
+      const int rs_n = rs + D - 1 >= L::NREC ? rs + D - 1 - L::NREC : rs + D - 1;
+      const int rs_f = rs + D >= L::NREC ? rs + D - L::NREC : rs + D;
+      const int rs_m = rs == 0 ? L::NREC - 1 : rs - 1;
+      const int cnt = issue_tile(rs_n, st_n) + 1;
+      issue_meta(tile_of(i + 2 * D - 1), rs_m);
+      fetch(rs_f);
+#pragma unroll
+      for (int k = D - 2; k > 0; --k) inflight[k] = inflight[k - 1];
+      if (D > 2) inflight[0] = cnt;
+      asm volatile("" ::: "memory");
+      st = st + 1 == D ? 0 : st + 1;
+      rs = rs + 1 == L::NREC ? 0 : rs + 1;
+    }
+    ring_wait_vm<0>();                              // no LDS-DMA may be in flight when the workgroup ends
+    return;
+  }
+
+  // ================================= consumers: MFMA reduction, epilogue, store =================================
+  float* __restrict__ Y = (float*)a.Y;
+  const int m = lane & 15, fg = lane >> 4;          // MFMA: tile row (B / result column), k lane; the result: channels 4 fg .. + 3
+  int xo[BPW], eo[BPW];
+#pragma unroll
+  for (int nb = 0; nb < BPW; ++nb) {
+    const int blk = wave * BPW + nb;
+    xo[nb] = fg * ROWB + ((((blk * 4 + (m >> 2)) ^ (fg << 2)) << 4) | ((m & 3) << 2));      // channel blk * 16 + m of slot 4 s + fg
+    eo[nb] = m * ROWB + (((blk * 4 + fg) ^ m) << 4);                                        // channels blk * 16 + 4 fg .. of row m
+  }
+  SG_RING_BARRIER();                                // (P0): the first records are there
+  int c_nu, c_nrows, c_row;
+  float c_sd;
+  auto fetch = [&](int slot) {
+    const uint8_t* rec = smem + L::oRec + slot * kRecBytes;
+    c_nu = *(const int32_t*)(rec + kRecNu);
+    c_nrows = *(const int32_t*)(rec + kRecNrows);
+    c_sd = ((const float*)(rec + kRecSd))[m];
+    c_row = ((const int32_t*)(rec + kRecRow))[m];
+  };
+  fetch(0);
+  int st = 0, rs = 0;
+  for (int i = 0; i < n_my; ++i) {
+    SG_RING_BARRIER();
+    const uint8_t* rec = smem + L::oRec + rs * kRecBytes;
+    const uint8_t* stage = smem + st * L::kStage;
+    const int nu = __builtin_amdgcn_readfirstlane(c_nu);
+    const int nrows = __builtin_amdgcn_readfirstlane(c_nrows);
+    const float sd = c_sd;
+    const int row = c_row;
+    // ---- the LDS reads of this iteration, in one batch ----
+    const uint8_t* Ab = stage + L::oA + m * kRingFARow + fg * 64;
+    f32x4 wq[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) wq[qq] = *(const f32x4*)(Ab + qq * 16);       // the weights of steps 4 qq .. 4 qq + 3
+    f32x4 x0v[BPW], x1v[BPW];
+#pragma unroll
+    for (int nb = 0; nb < BPW; ++nb) {
+      x0v[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      x1v[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (NEPI >= 1) x0v[nb] = *(const f32x4*)(stage + L::oEpi + eo[nb]);
+      if (NEPI >= 2) x1v[nb] = *(const f32x4*)(stage + L::oEpi + L::kEpi + eo[nb]);
+    }
+    fetch(rs + 1 == L::NREC ? 0 : rs + 1);          // (past the end: a copy of the last record)
+    float xs[14][BPW];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq)
+      if (nu > 16 * qq) {                           // wave-uniform: a group of four steps (the last group: two)
+#pragma unroll
+        for (int s = 4 * qq; s < 4 * qq + 4 && s < 14; ++s)
+#pragma unroll
+          for (int nb = 0; nb < BPW; ++nb) xs[s][nb] = *(const float*)(stage + 4 * s * ROWB + xo[nb]);
+      }
+    f32x4 acc[BPW];
+#pragma unroll
+    for (int nb = 0; nb < BPW; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nu > 0) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+        if (nu > 16 * qq) {
+#pragma unroll
+          for (int s = 4 * qq; s < 4 * qq + 4 && s < 14; ++s)
+#pragma unroll
+            for (int nb = 0; nb < BPW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[s][nb], wq[qq][s & 3], acc[nb], 0, 0, 0);
+        }
+    } else {          // rare: the tile's sources do not fit; its rows are gathered from global memory (sequential fma chain)
+      const int r0 = *(const int32_t*)(rec + kRecR0);
+      if (m < nrows) {
+        const int gs = a.rowptr[r0 + m], ge = a.rowptr[r0 + m + 1];
+        for (int k = gs; k < ge; ++k) {
+          const int2 e = a.lt_idx_w[k];
+          const float w = __int_as_float(e.y);
+#pragma unroll
+          for (int nb = 0; nb < BPW; ++nb) {
+            const f32x4 xv = *(const f32x4*)(X + (int64_t)e.x * a.ldx + (wave * BPW + nb) * 16 + 4 * fg);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[nb][c] = fmaf(w, xv[c], acc[nb][c]);
+          }
+        }
+      }
+    }
+    const float sdst = a.alpha * sd;
+#pragma unroll
+    for (int nb = 0; nb < BPW; ++nb) {
+      f32x4 y;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float t = sdst * acc[nb][c];
+        if (NEPI >= 1) t = fmaf(a.beta, x0v[nb][c], t);
+        if (NEPI >= 2) t = fmaf(a.gamma, x1v[nb][c], t);
+        y[c] = t;
+      }
+      if (m < nrows) *(f32x4*)(Y + (int64_t)row * a.ldy + (wave * BPW + nb) * 16 + 4 * fg) = y;
+    }
+    st = st + 1 == D ? 0 : st + 1;
+    rs = rs + 1 == L::NREC ? 0 : rs + 1;
+  }
+}
+
+template <int NBW, int NEPI, int D, int BPW>
+int launch_ring_f32_k(const SpmmArgs& b, hipStream_t stream) {
+  constexpr int lds = RingLdsF<256 * NBW, NEPI, D>::total;
+  int per_cu = (160 * 1024) / lds;
+  per_cu = per_cu > 2 ? 2 : per_cu;
+  int64_t nb = (int64_t)per_cu * 256;
+  if (nb > b.lt_nrec) nb = b.lt_nrec;
+  nb = (nb + 7) / 8 * 8;
+  spmm_ring_f32<NBW, NEPI, D, BPW><<<(int)nb, 64 * (4 * NBW / BPW) + 256, 0, stream>>>(b, b.lt_nrec);
+  SG_HIP_TRY(hipGetLastError());
+  return SG_OK;
+}
+
+// 128 channels: one launch.  256 channels: the two 128-channel halves of the rows, one launch each -- a 1 KB row leaves room
+// for only two ring stages (one tile in flight: 0.59 of the peak, measured), two passes over 512-byte half rows at three
+// stages reach 0.65 (tools/ring_f32_probe.py, profiles/r05_ring_f32_probe.txt) although the tile records are read twice.
+// false: the shape stays with the other kernels (plain 256-channel rows: the shared-gather kernel is level with two passes).
+bool launch_ring_f32(const SpmmArgs& a, hipStream_t stream, int* rc) {
+  SpmmArgs b = a;
+  if (!a.X0 && a.X1) { b.X0 = a.X1; b.ldx0 = a.ldx1; b.beta = a.gamma; b.X1 = nullptr; b.ldx1 = 0; b.gamma = 0.f; }
+  const int nepi = (b.X0 ? 1 : 0) + (b.X1 ? 1 : 0);
+  if (a.C == 256 && nepi == 0) return false;
+  const int halves = a.C / 128;
+  b.C = 128;
+  for (int h = 0; h < halves; ++h) {
+    *rc = nepi == 2 ? launch_ring_f32_k<2, 2, 3, 2>(b, stream) : nepi == 1 ? launch_ring_f32_k<2, 1, 3, 2>(b, stream) : launch_ring_f32_k<2, 0, 3, 2>(b, stream);
+    if (*rc != SG_OK) return true;
+    b.X = (const float*)b.X + 128;
+    b.Y = (float*)b.Y + 128;
+    if (b.X0) b.X0 = (const float*)b.X0 + 128;
+    if (b.X1) b.X1 = (const float*)b.X1 + 128;
+  }
+  return true;
+}
+
 // Any C, any stride, any alignment: one thread per output element, lanes along the channel.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spmm_scalar(const SpmmArgs a) {
@@ -1526,6 +1845,10 @@ int launch_typed_one(const SpmmArgs& a, hipStream_t stream) {
     if (a.C == 128) return launch_ring<2>(a, stream);
     if (a.C == 256) return launch_ring<4>(a, stream);
   }
+  if (!(g_tuning.flags & (kFlagNoRing | kFlagNoRingF32)) && esz == 4 && a.lt_rec && a.lt_nrec > 0 && a.n_cols < ((int64_t)1 << 31)) {
+    int rc = SG_OK;
+    if ((a.C == 128 || a.C == 256) && launch_ring_f32(a, stream, &rc)) return rc;
+  }
   if ((g_tuning.flags & kFlagLdsTiles) && a.lt_uptr && a.ldx % VEC == 0 && a.n_cols < ((int64_t)1 << 31)) {
     if (nvec == 16) return launch_lds<T, 16>(a, stream);
     if (nvec == 32) return launch_lds<T, 32>(a, stream);
@@ -1574,6 +1897,7 @@ int launch_typed(const SpmmArgs& a, hipStream_t stream) {
 bool tiles_enabled() { return g_tuning.tiled_min_row_bytes != 0; }
 bool lds_tiles_enabled() { return (g_tuning.flags & kFlagLdsTiles) != 0; }
 bool ring_enabled() { return (g_tuning.flags & kFlagNoRing) == 0; }
+bool ring_f32_enabled() { return (g_tuning.flags & (kFlagNoRing | kFlagNoRingF32)) == 0; }
 
 int set_tuning(int knob, int value) {
   switch (knob) {

@@ -1682,6 +1682,103 @@ def test_ring_kernel_tiles_that_do_not_fit_gather_from_global_memory():
         assert torch.equal(r, q)
 
 
+NO_RING_F32 = 8192     # SG_TUNE_FLAGS bit 13: float32 rows stay on spmm_rows
+
+
+def _f32_ring_and_rows(calls):
+    out = {}
+    for flags in (1 | NO_RING_F32, 1):
+        capi.tuning_set(capi.TUNE_FLAGS, flags)
+        try:
+            out[flags] = [f() for f in calls]
+        finally:
+            capi.tuning_set(capi.TUNE_FLAGS, 1)
+    return out[1 | NO_RING_F32], out[1]
+
+
+@pytest.mark.parametrize("C", [128, 256])
+def test_f32_ring_kernel_equals_the_rows_kernel_bit_for_bit(C):
+    """spmm_ring_f32 (float32 rows of 128 channels, rows of 256 as their two halves -- the reference's own precision;
+    SG_TUNE_FLAGS bit 13 switches it off): the tile pipeline of spmm_ring with float32 operands on v_mfma_f32_16x16x4_f32.
+    The matrix core adds the products of a step in slot order into its float32 accumulator, the slots of a tile are its
+    sources in ascending order and an unused slot contributes weight 0: the sum of every row is spmm_rows' fma chain over
+    the neighbours in ascending id -- the SAME BITS (and so the same distance from the float64 oracle).  Morton-ordered mesh
+    and the locality view of a randomly numbered one, every epilogue arity, column blocks of a wider buffer.  (That the tiled
+    kernel is what runs: tools/ring_f32_probe.py times the two, profiles/r05_ring_f32_probe.txt.)"""
+    from semigcn_amd import reorder
+    for permute in (False, True):
+        m = synth.torus_mesh(320, 250, permute=permute, masks=False)
+        V = m.num_vertices
+        ei = torch.from_numpy(m.edge_index).to(DEV)
+        if not permute:
+            ei = reorder.permute_edge_index(ei, reorder.morton_order(torch.from_numpy(m.x_pos).to(DEV))[1])
+        g = _ring_graph(ei, V)
+        gen = torch.Generator(device=DEV).manual_seed(C)
+        wide = torch.randn(V, 3 * C, device=DEV, generator=gen)
+        x, x0, x1 = wide[:, :C], wide[:, C:2 * C], wide[:, 2 * C:]
+        outw = torch.zeros((V, C + 8), device=DEV)
+        calls = [lambda: g.spmm(x, torch.empty((V, C), device=DEV)),
+                 lambda: g.spmm(x, torch.empty((V, C), device=DEV), alpha=2.0, X0=x0, beta=-1.0),
+                 lambda: g.spmm(x, torch.empty((V, C), device=DEV), alpha=1.0, X0=x0, beta=1.0, X1=x1, gamma=-1.0),
+                 lambda: g.spmm(x, outw[:, 4:4 + C], alpha=2.0, X0=x0, beta=-1.0).clone()]
+        rows, ring = _f32_ring_and_rows(calls)
+        assert torch.all(outw[:, :4] == 0) and torch.all(outw[:, 4 + C:] == 0)
+        for a, b in zip(rows, ring):
+            assert torch.equal(a, b)
+        assert rel(ring[0], oracle_lhat(ei.cpu(), x.cpu())) < 1e-6
+
+
+@pytest.mark.parametrize("C", [128, 256])
+def test_f32_ring_kernel_on_nasty_tiny_and_random_graphs(C):
+    """The float32 tile kernel where the bf16 one is tortured: a hub row, repeated edges, self loops, isolated vertices, no
+    symmetry (both directions); vertex counts around the tile and workgroup boundaries, random graphs from half an edge to
+    eight per vertex (records that fit and records that do not), every epilogue arity: the bits of spmm_rows."""
+    rs = np.random.RandomState(1)
+    graphs = [(nasty_graph().to(DEV), 500)]
+    for V in (1, 2, 15, 16, 17, 33, 100, 257, 1000, 4099):
+        for density in (0.5, 3, 8):
+            graphs.append((torch.from_numpy(rs.randint(0, V, size=(2, max(1, int(V * density))))).long().to(DEV), V))
+    checked = 0
+    try:
+        for ei, V in graphs:
+            g = capi.GraphHandle.from_edge_index(ei, V)
+            x, x0, x1 = (torch.randn(V, C, device=DEV) for _ in range(3))
+            for kw in ({}, {"alpha": 2.0, "X0": x0, "beta": -1.0}, {"alpha": 1.0, "X0": x0, "beta": 1.0, "X1": x1, "gamma": -1.0},
+                       {"transpose": True}, {"transpose": True, "alpha": 2.0, "X0": x0, "beta": -1.0}):
+                outs = []
+                for flags in (1 | NO_RING_F32, 1):
+                    capi.tuning_set(capi.TUNE_FLAGS, flags)
+                    outs.append(g.spmm(x, torch.full((V, C), 7.0, device=DEV), **kw))
+                assert torch.equal(outs[1], outs[0]), (V, C, list(kw), float((outs[1] - outs[0]).abs().max()))
+                checked += 1
+    finally:
+        capi.tuning_set(capi.TUNE_FLAGS, 1)
+    assert checked == 155
+
+
+def test_f32_ring_kernel_tiles_that_do_not_fit_gather_from_global_memory():
+    """No tile of a graph without locality fits: every record says so and the in-loop fallback of spmm_ring_f32 sums the rows
+    from global memory with the sequential fma chain of spmm_rows: identical bits."""
+    V, C = 5000, 256
+    gen = torch.Generator().manual_seed(7)
+    a = torch.randint(0, V, (50000,), generator=gen)
+    b = torch.randint(0, V, (50000,), generator=gen)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])]).to(DEV)
+    capi.tuning_set(capi.TUNE_GRAPH_REORDER, 1)
+    try:
+        g = _ring_graph(ei, V)
+    finally:
+        capi.tuning_set(capi.TUNE_GRAPH_REORDER, 0)
+    x, x0 = torch.randn(V, C, device=DEV), torch.randn(V, C, device=DEV)
+    calls = [lambda: g.spmm(x, torch.empty((V, C), device=DEV)),
+             lambda: g.spmm(x, torch.empty((V, C), device=DEV), alpha=2.0, X0=x0, beta=-1.0)]
+    rows, ring = _f32_ring_and_rows(calls)
+    for r, q in zip(rows, ring):
+        assert torch.equal(r, q)
+
+
 # --------------------------------------------------------------------------------------
 # documented deviations from the reference's arithmetic (include/semigcn.h), one test each
 # --------------------------------------------------------------------------------------
