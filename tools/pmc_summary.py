@@ -44,6 +44,10 @@ def main():
             if ring:
                 agg[("ring", "bfloat16", 8 * int(ring.group(1)), 1, int(ring.group(2)))].append(float(r["Counter_Value"]))
                 continue
+            rf = re.search(r"spmm_ring_f32<(\d+), (\d+), (\d+), (\d+)>", r["Kernel_Name"])  # <channels / 64, epilogue operands, ring depth, blocks per wavefront>
+            if rf:
+                agg[("ring_f32", "float32", 16 * int(rf.group(1)), 1, int(rf.group(2)))].append(float(r["Counter_Value"]))
+                continue
             m = re.search(r"spmm_(rows|shared)<(.+?), (\d+), (\d+), (\d+)(?:, (?:true|false))?(?:, \d+)?>", r["Kernel_Name"])
             if not m:
                 continue
@@ -59,6 +63,15 @@ def main():
                     "launches": len(per["FETCH_SIZE"][key]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                     "read_bytes_corrected": round(2 * f * 1024), "write_bytes": round(w * 1024),
                     "traffic_bytes_per_launch": round(2 * f * 1024 + w * 1024)})
+    # float32 rows of 256 channels with epilogue operands run as TWO launches of the 128-channel kernel (csrc/spmm.hip,
+    # launch_ring_f32): one sg_spmm call = twice that kernel's per-launch traffic
+    for k in list(res):
+        if k["kernel"] == "spmm_ring_f32" and k["lanes_per_row"] == 32 and k["epilogue_operands"] >= 1:
+            d = dict(k)
+            d.update({"kernel": "spmm_ring_f32 x 2 (128-channel halves)", "lanes_per_row": 64, "derived": "2 x the 128-channel launch",
+                      "read_bytes_corrected": 2 * k["read_bytes_corrected"], "write_bytes": 2 * k["write_bytes"],
+                      "traffic_bytes_per_launch": 2 * k["traffic_bytes_per_launch"]})
+            res.append(d)
     json.dump({"command": cmd, "commit": commit, "spmm_hip_sha16": sha, "correction": "reads = 2 * FETCH_SIZE * 1024 (gfx950 wide-read under-count), writes = WRITE_SIZE * 1024",
                "kernels": res}, open(out, "w"), indent=1)
     print("wrote", out, len(res), "kernel variants")
