@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 #include "semigcn.h"
@@ -314,7 +315,7 @@ int launch_mesh_loss_bwd_vertex_add(const float* pos, const float* tpos, const f
                                     float* grad, hipStream_t stream);
 
 // trace.hip -- optional per-launch event timing (sg_trace_*)
-extern bool g_trace_on;
+extern std::atomic<bool> g_trace_on;
 void trace_open(int kind, int dtype, int engine, int64_t a, int64_t b, int64_t c, hipStream_t stream, int64_t* slot);
 void trace_close(int64_t slot, hipStream_t stream);
 struct TraceScope {

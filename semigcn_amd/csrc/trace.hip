@@ -5,11 +5,13 @@
 #include <mutex>
 #include <vector>
 
+#include <atomic>
+
 #include "sg_common.h"
 
 namespace sg {
 
-bool g_trace_on = false;
+std::atomic<bool> g_trace_on{false};      // read on the autograd thread, written on the caller's
 
 namespace {
 struct Rec {

@@ -1041,15 +1041,17 @@ class BlockPlan:
         conv.__dict__.setdefault("_block_plans_of", []).append(weakref.ref(self))    # (ChebConv.invalidate_weight_cache finds us)
 
     def fingerprint(self):
-        """Identity and address of the first weight and of the BatchNorm weight: when they are what they were, the cached
-        references to all parameter tensors (and every address derived from them) are taken to be current.  (``.to()``,
-        ``load_state_dict`` and optimiser steps keep the Parameter objects; a module whose parameter OBJECT is replaced by
-        hand also gets new first-weight / BatchNorm-weight objects in every case the reference or these tests produce.)"""
-        w0 = self.conv.lins[0]._parameters["weight"]
-        g = self.bn._parameters["weight"]
-        mark = (id(w0), w0.data_ptr(), id(g), g.data_ptr(), self.bn._buffers["running_mean"] is None)
+        """Identity and address of every tensor the descriptors point at -- the K weights, the conv bias, the BatchNorm's
+        weight / bias / running statistics / batch counter -- and the BatchNorm's momentum and eps: when they are what they
+        were, the cached references (and every address derived from them) are current.  (``.to()``, ``load_state_dict`` and
+        optimiser steps keep the objects; replacing ANY of them by hand, or changing ``bn.momentum`` / ``bn.eps``, moves the
+        mark and the descriptors are bound again -- as the per-module path, which re-reads the module on every call.)"""
+        conv, bn = self.conv, self.bn
+        bp, bb = bn._parameters, bn._buffers
+        parts = [lin._parameters["weight"] for lin in conv.lins]
+        parts += [conv._parameters.get("bias"), bp["weight"], bp["bias"], bb["running_mean"], bb["running_var"], bb.get("num_batches_tracked")]
+        mark = tuple((id(t), t.data_ptr()) if t is not None else None for t in parts) + (bn.momentum, bn.eps)
         if mark != self._mark:
-            conv, bn = self.conv, self.bn
             self.weights = [lin.weight for lin in conv.lins]
             self.cbias, self.gamma, self.beta = conv.bias, bn.weight, bn.bias
             self.rm, self.rv, self.nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked

@@ -84,6 +84,14 @@ class ChebConv(nn.Module):
         self.invalidate_weight_cache()
         return super()._load_from_state_dict(*args, **kwargs)
 
+    def __getstate__(self):
+        """Pickling / ``copy.deepcopy`` / ``torch.save(model)``: the caches of the block calls (weak references to plans,
+        packed weight copies on the device) belong to THIS object and are rebuilt on the copy's first call."""
+        state = dict(self.__dict__)
+        state.pop("_weight_cache", None)
+        state.pop("_block_plans_of", None)
+        return state
+
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_weight_cache()
         return super()._apply(fn, *args, **kwargs)
@@ -196,6 +204,13 @@ class Sequential(nn.Module):
             if isinstance(prv, ChebConv) and prv.out_channels == bn.num_features and self._plan[i - 1][2] == in0:
                 grad_widen = prv.grad_buffer_blocks()
         return slope, widen, grad_widen
+
+    def __getstate__(self):
+        """(see ChebConv.__getstate__: block plans and the leading-block look-up are per-object caches)"""
+        state = dict(self.__dict__)
+        state.pop("_block_plans", None)
+        state.pop("_lead", None)
+        return state
 
     def _block_at(self, i: int):
         """(BlockPlan, index of its activation entry, widen) when entries i.. read ChebConv [-> MeshPool | MeshUnpool] ->

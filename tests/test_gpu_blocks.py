@@ -393,3 +393,70 @@ def test_launch_trace_sees_the_kernels_of_a_block():
     assert all(t["ms"] > 0 for t in recs)
     fwd = [t for t in recs if t["kind"] == "nt"][0]
     assert (fwd["a"], fwd["b"], fwd["c"]) == (m.num_vertices, 128, 192)
+
+
+def test_block_plan_follows_replaced_buffers_and_changed_hyperparameters_and_the_model_pickles():
+    """the descriptors of a block are bound once and re-bound when the plan's fingerprint moves.  The fingerprint
+    covers every tensor the descriptors point at and the BatchNorm's momentum / eps: replacing ``bn.running_mean`` by a new
+    tensor, or changing ``bn.momentum``, after the first call is seen by the next one (the per-module path re-reads the module
+    on every call; the two must agree).  And a model that has run (plans cached on its modules, weak references, packed
+    weights on the device) can be pickled and deep-copied: the copy rebuilds its caches and computes the same."""
+    import copy
+    import pickle
+    m = synth.torus_mesh(40, 30)
+    g = MeshGraph.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), m.num_vertices)
+    seq = _block_module(16, 32)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(m.num_vertices, 16, generator=gen).to(DEV)
+    r = torch.randn(m.num_vertices, 32, generator=gen).to(DEV)
+    _run(seq, g, x, r)                                       # plans and descriptors exist now
+    bn = seq[1]
+    old_mean = bn.running_mean
+    bn.running_mean = torch.zeros_like(old_mean)             # a NEW tensor object
+    bn.momentum = 0.5
+    kept = old_mean.clone()
+    var_before = bn.running_var.clone()
+    _run(seq, g, x, r)
+    assert torch.equal(old_mean, kept)                       # the replaced tensor is no longer written ...
+    # ... the new one is, with the new momentum -- what the per-module path computes from the same state
+    ref_seq = _block_module(16, 32)
+    ref_seq.load_state_dict(seq.state_dict())
+    ref_seq[1].running_mean.zero_()
+    ref_seq[1].running_var.copy_(var_before)
+    ref_seq[1].momentum = 0.5
+    old = F_sg.USE_BLOCK_CALLS
+    F_sg.USE_BLOCK_CALLS = False
+    try:
+        _run(ref_seq, g, x, r)
+    finally:
+        F_sg.USE_BLOCK_CALLS = old
+    assert float(bn.running_mean.abs().max()) > 0
+    assert float((bn.running_mean - ref_seq[1].running_mean).abs().max()) < 1e-6
+    assert float((bn.running_var - ref_seq[1].running_var).abs().max()) < 1e-6
+    # pickling and deep copies after a forward
+    blob = pickle.dumps(seq)
+    for clone in (pickle.loads(blob), copy.deepcopy(seq)):
+        assert "_block_plans" not in clone.__dict__ and "_block_plans_of" not in clone[0].__dict__
+        clone.load_state_dict(seq.state_dict())
+        a, b = _run(clone, g, x, r), _run(seq, g, x, r)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second device")
+def test_block_calls_on_a_device_that_is_not_the_current_one():
+    """a model whose tensors live on cuda:1 while cuda:0 is the process's current device -- the block
+    calls take the device of their tensors (capi._on_device around sg_block_chain_* / sg_block_run), as every per-operator
+    wrapper does; the results equal those of the same block on cuda:0."""
+    m = synth.torus_mesh(40, 30)
+    ei = torch.from_numpy(m.edge_index)
+    outs = []
+    for dev in ("cuda:0", "cuda:1"):
+        torch.cuda.set_device(0)
+        g = MeshGraph.from_edge_index(ei.to(dev), m.num_vertices)
+        seq = _block_module(16, 32).to(dev)
+        gen = torch.Generator().manual_seed(5)
+        x = torch.randn(m.num_vertices, 16, generator=gen).to(dev)
+        r = torch.randn(m.num_vertices, 32, generator=gen).to(dev)
+        outs.append([t.cpu() for t in _run(seq, g, x, r)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
