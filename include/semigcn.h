@@ -667,7 +667,8 @@ enum sg_tune_knob {
   SG_TUNE_F32_ENGINE = 8   /* dense products on float32 features: 0 (default) = the split-bf16 MFMA kernels (csrc/gemm_split.hip)
                               wherever they take the shape, the BLAS library for the rest; bit 0 = the BLAS library for all of
                               them (A/B switch); bits 1 / 2 / 3 = only the forward / input-gradient / weight-gradient products go to the
-                              library (bisecting aid) */
+                              library (bisecting aid); bit 4 = the split kernels also below 16 K rows, where the library is
+                              faster on the forward / input-gradient products (A/B switch) */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

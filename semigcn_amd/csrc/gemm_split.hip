@@ -637,6 +637,7 @@ int set_split_tuning(int value) {
   g_split_variant = value;
   return SG_OK;
 }
+bool split_nt_pays(int64_t M) { return M >= kSplitNtPaysRows || (g_split_variant & 16); }      // bit 4: no row threshold (A/B)
 bool split_engine_enabled(int kind) { return !(g_split_variant & 1) && !(g_split_variant & (2 << kind)); }      // kind 0 nt, 1 nn, 2 tn
 
 static inline int split_nf(int64_t N) { return N % 256 == 0 || N > 640 ? 16 : (N % 128 == 0 || N <= 128 ? 8 : 16); }
