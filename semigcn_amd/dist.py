@@ -298,6 +298,9 @@ class DistMeshGraph(_RowExchange):
     L^ on the owned AND ring-1 rows (Tx1 recomputed redundantly on ring 1 -- a few per cent of the rows), ``handle``
     on the owned rows only (Tx2).  Ring-2 rows carry no edges in ``handle_wide`` (their output rows are not used)."""
     sg_partitioned = True
+    #: True: a Sequential that meets this graph runs its runs of plain blocks phase by phase below the C ABI (part_blocks;
+    #: set by partition_mgcn -- the SGCN's trainer calls part_chain itself)
+    phases = False
 
     def __init__(self, edge_index: torch.Tensor, num_vertices: int, rank: int, world: int,
                  group=None, bounds: Optional[Sequence[int]] = None):
@@ -502,6 +505,7 @@ class FoldedLayout:
         dev, W, rank, n = g.device, g.world, g.rank, g.n_own
         self.graph, self.world, self.rank, self.group, self.n_own = g, W, rank, g.group, n
         self._comm = None
+        self._send_rows = self._send_pad = None
         V = g.num_vertices_global
         ext_of = torch.full((V,), -1, dtype=torch.long, device=dev)
         ext_of[g.start:g.end] = torch.arange(n, device=dev)
@@ -588,7 +592,26 @@ class FoldedLayout:
         """One all-to-all: ``send`` [n_send, C] (peer segments with their pad rows) -> ``recv`` = rows [n_own:] of a buffer."""
         if _solo(self.world):
             return
+        comm = self.native_comm() if (send.is_cuda and send.is_contiguous() and recv.is_contiguous()) else None
+        if comm is not None:
+            collective_counts["all_to_all"] += 1
+            comm.halo_exchange(recv, send)
+            return
         _all_to_all_rows(recv, send, self.recv_splits, self.send_splits, self.group)
+
+    def halo_rows(self, x_own: torch.Tensor) -> torch.Tensor:
+        """Rows ``[n_own:]`` of the folded buffer of a tensor this rank holds the owned rows of: ONE exchange (the rows the
+        peers need, packed with zero pad rows).  No gradient flows through it (see part_blocks)."""
+        with torch.no_grad():
+            if self._send_rows is None:
+                idx = self.send_index.long()
+                self._send_rows, self._send_pad = idx.clamp(min=0), (idx < 0)
+            send = x_own.detach().index_select(0, self._send_rows) if self.n_send else x_own.new_zeros((0, x_own.shape[1]))
+            if self.n_send:
+                send[self._send_pad] = 0
+            recv = x_own.new_zeros((self.n_ext - self.n_own, x_own.shape[1]))
+            self.exchange(recv, send)
+        return recv
 
 
 class PartChain:
@@ -966,23 +989,36 @@ class _PartChainFn(torch.autograd.Function):
 
 
 def part_chain(sequentials, graph: "DistMeshGraph", x_own: torch.Tensor, x_halo: torch.Tensor):
-    """Blocks that START every Sequential of ``sequentials`` (each [ChebConv, BatchNorm1d, LeakyReLU (, ...)]) on this rank's
-    rows, phase by phase below the C ABI; returns (activation of the last block on the owned rows, index of the first entry
-    of the last Sequential that was NOT run), or None when the run cannot take this path (then the caller's per-module path
-    does)."""
+    """Blocks that START every Sequential of ``sequentials`` (each [ChebConv, BatchNorm1d, LeakyReLU (, ...)] one or more
+    times) on this rank's rows, phase by phase below the C ABI; returns (activation of the last block on the owned rows, index
+    of the first entry of the last Sequential that was NOT run), or None when the run cannot take this path (then the caller's
+    per-module path does)."""
     from . import functional as F_sg
     if not (x_own.is_cuda and F_sg.blocks_enabled() and dist.is_initialized()):
         return None
     plans = []
     sequentials = list(sequentials)
+    tail = 0
     for k, seq in enumerate(sequentials):
         lead = seq._leading_blocks() if hasattr(seq, "_leading_blocks") else None
-        if lead is None or len(lead[0]) != 1:
+        if lead is None or not lead[0]:
             return None
         if k + 1 < len(sequentials) and lead[1] != len(seq):
-            return None              # modules behind the block of an INNER Sequential (a Dropout, a second conv) would be skipped
-        plans.append(lead[0][0])
+            return None              # modules behind the blocks of an INNER Sequential (a Dropout, a pooled conv) would be skipped
+        plans.extend(lead[0])
         tail = lead[1]
+    y = part_blocks(plans, graph, x_own, x_halo)
+    return None if y is None else (y, tail)
+
+
+def part_blocks(plans, graph: "DistMeshGraph", x_own: torch.Tensor, x_halo: Optional[torch.Tensor] = None):
+    """A run of consecutive [ChebConv -> BatchNorm1d -> LeakyReLU] blocks (functional.BlockPlan, no pool between conv and
+    BatchNorm) on one partitioned graph, phase by phase below the C ABI (``PartChain``); ``x_halo``: the halo rows of the input
+    in the folded numbering, fetched with ONE exchange when the caller has none (forward-only copies: the backward pass is
+    owner-computes on exchanged gradient rows).  None when the run cannot take this path."""
+    from . import functional as F_sg
+    if not (x_own.is_cuda and F_sg.blocks_enabled() and dist.is_initialized()) or not plans:
+        return None
     cin = x_own.shape[1]
     for p in plans:
         p.fingerprint()
@@ -994,6 +1030,10 @@ def part_chain(sequentials, graph: "DistMeshGraph", x_own: torch.Tensor, x_halo:
             return None
         cin = p.Cout
     lay = graph.folded()
+    if x_own.shape[0] != lay.n_own:
+        return None
+    if x_halo is None:
+        x_halo = lay.halo_rows(x_own)
     key = tuple(id(p) for p in plans)
     pc = graph.__dict__.setdefault("_part_chains", {}).get(key)
     if pc is None:
@@ -1001,7 +1041,7 @@ def part_chain(sequentials, graph: "DistMeshGraph", x_own: torch.Tensor, x_halo:
     params = []
     for p in plans:
         params.extend(p.param_tuple)
-    return _PartChainFn.apply(pc, x_own, x_halo, *params), tail
+    return _PartChainFn.apply(pc, x_own, x_halo, *params)
 
 
 # --------------------------------------------------------------------------------------
@@ -1503,12 +1543,16 @@ class MGCNPartition:
     group: object = None
 
 
-def partition_mgcn(model: nn.Module, rank: int, world: int, group=None) -> MGCNPartition:
+def partition_mgcn(model: nn.Module, rank: int, world: int, group=None, phases: bool = True) -> MGCNPartition:
     """Switch ``model`` (semigcn_amd.meshnet.MGCN, already on its device) to run on rank ``rank``'s share
     of every level, in place.  Level 0 is cut into balanced blocks along the Morton curve of its smooth
     positions; a coarse vertex goes to the owner of its first member (in processing order) and the
     coarse level is numbered by that member, so blocks stay contiguous and local at every level.
-    Parameters stay replicated; BatchNorm statistics become mesh-wide."""
+    Parameters stay replicated; BatchNorm statistics become mesh-wide.  ``phases`` (default): the runs of plain [ChebConv ->
+    BatchNorm -> LeakyReLU] blocks of every stage -- 4 of the 5 blocks of a DownConv, 4 of 5 of an UpConv, the block of each
+    head: 25 of the 33 -- go phase by phase below the C ABI (part_blocks) in train mode, one exchange for the run's input and
+    one per block inside it with the BatchNorm statistics in its pad rows; the blocks with a pool between conv and BatchNorm
+    (the rows change owner there: DistPool) stay module by module."""
     dev = model.smposs_list[0].device
     n_levels = len(model.smposs_list)
     order, rank_of = _reorder.morton_order(model.smposs_list[0])
@@ -1534,6 +1578,8 @@ def partition_mgcn(model: nn.Module, rank: int, world: int, group=None) -> MGCNP
                             model.smposs_list[l].shape[0], rank, world, group, bounds=bounds[l])
               for l in range(n_levels)]
     pools = [DistPool(f, c, bounds[l], bounds[l + 1], rank, world, group) for l, (f, c) in enumerate(pairs)]
+    for g in graphs:
+        g.phases = bool(phases)
     own_ids = [orders[l][bounds[l][rank]:bounds[l][rank + 1]] for l in range(n_levels)]
     part = MGCNPartition(graphs, pools, bounds, own_ids, ranks,
                          [model.smposs_list[l].index_select(0, own_ids[l]) for l in range(n_levels)], rank, world, group)

@@ -276,6 +276,23 @@ class Sequential(nn.Module):
             name, ins, outs = self._plan[i]
             vals = [scope[a] for a in ins]
             on_dev = len(vals) >= 1 and torch.is_tensor(vals[0]) and vals[0].is_cuda and vals[0].dim() == 2
+            if on_dev and len(vals) == 2 and blocks_on and getattr(vals[1], "phases", False) and self.training:
+                # one rank of a vertex partition (dist.partition_mgcn): the run of plain blocks that starts here, phase by
+                # phase below the C ABI with the rank's collectives between the phases (dist.part_blocks)
+                plans, j = [], i
+                while j < n and self._plan[j][1] == ins and self._plan[j][2] == outs:
+                    nxt = self._block_at(j)
+                    if nxt is None or nxt[0].pool is not None:
+                        break
+                    plans.append(nxt[0])
+                    j = nxt[1] + 1
+                if plans:
+                    from .dist import part_blocks
+                    y = part_blocks(plans, vals[1], vals[0])
+                    if y is not None:
+                        scope[outs[0]] = result = y
+                        i = j
+                        continue
             if on_dev and len(vals) == 2 and blocks_on:
                 blk = self._block_at(i)          # conv [-> pool] -> BatchNorm -> activation below the C ABI ...
                 if blk is not None and blk[0].usable(vals[0]):

@@ -211,6 +211,8 @@ def test_partitioned_sgcn_and_mgcn_equal_single_rank_on_device(world):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "dist_selftest OK" in r.stdout and "path=phases collectives=44" in r.stdout
     assert "phases vs per-module path on the same partition" in r.stdout
+    # the MGCN: the runs of plain blocks of every stage phase by phase below the C ABI (27 of its 33 blocks: round 5)
+    assert r.stdout.count("MGCN phases=True blocks below the C ABI [27, 27]") == world, r.stdout[-2000:]
     print(r.stdout[-1500:])
 
 
@@ -286,6 +288,20 @@ def test_one_rank_phase_path_collectives_below_the_c_abi_equal_the_torch_distrib
         assert (counts["all_to_all"], counts["all_gather"], counts["all_reduce"]) == (27, 1, 17), counts
     assert out["1"][1] == "[1, 1]" and out["0"][1] == "[0, 0]", out
     assert out["1"][0] == out["0"][0], out
+
+
+def test_one_rank_mgcn_phase_runs_over_rccl_and_per_module_mgcn_two_ranks():
+    """The partitioned MGCN with its runs of plain blocks on dist.part_blocks (27 of 33 blocks; the pooled blocks module by
+    module): one rank over RCCL with every collective issued -- the runs' forward and backward passes are sg_part_run calls
+    with the library's own communicator, the input of every run fetched by one sg_halo_exchange -- against the single-device
+    MGCN (asserted inside the rank: positions 1e-5, loss 5e-6); and the per-module MGCN of rounds 1-4 on two ranks (the
+    supervisor's fallback for it)."""
+    r = _run_selftest(1, "nccl", SEMIGCN_DIST_FORCE_COLLECTIVES="1", SEMIGCN_SELFTEST_PATH="phases-sunk", SEMIGCN_SELFTEST_PREFIX="0")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "dist_selftest OK" in r.stdout and "MGCN phases=True blocks below the C ABI [27, 27]" in r.stdout
+    r = _run_selftest(2, "gloo", SEMIGCN_SELFTEST_PATH="modules")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "dist_selftest OK" in r.stdout and r.stdout.count("MGCN phases=False") == 2
 
 
 def test_halo_exchange_entry_points_on_a_one_rank_communicator():

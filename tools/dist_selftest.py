@@ -163,7 +163,7 @@ def main():
     else:
         assert e_pos < 1e-5 and e_loss < 2e-6 and worst < 3e-2
     if os.environ.get("SEMIGCN_SELFTEST_SKIP_MGCN") != "1":
-        mgcn_selftest(rank, world, dev)
+        mgcn_selftest(rank, world, dev, phases=(path != "modules"))
     dist.barrier()
     if rank == 0:
         import json
@@ -220,8 +220,10 @@ def block_prefix_check(model, ref, part, batch, rank, world, dev, bf16):
             p.grad = None
 
 
-def mgcn_selftest(rank, world, dev):
-    """Partitioned MGCN (pool / unpool across the cut) against the plain single-GPU MGCN, real kernels."""
+def mgcn_selftest(rank, world, dev, phases=True):
+    """Partitioned MGCN (pool / unpool across the cut) against the plain single-GPU MGCN, real kernels.  ``phases``: the runs of
+    plain blocks of every stage phase by phase below the C ABI (dist.part_blocks: 25 of the 33 blocks), the pooled blocks module
+    by module; False: every module on its own (rounds 1-4)."""
     import numpy as np
     import golden_util as GU
     from semigcn_amd import dist as sgdist, meshprep, synth, train
@@ -252,12 +254,23 @@ def mgcn_selftest(rank, world, dev):
     rloss.backward()
 
     net = build()
-    part = sgdist.partition_mgcn(net, rank, world)
+    part = sgdist.partition_mgcn(net, rank, world, phases=phases)
     tr = sgdist.DistMGCNTrainer(net, part, batch, accumulate=1000)
     net.train()
+    from semigcn_amd import functional as F_sg
+    c0, b0 = dict(sgdist.collective_counts), list(F_sg.block_calls)
     poss = net(batch.data, None)
     loss = tr.loss(poss)
-    loss.backward()
+    if phases:
+        tr.grads.zero()
+        with F_sg.sink_param_grads():       # (what DistMGCNTrainer.iteration_step does: the backward pass of a run is one call too)
+            loss.backward()
+    else:
+        loss.backward()
+    n_coll = sum(sgdist.collective_counts.values()) - sum(c0.values())
+    blocks = [F_sg.block_calls[0] - b0[0], F_sg.block_calls[1] - b0[1]]
+    if phases and dev.type == "cuda":
+        assert blocks == [25, 25], blocks       # 4 + 4 + 4 (encoders), 4 + 4 + 4 (decoders), 1 (the head of the finest level)
     sgdist.all_reduce_gradients(tr.params)
     e_pos = max(float((p.detach() - r.detach()[ids]).norm() / r.detach()[ids].norm())
                 for p, r, ids in zip(poss, rposs, part.own_ids))
@@ -270,6 +283,7 @@ def mgcn_selftest(rank, world, dev):
         scale = max(float(q.grad.norm()), 1e-3 * gmax * q.grad.numel() ** 0.5)
         worst = max(worst, float((p.grad - q.grad).norm()) / scale)
     halos = [(g.n_own, g.n_halo) for g in part.graphs]
+    print(f"[rank {rank}/{world}] MGCN phases={phases} blocks below the C ABI {blocks} collectives {n_coll}", flush=True)
     print(f"[rank {rank}/{world}] MGCN levels (own, halo) {halos} pool halos "
           f"{[(q.fine_plan.n_halo, q.coarse_plan.n_halo) for q in part.pools]}  pos rel-L2 {e_pos:.2e}  "
           f"loss rel {e_loss:.2e}  worst param-grad rel-L2 {worst:.2e}", flush=True)
