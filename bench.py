@@ -315,9 +315,10 @@ def build_trainer(args, dtype, device, world, rank, mesh):
         if dtype != torch.float32:
             model.set_feature_dtype(dtype)
         eis = model.edge_inds
-        if world > 1:                                    # every level cut into `world` blocks (dist.partition_mgcn)
+        if DIST_ON:                                      # every level cut into `world` blocks (dist.partition_mgcn)
             from semigcn_amd import dist as sgdist
-            trainer = sgdist.DistMGCNTrainer(model, sgdist.partition_mgcn(model, rank, world), batch)
+            trainer = sgdist.DistMGCNTrainer(model, sgdist.partition_mgcn(model, rank, world, phases=not args.no_phases), batch)
+            trainer.phases = not args.no_phases          # (27 of the 33 blocks phase by phase below the C ABI; the pooled ones per module)
         else:
             trainer = train.MGCNTrainer(model, batch, capture=args.graph)
         agg_edges = 2 * sum(n * e.shape[1] for n, e in zip((6, 11, 11, 5), eis))
@@ -332,7 +333,7 @@ def build_trainer(args, dtype, device, world, rank, mesh):
                 f"E={mesh.num_edges} directed, {'random' if args.permute else 'grid'} vertex order, "
                 f"{'fp32' if dtype == torch.float32 else 'bf16'} features"
                 + (", iteration replayed from a hipGraph" if args.graph else "")
-                + (f", every level vertex-partitioned into {world} blocks" if world > 1 else ""))
+                + (f", every level vertex-partitioned into {world} blocks" if DIST_ON else ""))
     return trainer, workload, agg_edges
 
 

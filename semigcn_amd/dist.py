@@ -1550,7 +1550,7 @@ def partition_mgcn(model: nn.Module, rank: int, world: int, group=None, phases: 
     coarse level is numbered by that member, so blocks stay contiguous and local at every level.
     Parameters stay replicated; BatchNorm statistics become mesh-wide.  ``phases`` (default): the runs of plain [ChebConv ->
     BatchNorm -> LeakyReLU] blocks of every stage -- 4 of the 5 blocks of a DownConv, 4 of 5 of an UpConv, the block of each
-    head: 25 of the 33 -- go phase by phase below the C ABI (part_blocks) in train mode, one exchange for the run's input and
+    head: 27 of the 33 -- go phase by phase below the C ABI (part_blocks) in train mode, one exchange for the run's input and
     one per block inside it with the BatchNorm statistics in its pad rows; the blocks with a pool between conv and BatchNorm
     (the rows change owner there: DistPool) stay module by module."""
     dev = model.smposs_list[0].device

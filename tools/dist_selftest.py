@@ -222,7 +222,7 @@ def block_prefix_check(model, ref, part, batch, rank, world, dev, bf16):
 
 def mgcn_selftest(rank, world, dev, phases=True):
     """Partitioned MGCN (pool / unpool across the cut) against the plain single-GPU MGCN, real kernels.  ``phases``: the runs of
-    plain blocks of every stage phase by phase below the C ABI (dist.part_blocks: 25 of the 33 blocks), the pooled blocks module
+    plain blocks of every stage phase by phase below the C ABI (dist.part_blocks: 27 of the 33 blocks), the pooled blocks module
     by module; False: every module on its own (rounds 1-4)."""
     import numpy as np
     import golden_util as GU
@@ -270,7 +270,7 @@ def mgcn_selftest(rank, world, dev, phases=True):
     n_coll = sum(sgdist.collective_counts.values()) - sum(c0.values())
     blocks = [F_sg.block_calls[0] - b0[0], F_sg.block_calls[1] - b0[1]]
     if phases and dev.type == "cuda":
-        assert blocks == [25, 25], blocks       # 4 + 4 + 4 (encoders), 4 + 4 + 4 (decoders), 1 (the head of the finest level)
+        assert blocks == [27, 27], blocks       # 3 x 4 (encoders), 3 x 4 (decoders), the conv block of each of the 3 heads
     sgdist.all_reduce_gradients(tr.params)
     e_pos = max(float((p.detach() - r.detach()[ids]).norm() / r.detach()[ids].norm())
                 for p, r, ids in zip(poss, rposs, part.own_ids))
