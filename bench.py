@@ -378,8 +378,13 @@ def timed_run(trainer, args, device, world, with_timer: bool):
             torch.cuda.synchronize(device)
 
     for i in range(args.warmup):
-        trainer.iteration_step()
+        loss = trainer.iteration_step()
         torch.cuda.synchronize(device)
+        if i == 0:
+            # the loss of the very first iteration (initial weights, mask 0, before any optimiser step) is a function of the
+            # workload alone: the lines of an N = 1 and an N = 8 run of the same mesh must agree on it to the precision of the
+            # features (~1e-3 relative with bf16 storage, ~1e-6 with fp32) -- a parity check across real devices for free
+            timed_run.first_loss = float(loss.detach()) if torch.is_tensor(loss) else None
         log(f"warm-up iteration {i} done")
         if i == 0:
             log_all("first warm-up iteration done")
@@ -516,6 +521,7 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
             "dtype": "f32" if dtype == torch.float32 else "bf16 storage / f32 accumulate",
             "edges_aggregated_per_s": agg_edges * value, "optimizer_steps_per_s": value / 5.0,
             "mean_loss": float(trainer.loss_sum.item()) / max(trainer.iteration, 1),
+            "first_iteration_loss": getattr(timed_run, "first_loss", None),
             "roofline": roof, "aggregation_kernels": kernels}
 
 
@@ -932,6 +938,7 @@ def main():
                        "aggregations_per_iteration": AGG_PER_ITER if args.model == "sgcn" else 66},
             "edges_aggregated_per_s": main_res["edges_aggregated_per_s"],
             "optimizer_steps_per_s": main_res["optimizer_steps_per_s"], "mean_loss": main_res["mean_loss"],
+            "first_iteration_loss": main_res.get("first_iteration_loss"),
             "roofline": main_res["roofline"], "aggregation_kernels": main_res["aggregation_kernels"],
             "dense_products": main_res["dense_products"],
         }
