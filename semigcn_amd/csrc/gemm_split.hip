@@ -389,6 +389,9 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
   bool a_ok = false, b_ok = false;                     // N, Kp % 4 == 0
   const float* a_src = g.A;
   const float* b_src = g.B;
+  uint32_t offa[4], offb[2];                           // byte offset of the thread's float4s inside a 32-row step of its operand
+  const int64_t step_a = (int64_t)32 * g.lda * 4, step_b = (int64_t)32 * g.ldb * 4;
+  const int full_steps = g.M >> 5;                     // steps whose 32 rows all exist
   auto set_item = [&](int item) {
     const int tile = item % g.n_tiles;
     slab = xg + 8 * (item / g.n_tiles);
@@ -398,8 +401,15 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
     count = q + (slab < rem ? 1 : 0);
     a_ok = n0 + 4 * ca < g.N;
     b_ok = k0 + 4 * cb < g.Kp;
-    a_src = g.A + (a_ok ? n0 + 4 * ca : 0);
-    b_src = g.B + (b_ok ? k0 + 4 * cb : 0);
+    // (columns past N / Kp of the last tile: the thread reads column 0 instead -- what it stashes only reaches rows / columns
+    //  of the result that are never stored, so it needs no zeroing; rows past M do: see fetch)
+    const int acol = a_ok ? n0 + 4 * ca : 0, bcol = b_ok ? k0 + 4 * cb : 0;
+    a_src = g.A + acol;
+    b_src = g.B + bcol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offa[i] = (uint32_t)((((tid >> 6) + 8 * i) * g.lda + acol) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) offb[i] = (uint32_t)((((tid >> 5) + 16 * i) * g.ldb + bcol) * 4);
   };
   int dst[6];                                          // byte offset of the thread's float4 q in plane 0 of its operand
 #pragma unroll
@@ -413,31 +423,42 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
     dst[4 + i] = 3 * PA + r * 256 + ((((cb >> 2) ^ tn_swz(r)) << 5) | ((cb & 3) << 3));
   }
   f32x4 raw[2][6];                                     // two steps of this thread's rows in flight
-  uint32_t keep[2];                                    // bit q: float4 q of the set is inside the matrix (else it is stashed as zeros)
-  // (the loaded values are NOT touched here: a select on them would make hipcc wait for the loads right behind their issue)
-  auto fetch = [&](f32x4 (&r)[6], uint32_t& kp, int step) {
-    const int m0 = (first + step) * 32;
-    kp = 0;
+  // A step's rows come from a wave-uniform base (SGPRs, advanced by the scalar unit) + the thread's constant 32-bit offset: no
+  // vector address arithmetic per load (the first version computed row * ld per load: 54 of its 228 VALU instructions per
+  // step, beside 24 selects of the validity masks -- matrix pipe busy 0.40, PMC).  Only a step that holds rows past M (the
+  // last one when M % 32 != 0, and the prefetches behind it) takes the path with per-thread clamps and zeroed rows.
+  auto fetch = [&](f32x4 (&r)[6], int step) {
+    const int st = first + step;                       // wave-uniform
+    if (st < full_steps) {
+      const char* const pa = (const char*)g.A + st * step_a;
+      const char* const pb = (const char*)g.B + st * step_b;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = m0 + (tid >> 6) + 8 * i;
-      const bool in = m < g.M;
-      m = in ? m : g.M - 1;
-      r[i] = *(const f32x4*)(a_src + (int64_t)m * g.lda);
-      kp |= (in && a_ok) ? 1u << i : 0u;
-    }
+      for (int i = 0; i < 4; ++i) r[i] = *(const f32x4*)(pa + offa[i]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int m = m0 + (tid >> 5) + 16 * i;
-      const bool in = m < g.M;
-      m = in ? m : g.M - 1;
-      r[4 + i] = *(const f32x4*)(b_src + (int64_t)m * g.ldb);
-      kp |= (in && b_ok) ? 16u << i : 0u;
+      for (int i = 0; i < 2; ++i) r[4 + i] = *(const f32x4*)(pb + offb[i]);
+    } else {
+      const int m0 = st * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int m = m0 + (tid >> 6) + 8 * i;
+        const bool in = m < g.M;
+        m = in ? m : g.M - 1;
+        const f32x4 v = *(const f32x4*)(a_src + (int64_t)m * g.lda);
+        r[i] = in ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int m = m0 + (tid >> 5) + 16 * i;
+        const bool in = m < g.M;
+        m = in ? m : g.M - 1;
+        const f32x4 v = *(const f32x4*)(b_src + (int64_t)m * g.ldb);
+        r[4 + i] = in ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   // one float4 of the thread -> its 3 x 8 bytes in the planes of buffer `buf` (the empty asm pins the arithmetic here)
-  auto slice = [&](const f32x4 v, uint32_t kp, int qq, int buf) {
-    Pieces4 p = split4((kp >> qq) & 1u ? v : f32x4{0.f, 0.f, 0.f, 0.f});
+  auto slice = [&](const f32x4 v, int qq, int buf) {
+    Pieces4 p = split4(v);
     asm volatile("" : "+v"(p.h), "+v"(p.m), "+v"(p.l));
     uint8_t* const d = lds + buf * BUF + dst[qq];
     const int plane = qq < 4 ? PA : PB;
@@ -518,7 +539,7 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
 #define TN_STEP(PAR)                                                                      \
   do {                                                                                    \
     constexpr uint32_t boff = (PAR) * BUF;                                                \
-    fetch(raw[PAR], keep[PAR], s + 2);                                                    \
+    fetch(raw[PAR], s + 2);                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                    \
     TN_RDA(0, boff);                                                                      \
     TN_RDA(1, boff);                                                                      \
@@ -526,12 +547,12 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
     TN_READYA(0);                                                                         \
     TN_READYA(1);                                                                         \
     TN_J(0, boff, (void)0);                                                               \
-    TN_J(1, boff, slice(raw[(PAR) ^ 1][0], keep[(PAR) ^ 1], 0, (PAR) ^ 1));               \
-    TN_J(2, boff, slice(raw[(PAR) ^ 1][1], keep[(PAR) ^ 1], 1, (PAR) ^ 1));               \
-    TN_J(3, boff, slice(raw[(PAR) ^ 1][2], keep[(PAR) ^ 1], 2, (PAR) ^ 1));               \
-    TN_J(4, boff, slice(raw[(PAR) ^ 1][3], keep[(PAR) ^ 1], 3, (PAR) ^ 1));               \
-    TN_J(5, boff, slice(raw[(PAR) ^ 1][4], keep[(PAR) ^ 1], 4, (PAR) ^ 1));               \
-    TN_J(6, boff, slice(raw[(PAR) ^ 1][5], keep[(PAR) ^ 1], 5, (PAR) ^ 1));               \
+    TN_J(1, boff, slice(raw[(PAR) ^ 1][0], 0, (PAR) ^ 1));               \
+    TN_J(2, boff, slice(raw[(PAR) ^ 1][1], 1, (PAR) ^ 1));               \
+    TN_J(3, boff, slice(raw[(PAR) ^ 1][2], 2, (PAR) ^ 1));               \
+    TN_J(4, boff, slice(raw[(PAR) ^ 1][3], 3, (PAR) ^ 1));               \
+    TN_J(5, boff, slice(raw[(PAR) ^ 1][4], 4, (PAR) ^ 1));               \
+    TN_J(6, boff, slice(raw[(PAR) ^ 1][5], 5, (PAR) ^ 1));               \
     TN_READYB(1, 0);      /* fragment 7, and every LDS write of this wavefront's stash */ \
     TN_MM(1, 7)                                                                           \
     __builtin_amdgcn_s_barrier();      /* step s + 1 is in LDS; buffer PAR is free */     \
@@ -548,10 +569,10 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_tn_f32s(const SplitTn g
 
   if (count > 0) {
     // ---- prologue: step 0 stashed into buffer 0 and visible, step 1 in raw set 1
-    fetch(raw[0], keep[0], 0);
+    fetch(raw[0], 0);
 #pragma unroll
-    for (int qq = 0; qq < 6; ++qq) slice(raw[0][qq], keep[0], qq, 0);
-    fetch(raw[1], keep[1], 1);
+    for (int qq = 0; qq < 6; ++qq) slice(raw[0][qq], qq, 0);
+    fetch(raw[1], 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < count; s += 2) {
