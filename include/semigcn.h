@@ -664,11 +664,14 @@ enum sg_tune_knob {
                              N = 192 (A/B switch), 5 = 128 x 192 tiles also for N = 384 (A/B switch; measured slower) */
   SG_TUNE_BLOCK_PLANES = 7, /* sg_block_*: 1 (default) = narrow layers keep their recurrence buffers as planes
                               (sg_block_planar), 0 = column blocks everywhere (A/B switch) */
-  SG_TUNE_F32_ENGINE = 8   /* dense products on float32 features: 0 (default) = the split-bf16 MFMA kernels (csrc/gemm_split.hip)
+  SG_TUNE_F32_ENGINE = 8,  /* dense products on float32 features: 0 (default) = the split-bf16 MFMA kernels (csrc/gemm_split.hip)
                               wherever they take the shape, the BLAS library for the rest; bit 0 = the BLAS library for all of
                               them (A/B switch); bits 1 / 2 / 3 = only the forward / input-gradient / weight-gradient products go to the
                               library (bisecting aid); bit 4 = the split kernels also below 16 K rows, where the library is
                               faster on the forward / input-gradient products (A/B switch) */
+  SG_TUNE_BN_ROWS = 9      /* BatchNorm + activation apply passes: 0 (default) = by shape (rows of >= 1 KB, backward passes from 512 B:
+                              every workgroup walks ONE contiguous range of rows; else row groups strided over the grid), 1 = contiguous
+                              everywhere, 2 = strided everywhere (A/B switch) */
 };
 SG_API int sg_tuning_set(int knob, int value);
 

@@ -242,6 +242,8 @@ def load():
     _lib = lib
     if os.environ.get("SEMIGCN_F32_ENGINE"):               # A/B and bisecting runs: see SG_TUNE_F32_ENGINE in include/semigcn.h
         lib.sg_tuning_set(8, int(os.environ["SEMIGCN_F32_ENGINE"]))
+    if os.environ.get("SEMIGCN_BN_ROWS"):                  # A/B runs: SG_TUNE_BN_ROWS
+        lib.sg_tuning_set(9, int(os.environ["SEMIGCN_BN_ROWS"]))
     return lib
 
 
@@ -522,6 +524,7 @@ class PoolHandle:
 TUNE_CHUNK_ROWS, TUNE_FLAGS, TUNE_UNROLL, TUNE_SLAB, TUNE_TILED_MIN_ROW_BYTES, TUNE_GEMM_TILE, TUNE_GRAPH_REORDER = 0, 1, 2, 3, 4, 5, 6
 TUNE_BLOCK_PLANES = 7
 TUNE_F32_ENGINE = 8
+TUNE_BN_ROWS = 9
 
 
 def tuning_set(knob: int, value: int) -> None:

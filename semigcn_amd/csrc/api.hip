@@ -429,6 +429,7 @@ SG_API int sg_tuning_set(int knob, int value) {
   if (knob == SG_TUNE_GRAPH_REORDER) return set_graph_reorder_mode(value);
   if (knob == SG_TUNE_BLOCK_PLANES) return set_block_planes(value);
   if (knob == SG_TUNE_F32_ENGINE) return set_split_tuning(value);
+  if (knob == SG_TUNE_BN_ROWS) return set_bn_rows_tuning(value);
   return set_tuning(knob, value);
 }
 

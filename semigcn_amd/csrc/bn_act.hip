@@ -249,7 +249,8 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ kk, const float* __restrict__ c1,
                                                          const float* __restrict__ c2, float slope, void* Y_, int64_t ldy,
-                                                         int64_t V, int C, int tpr_log2, float* __restrict__ colsum = nullptr) {
+                                                         int64_t V, int C, int tpr_log2, float* __restrict__ colsum = nullptr,
+                                                         int64_t rows_per_block = 0) {
   using IO = Io<DT>;
   using elem_t = typename IO::elem;
   using raw_t = typename IO::raw;
@@ -291,14 +292,19 @@ __global__ __launch_bounds__(kBlock) void col_apply_rows(const void* A_, int64_t
       }
     }
   }
-  const int64_t step = (int64_t)gridDim.x * groups;
-  for (int64_t r = (int64_t)blockIdx.x * groups + tg; col_on && r < V; r += step * U) {
+  // rows of a workgroup: rows_per_block == 0: row groups strided over the grid (block b: b, b + gridDim, ..); > 0: ONE
+  // contiguous range per workgroup, walked front to back (what a plain copy kernel does: every workgroup is a sequential stream)
+  const int64_t step = rows_per_block ? groups : (int64_t)gridDim.x * groups;
+  const int64_t r_first = rows_per_block ? (int64_t)blockIdx.x * rows_per_block : (int64_t)blockIdx.x * groups;
+  int64_t r_end = rows_per_block ? r_first + rows_per_block : V;
+  r_end = r_end < V ? r_end : V;
+  for (int64_t r = r_first + tg; col_on && r < r_end; r += step * U) {
     raw_t xa[U], xh[U];
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int64_t ru = r + u * step;
-      live[u] = ru < V;
+      live[u] = ru < r_end;
       ru = live[u] ? ru : r;
       xa[u] = *(const raw_t*)(A + ru * lda + c0);
       if (MODE == 1) xh[u] = *(const raw_t*)(H + ru * ldh + c0);
@@ -750,6 +756,14 @@ int launch_colsum_finalize(const float* partial, int64_t nb, int64_t C, float* o
   return SG_OK;
 }
 
+// SG_TUNE_BN_ROWS: 0 = by shape (below), 1 = every workgroup of col_apply_rows walks one contiguous range of rows, 2 = row
+// groups strided over the grid (A/B)
+int g_bn_rows_contiguous = 0;
+int set_bn_rows_tuning(int value) {
+  g_bn_rows_contiguous = value;
+  return SG_OK;
+}
+
 int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_t ldh, const float* scale,
                      const float* shift, const float* mean, const float* invstd, const float* kk, const float* c1,
                      const float* c2, float slope, void* Y, int64_t ldy, int64_t V, int64_t C, int dtype,
@@ -769,9 +783,16 @@ int launch_col_apply(int mode, const void* A, int64_t lda, const void* H, int64_
       if (nbr > 256 * 16) nbr = 256 * 16;
       if (nbr < 1) nbr = 1;
       if (colsum) SG_REQUIRE(mode == 1 && nbr == col_apply_blocks(V, C, dtype), "column sums: wrong partial buffer size");
-      if (mode == 0) col_apply_rows<DT, 0><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg);
-      else if (colsum) col_apply_rows<DT, 1, true><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg, colsum);
-      else col_apply_rows<DT, 1><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg);
+      // rows of a workgroup: one contiguous range where it pays (measured at V = 1 M, tools/bn_bench.py --rows 0 / 1, GB/s:
+      // fp32 C = 256 apply 4 540 -> 5 290, backward 4 810 -> 5 300; fp32 C = 512 4 530 -> 5 230 / 4 600 -> 5 300; bf16 C = 512
+      // backward 4 820 -> 5 400; bf16 C = 256 forward 5 470 -> 5 345: not there; 128-byte rows level), else strided over the grid
+      const int64_t row_bytes = C * (int64_t)sizeof(typename Io<DT>::elem);
+      const bool contiguous = g_bn_rows_contiguous == 1 || (g_bn_rows_contiguous == 0 && (row_bytes >= 1024 || (mode == 1 && row_bytes >= 512)));
+      int64_t rpb = 0;
+      if (contiguous) rpb = ((V + nbr - 1) / nbr + groups - 1) / groups * groups;
+      if (mode == 0) col_apply_rows<DT, 0><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg, nullptr, rpb);
+      else if (colsum) col_apply_rows<DT, 1, true><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg, colsum, rpb);
+      else col_apply_rows<DT, 1><<<(int)nbr, kBlock, 0, stream>>>(A, lda, H, ldh, scale, shift, mean, invstd, kk, c1, c2, slope, Y, ldy, V, (int)C, lg, nullptr, rpb);
       SG_HIP_TRY(hipGetLastError());
       return SG_OK;
     }

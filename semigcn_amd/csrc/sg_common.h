@@ -279,6 +279,7 @@ int64_t gemm_nt_f32s_workspace(int64_t N, int64_t K);
 int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes, hipStream_t stream);
 int set_split_tuning(int value);
+int set_bn_rows_tuning(int value);
 bool split_engine_enabled(int kind = 0);
 bool gemm_tn_f32s_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 int64_t gemm_tn_f32s_workspace(int64_t M, int64_t N, int64_t Kp);

@@ -30,7 +30,10 @@ def timed(fn, reps=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--V", type=int, default=1_000_000)
+    ap.add_argument("--rows", type=int, default=-1, help="SG_TUNE_BN_ROWS (0 by shape, 1 contiguous row ranges, 2 strided); -1: the library's default")
     a = ap.parse_args()
+    if a.rows >= 0:
+        capi.tuning_set(capi.TUNE_BN_ROWS, a.rows)
     V = a.V
     rows = []
     for dt in (torch.float32, torch.bfloat16):
