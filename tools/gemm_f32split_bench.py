@@ -97,7 +97,7 @@ def main():
             emit(r)
     V = a.V
     # (Cin, Cout) of the SGCN's ChebConv layers (K = 3); aggregate-first layers multiply [V, 3 Cin] x [3 Cin, Cout]
-    layers = [(256, 512), (256, 256), (128, 256), (64, 128)] if a.quick else [(256, 512), (256, 256), (128, 256), (64, 128), (32, 64)]
+    layers = [(256, 512), (256, 256), (128, 256), (64, 128)] if a.quick else [(256, 512), (256, 256), (128, 256), (64, 128), (32, 64), (16, 32)]
     seq = 0
     for (ci, co) in layers:
         K, N = 3 * ci, co
