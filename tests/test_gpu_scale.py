@@ -376,6 +376,15 @@ def test_bench_gpus_2_starts_its_own_ranks():
     # a partitioned rank is always eager: its hipGraph replay modes of rounds 2-4 are gone
     r = subprocess.run(base + ["--graph"], env=_child_env(SEMIGCN_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and "one GPU only" in r.stderr
+    # the cross-N parity check the lines carry: the loss of the very first iteration is a function of the workload alone -- the
+    # two-rank line and the one-GPU line of the same mesh agree on it (fp32 features: to float32 summation order)
+    solo = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--mesh", "96x64",
+                           "--no-cpu-baseline", "--dtype", "fp32", "--single-dtype", "--no-second-order", "--no-distributed-estimate"],
+                          env=_child_env(), capture_output=True, text=True, timeout=600)
+    assert solo.returncode == 0, solo.stderr[-2000:]
+    l1 = json.loads(solo.stdout.splitlines()[-1])["first_iteration_loss"]
+    l2 = line["first_iteration_loss"]
+    assert l1 is not None and l2 is not None and abs(l1 - l2) <= 2e-6 * abs(l1), (l1, l2)
 
 
 def test_bench_supervisor_retries_same_path_then_per_module_after_stalls():
