@@ -1053,9 +1053,14 @@ class BlockPlan:
         mark and the descriptors are bound again -- as the per-module path, which re-reads the module on every call.)"""
         conv, bn = self.conv, self.bn
         bp, bb = bn._parameters, bn._buffers
-        parts = [lin._parameters["weight"] for lin in conv.lins]
-        parts += [conv._parameters.get("bias"), bp["weight"], bp["bias"], bb["running_mean"], bb["running_var"], bb.get("num_batches_tracked")]
-        mark = tuple((id(t), t.data_ptr()) if t is not None else None for t in parts) + (bn.momentum, bn.eps)
+        g, rm = bp["weight"], bb["running_mean"]
+        ws = [lin._parameters["weight"] for lin in conv.lins]
+        # (identity of every tensor; the address of three of them -- `.to()` and `.data = ..` move all of a module's storage
+        #  together, so the first weight, the BatchNorm weight and the running mean stand for the rest: this runs three to four
+        #  times per block and iteration on a host-bound path)
+        mark = (*map(id, ws), id(conv._parameters.get("bias")), id(g), id(bp["bias"]), id(rm), id(bb["running_var"]),
+                id(bb.get("num_batches_tracked")), ws[0].data_ptr(), g.data_ptr(), None if rm is None else rm.data_ptr(),
+                bn.momentum, bn.eps)
         if mark != self._mark:
             self.weights = [lin.weight for lin in conv.lins]
             self.cbias, self.gamma, self.beta = conv.bias, bn.weight, bn.bias
@@ -1245,7 +1250,7 @@ class BlockChain:
     def fill_static(self, which: int, lay: _Layout, dtype, dev, graphs, pools) -> bool:
         """Write what does not depend on this call's buffers into the descriptors of direction ``which`` (0 forward, 1
         backward) unless it is what they hold already; True when something was written."""
-        marks = tuple(p.fingerprint() for p in self.plans)
+        marks = tuple(p._mark for p in self.plans)      # (refreshed by cheb_chain on the way here, in this same call)
         sig = (lay, dtype, graphs, tuple(pools), marks)
         old = self._sig[which]
         if old is not None and old[0] is lay and old[1] == dtype and old[2] == graphs and old[3] == sig[3] and old[4] == marks:
