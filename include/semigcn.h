@@ -624,7 +624,7 @@ SG_API int sg_part_run(sg_comm* comm, const sg_part_step* steps, int64_t n, void
  * has synchronised the device, sg_trace_read copies up to n records out (returns their number, negative on error) and
  * sg_trace_end releases the events.  Record: kind 0 = aggregation (a = C, b = epilogue operands, c = rows processed),
  * 1 = product C = A B^T / A B (a = M, b = N, c = K), 2 = weight gradient A^T B (a = M, b = N, c = Kp); engine 0 = the
- * library's aggregation kernels, 1 = own MFMA kernels, 2 = thin-product kernels, 3 = BLAS library, 4 = split-bf16 MFMA kernels
+ * library's aggregation kernels, 1 = own MFMA kernels, 2 = thin-product and small-weight kernels (vector ALUs: thin_gemm.hip, gemm_mid.hip), 3 = BLAS library, 4 = split-bf16 MFMA kernels
  * (float32 features). */
 typedef struct sg_trace_record {
   int32_t kind, dtype, engine, reserved_;
