@@ -1831,3 +1831,32 @@ def test_empty_coarse_cluster_yields_zero_where_the_reference_yields_nan():
     # and the gradient of the empty row goes nowhere
     assert torch.equal(pool.pool_mean_bwd(torch.ones(3, 2, device=DEV)).cpu(),
                        torch.tensor([[0.5] * 2] * 2 + [[1.0 / 3] * 2] * 3))
+
+
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 256), (torch.float32, 512), (torch.bfloat16, 512), (torch.bfloat16, 256), (torch.float32, 64)])
+def test_batchnorm_apply_passes_do_not_depend_on_which_rows_a_workgroup_takes(dtype, C):
+    """SG_TUNE_BN_ROWS (round 5): the apply passes of BatchNorm + LeakyReLU give every workgroup one contiguous range of rows
+    where the rows are wide, row groups strided over the grid elsewhere.  The value of every element is a function of its own
+    row alone: the two assignments write the same bits (forward and backward, column blocks of wider buffers, a row count that
+    is no multiple of anything); the column sums taken on the way (the bias gradient) add the same values in another order."""
+    V = 100003
+    g = torch.Generator(device=DEV).manual_seed(C)
+    wide = torch.randn((V, 3 * C), device=DEV, generator=g).to(dtype)
+    x, da = wide[:, C:2 * C], wide[:, 2 * C:]
+    vec = [torch.rand(C, device=DEV, generator=g) + 0.5 for _ in range(7)]
+    res = {}
+    try:
+        for rows in (1, 2):
+            capi.tuning_set(capi.TUNE_BN_ROWS, rows)
+            outw = torch.zeros((V, 2 * C), device=DEV, dtype=dtype)
+            y = capi.scale_shift_act(x, vec[0], vec[1], 0.01, out=outw[:, C:])
+            dh, sums = capi.bn_act_bwd_apply_colsum(da, x, *vec, 0.01)
+            assert bool((outw[:, :C] == 0).all())
+            res[rows] = (y.clone(), dh, sums)
+    finally:
+        capi.tuning_set(capi.TUNE_BN_ROWS, 0)
+    assert torch.equal(res[1][0], res[2][0]) and torch.equal(res[1][1], res[2][1])
+    if res[1][2] is not None:
+        ref = res[1][1].double().sum(0)
+        for rows in (1, 2):
+            assert float((res[rows][2].double() - ref).abs().max()) <= 2e-5 * float(res[1][1].double().abs().sum(0).max())
