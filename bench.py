@@ -322,6 +322,7 @@ def build_trainer(args, dtype, device, world, rank, mesh):
         else:
             trainer = train.MGCNTrainer(model, batch, capture=args.graph)
         agg_edges = 2 * sum(n * e.shape[1] for n, e in zip((6, 11, 11, 5), eis))
+        trainer.levels = {int(p.shape[0]): int(e.shape[1]) for p, e in zip(model.poss_list, eis)}
     else:
         model = SingleScaleGCN(device).to(device)
         if dtype != torch.float32:
@@ -360,6 +361,8 @@ class TraceTimer:
                 continue
             if r["kind"] == "agg":
                 key = (r["a"], r["dtype"], r["b"], r["c"])
+            elif r["kind"] == "pool":
+                key = ("pool", r["a"], r["dtype"], r["b"], r["c"])
             else:
                 key = (r["kind"], r["a"], r["b"], r["c"], r["dtype"], r["engine"])
             out.setdefault(key, []).append(r["ms"])
@@ -413,7 +416,7 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     sync()
     capi.set_launch_timer(timer)
     if traced:
-        timer = TraceTimer(("agg",))
+        timer = TraceTimer(("agg", "pool"))
     if DIST_ON:
         from semigcn_amd import dist as sgdist
         c0 = dict(sgdist.collective_counts)
@@ -470,9 +473,24 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
     elem = 4 if dtype == torch.float32 else 2
     V_local, E_local = V_total // world, E_total // world
     nu, nv = map(int, args.mesh.split("x"))
-    kernels, roof = [], None
+    kernels, roof, pools = [], None, []
+    # rows of a launch -> directed edges of the graph it ran on (SGCN: the one mesh; MGCN: one entry per level)
+    levels = getattr(trainer, "levels", None) or {V_total: E_total}
     if timer is not None:
         results = timer.results()
+        for key in [k for k in results if k[0] == "pool"]:
+            _, C, dt_name, rows_w, rows_r = key
+            times = results.pop(key)
+            es = 4 if dt_name == "float32" else 2
+            # SURVEY 8(d) per-unit figure for MeshPool / MeshUnpool (util/meshnet.py:9-27): both feature tensors once + one index
+            # word per row on either side
+            B = (rows_w + rows_r) * C * es + 4 * rows_w + 4 * rows_r
+            mean_ms = float(np.mean(times))
+            pools.append({"C": C, "dtype": dt_name, "rows_written": rows_w, "rows_read": rows_r, "launches": len(times),
+                          "mean_ms": round(mean_ms, 4), "total_ms": round(float(np.sum(times)), 3),
+                          "algorithmic_MB": round(B / 1e6, 3), "achieved_GBs": round(B / mean_ms / 1e6, 1),
+                          "hbm_frac": round(B / mean_ms / 1e6 / HBM_PEAK_GBS, 4)})
+        pools.sort(key=lambda k: -k["total_ms"])
         # launches that compute a rank's whole block (N > 1 also has row-subset launches for the overlap with the halo
         # exchange: interior rows / boundary + ring-1 rows; they are left out of the per-kernel roofline)
         full_rows = max(r for (_, _, _, r) in results) if results else 0
@@ -485,21 +503,26 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
                 full_rows = Counter(r for (_, _, _, r), t in results.items() for _ in t).most_common(1)[0][0]
         merged = {}
         for (C, dt_name, n_epi, rows), times in results.items():
-            if not DIST_ON or rows == full_rows:
-                merged.setdefault((C, dt_name, n_epi), []).extend(times)
+            if DIST_ON:
+                if rows == full_rows:
+                    merged.setdefault((C, dt_name, n_epi, rows), []).extend(times)
+            elif rows in levels:
+                merged.setdefault((C, dt_name, n_epi, rows), []).extend(times)
         if DIST_ON:
             V_local, E_local = full_rows, int(E_total * full_rows / max(V_total, 1))
-        for (C, dt_name, n_epi), times in sorted(merged.items(), key=lambda kv: -sum(kv[1])):
+            levels = {full_rows: E_local}
+        for (C, dt_name, n_epi, rows), times in sorted(merged.items(), key=lambda kv: -sum(kv[1])):
             mean_ms = float(np.mean(times))
-            B = algorithmic_bytes(V_local, E_local, C, elem, n_epi)
-            kernels.append({"C": C, "dtype": dt_name, "epilogue_operands": n_epi, "launches": len(times),
+            B = algorithmic_bytes(rows, levels[rows], C, 4 if dt_name == "float32" else 2, n_epi)
+            kernels.append({"C": C, "dtype": dt_name, "epilogue_operands": n_epi,
+                            **({"V": rows, "E": levels[rows]} if len(levels) > 1 else {}), "launches": len(times),
                             "mean_ms": round(mean_ms, 4), "total_ms": round(float(np.sum(times)), 3),
                             "algorithmic_MB": round(B / 1e6, 2), "achieved_GBs": round(B / mean_ms / 1e6, 1)})
         total_B = sum(k["algorithmic_MB"] * k["launches"] for k in kernels)
         total_t = sum(k["total_ms"] for k in kernels)
         dom = kernels[0]
         traffic = pmc_traffic(dom["C"], dom["dtype"], dom["epilogue_operands"], elem) if (
-            not DIST_ON and (nu, nv) == (1000, 1000) and not args.permute) else None
+            not DIST_ON and (nu, nv) == (1000, 1000) and not args.permute and args.model == "sgcn") else None
         roof = {"bound": "hbm", "kernel": f"sg::{aggregation_kernel_name(dom['C'], elem, dom['epilogue_operands'])} C={dom['C']} "
                                           f"{dom['dtype']} (+{dom['epilogue_operands']} epilogue operands)",
                 "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -515,6 +538,8 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
                 "all_aggregations_frac": round(total_B / total_t / HBM_PEAK_GBS, 4),
                 "aggregation_share_of_step": round(total_t / (getattr(timed_run, "timer_dt", dt) * 1e3), 4),
                 "measured_over": "the timed region"}
+        if len(levels) > 1:
+            roof["kernel"] += f" on the level with V={dom['V']} E={dom['E']}"
     dense = dense_products(getattr(timed_run, "gemm_timer", None), getattr(timed_run, "gemm_steps", 0),
                            getattr(timed_run, "gemm_dt", 0.0))
     return {"value": value, "ms_per_step": dt / args.steps * 1e3, "dense_products": dense,
@@ -522,47 +547,71 @@ def summarize(dt, timer, args, dtype, mesh, world, agg_edges, trainer):
             "edges_aggregated_per_s": agg_edges * value, "optimizer_steps_per_s": value / 5.0,
             "mean_loss": float(trainer.loss_sum.item()) / max(trainer.iteration, 1),
             "first_iteration_loss": getattr(timed_run, "first_loss", None),
-            "roofline": roof, "aggregation_kernels": kernels}
+            "roofline": roof, "aggregation_kernels": kernels, "pool_kernels": pools or None}
 
 
 MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3}     # MI355X_MICROARCH.md, dense peaks (bf16 MFMA; f32-input MFMA)
 
 
+def _pipe(engine: str, dt_name: str):
+    """(peak TFLOP/s of the pipe the launch runs on, instructions' flops issued per algorithmic flop, name of the pipe).
+    Engine "split" computes a float32 product from SIX bf16 piece products on the bf16 matrix pipe (csrc/gemm_split.hip): it
+    is priced against the 2.5 PF bf16 peak with the six products counted, never against the 157 TF float32-MFMA peak."""
+    if engine == "split":
+        return MFMA_PEAK_TFLOPS["bfloat16"], 6.0, "bf16 MFMA, six piece products per float32 product"
+    if dt_name == "float32":
+        return MFMA_PEAK_TFLOPS["float32"], 1.0, "float32 MFMA / vector ALUs"
+    return MFMA_PEAK_TFLOPS["bfloat16"], 1.0, "bf16 MFMA"
+
+
 def dense_products(timer, steps: int, dt: float):
     """The dense per-vertex feature x weight products (ChebConv's `lins`, util/networks.py:42,49, and their autograd) of
     the timed region, each launch timed with HIP events on its stream: per shape the MFMA roofline fraction
-    (flops = 2 M N K against the dense peak of the operand type) next to the HBM one (operand + result bytes, the weight
-    matrix L2-resident), and the totals -- which engine ran it: "mfma" = csrc/gemm_mfma.hip, "blas" = hipBLASLt.
-    Measured over `steps` extra iterations right after the timed region (see timed_run)."""
+    (issued flops against the dense peak of the pipe the engine runs on: `_pipe`) next to the HBM one (operand + result
+    bytes, the weight matrix L2-resident), and the totals -- which engine ran it: "mfma" = csrc/gemm_mfma*.hip,
+    "split" = csrc/gemm_split.hip, "thin" = vector-ALU kernels, "blas" = hipBLASLt.  `frac` is the share of the products' time
+    their issued flops would take at the peak of their own pipe (sum of issued / peak over the launches, divided by the time):
+    it cannot exceed 1.  Measured over `steps` extra iterations right after the timed region (see timed_run)."""
     if timer is None or not timer.records or steps < 1:
         return None
     shapes, by_engine = [], {}
-    tot_ms = tot_flops = 0.0
+    tot_ms = tot_flops = tot_peak_ms = 0.0
     for (kind, M, N, K, dt_name, engine), times in sorted(timer.results().items(), key=lambda kv: -sum(kv[1])):
         elem = 4 if dt_name == "float32" else 2
         mean_ms = float(np.mean(times))
         flops = 2.0 * M * N * K
+        peak, issued_per_flop, pipe = _pipe(engine, dt_name)
         # "nt": A [M,K] read, C [M,N] written;  "tn" (weight gradient): both [M,N] and [M,K] operands read, result tiny
         byts = (M * K + M * N) * elem
-        peak = MFMA_PEAK_TFLOPS[dt_name]
-        shapes.append({"kind": kind, "M": M, "N": N, "K": K, "dtype": dt_name, "engine": engine, "launches": len(times),
-                       "mean_ms": round(mean_ms, 4), "TFLOPs": round(flops / mean_ms / 1e9, 1),
-                       "mfma_frac": round(flops / mean_ms / 1e9 / peak, 4),
-                       "hbm_frac": round(byts / mean_ms / 1e6 / HBM_PEAK_GBS, 4)})
-        e = by_engine.setdefault(engine, {"ms_per_iteration": 0.0, "TFLOP_per_iteration": 0.0})
+        row = {"kind": kind, "M": M, "N": N, "K": K, "dtype": dt_name, "engine": engine, "launches": len(times),
+               "mean_ms": round(mean_ms, 4), "TFLOPs": round(flops / mean_ms / 1e9, 1),
+               "mfma_frac": round(flops * issued_per_flop / mean_ms / 1e9 / peak, 4),
+               "hbm_frac": round(byts / mean_ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if issued_per_flop != 1.0:
+            row["issued_TFLOPs"] = round(flops * issued_per_flop / mean_ms / 1e9, 1)
+        shapes.append(row)
+        e = by_engine.setdefault(engine, {"ms_per_iteration": 0.0, "TFLOP_per_iteration": 0.0, "pipe": pipe, "peak": peak,
+                                          "issued_per_flop": issued_per_flop})
         e["ms_per_iteration"] += sum(times) / steps
         e["TFLOP_per_iteration"] += flops * len(times) / steps / 1e12
         tot_ms += sum(times)
         tot_flops += flops * len(times)
+        tot_peak_ms += flops * issued_per_flop * len(times) / peak / 1e9
     for e in by_engine.values():
         e["TFLOPs"] = round(e["TFLOP_per_iteration"] / e["ms_per_iteration"] * 1e3, 1)
+        e["issued_TFLOPs"] = round(e["TFLOPs"] * e["issued_per_flop"], 1)
+        e["frac_of_pipe_peak"] = round(e["issued_TFLOPs"] / e["peak"], 4)
         e["ms_per_iteration"], e["TFLOP_per_iteration"] = round(e["ms_per_iteration"], 3), round(e["TFLOP_per_iteration"], 3)
-    dt_name = shapes[0]["dtype"]
-    return {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS[dt_name], "unit": "TFLOP/s",
-            "achieved": round(tot_flops / tot_ms / 1e9, 1), "frac": round(tot_flops / tot_ms / 1e9 / MFMA_PEAK_TFLOPS[dt_name], 4),
+    dom = max(by_engine.values(), key=lambda e: e["ms_per_iteration"])
+    return {"bound": "mfma", "peak": dom["peak"], "pipe": dom["pipe"], "unit": "TFLOP/s",
+            "achieved": round(tot_peak_ms / tot_ms * dom["peak"], 1), "frac": round(tot_peak_ms / tot_ms, 4),
+            "algorithmic_TFLOPs": round(tot_flops / tot_ms / 1e9, 1),
+            "achieved_note": "issued flops per second in units of the dominant engine's pipe (`pipe`): the time-weighted mean of "
+                             "every launch's fraction of its OWN pipe's peak, times `peak`; `algorithmic_TFLOPs` = 2 M N K per "
+                             "launch over the same time (for engine `split` the float32-equivalent rate)",
             "ms_per_iteration": round(tot_ms / steps, 3), "share_of_step": round(tot_ms / (dt * 1e3), 4),
             "measured_over": f"{steps} iterations after the timed region (HIP events on the launching stream)",
-            "by_engine": by_engine, "shapes": shapes[:12] + [s for s in shapes[12:] if s["engine"] != "mfma"]}
+            "by_engine": by_engine, "shapes": shapes[:12] + [s for s in shapes[12:] if s["engine"] not in ("mfma", "split")]}
 
 
 def distributed_estimate(args, ms_per_step_n1: float):
@@ -874,7 +923,7 @@ def main():
     if args.graph and args.warmup < 4:
         raise SystemExit("--graph: --warmup must be >= 4 (3 eager iterations + the capture)")
     # byte accounting assumes the finest mesh only; inside a whole-iteration hipGraph launches cannot be timed
-    with_timer = not args.no_launch_timer and args.model == "sgcn" and not args.graph
+    with_timer = not args.no_launch_timer and not args.graph and (args.model == "sgcn" or not DIST_ON)
 
     trainer, workload, agg_edges = build_trainer(args, dtypes[args.dtype], device, world, rank, mesh)
     log("model built; warm-up")
@@ -942,6 +991,8 @@ def main():
             "roofline": main_res["roofline"], "aggregation_kernels": main_res["aggregation_kernels"],
             "dense_products": main_res["dense_products"],
         }
+        if main_res.get("pool_kernels"):
+            line["pool_kernels"] = main_res["pool_kernels"]
         if other is not None:
             line["fp32_features" if other["dtype"] == "f32" else "bf16_features"] = other
         if order2 is not None:

@@ -132,9 +132,12 @@ SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, 
  * accumulation order -- same error bound, a different last bit in ~1 % of the
  * bf16 outputs (SG_TUNE_FLAGS bit 11 restores the fma chain).  float32 rows of 128
  * channels (and of 256 with at most one epilogue operand) take the same tiled
- * pipeline with float32 operands on v_mfma_f32_16x16x4_f32: the nonzero terms of a row
- * are still added in ascending neighbour id, the matrix core's 4-term inner sum rounds
- * differently from an fma chain (a few ulp; SG_TUNE_FLAGS bit 13 restores the chain).
+ * pipeline with float32 operands on v_mfma_f32_16x16x4_f32: the matrix core adds the
+ * products of a step in slot order into its float32 accumulator, a tile's slots are its
+ * sources in ascending id and an unused slot carries weight 0, so every row's sum is the
+ * fma chain over its neighbours in ascending id -- the SAME BITS as the chain kernel
+ * (tests/test_gpu_parity.py::test_f32_ring_kernel_equals_the_rows_kernel_bit_for_bit;
+ * SG_TUNE_FLAGS bit 13 switches the tiled float32 pipeline off, for A/B timing only).
  * The tile records are built by the first aggregation that can use them.
  * Non-finite inputs: the gathers run in fixed-size batches whose unused slots
  * are switched off by a ZERO WEIGHT on a row that is read anyway (a neighbour of
@@ -611,19 +614,38 @@ typedef struct sg_part_step {
 SG_API int sg_comm_available(void);
 SG_API int sg_comm_unique_id(void* id128);
 SG_API int sg_comm_create(const void* id128, int rank, int world, const int64_t* send_rows, const int64_t* recv_rows, sg_comm** out);
+/* A second handle on the SAME RCCL communicator with other per-peer row counts (one exchange layout per MGCN level): no
+ * ncclCommInitRank, no new buffers; the communicator is destroyed with its last handle. */
+SG_API int sg_comm_share(const sg_comm* base, const int64_t* send_rows, const int64_t* recv_rows, sg_comm** out);
 SG_API int sg_comm_destroy(sg_comm* comm);
 SG_API int sg_halo_exchange(sg_comm* comm, const void* send, void* recv, int64_t row_bytes, void* stream);
 SG_API int sg_comm_all_reduce_f32(sg_comm* comm, float* buf, int64_t n, void* stream);
 SG_API int sg_comm_all_gather(sg_comm* comm, const void* in, void* out, int64_t bytes_per_rank, void* stream);
 SG_API int64_t sg_part_step_sizeof(void);
 SG_API int sg_part_run(sg_comm* comm, const sg_part_step* steps, int64_t n, void* stream);
+/* After a failed sg_part_run on this thread: the index of the step that failed (steps before it are enqueued, so this rank's
+ * collective sequence is out of step with its peers' and the job must be aborted, not retried on another communicator);
+ * -1 after a successful run. */
+SG_API int64_t sg_part_failed_step(void);
+/* TEST INFRASTRUCTURE (tests/test_comm_stub.py; never called by the product): sg_comm_test_stub(1) replaces RCCL by an
+ * in-process stand-in -- every communicator created afterwards is a "rank" of THIS process, buffers are host memory, sends
+ * meet their receives in a mailbox, an all-reduce / all-gather completes when the last rank has called -- so that the peer
+ * offsets of sg_halo_exchange and the schedule walk of sg_part_run can be checked for world sizes > 1 on a box with no (or
+ * one) GPU; sg_comm_test_stub(0) restores the real library.  sg_comm_test_fail_send(n): the n-th ncclSend from now fails.
+ * sg_comm_test_log: the calls made so far as records of five int64 {kind 0 send / 1 recv / 2 all-reduce / 3 all-gather /
+ * 4 group start / 5 group end, rank, peer, pointer, bytes}; state[3] = {operations still unmatched, size mismatches, groups
+ * left open}. */
+SG_API int sg_comm_test_stub(int on);
+SG_API int sg_comm_test_fail_send(int nth);
+SG_API int64_t sg_comm_test_log(int64_t* out, int64_t n, int64_t* state);
 
 /* Per-launch timing of the kernels the library starts (benchmarking aid; off by default, costs two hipEventRecord per kernel
  * when on).  sg_trace_begin(capacity, kinds) starts recording up to `capacity` launches of the kinds in the bit mask
  * `kinds` (bit k = record kind k) made from this process' sg_spmm / sg_block_* calls: an event pair on the launching stream around each aggregation and each dense product.  After the caller
  * has synchronised the device, sg_trace_read copies up to n records out (returns their number, negative on error) and
  * sg_trace_end releases the events.  Record: kind 0 = aggregation (a = C, b = epilogue operands, c = rows processed),
- * 1 = product C = A B^T / A B (a = M, b = N, c = K), 2 = weight gradient A^T B (a = M, b = N, c = Kp); engine 0 = the
+ * 1 = product C = A B^T / A B (a = M, b = N, c = K), 2 = weight gradient A^T B (a = M, b = N, c = Kp), 3 = MeshPool / MeshUnpool pass and their transposes (sg_pool_mean,
+ * sg_unpool, *_bwd: a = C, b = rows written, c = rows read); engine 0 = the
  * library's aggregation kernels, 1 = own MFMA kernels, 2 = thin-product and small-weight kernels (vector ALUs: thin_gemm.hip, gemm_mid.hip), 3 = BLAS library, 4 = split-bf16 MFMA kernels
  * (float32 features). */
 typedef struct sg_trace_record {

@@ -164,12 +164,17 @@ _SIGNATURES = {
     "sg_comm_available": (c_int, []),
     "sg_comm_unique_id": (c_int, [c_void_p]),
     "sg_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_void_p)]),
+    "sg_comm_share": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_void_p)]),
     "sg_comm_destroy": (c_int, [c_void_p]),
     "sg_halo_exchange": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sg_comm_all_reduce_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "sg_comm_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sg_part_step_sizeof": (c_int64, []),
     "sg_part_run": (c_int, [c_void_p, POINTER(sg_part_step), c_int64, c_void_p]),
+    "sg_part_failed_step": (c_int64, []),
+    "sg_comm_test_stub": (c_int, [c_int]),
+    "sg_comm_test_fail_send": (c_int, [c_int]),
+    "sg_comm_test_log": (c_int64, [POINTER(c_int64), c_int64, POINTER(c_int64)]),
     "sg_block_chain_forward": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
     "sg_block_chain_backward": (c_int, [POINTER(sg_block), c_int64, c_void_p]),
     "sg_trace_begin": (c_int, [c_int64, c_int]),
@@ -1267,10 +1272,32 @@ class Comm:
         with _on_device(self.device):
             _check(_lib.sg_comm_all_gather(self._h, inp.data_ptr(), out.data_ptr(), nb, _stream(inp)), "sg_comm_all_gather")
 
+    def share(self, send_rows, recv_rows) -> "Comm":
+        """A second handle on the SAME RCCL communicator with other per-peer row counts (``sg_comm_share``): one exchange
+        layout per MGCN level without one ncclCommInitRank per level.  Not a collective call."""
+        other = object.__new__(Comm)
+        other.rank, other.world, other.device = self.rank, self.world, self.device
+        srows = (c_int64 * self.world)(*[int(v) for v in send_rows])
+        rrows = (c_int64 * self.world)(*[int(v) for v in recv_rows])
+        h = c_void_p()
+        _check(load().sg_comm_share(self._h, srows, rrows, ctypes.byref(h)), "sg_comm_share")
+        other._h = h
+        return other
+
     def close(self) -> None:
         h, self._h = self._h, None
         if h and _lib is not None:
             _lib.sg_comm_destroy(h)
+
+
+class PartRunError(SemigcnLibraryError):
+    """sg_part_run stopped at ``step`` with the steps before it already enqueued: this rank's collective sequence is out of
+    step with its peers' -- the job must be aborted (a retry on another communicator would meet peers that are somewhere else
+    in the schedule)."""
+
+    def __init__(self, msg: str, step: int):
+        super().__init__(msg)
+        self.step = step
 
 
 def part_run(comm: Optional["Comm"], steps, n: int, stream: int, device: Optional[torch.device] = None) -> None:
@@ -1278,7 +1305,11 @@ def part_run(comm: Optional["Comm"], steps, n: int, stream: int, device: Optiona
     with (_NO_GUARD if device is None else _on_device(device)):
         rc = _lib.sg_part_run(comm._h if comm is not None else None, steps, n, stream)
     if rc:
-        _check(rc, "sg_part_run")
+        step = int(_lib.sg_part_failed_step())
+        try:
+            _check(rc, "sg_part_run")
+        except SemigcnLibraryError as e:
+            raise PartRunError(str(e), step) from None
 
 
 def block_chain_backward(blks, n: int, stream: int, device: Optional[torch.device] = None) -> None:
@@ -1297,8 +1328,8 @@ def block_chain_backward(blks, n: int, stream: int, device: Optional[torch.devic
 class LaunchTrace:
     """Per-launch HIP-event timing INSIDE the library (sg_trace_*): the aggregations and dense products a block call
     launches, which no Python-side timer can bracket any more.  ``with LaunchTrace(capacity) as t: ...`` then, after a
-    device synchronize, ``t.records()`` -> list of dicts (kind "agg" / "nt" / "tn", dtype, engine, a, b, c, ms)."""
-    KINDS = {0: "agg", 1: "nt", 2: "tn"}
+    device synchronize, ``t.records()`` -> list of dicts (kind "agg" / "nt" / "tn" / "pool", dtype, engine, a, b, c, ms)."""
+    KINDS = {0: "agg", 1: "nt", 2: "tn", 3: "pool"}
     ENGINES = {0: "agg", 1: "mfma", 2: "thin", 3: "blas", 4: "split"}
 
     def __init__(self, capacity: int = 1 << 16, kinds=("agg", "nt", "tn")):

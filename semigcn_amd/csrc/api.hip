@@ -399,6 +399,7 @@ SG_API int sg_pool_destroy(sg_pool* p) {
 SG_API int sg_pool_mean(const sg_pool* p, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t C, int dtype,
                  void* stream) {
   SG_REQUIRE(p != nullptr, "sg_pool_mean: null pool");
+  TraceScope trace(3, dtype, 0, C, p->by_coarse.n_rows, p->by_coarse.n_cols, (hipStream_t)stream);
   return run_csr(p->by_coarse, p->inv_count, nullptr, X, ldx, nullptr, 0, nullptr, 0, Y, ldy, C, dtype,
                  1.f, 0.f, 0.f, (hipStream_t)stream);
 }
@@ -406,6 +407,7 @@ SG_API int sg_pool_mean(const sg_pool* p, const void* X, int64_t ldx, void* Y, i
 SG_API int sg_pool_mean_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* dX, int64_t lddx, int64_t C,
                      int dtype, void* stream) {
   SG_REQUIRE(p != nullptr, "sg_pool_mean_bwd: null pool");
+  TraceScope trace(3, dtype, 0, C, p->by_fine.n_rows, p->by_fine.n_cols, (hipStream_t)stream);
   return run_csr(p->by_fine, nullptr, p->inv_count, dY, lddy, nullptr, 0, nullptr, 0, dX, lddx, C, dtype,
                  1.f, 0.f, 0.f, (hipStream_t)stream);
 }
@@ -413,6 +415,7 @@ SG_API int sg_pool_mean_bwd(const sg_pool* p, const void* dY, int64_t lddy, void
 SG_API int sg_unpool(const sg_pool* p, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t C, int dtype,
               void* stream) {
   SG_REQUIRE(p != nullptr, "sg_unpool: null pool");
+  TraceScope trace(3, dtype, 0, C, p->by_fine.n_rows, p->by_fine.n_cols, (hipStream_t)stream);
   return run_csr(p->by_fine, nullptr, nullptr, X, ldx, nullptr, 0, nullptr, 0, Y, ldy, C, dtype, 1.f, 0.f,
                  0.f, (hipStream_t)stream);
 }
@@ -420,6 +423,7 @@ SG_API int sg_unpool(const sg_pool* p, const void* X, int64_t ldx, void* Y, int6
 SG_API int sg_unpool_bwd(const sg_pool* p, const void* dY, int64_t lddy, void* dX, int64_t lddx, int64_t C,
                   int dtype, void* stream) {
   SG_REQUIRE(p != nullptr, "sg_unpool_bwd: null pool");
+  TraceScope trace(3, dtype, 0, C, p->by_coarse.n_rows, p->by_coarse.n_cols, (hipStream_t)stream);
   return run_csr(p->by_coarse, nullptr, nullptr, dY, lddy, nullptr, 0, nullptr, 0, dX, lddx, C, dtype,
                  1.f, 0.f, 0.f, (hipStream_t)stream);
 }

@@ -20,15 +20,27 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #include <rccl/rccl.h>
 
 #include "sg_common.h"
 
-struct sg_comm {
+// One RCCL communicator per process group, shared by every sg_comm made from it (sg_comm_share): a partitioned MGCN has one
+// exchange layout per level and used to pay an ncclCommInitRank -- and its buffers -- for each of them.
+struct sg_comm_core {
   ncclComm_t comm = nullptr;
+  ~sg_comm_core();
+};
+
+struct sg_comm {
+  std::shared_ptr<sg_comm_core> core;
+  ncclComm_t comm = nullptr;                       // == core->comm
   int rank = 0, world = 1;
   std::vector<int64_t> send_rows, recv_rows;      // per peer, rows of one exchange (pad rows included)
 };
@@ -56,6 +68,139 @@ std::mutex g_rccl_mu;
 RcclApi g_rccl;
 bool g_rccl_tried = false;
 
+// ---- an in-process stand-in for RCCL (sg_comm_test_stub): TEST INFRASTRUCTURE ---------------------------------------------
+// No box available to this build has two GPUs, so the one thing a one-rank communicator cannot show -- a wrong peer offset in
+// exchange() -- is checked on the CPU: with the stub installed, every "rank" is a communicator of THIS process, its buffers
+// are host memory, and the calls of all ranks (made one after the other from one thread) meet in a mailbox: a send from a to
+// b is copied into the matching receive of b from a as soon as both have been posted (FIFO per ordered pair, as RCCL matches
+// them inside a group), an all-reduce / all-gather completes when the last rank has called.  Every call is logged
+// (sg_comm_test_log) so that a test can also compare (pointer, bytes, peer) with the split lists of dist.FoldedLayout.
+struct StubComm {
+  int rank, world, group;
+  int64_t coll_seq = 0;
+};
+struct StubLogRec {
+  int64_t kind, rank, peer, ptr, bytes;             // kind 0 send, 1 recv, 2 all-reduce, 3 all-gather, 4 group start, 5 group end
+};
+struct StubColl {
+  std::vector<std::tuple<int, const void*, void*, size_t>> parts;      // (rank, in, out, count)
+};
+struct StubState {
+  std::mutex mu;
+  bool on = false;
+  int next_group = 1;
+  int fail_send_after = -1;                          // test hook: the n-th ncclSend from now fails (ncclInternalError)
+  int64_t mismatched = 0;
+  std::map<std::tuple<int, int, int>, std::deque<std::pair<const void*, size_t>>> sends;    // (group, from, to)
+  std::map<std::tuple<int, int, int>, std::deque<std::pair<void*, size_t>>> recvs;
+  std::map<std::tuple<int, int64_t, int>, StubColl> colls;                                  // (group, seq, kind)
+  std::vector<StubLogRec> log;
+  int open_groups = 0;
+};
+StubState g_stub;
+
+void stub_match(int group, int from, int to) {
+  auto& sq = g_stub.sends[{group, from, to}];
+  auto& rq = g_stub.recvs[{group, from, to}];
+  while (!sq.empty() && !rq.empty()) {
+    if (sq.front().second != rq.front().second) ++g_stub.mismatched;
+    memcpy(rq.front().first, sq.front().first, std::min(sq.front().second, rq.front().second));
+    sq.pop_front();
+    rq.pop_front();
+  }
+}
+size_t stub_elem(ncclDataType_t t) { return t == ncclFloat32 ? 4 : 1; }
+ncclResult_t stub_GetUniqueId(ncclUniqueId* id) {
+  std::lock_guard<std::mutex> lock(g_stub.mu);
+  memset(id, 0, sizeof(*id));
+  const int grp = g_stub.next_group++;
+  memcpy(id, &grp, sizeof(grp));
+  return ncclSuccess;
+}
+ncclResult_t stub_CommInitRank(ncclComm_t* out, int world, ncclUniqueId id, int rank) {
+  int grp = 0;
+  memcpy(&grp, &id, sizeof(grp));
+  *out = (ncclComm_t) new StubComm{rank, world, grp};
+  return ncclSuccess;
+}
+ncclResult_t stub_CommDestroy(ncclComm_t c) {
+  delete (StubComm*)c;
+  return ncclSuccess;
+}
+ncclResult_t stub_GroupStart() {
+  std::lock_guard<std::mutex> lock(g_stub.mu);
+  ++g_stub.open_groups;
+  g_stub.log.push_back({4, -1, -1, 0, 0});
+  return ncclSuccess;
+}
+ncclResult_t stub_GroupEnd() {
+  std::lock_guard<std::mutex> lock(g_stub.mu);
+  --g_stub.open_groups;
+  g_stub.log.push_back({5, -1, -1, 0, 0});
+  return ncclSuccess;
+}
+ncclResult_t stub_Send(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t) {
+  StubComm* c = (StubComm*)comm;
+  std::lock_guard<std::mutex> lock(g_stub.mu);
+  if (g_stub.fail_send_after >= 0 && g_stub.fail_send_after-- == 0) return ncclInternalError;
+  g_stub.log.push_back({0, c->rank, peer, (int64_t)(uintptr_t)buf, (int64_t)(count * stub_elem(t))});
+  g_stub.sends[{c->group, c->rank, peer}].push_back({buf, count * stub_elem(t)});
+  stub_match(c->group, c->rank, peer);
+  return ncclSuccess;
+}
+ncclResult_t stub_Recv(void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t) {
+  StubComm* c = (StubComm*)comm;
+  std::lock_guard<std::mutex> lock(g_stub.mu);
+  g_stub.log.push_back({1, c->rank, peer, (int64_t)(uintptr_t)buf, (int64_t)(count * stub_elem(t))});
+  g_stub.recvs[{c->group, peer, c->rank}].push_back({buf, count * stub_elem(t)});
+  stub_match(c->group, peer, c->rank);
+  return ncclSuccess;
+}
+ncclResult_t stub_AllReduce(const void* in, void* out, size_t count, ncclDataType_t t, ncclRedOp_t, ncclComm_t comm, hipStream_t) {
+  StubComm* c = (StubComm*)comm;
+  std::lock_guard<std::mutex> lock(g_stub.mu);
+  if (t != ncclFloat32) return ncclInvalidArgument;
+  g_stub.log.push_back({2, c->rank, -1, (int64_t)(uintptr_t)out, (int64_t)(count * 4)});
+  StubColl& k = g_stub.colls[{c->group, c->coll_seq++, 2}];
+  k.parts.emplace_back(c->rank, in, out, count);
+  if ((int)k.parts.size() == c->world) {
+    std::vector<double> sum(count, 0.0);
+    for (auto& p : k.parts) {
+      if (std::get<3>(p) != count) ++g_stub.mismatched;
+      for (size_t i = 0; i < std::min(count, std::get<3>(p)); ++i) sum[i] += ((const float*)std::get<1>(p))[i];
+    }
+    for (auto& p : k.parts)
+      for (size_t i = 0; i < std::min(count, std::get<3>(p)); ++i) ((float*)std::get<2>(p))[i] = (float)sum[i];
+    k.parts.clear();
+  }
+  return ncclSuccess;
+}
+ncclResult_t stub_AllGather(const void* in, void* out, size_t count, ncclDataType_t t, ncclComm_t comm, hipStream_t) {
+  StubComm* c = (StubComm*)comm;
+  std::lock_guard<std::mutex> lock(g_stub.mu);
+  const size_t bytes = count * stub_elem(t);
+  g_stub.log.push_back({3, c->rank, -1, (int64_t)(uintptr_t)out, (int64_t)bytes});
+  StubColl& k = g_stub.colls[{c->group, c->coll_seq++, 3}];
+  k.parts.emplace_back(c->rank, in, out, bytes);
+  if ((int)k.parts.size() == c->world) {
+    std::vector<std::vector<char>> ins(c->world);
+    for (auto& p : k.parts) {
+      if (std::get<3>(p) != bytes) ++g_stub.mismatched;
+      ins[std::get<0>(p)].assign((const char*)std::get<1>(p), (const char*)std::get<1>(p) + bytes);
+    }
+    for (auto& p : k.parts)
+      for (int q = 0; q < c->world; ++q) memcpy((char*)std::get<2>(p) + q * bytes, ins[q].data(), bytes);
+    k.parts.clear();
+  }
+  return ncclSuccess;
+}
+const char* stub_GetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "stub: injected / invalid"; }
+ncclResult_t stub_GetVersion(int* v) {
+  *v = 0;
+  return ncclSuccess;
+}
+RcclApi g_stub_api;
+
 template <class F>
 bool bind(void* so, const char* name, F* out) {
   *out = (F)dlsym(so, name);
@@ -64,6 +209,7 @@ bool bind(void* so, const char* name, F* out) {
 
 const RcclApi& rccl() {
   std::lock_guard<std::mutex> lock(g_rccl_mu);
+  if (g_stub.on) return g_stub_api;
   if (g_rccl_tried) return g_rccl;
   g_rccl_tried = true;
   void* so = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);           // the copy the process already uses (PyTorch's)
@@ -111,15 +257,28 @@ int exchange(sg_comm* c, const void* send, void* recv, int64_t row_bytes, hipStr
   const RcclApi& api = *ap;
   SG_NCCL_TRY(api.GroupStart());
   int64_t so = 0, ro = 0;
+  // An error between GroupStart and GroupEnd must not leave the calling thread's group open: every later RCCL call of the
+  // thread (torch.distributed's fallback collectives included) would be queued into it and hang instead of failing.
+#define SG_NCCL_TRY_IN_GROUP(expr)                                                                        \
+  do {                                                                                                    \
+    ncclResult_t r__ = (expr);                                                                            \
+    if (r__ != ncclSuccess) {                                                                             \
+      (void)api.GroupEnd();                                                                               \
+      set_error("%s failed for peer %d of %d: %s (%s:%d); the group was closed", #expr, q, c->world,      \
+                api.GetErrorString(r__), __FILE__, __LINE__);                                             \
+      return SG_ERR_HIP;                                                                                  \
+    }                                                                                                     \
+  } while (0)
   for (int q = 0; q < c->world; ++q) {
     const int64_t sb = c->send_rows[q] * row_bytes, rb = c->recv_rows[q] * row_bytes;
     // (rows for the rank itself are legal -- a send and a receive to one's own rank inside a group is a copy -- and let a
     //  ONE-rank communicator drive this whole path on a single GPU: tests/test_gpu_scale.py)
-    if (sb) SG_NCCL_TRY(api.Send((const char*)send + so, (size_t)sb, ncclInt8, q, c->comm, stream));
-    if (rb) SG_NCCL_TRY(api.Recv((char*)recv + ro, (size_t)rb, ncclInt8, q, c->comm, stream));
+    if (sb) SG_NCCL_TRY_IN_GROUP(api.Send((const char*)send + so, (size_t)sb, ncclInt8, q, c->comm, stream));
+    if (rb) SG_NCCL_TRY_IN_GROUP(api.Recv((char*)recv + ro, (size_t)rb, ncclInt8, q, c->comm, stream));
     so += sb;
     ro += rb;
   }
+#undef SG_NCCL_TRY_IN_GROUP
   SG_NCCL_TRY(api.GroupEnd());
   return SG_OK;
 }
@@ -127,7 +286,16 @@ int exchange(sg_comm* c, const void* send, void* recv, int64_t row_bytes, hipStr
 }  // namespace
 }  // namespace sg
 
+sg_comm_core::~sg_comm_core() {
+  const sg::RcclApi& api = sg::rccl();
+  if (api.ok && comm) api.CommDestroy(comm);
+}
+
 using namespace sg;
+
+namespace {
+thread_local int64_t t_failed_step = -1;
+}
 
 extern "C" {
 
@@ -168,21 +336,39 @@ SG_API int sg_comm_create(const void* id128, int rank, int world, const int64_t*
   }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
-  ncclResult_t r = api.CommInitRank(&c->comm, world, id, rank);
+  c->core = std::make_shared<sg_comm_core>();
+  ncclResult_t r = api.CommInitRank(&c->core->comm, world, id, rank);
   if (r != ncclSuccess) {
     set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, api.GetErrorString(r));
+    c->core->comm = nullptr;
     delete c;
     return SG_ERR_HIP;
   }
+  c->comm = c->core->comm;
+  *out = c;
+  return SG_OK;
+}
+
+SG_API int sg_comm_share(const sg_comm* base, const int64_t* send_rows, const int64_t* recv_rows, sg_comm** out) {
+  SG_REQUIRE(out != nullptr, "sg_comm_share: null output");
+  *out = nullptr;
+  SG_REQUIRE(base != nullptr && base->core && send_rows && recv_rows, "sg_comm_share: null argument");
+  for (int q = 0; q < base->world; ++q)
+    SG_REQUIRE(send_rows[q] >= 0 && recv_rows[q] >= 0 && (q != base->rank || send_rows[q] == recv_rows[q]),
+               "sg_comm_share: bad row counts for peer %d", q);
+  sg_comm* c = new sg_comm;
+  c->core = base->core;                                  // the RCCL communicator lives as long as its last user
+  c->comm = base->comm;
+  c->rank = base->rank;
+  c->world = base->world;
+  c->send_rows.assign(send_rows, send_rows + base->world);
+  c->recv_rows.assign(recv_rows, recv_rows + base->world);
   *out = c;
   return SG_OK;
 }
 
 SG_API int sg_comm_destroy(sg_comm* c) {
-  if (!c) return SG_OK;
-  const RcclApi& api = rccl();
-  if (api.ok && c->comm) api.CommDestroy(c->comm);
-  delete c;
+  delete c;                                              // (the shared core destroys the RCCL communicator with its last user)
   return SG_OK;
 }
 
@@ -220,9 +406,13 @@ SG_API int sg_comm_all_gather(sg_comm* c, const void* in, void* out, int64_t byt
 
 SG_API int64_t sg_part_step_sizeof(void) { return (int64_t)sizeof(sg_part_step); }
 
+SG_API int64_t sg_part_failed_step(void) { return t_failed_step; }
+
 SG_API int sg_part_run(sg_comm* c, const sg_part_step* steps, int64_t n, void* stream) {
+  t_failed_step = -1;
   SG_REQUIRE(n >= 0 && (n == 0 || steps != nullptr), "sg_part_run: bad argument");
   for (int64_t i = 0; i < n; ++i) {
+    t_failed_step = i;                                    // (the SG_REQUIREs below return from inside the loop)
     const sg_part_step& s = steps[i];
     int rc = SG_OK;
     switch (s.kind) {
@@ -245,9 +435,74 @@ SG_API int sg_part_run(sg_comm* c, const sg_part_step* steps, int64_t n, void* s
         set_error("sg_part_run: step %lld has kind %d", (long long)i, s.kind);
         return SG_ERR_INVALID;
     }
-    if (rc != SG_OK) return rc;
+    if (rc != SG_OK) {
+      // steps [0, i) are enqueued and the peers will enqueue theirs: the collective sequence of this rank is now out of step
+      // with the group's -- the host must abort the job, not retry on another communicator (sg_part_failed_step() = i)
+      const std::string why = sg_last_error();
+      set_error("sg_part_run: step %lld of %lld (kind %d) failed after %lld steps were enqueued: %s", (long long)i, (long long)n,
+                s.kind, (long long)i, why.c_str());
+      return rc;
+    }
   }
+  t_failed_step = -1;
   return SG_OK;
+}
+
+// ---- test infrastructure: the in-process RCCL stand-in (see StubState) ---------------------------------------------------------
+SG_API int sg_comm_test_stub(int on) {
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  std::lock_guard<std::mutex> lock2(g_stub.mu);
+  if (on) {
+    g_stub_api.GetUniqueId = stub_GetUniqueId;
+    g_stub_api.CommInitRank = stub_CommInitRank;
+    g_stub_api.CommDestroy = stub_CommDestroy;
+    g_stub_api.GroupStart = stub_GroupStart;
+    g_stub_api.GroupEnd = stub_GroupEnd;
+    g_stub_api.Send = stub_Send;
+    g_stub_api.Recv = stub_Recv;
+    g_stub_api.AllReduce = stub_AllReduce;
+    g_stub_api.AllGather = stub_AllGather;
+    g_stub_api.GetErrorString = stub_GetErrorString;
+    g_stub_api.GetVersion = stub_GetVersion;
+    g_stub_api.ok = true;
+  }
+  g_stub.on = on != 0;
+  g_stub.sends.clear();
+  g_stub.recvs.clear();
+  g_stub.colls.clear();
+  g_stub.log.clear();
+  g_stub.mismatched = 0;
+  g_stub.open_groups = 0;
+  g_stub.fail_send_after = -1;
+  return SG_OK;
+}
+
+SG_API int sg_comm_test_fail_send(int nth) {
+  std::lock_guard<std::mutex> lock(g_stub.mu);
+  g_stub.fail_send_after = nth;
+  return SG_OK;
+}
+
+// out: n records of five int64 {kind, rank, peer, pointer, bytes}; returns the number of records logged since the stub was
+// installed (copies min(n, that)); state[0] = unmatched sends + receives + incomplete collectives, state[1] = size mismatches,
+// state[2] = groups left open
+SG_API int64_t sg_comm_test_log(int64_t* out, int64_t n, int64_t* state) {
+  std::lock_guard<std::mutex> lock(g_stub.mu);
+  const int64_t have = (int64_t)g_stub.log.size();
+  for (int64_t i = 0; i < have && i < n && out; ++i) {
+    const StubLogRec& r = g_stub.log[i];
+    out[5 * i + 0] = r.kind; out[5 * i + 1] = r.rank; out[5 * i + 2] = r.peer; out[5 * i + 3] = r.ptr; out[5 * i + 4] = r.bytes;
+  }
+  if (state) {
+    int64_t open = 0;
+    for (auto& kv : g_stub.sends) open += (int64_t)kv.second.size();
+    for (auto& kv : g_stub.recvs) open += (int64_t)kv.second.size();
+    for (auto& kv : g_stub.colls) open += (int64_t)kv.second.parts.size();
+    state[0] = open;
+    state[1] = g_stub.mismatched;
+    state[2] = g_stub.open_groups;
+  }
+  return have;
 }
 
 }  // extern "C"

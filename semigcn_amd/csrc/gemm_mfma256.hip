@@ -30,6 +30,15 @@
 //    vmcnt(8 + 16) instead of vmcnt(8): exactly 16 stores are issued per wavefront per full tile (a partial tile is the
 //    last of its stream: nothing follows it).
 //
+// Round 6, measured and not kept (profiles/r06_gemm256_two_phase_ab.txt, r06_gemm_stream256_ab.txt, r06_pmc_gemm256.json):
+// TWO phases per K step (four barriers instead of eight, 32-MFMA segments; identical bits) ran 1-2 % slower at N <= 512 and
+// 12-14 % slower at N = 768; A streamed global -> VGPR as MFMA fragments with only B through an LDS ring (one barrier per K
+// block) ran 1.5-1.8 x slower -- a fragment load is 64 separate 16-byte requests to the address unit.  The counters say why
+// neither helps: matrix pipe busy 0.41-0.47 at 1.81-1.98 GHz here, 0.52 at 1.67 GHz in gemm_tn_256, 0.51 at 1.74 GHz in
+// hipBLASLt's kernel for the same product -- busy x clock = 0.81-0.88 GHz in all three (0.34-0.37 of the nominal peak): a bf16
+// product at this flop : byte mix runs into the chip's power envelope whatever the schedule; the split kernel (six MFMAs per
+// operand byte moved) reaches 1.4.
+//
 // Column tiles of one row tile are walked by sibling workgroups on ONE XCD (block ids b, b + 8, ..) in step, so A leaves
 // HBM once and is re-read through that XCD's L2.  Needs K % 64 == 0 and N % 256 == 0; everything else stays with
 // sg::gemm_nt_bf16.

@@ -33,11 +33,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--nt-only", action="store_true")
+    ap.add_argument("--only", default=None, help="comma-separated variants to run (tile256,tile128,blas)")
+    ap.add_argument("--shapes", default=None, help="comma-separated indices into SHAPES")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M = a.V
     res = []
-    for name, N, K in SHAPES[:5]:
+    for name, N, K in ([SHAPES[int(i)] for i in a.shapes.split(",")] if a.shapes else SHAPES[:5]):
         A = torch.randn(M, K, device=dev).to(torch.bfloat16)
         B = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
         bias = torch.randn(N, device=dev)
@@ -51,6 +54,8 @@ def main():
                 capi.tuning_set(capi.TUNE_GEMM_TILE, 0)
             return run
         variants = {"tile256": own(3), "tile128": own(1), "blas": lambda: torch.addmm(bias16, A, B.t(), out=out)}
+        if a.only:
+            variants = {k: v for k, v in variants.items() if k in a.only.split(",")}
         times = {k: [] for k in variants}
         for rnd in range(a.rounds + 1):
             for k, fn in variants.items():
@@ -62,7 +67,7 @@ def main():
                 torch.cuda.synchronize()
                 if rnd:
                     times[k].append(e0.elapsed_time(e1) / a.reps)
-        own(3)()
+        (own(3) if "tile256" in variants else list(variants.values())[0])()
         ref = A[:4096].float() @ B.float().t() + bias
         err = float((out[:4096].float() - ref).abs().max() / ref.abs().max())
         flops, byts = 2.0 * M * N * K, (M * K + M * N) * 2.0
@@ -72,12 +77,12 @@ def main():
             row[k] = {"ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1), "mfma_frac": round(flops / ms / 1e9 / 2500.0, 4),
                       "hbm_frac": round(byts / ms / 1e6 / 8000.0, 4)}
         res.append(row)
-        print(f"{name:40s} 256: {row['tile256']['ms']:.3f} ms ({row['tile256']['mfma_frac']:.3f} mfma, {row['tile256']['hbm_frac']:.3f} hbm)  "
-              f"128: {row['tile128']['ms']:.3f}  blas: {row['blas']['ms']:.3f} ({row['blas']['mfma_frac']:.3f})  err {err:.1e}", flush=True)
+        print(f"{name:40s} " + "  ".join(f"{k}: {row[k]['ms']:.3f} ms ({row[k]['mfma_frac']:.3f} mfma, {row[k]['hbm_frac']:.3f} hbm)"
+                                         for k in variants) + f"  err {err:.1e}", flush=True)
         del A, out
     # the weight gradients of the same layers: out[N, Kp] = A[M, N]^T B[M, Kp]
     from semigcn_amd import functional as F_sg
-    for name, N, Kp in (("L5/L8 dW  [256,V]x[V,768]", 256, 768), ("L6 dW  [512,V]x[V,768]", 512, 768), ("L7 dW  [768,V]x[V,512]", 768, 512)):
+    for name, N, Kp in () if a.nt_only else (("L5/L8 dW  [256,V]x[V,768]", 256, 768), ("L6 dW  [512,V]x[V,768]", 512, 768), ("L7 dW  [768,V]x[V,512]", 768, 512)):
         A = torch.randn(M, N, device=dev).to(torch.bfloat16)
         B = torch.randn(M, Kp, device=dev).to(torch.bfloat16)
 
@@ -97,6 +102,8 @@ def main():
             finally:
                 F_sg.USE_MFMA_GEMM = old
         variants = {"tile256": own(3), "tile128": own(1), "blas": blas}
+        if a.only:
+            variants = {k: v for k, v in variants.items() if k in a.only.split(",")}
         times = {k: [] for k in variants}
         for rnd in range(a.rounds + 1):
             for k, fn in variants.items():
@@ -109,14 +116,16 @@ def main():
                 if rnd:
                     times[k].append(e0.elapsed_time(e1) / a.reps)
         err = float((own(3)() - blas()).abs().max() / blas().abs().max())
+        for k in ("tile256", "tile128", "blas"):
+            row_fill = k in variants
         flops = 2.0 * M * N * Kp
         row = {"product": name, "M": M, "N": N, "K": Kp, "rel_diff_256_vs_blas": err}
         for k in variants:
             ms = float(np.median(times[k]))
             row[k] = {"ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1), "mfma_frac": round(flops / ms / 1e9 / 2500.0, 4)}
         res.append(row)
-        print(f"{name:40s} 256: {row['tile256']['ms']:.3f} ms ({row['tile256']['mfma_frac']:.3f} mfma)  128: {row['tile128']['ms']:.3f}  "
-              f"blas: {row['blas']['ms']:.3f} ({row['blas']['mfma_frac']:.3f})  diff {err:.1e}", flush=True)
+        print(f"{name:40s} " + "  ".join(f"{k}: {row[k]['ms']:.3f} ms ({row[k]['mfma_frac']:.3f} mfma)" for k in variants)
+              + f"  diff {err:.1e}", flush=True)
         del A, B
     if a.json:
         os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)

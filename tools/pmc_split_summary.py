@@ -12,19 +12,21 @@ import sys
 
 def main():
     root, out = sys.argv[1], sys.argv[2]
+    pat = r"(gemm_[nt][nt]_f32s(<[^>]*>)?|Cijk_\w{4}_\w{4})" if len(sys.argv) < 4 else "(" + sys.argv[3] + r"|Cijk_\w{4}_\w{4})"
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(root + "/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            m = re.search(r"(gemm_[nt][nt]_f32s(<[^>]*>)?|Cijk_\w{4}_\w{4})", r["Kernel_Name"])
+            m = re.search(pat, r["Kernel_Name"])
             if m:
                 key = m.group(1) + " grid=" + r.get("Grid_Size", "?")
                 acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     dur = collections.defaultdict(list)
     for f in glob.glob(root + "/trace/**/*_kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            m = re.search(r"(gemm_[nt][nt]_f32s(<[^>]*>)?|Cijk_\w{4}_\w{4})", r["Kernel_Name"])
+            m = re.search(pat, r["Kernel_Name"])
             if m:
-                dur[m.group(1) + " grid=" + r.get("Grid_Size", "?")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                grid = r.get("Grid_Size") or str(int(r.get("Grid_Size_X", 0)) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1))
+                dur[m.group(1) + " grid=" + grid].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     res = {}
     for k, cs in sorted(acc.items()):
         d = {c: statistics.mean(v) for c, v in cs.items()}
@@ -46,7 +48,7 @@ def main():
             q["SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0) / d["SQ_LDS_IDX_ACTIVE"], 4)
         d["quotients"] = q
         res[k] = d
-    json.dump({"command": "tools/pmc_split.sh", "kernels": res}, open(out, "w"), indent=1)
+    json.dump({"command": "tools/pmc_split.sh" if len(sys.argv) < 4 else "tools/pmc_gemm256.sh", "kernels": res}, open(out, "w"), indent=1)
     print("wrote", out, len(res), "kernels")
 
 
