@@ -395,7 +395,7 @@ SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, in
  *   sg_gemm_nt_f32:  C[M, N] = A[M, K] op(W) (+ bias[N]); W element (n, k) at W[n * w_rs + k * w_cs] -- (ldw, 1) for the
  *                    [N, K] weights of the forward product, (1, ldw) for a [K, N] matrix (the input gradient dOut * Wcat
  *                    without a transposed copy).  workspace: sg_gemm_nt_f32_workspace(N, K) bytes (the split image of W,
- *                    rebuilt by every call: microseconds).  K % 32 == 0, K >= 64, N % 4 == 0, N >= 64, M >= 256, row
+ *                    rebuilt by every call: microseconds).  K % 32 == 0, K >= 64, N % 4 == 0, N >= 64, M >= 128, row
  *                    strides multiples of 4, 16-byte aligned buffers: sg_gemm_nt_f32_supported; else SG_ERR_INVALID.
  *   sg_gemm_tn_f32:  out[N, Kp] (row stride ldo) = A[M, N]^T B[M, Kp], a reduction over all M vertices; workspace: float32
  *                    [sg_gemm_tn_f32_slabs(M, N, Kp), N_pad, Kp_pad] slab partials (sg_gemm_tn_f32_workspace bytes), added
@@ -405,6 +405,12 @@ SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, in
  * no workspace for nt, sg_gemm_tn_f32_workspace bytes of block partials for tn, same deterministic reduce).
  * ------------------------------------------------------------------------- */
 SG_API int sg_gemm_nt_f32_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
+/* 1 when sg_gemm_nt_f32 is the faster choice for a supported product of this size, 0 when the caller's BLAS library is: the ONE
+ * place that rule lives (sg_block_* and the per-module host path both ask here).  Since round 6 a product with fewer than 16 K
+ * rows runs on 128 x 128 tiles (four wavefronts, two workgroups per CU); the answer is 0 only where the A/B still loses: fewer
+ * than 128 such tiles over K >= 384 (at 5 K rows: [V,768]x[768,256] and [V,384]x[384,256]).  SG_TUNE_F32_ENGINE bit 5 switches
+ * the variant off (then: 1 from 16 384 rows on, or always with bit 4). */
+SG_API int sg_gemm_nt_f32_pays(int64_t M, int64_t N, int64_t K);
 SG_API int64_t sg_gemm_nt_f32_workspace(int64_t N, int64_t K);
 SG_API int sg_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
                           int64_t ldc, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream);
@@ -689,8 +695,8 @@ enum sg_tune_knob {
   SG_TUNE_F32_ENGINE = 8,  /* dense products on float32 features: 0 (default) = the split-bf16 MFMA kernels (csrc/gemm_split.hip)
                               wherever they take the shape, the BLAS library for the rest; bit 0 = the BLAS library for all of
                               them (A/B switch); bits 1 / 2 / 3 = only the forward / input-gradient / weight-gradient products go to the
-                              library (bisecting aid); bit 4 = the split kernels also below 16 K rows, where the library is
-                              faster on the forward / input-gradient products (A/B switch) */
+                              library (bisecting aid); bit 5 = no 128-row tiles: forward / input-gradient products below 16 K rows
+                              go to the library as in round 5 (A/B switch) -- unless bit 4 sends them to the 256-row kernel */
   SG_TUNE_BN_ROWS = 9      /* BatchNorm + activation apply passes: 0 (default) = by shape (rows of >= 1 KB, backward passes from 512 B:
                               every workgroup walks ONE contiguous range of rows; else row groups strided over the grid), 1 = contiguous
                               everywhere, 2 = strided everywhere (A/B switch) */

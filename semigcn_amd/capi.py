@@ -109,6 +109,7 @@ _SIGNATURES = {
     "sg_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                            c_int, c_void_p, c_void_p]),
     "sg_gemm_nt_f32_supported": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
+    "sg_gemm_nt_f32_pays": (c_int, [c_int64, c_int64, c_int64]),
     "sg_gemm_nt_f32_workspace": (c_int64, [c_int64, c_int64]),
     "sg_gemm_nt_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                c_int64, c_void_p, c_int64, c_void_p]),
@@ -823,6 +824,11 @@ def gemm_nt_f32_supported(A: torch.Tensor, N: int, ldc: Optional[int] = None) ->
         return False
     M, K = A.shape
     return bool(_sizes("sg_gemm_nt_f32_supported", int(M), int(N), int(K), int(A.stride(0)), int(ldc if ldc is not None else N)))
+
+
+def gemm_nt_f32_pays(M: int, N: int, K: int) -> bool:
+    """The library's rule for "own float32 kernels or the BLAS library" (``sg_gemm_nt_f32_pays``; follows SG_TUNE_F32_ENGINE)."""
+    return bool(load().sg_gemm_nt_f32_pays(int(M), int(N), int(K)))
 
 
 def gemm_nt_f32(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,

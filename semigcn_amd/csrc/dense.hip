@@ -284,7 +284,7 @@ int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64
     TraceScope ts(1, dtype, 1, M, N, K, stream);
     return launch_gemm_nt(A, lda, Bp, ldb, bias, C, ldc, M, N, K, dtype, mom, stream);
   }
-  if (dtype == SG_F32 && split_engine_enabled(0) && split_nt_pays(M) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) && blas_ws &&
+  if (dtype == SG_F32 && split_engine_enabled(0) && split_nt_pays(M, N, K) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) && blas_ws &&
       (int64_t)blas_ws_bytes >= gemm_nt_f32s_workspace(N, K)) {
     TraceScope ts(1, dtype, 4, M, N, K, stream);
     return launch_gemm_nt_f32s((const float*)A, lda, (const float*)Bp, ldb, 1, bias, (float*)C, ldc, M, N, K, blas_ws,
@@ -318,7 +318,7 @@ int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void
     TraceScope ts(1, dtype, 1, M, N, K, stream);
     return launch_gemm_nt(A, lda, Bt, ldbt, nullptr, C, ldc, M, N, K, dtype, nullptr, stream);
   }
-  if (dtype == SG_F32 && split_engine_enabled(1) && split_nt_pays(M) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) && blas_ws &&
+  if (dtype == SG_F32 && split_engine_enabled(1) && split_nt_pays(M, N, K) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) && blas_ws &&
       (int64_t)blas_ws_bytes >= gemm_nt_f32s_workspace(N, K)) {
     TraceScope ts(1, dtype, 4, M, N, K, stream);      // B is [K, N]: element (n, k) at Bp[k * ldb + n]
     return launch_gemm_nt_f32s((const float*)A, lda, (const float*)Bp, 1, ldb, nullptr, (float*)C, ldc, M, N, K, blas_ws,

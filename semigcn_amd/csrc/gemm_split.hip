@@ -121,12 +121,18 @@ struct SplitNt {
 // each half right after the barrier that frees the slot -- measured 1-2 % faster alone on the GPU and NOT deterministic with
 // four processes sharing it: 1-6 of 60 repetitions of a product differed, tools/split_stress2.py; the cause was not found and
 // the variant was removed)
-template <int NF>
-__global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g) {
+//
+// WAVES = 4 (round 6): the same kernel on 128-row tiles -- four wavefronts, a ring of three 128-column K blocks (72 KB: two
+// workgroups per CU).  A product with few rows (the reference's own mesh sizes: 5 K vertices, the coarse levels of an MGCN) is
+// a handful of 256-row tiles on 256 CUs; 128 x 128 tiles make four times as many work items, and the BLAS library leaves the
+// float32 iteration at every size (launch_gemm_nt_f32s picks the variant by the row count).
+template <int NF, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gemm_nt_f32s(const SplitNt g) {
   constexpr int SLOT = 3 * NF * 1024;              // one K block of the column tile: 48 KB (NT = 256) / 24 KB (NT = 128)
-  constexpr int RING = NF == 16 ? 3 : 4;
+  constexpr int RING = WAVES == 4 ? 3 : (NF == 16 ? 3 : 4);
   constexpr int D = RING - 1;                      // K blocks the DMA runs ahead
-  constexpr int P = SLOT / 1024 / 8;               // DMA instructions per wavefront and K block
+  constexpr int P = SLOT / 1024 / WAVES;           // DMA instructions per wavefront and K block
+  constexpr int RT = 32 * WAVES;                   // rows of a tile
   constexpr int NSTORE = 2 * NF;                   // stores per wavefront and finished tile
   constexpr int NT = NF * 16;
   __shared__ __attribute__((aligned(1024))) uint8_t lds[RING * SLOT + NT * 4];      // the ONLY LDS object
@@ -146,9 +152,9 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
   const int total = my_tiles * nkb;
   const bool exact_stores = (ct + 1) * NT <= g.N;         // every store instruction of a full tile has an active lane
 
-  if (tid < NT) {
-    const int col = ct * NT + tid;
-    bias_s[tid] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+  for (int i = tid; i < NT; i += 64 * WAVES) {
+    const int col = ct * NT + i;
+    bias_s[i] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
   const float* pa[2];
   int rt = 0, rk = 0;                                     // A cursor: tile, K block (clamped to the stream's last step)
   auto set_tile = [&](int t) {
-    const int row0 = (stream + t * g.streams) * 256 + wave * 32 + fr;
+    const int row0 = (stream + t * g.streams) * RT + wave * 32 + fr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int r = row0 + 16 * i;
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(kSplitThreads, 1) void gemm_nt_f32s(const SplitNt g
     since = since < D ? since + 1 : D;
 
     if (++ck == nkb) {                                    // the tile is complete: + bias, store, restart the sums
-      const int row0 = (stream + ctile * g.streams) * 256 + wave * 32 + fr;
+      const int row0 = (stream + ctile * g.streams) * RT + wave * 32 + fr;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = row0 + 16 * i;
@@ -658,13 +664,27 @@ int set_split_tuning(int value) {
   g_split_variant = value;
   return SG_OK;
 }
-bool split_nt_pays(int64_t M) { return M >= kSplitNtPaysRows || (g_split_variant & 16); }      // bit 4: no row threshold (A/B)
+// (round 6: with the 128-row variant the split kernels take a float32 product at every row count; bit 5 switches that variant
+//  off -- then, as in round 5, products below kSplitNtPaysRows rows go to the BLAS library unless bit 4 is set)
+// Where the library still wins (A/B at 5 K rows, profiles/r06_gemm_f32split_5k.json): a product that makes fewer than 128 of the
+// 128 x 128 work items (half the CUs: one wavefront per SIMD, nothing to overlap its waits with) over a long K loop -- at 5 K
+// rows [V,768]x[768,256] 0.043 ms against 0.030, [V,384]x[384,256] 0.027 against 0.025; every other shape of the SGCN is level
+// (1.0-1.1 x) or ahead (1.3-1.9 x on the narrow layers).
+bool split_nt_pays(int64_t M, int64_t N, int64_t K) {
+  if (M >= kSplitNtPaysRows || (g_split_variant & 16)) return true;
+  if (g_split_variant & 32) return false;
+  const int64_t items = ((M + 127) / 128) * ((N + 127) / 128);
+  return !(items < 128 && K >= 384);
+}
 bool split_engine_enabled(int kind) { return !(g_split_variant & 1) && !(g_split_variant & (2 << kind)); }      // kind 0 nt, 1 nn, 2 tn
 
 static inline int split_nf(int64_t N) { return N % 256 == 0 || N > 640 ? 16 : (N % 128 == 0 || N <= 128 ? 8 : 16); }
+// few rows: 128 x 128 tiles on four wavefronts (the 128-column weight image is never larger than the 256-column one, so the
+// workspace size -- a function of N and K alone -- covers both)
+static inline bool split_small_rows(int64_t M) { return M < kSplitNtPaysRows && !(g_split_variant & 32); }
 
 bool gemm_nt_f32s_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
-  return M >= 256 && M < ((int64_t)1 << 31) - 512 && N >= 64 && N % 4 == 0 && K >= 64 && K % 32 == 0 && lda % 4 == 0 &&
+  return M >= 128 && M < ((int64_t)1 << 31) - 512 && N >= 64 && N % 4 == 0 && K >= 64 && K % 32 == 0 && lda % 4 == 0 &&
          ldc % 4 == 0 && N < (1 << 20) && K < (1 << 20);
 }
 
@@ -682,8 +702,10 @@ int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_r
   SG_REQUIRE((((uintptr_t)A | (uintptr_t)C | (uintptr_t)ws) & 15) == 0, "sg_gemm_nt_f32: misaligned operand");
   SG_REQUIRE(ws && ws_bytes >= gemm_nt_f32s_workspace(N, K), "sg_gemm_nt_f32: workspace too small (%lld bytes given, %lld needed)",
              (long long)ws_bytes, (long long)gemm_nt_f32s_workspace(N, K));
-  const int nf = split_nf(N);
+  const bool small = split_small_rows(M);
+  const int nf = small ? 8 : split_nf(N);
   const int nt = nf * 16;
+  const int rt = small ? 128 : 256;
   PackSplit p;
   p.W = W; p.rs = w_rs; p.cs = w_cs;
   p.N = (int)N; p.K = (int)K; p.NF = nf;
@@ -700,18 +722,19 @@ int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_r
   g.C = C; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.n_col_tiles = p.n_col_tiles;
-  g.n_row_tiles = (int)((M + 255) / 256);
+  g.n_row_tiles = (int)((M + rt - 1) / rt);
   int dev = 0, cus = 256;
   SG_HIP_TRY(hipGetDevice(&dev));
   SG_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  int streams = (cus / g.n_col_tiles) / 8 * 8;
+  int streams = ((small ? 2 * cus : cus) / g.n_col_tiles) / 8 * 8;      // (the 128-row variant: two workgroups per CU)
   streams = streams < 8 ? 8 : streams;
   const int need = (g.n_row_tiles + 7) / 8 * 8;
   streams = streams > need ? need : streams;
   g.streams = streams;
   const int grid = streams * g.n_col_tiles;
-  if (nf == 16) gemm_nt_f32s<16><<<grid, kSplitThreads, 0, stream>>>(g);
-  else gemm_nt_f32s<8><<<grid, kSplitThreads, 0, stream>>>(g);
+  if (small) gemm_nt_f32s<8, 4><<<grid, 256, 0, stream>>>(g);
+  else if (nf == 16) gemm_nt_f32s<16, 8><<<grid, kSplitThreads, 0, stream>>>(g);
+  else gemm_nt_f32s<8, 8><<<grid, kSplitThreads, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

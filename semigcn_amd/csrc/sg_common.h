@@ -290,7 +290,7 @@ int launch_split_tn_reduce(const float* ws, int n_slabs, int64_t N, int64_t Kp, 
 // 5 K rows 0.096 ms against 0.033-0.051, 50 K rows 0.21 against 0.41: profiles/r05_configs_n1.jsonl, r04_configs_n1.jsonl);
 // the weight gradient (a reduction over the rows, cut into slabs) is level or ahead from 4 K rows on
 constexpr int64_t kSplitNtPaysRows = 16384;
-bool split_nt_pays(int64_t M);
+bool split_nt_pays(int64_t M, int64_t N, int64_t K);
 bool mid_shape(int64_t N, int64_t K);
 int64_t mid_tn_workspace(int64_t M, int64_t N, int64_t Kp);      // float32 elements
 int launch_mid_nt(const float* X, int64_t ldx, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* Y, int64_t ldy,

@@ -220,6 +220,7 @@ class _RowExchange:
             def start():
                 collective_counts["all_to_all"] += 1
                 work["w"] = _pg_all_to_all(recv, send, self.recv_splits, self.send_splits, self.group)
+                _c10d_in_flight[0] += 1          # the one torch.distributed collective left un-awaited across calls
             start()
         else:
             self._a2a(recv, send, self.recv_splits, self.send_splits)
@@ -234,6 +235,7 @@ class _RowExchange:
                 w = work.pop("w", None)
                 if w is not None:
                     w.wait()           # the CURRENT stream waits for the collective; the host does not block
+                    _c10d_in_flight[0] -= 1
             wait()
         blk_ext[self.n_own:].copy_(recv)
 
@@ -494,6 +496,171 @@ _comm_seq = [0]
 native_runs = [0, 0]
 
 
+#: SEMIGCN_DIST_KNOWN_ANSWER_TIMEOUT (seconds, 0 = off): bench.py's supervisor sets it for its workers.  The known-answer
+#: collectives below are the FIRST time csrc/comm.hip talks to a real peer; if they hang (rather than disagree), the worker
+#: would sit in a device synchronise until the supervisor's attempt limit (300 s on the 4 M mesh).  With the switch on, a timer
+#: thread ends THIS process after that many seconds (exit code 86, a line on stderr, a mark in SEMIGCN_BENCH_MARK): the
+#: supervisor sees a failed attempt at once and starts a fresh worker with the collectives on torch.distributed.  Nothing is
+#: exec'ed; a library user who never sets the variable never has a process ended under them.
+KNOWN_ANSWER_TIMEOUT_S = float(os.environ.get("SEMIGCN_DIST_KNOWN_ANSWER_TIMEOUT", "0") or 0)
+EXIT_NATIVE_HANG = 86
+
+
+class _HangGuard:
+    def __init__(self, what: str, seconds: float = None):
+        self.what, self.seconds, self.timer = what, KNOWN_ANSWER_TIMEOUT_S if seconds is None else seconds, None
+
+    def _fire(self):
+        import sys
+        msg = (f"semigcn_amd.dist: {self.what} did not finish within {self.seconds:.0f} s -- the library's own communicator "
+               f"hangs against its peers; ending this worker (exit {EXIT_NATIVE_HANG}) so that the supervisor retries with "
+               "SEMIGCN_DIST_NATIVE=0")
+        try:
+            print(msg, file=sys.stderr, flush=True)
+            mark = os.environ.get("SEMIGCN_BENCH_MARK")
+            if mark:
+                with open(os.path.join(mark, f"native_comm_hang_rank{os.environ.get('RANK', '0')}"), "w") as f:
+                    f.write(msg)
+        finally:
+            os._exit(EXIT_NATIVE_HANG)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import threading
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
+class _SharedComm:
+    """A handle from `Comm.share` that keeps its base alive and closes with it."""
+
+    def __init__(self, comm, base):
+        self._c, self._base = comm, base
+        self._h = comm._h
+
+    def __getattr__(self, name):
+        return getattr(self._c, name)
+
+
+_base_comms: dict = {}     # id(process group) -> (group, capi.Comm or False)
+
+
+def _agree(ok: bool, group, dev) -> bool:
+    """True when EVERY rank of the group says ok (an all-reduce on the torch process group: the fallback path itself)."""
+    flag = torch.tensor([0.0 if ok else 1.0], device=dev)
+    _pg_all_reduce(flag, dist.ReduceOp.SUM, group)
+    return float(flag.item()) == 0.0
+
+
+def _base_comm(lay):
+    """The process group's ONE library communicator, created (collectively) by the first layout that asks, or None.
+
+    Nothing below may strand a peer inside ncclCommInitRank or a native collective, so every stage is agreed on through the
+    TORCH process group before the next one starts:
+      1. every rank loads librccl and obtains the 128-byte id (rank 0 draws it, the store carries it)     -> agree
+      2. every rank creates its communicator (ncclCommInitRank: collective, all ranks are known to arrive) -> agree
+      3. known answers, bit for bit against torch.distributed's own collectives on the same buffers: ONE exchange with this
+         layout's per-peer rows (row r of what rank p sends carries (p, r): a wrong peer offset shows), ONE all-reduce, ONE
+         all-gather -- the three collectives sg_part_run issues                                             -> agree
+    On any disagreement every rank drops its communicator and the phase path keeps its collectives on torch.distributed."""
+    pg = _pg(lay.group)
+    ent = _base_comms.get(id(pg))
+    if ent is not None and ent[0] is pg:
+        return ent[1] or None
+    if len(_base_comms) > 16:
+        _base_comms.clear()
+    _base_comms[id(pg)] = (pg, False)
+    dev = lay.graph.device
+    import warnings
+
+    def give_up(why: str):
+        warnings.warn(f"semigcn_amd.dist: {why}; the phase path keeps its collectives on torch.distributed")
+        return None
+    # -- 1. library + id
+    uid, err = None, None
+    try:
+        if not capi.Comm.available():
+            raise RuntimeError("librccl is not loadable from the library")
+        store = dist.distributed_c10d._get_default_store()
+        ranks = dist.get_process_group_ranks(pg)
+        _comm_seq[0] += 1
+        key = "semigcn/sg_comm/%s/%d" % ("-".join(map(str, ranks)), _comm_seq[0])
+        if lay.rank == 0:
+            uid = capi.Comm.unique_id()
+            store.set(key, uid)
+        else:
+            uid = bytes(store.get(key))
+    except Exception as e:                                  # noqa: BLE001 -- whatever went wrong, the peers must hear of it
+        err = f"{type(e).__name__}: {e}"
+    if not _agree(err is None, lay.group, dev):
+        return give_up("a rank could not load RCCL or obtain the communicator id" + (f" (here: {err})" if err else ""))
+    # -- 2. the communicator
+    comm = None
+    try:
+        comm = capi.Comm(uid, lay.rank, lay.world, lay.send_splits, lay.recv_splits, dev)
+    except Exception as e:                                  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if not _agree(comm is not None, lay.group, dev):
+        if comm is not None:
+            comm.close()
+        return give_up("ncclCommInitRank failed on a rank" + (f" (here: {err})" if err else ""))
+    # -- 3. known answers (the two-communicator rule below holds: every torch collective is awaited before a native one starts)
+    ok = True
+    try:
+        with _HangGuard("the known-answer exchange of the library's own communicator"):
+            send = torch.empty((lay.n_send, 4), dtype=torch.float32, device=dev)
+            send[:, 0] = float(lay.rank)
+            send[:, 1] = torch.arange(lay.n_send, device=dev, dtype=torch.float32)
+            send[:, 2:] = 0.5
+            got = torch.full((lay.n_ext - lay.n_own, 4), -1.0, device=dev)
+            want = torch.full_like(got, -2.0)
+            comm.halo_exchange(got, send)
+            _all_to_all_rows(want, send, lay.recv_splits, lay.send_splits, lay.group)
+            collective_counts["all_to_all"] -= 1
+            red = torch.arange(7, device=dev, dtype=torch.float32) * float(lay.rank + 1)
+            red_want = red.clone()
+            comm.all_reduce_(red)
+            _pg_all_reduce(red_want, dist.ReduceOp.SUM, lay.group)
+            gin = torch.arange(5, device=dev, dtype=torch.float32) + 10.0 * lay.rank
+            gout = torch.full((lay.world * 5,), -1.0, device=dev)
+            gwant = torch.full_like(gout, -2.0)
+            comm.all_gather(gout, gin)
+            _pg_all_gather(gwant, gin, lay.group)
+            ok = bool(torch.equal(got, want)) and bool(torch.equal(red, red_want)) and bool(torch.equal(gout, gwant))
+    except Exception as e:                                  # noqa: BLE001
+        ok, err = False, f"{type(e).__name__}: {e}"
+    if not _agree(ok, lay.group, dev):
+        comm.close()
+        return give_up("the library's own collectives disagreed with torch.distributed's on the known-answer buffers"
+                       + (f" (here: {err})" if err else ""))
+    comm.layout = lay
+    _base_comms[id(pg)] = (pg, comm)
+    return comm
+
+
+def _assert_c10d_drained() -> None:
+    """THE TWO-COMMUNICATOR RULE.  A rank holds two RCCL communicators on one device: torch.distributed's (input bounds, loss
+    sums, the flat gradient all-reduce: 4 collectives per iteration) and the library's (the 40 of the phase path).  Two
+    communicators must never have work interleaved on the device in different orders on different ranks, so: every
+    torch.distributed collective this module starts is AWAITED ON THE COMPUTE STREAM (`work.wait()`) before the call that
+    started it returns or, for the one asynchronous exchange (`_Exchange`), before any native collective is enqueued --
+    and the native ones are enqueued on that same stream.  `_c10d_in_flight` counts the asynchronous ones; sg_part_run must
+    find it at zero.  Anyone adding `async_op=True` elsewhere has to count it here too."""
+    if _c10d_in_flight[0] != 0:
+        raise RuntimeError(f"semigcn_amd.dist: {_c10d_in_flight[0]} torch.distributed collective(s) still un-awaited when a "
+                           "native collective is about to be enqueued (two RCCL communicators would interleave)")
+
+
+_c10d_in_flight = [0]
+
+
 class FoldedLayout:
     """One rank's operators and exchange plan on the folded row numbering ``[owned | per peer q != rank, ascending: q's rows
     of the two-ring halo (ascending global id), PAD_ROWS pad rows]``.  The pad rows of a peer's segment carry that peer's
@@ -539,47 +706,21 @@ class FoldedLayout:
         self.handle_wide = capi.GraphHandle.from_partition(ext_of[dst[e_wide]], ext_of[src[e_wide]], self.n_ext, self.n_ext, dis_ext)
 
     def native_comm(self):
-        """The library's own communicator for this layout (capi.Comm), created at first use -- a collective call, so every
-        rank decides alike: RCCL groups only (gloo has no device path), switch on, librccl loadable.  The 128-byte id goes
-        from rank 0 to the others through the process group's store.  Before it is trusted, ONE exchange of a known
-        pattern is compared, bit for bit, with torch.distributed's all-to-all on the same rows (all ranks agree on the
-        verdict through an all-reduce): a first multi-GPU run checks the peer offsets it could never exercise on one GPU.
-        Returns None when the phase path keeps its collectives on torch.distributed."""
+        """The library's own communicator for this layout (capi.Comm) -- a collective call at FIRST use, which PartChain and
+        part_blocks make at partition set-up, not inside a forward pass.  ONE RCCL communicator per process group
+        (`_base_comm`): the first layout of a group creates it, every later one (the other levels of an MGCN) takes a second
+        handle on it with its own per-peer row counts (`sg_comm_share`: no ncclCommInitRank, no buffers).  Returns None when the
+        phase path keeps its collectives on torch.distributed."""
         if self._comm is not None:
             return self._comm or None
         self._comm = False
-        if not NATIVE_COLLECTIVES or _solo(self.world) or _backend(self.group) != "nccl" or not capi.Comm.available():
+        if not NATIVE_COLLECTIVES or _solo(self.world) or _backend(self.group) != "nccl":
             return None
-        dev = self.graph.device
-        store = dist.distributed_c10d._get_default_store()
-        ranks = dist.get_process_group_ranks(_pg(self.group))
-        _comm_seq[0] += 1
-        key = "semigcn/sg_comm/%s/%d" % ("-".join(map(str, ranks)), _comm_seq[0])
-        if self.rank == 0:
-            uid = capi.Comm.unique_id()
-            store.set(key, uid)
-        else:
-            uid = bytes(store.get(key))
-        comm = capi.Comm(uid, self.rank, self.world, self.send_splits, self.recv_splits, dev)
-        # the known-answer exchange: row r of what rank p sends carries (p, r) -- against torch.distributed's own all-to-all
-        send = torch.empty((self.n_send, 4), dtype=torch.float32, device=dev)
-        send[:, 0] = float(self.rank)
-        send[:, 1] = torch.arange(self.n_send, device=dev, dtype=torch.float32)
-        send[:, 2:] = 0.5
-        got = torch.full((self.n_ext - self.n_own, 4), -1.0, device=dev)
-        want = torch.full_like(got, -2.0)
-        comm.halo_exchange(got, send)
-        _all_to_all_rows(want, send, self.recv_splits, self.send_splits, self.group)
-        collective_counts["all_to_all"] -= 1
-        bad = torch.tensor([0.0 if torch.equal(got, want) else 1.0], device=dev)
-        _pg_all_reduce(bad, dist.ReduceOp.SUM, self.group)
-        if float(bad.item()) != 0.0:
-            import warnings
-            warnings.warn("semigcn_amd.dist: the library's own halo exchange disagreed with torch.distributed's on the "
-                          "known-answer rows; the phase path keeps its collectives on torch.distributed")
+        base = _base_comm(self)
+        if base is None:
             return None
-        self._comm = comm
-        return comm
+        self._comm = base if base.layout is self else _SharedComm(base.share(self.send_splits, self.recv_splits), base)
+        return self._comm
 
     def halo_of(self, full: torch.Tensor) -> torch.Tensor:
         """Rows ``[n_own:]`` of the folded buffer of a mesh-wide [V, C] tensor in processing order (zeros in the pad rows)."""
@@ -628,6 +769,8 @@ class PartChain:
     def __init__(self, plans, layout: FoldedLayout):
         from . import functional as F_sg
         self.plans, self.lay = list(plans), layout
+        if dist.is_initialized():
+            layout.native_comm()        # (a collective call: at set-up, where every rank builds its chains in the same order)
         self._ws = {}
         self._free = {}                 # dtype -> [_PartBuffers, ..] not in use
         self._F = F_sg
@@ -885,6 +1028,7 @@ class _PartChainFn(torch.autograd.Function):
         if comm is not None:
             # ONE foreign call: the 14 runs of phases with the 12 exchanges and the statistics all-gather enqueued between them
             steps = b.schedule(False)
+            _assert_c10d_drained()
             capi.part_run(comm, steps, len(steps), stream, dev)
             collective_counts["all_to_all"] += n - 1
             collective_counts["all_gather"] += 1
@@ -953,6 +1097,7 @@ class _PartChainFn(torch.autograd.Function):
         comm = lay.native_comm() if all(sk[2] for sk in sunk) else None
         if comm is not None:
             steps = b.schedule(True)
+            _assert_c10d_drained()
             capi.part_run(comm, steps, len(steps), stream, dev)
             collective_counts["all_reduce"] += n
             collective_counts["all_to_all"] += n
@@ -988,6 +1133,20 @@ class _PartChainFn(torch.autograd.Function):
         return (None, dx0, None, *grads_out)
 
 
+def prepare_native_comm(graphs) -> None:
+    """At partition SET-UP (never inside a forward pass, where a failure would burn an attempt's time limit mid-iteration):
+    create the process group's library communicator and every level's handle on it, in level order -- collective calls that all
+    ranks make alike.  A no-op on CPU tensors, gloo groups and with SEMIGCN_DIST_NATIVE=0."""
+    if not (dist.is_initialized() and NATIVE_COLLECTIVES):
+        return
+    for g in graphs:
+        if g.device.type != "cuda" or _solo(g.world) or _backend(g.group) != "nccl":
+            return
+        if min(g.bounds[q + 1] - g.bounds[q] for q in range(len(g.bounds) - 1)) < 2:
+            continue                    # (part_blocks refuses this level on every rank)
+        g.folded().native_comm()
+
+
 def part_chain(sequentials, graph: "DistMeshGraph", x_own: torch.Tensor, x_halo: torch.Tensor):
     """Blocks that START every Sequential of ``sequentials`` (each [ChebConv, BatchNorm1d, LeakyReLU (, ...)] one or more
     times) on this rank's rows, phase by phase below the C ABI; returns (activation of the last block on the owned rows, index
@@ -1018,6 +1177,15 @@ def part_blocks(plans, graph: "DistMeshGraph", x_own: torch.Tensor, x_halo: Opti
     owner-computes on exchanged gradient rows).  None when the run cannot take this path."""
     from . import functional as F_sg
     if not (x_own.is_cuda and F_sg.blocks_enabled() and dist.is_initialized()) or not plans:
+        return None
+    # every refusal below is decided from what ALL ranks know alike (dtype, the plans, the partition's block bounds): a rank that
+    # left this path alone would issue other collectives than its peers.  The bounds are global knowledge: a level at which SOME
+    # rank owns fewer than two rows (the coarsest level of a small MGCN on many ranks) is refused by every rank, before the halo
+    # exchange below issues a collective
+    if x_own.dtype not in (torch.float32, torch.bfloat16):
+        return None
+    bounds = graph.bounds
+    if min(bounds[q + 1] - bounds[q] for q in range(len(bounds) - 1)) < 2:
         return None
     cin = x_own.shape[1]
     for p in plans:
@@ -1409,6 +1577,8 @@ class DistSGCNTrainer:
         self.loss_sum = torch.zeros((), device=part.z1.device)
         from .train import GradBuffer
         self.grads = GradBuffer(self.params)
+        if self.phases:
+            prepare_native_comm([part.graph])
 
     def _forward_backward(self, dm: torch.Tensor) -> torch.Tensor:
         from .functional import sink_param_grads
@@ -1580,6 +1750,8 @@ def partition_mgcn(model: nn.Module, rank: int, world: int, group=None, phases: 
     pools = [DistPool(f, c, bounds[l], bounds[l + 1], rank, world, group) for l, (f, c) in enumerate(pairs)]
     for g in graphs:
         g.phases = bool(phases)
+    if phases:
+        prepare_native_comm(graphs)
     own_ids = [orders[l][bounds[l][rank]:bounds[l][rank + 1]] for l in range(n_levels)]
     part = MGCNPartition(graphs, pools, bounds, own_ids, ranks,
                          [model.smposs_list[l].index_select(0, own_ids[l]) for l in range(n_levels)], rank, world, group)

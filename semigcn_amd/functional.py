@@ -106,10 +106,9 @@ def _nt_split(a: torch.Tensor, n: int, out: Optional[torch.Tensor]) -> bool:
         return False
     if out is not None and (out.dtype != torch.float32 or out.stride(1) != 1 or out.data_ptr() % 16):
         return False
-    # (below ~16 K rows the row-tile stream of the split kernel fills too few workgroups and the BLAS library is faster -- csrc/
-    #  sg_common.h kSplitNtPaysRows; small weight matrices run on the vector ALUs at any row count)
-    small = 4 <= n <= 48 and 4 <= a.shape[1] <= 48
-    if a.shape[0] < 16384 and not small:
+    # (own kernels or the BLAS library: the library's rule, asked where it lives -- sg_gemm_nt_f32_pays; since round 6 products
+    #  with few rows run on 128 x 128 tiles and the answer is yes at every size)
+    if not capi.gemm_nt_f32_pays(a.shape[0], n, a.shape[1]):
         return False
     return capi.gemm_nt_f32_supported(a, n, None if out is None else out.stride(0))
 

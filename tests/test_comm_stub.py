@@ -222,3 +222,35 @@ def test_a_failed_send_closes_its_group_and_names_the_step(stub):
         lib.sg_comm_test_fail_send(0)
         capi.part_run(type("H", (), {"_h": hs[0]})(), steps, 3, None)
     assert e.value.step == 1
+
+
+def test_hang_guard_ends_the_worker_with_its_own_exit_code(tmp_path):
+    """a known-answer exchange that HANGS must fail the attempt fast: with
+    SEMIGCN_DIST_KNOWN_ANSWER_TIMEOUT set (bench.py's supervisor sets 30 s for its workers) a timer thread ends the process
+    with exit code 86 and leaves a mark for the supervisor; without the variable nothing is ever ended."""
+    import subprocess
+    code = ("import os, sys, time; sys.path.insert(0, %r); from semigcn_amd import dist as d\n"
+            "with d._HangGuard('the test section'):\n    time.sleep(float(sys.argv[1]))\nprint('survived')\n" % ROOT)
+    env = dict(os.environ, SEMIGCN_DIST_KNOWN_ANSWER_TIMEOUT="1", SEMIGCN_BENCH_MARK=str(tmp_path), RANK="3")
+    r = subprocess.run([sys.executable, "-c", code, "20"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 86 and "did not finish within 1 s" in r.stderr and "survived" not in r.stdout
+    assert (tmp_path / "native_comm_hang_rank3").exists()
+    r = subprocess.run([sys.executable, "-c", code, "0.1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "survived" in r.stdout                      # a section that finishes in time cancels the timer
+    env.pop("SEMIGCN_DIST_KNOWN_ANSWER_TIMEOUT")
+    r = subprocess.run([sys.executable, "-c", code, "1.5"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "survived" in r.stdout                      # off by default
+
+
+def test_two_communicator_rule_is_asserted():
+    """a torch.distributed collective left un-awaited when sg_part_run is about to enqueue native ones
+    would interleave two RCCL communicators on one device: the phase path refuses."""
+    from semigcn_amd import dist as d
+    d._assert_c10d_drained()
+    d._c10d_in_flight[0] += 1
+    try:
+        with pytest.raises(RuntimeError, match="un-awaited"):
+            d._assert_c10d_drained()
+    finally:
+        d._c10d_in_flight[0] -= 1
+    d._assert_c10d_drained()

@@ -13,16 +13,28 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 # (M, N, K): 256- and 128-column tiles, ragged M / N, one and many K blocks, a tile stream with several tiles per workgroup
+# (below 16 384 rows: 128 x 128 tiles on four wavefronts, round 6 -- the reference's own mesh sizes; from there on 256-row tiles)
 NT_SHAPES = [(256, 64, 64), (1000, 256, 64), (4133, 384, 96), (2048, 192, 128), (777, 512, 256), (5000, 64, 768),
-             (70001, 256, 768), (66000, 768, 512), (300, 100, 160), (33000, 128, 192)]
+             (70001, 256, 768), (66000, 768, 512), (300, 100, 160), (33000, 128, 192), (130, 64, 64), (5000, 768, 512),
+             (10800, 256, 768), (16383, 192, 128)]
 
 
 def _ints(shape, lim, g):
     return torch.randint(-lim, lim + 1, shape, device=DEV, generator=g).float()
 
 
+@pytest.fixture(params=[0, 32], ids=["rows-pick-the-tile", "256-row-tiles-only"])
+def tile_rule(request):
+    """SG_TUNE_F32_ENGINE bit 5 switches the 128-row variant off: both kernels see the small shapes."""
+    capi.tuning_set(capi.TUNE_F32_ENGINE, request.param)
+    yield request.param
+    capi.tuning_set(capi.TUNE_F32_ENGINE, 0)
+
+
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
-def test_split_nt_integer_data_is_bit_exact(M, N, K):
+def test_split_nt_integer_data_is_bit_exact(M, N, K, tile_rule):
+    if tile_rule and M < 256:
+        pytest.skip("the 256-row kernel needs 256 rows")
     g = torch.Generator(device=DEV).manual_seed(M + 3 * N + 7 * K)
     a, w, bias = _ints((M, K), 8, g), _ints((N, K), 8, g), _ints((N,), 8, g)
     w[:, 0] = torch.arange(N, device=DEV).remainder(5).float() - 2           # asymmetric: a transposed write would show
@@ -42,7 +54,7 @@ def test_split_nt_integer_data_is_bit_exact(M, N, K):
     assert torch.equal(capi.gemm_nt_f32(a2, e), 4.0 * a2[:, torch.arange(N, device=DEV) % K])
 
 
-@pytest.mark.parametrize("M,N,K", NT_SHAPES[:8])
+@pytest.mark.parametrize("M,N,K", NT_SHAPES[:8] + NT_SHAPES[11:13])
 def test_split_nt_random_data_strides_and_error_vs_float64(M, N, K):
     g = torch.Generator(device=DEV).manual_seed(N + K)
     wide = torch.randn((M, K + 24), device=DEV, generator=g)
@@ -142,15 +154,18 @@ def test_split_products_reject_what_they_cannot_take():
     assert b"workspace" in lib.sg_last_error()
 
 
+@pytest.mark.parametrize("nu,nv", [(160, 128), (100, 50)])
 @pytest.mark.parametrize("cin,cout", [(64, 128), (256, 128)])
-def test_float32_block_runs_on_the_split_kernels_and_matches_the_blas_engine(cin, cout):
+def test_float32_block_runs_on_the_split_kernels_and_matches_the_blas_engine(cin, cout, nu, nv):
     """One [ChebConv -> BatchNorm -> LeakyReLU] block of float32 features, forward and backward, with the products on the
     split kernels (default) and on the BLAS library (SG_TUNE_F32_ENGINE bit 0): the launch trace names the engine of every
     product, and the two results agree to float32 rounding (both are float32-equivalent products of the same operands)."""
     from semigcn_amd import synth
     from semigcn_amd.graph import MeshGraph
     from test_gpu_blocks import _block_module, _run
-    m = synth.torus_mesh(160, 128)            # 20 480 rows: from 16 384 on the forward / input-gradient products leave the BLAS library
+    # 20 480 rows: 256-row tiles; 5 000 rows (BASELINE configs[0], the reference's own mesh size): 128-row tiles -- no product of a
+    # float32 block is left with the BLAS library at either size (round 5: below 16 384 rows the forward / input-gradient ones were)
+    m = synth.torus_mesh(nu, nv)
     g = MeshGraph.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), m.num_vertices)
     seq = _block_module(cin, cout)
     gen = torch.Generator(device=DEV).manual_seed(11)
@@ -172,7 +187,11 @@ def test_float32_block_runs_on_the_split_kernels_and_matches_the_blas_engine(cin
     res_s, rec_s = run(0)
     res_b, rec_b = run(1)
     assert len(rec_s) == len(rec_b) == 3                       # forward, input gradient, weight gradient
-    assert all(t["engine"] == "split" for t in rec_s), rec_s
+    # every product on the split kernels -- except where the library's own rule (sg_gemm_nt_f32_pays: fewer than 128 work items over
+    # K >= 384, the A/B of profiles/r06_gemm_f32split_5k.json) hands a forward / input-gradient product of a 5 K-row block back
+    want = ["split" if (t["kind"] == "tn" or capi.gemm_nt_f32_pays(t["a"], t["b"], t["c"])) else "blas" for t in rec_s]
+    assert [t["engine"] for t in rec_s] == want, rec_s
+    assert "split" in want[:2] or nu * nv >= 16384 or cin == 256, want
     assert all(t["engine"] == "blas" for t in rec_b), rec_b
     names = ["y", "dx"] + [n for n, _ in seq.named_parameters()] + ["running_mean", "running_var"]
     for n, a, b in zip(names, res_s[:-1], res_b[:-1]):

@@ -394,18 +394,18 @@ def test_bench_supervisor_retries_same_path_then_per_module_after_stalls():
     worker's start-up marks and its faulthandler dump.  A run that stalls in every attempt exits non-zero with the reasons."""
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "5",
             "--mesh", "96x64", "--no-cpu-baseline", "--dtype", "bf16"]
-    env = _child_env(SEMIGCN_BENCH_SHARE_GPU="1", SEMIGCN_BENCH_ATTEMPT_TIMEOUT="25")
+    env = _child_env(SEMIGCN_BENCH_SHARE_GPU="1", SEMIGCN_BENCH_ATTEMPT_TIMEOUT="22")
     r = subprocess.run(base + ["--stall-after-warmup", "600", "--stall-attempts", "2"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])["distributed"]
-    assert d["attempt"] == 3 and "within 25 s" in d["first_attempt_failure"] and "attempt 2" in d["first_attempt_failure"]
+    assert d["attempt"] == 3 and "within 22 s" in d["first_attempt_failure"] and "attempt 2" in d["first_attempt_failure"]
     assert d["per_module_path"] is True and 57 <= d["collectives_per_iteration"] <= 58 and d["block_calls_per_iteration"] == [0.0, 0.0]
     assert "starting a fresh worker on the SAME phase path" in r.stderr and "starting a fresh worker on the per-module path" in r.stderr
     # the post-mortem of the stalled worker: its marks up to the stall, and where its threads were shortly before the limit
     assert "marks of attempt 1" in r.stderr and "first warm-up iteration done" in r.stderr
     assert "traceback of attempt 1" in r.stderr and "in timed_run" in r.stderr
-    env["SEMIGCN_BENCH_ATTEMPT_TIMEOUT"] = "12"
+    env["SEMIGCN_BENCH_ATTEMPT_TIMEOUT"] = "9"
     r = subprocess.run(base + ["--stall-after-warmup", "-600"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and "all 3 attempts failed" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
