@@ -367,15 +367,20 @@ int backward(const sg_block& b, hipStream_t stream) {
                         dHp, lddh, s.Vo, s.Co, b.dtype, stream, w.colsum);
   if (rc != SG_OK) return rc;
   // d bias = column sums of the conv output's gradient; through a pool they equal the column sums of dH (every cluster's
-  // members share its gradient / count, an unpooled row's gradient goes to one parent)
-  rc = launch_colsum_finalize(w.colsum, col_apply_blocks(s.Vo, s.Co, b.dtype), s.Co, db, stream, b.acc_bias);
-  if (rc != SG_OK) return rc;
+  // members share its gradient / count, an unpooled row's gradient goes to one parent).  Nothing in this pass reads them, so
+  // with gradient accumulators they RIDE in the launch that finishes the weight gradient (GradSink::cs_*: the same sums in
+  // the same order, one launch fewer per block); a product whose engine has no accumulating reduce gets the launch of its own
   GradSink sink;                         // the K weight .grad accumulators: += in the kernel that finishes the reduction
   if (sink_w) {
     for (int k = 0; k < b.K; ++k) sink.dst[k] = b.acc_W[k];
     sink.mode = b.order == 0 ? 1 : 2;
     sink.Cin = (int)s.Ci;
     sink.Cout = (int)s.Co;
+    sink.cs_partial = w.colsum;
+    sink.cs_nb = col_apply_blocks(s.Vo, s.Co, b.dtype);
+    sink.cs_C = (int)s.Co;
+    sink.cs_out = db;
+    sink.cs_acc = b.acc_bias;
   }
   bool sunk = false;
   void* dHc = dHp;          // gradient of the conv output [V, Cout]
@@ -432,6 +437,10 @@ int backward(const sg_block& b, hipStream_t stream) {
     if (rc != SG_OK) return rc;
   }
 
+  if (!(sink_w && sunk)) {    // the bias sums did not ride (no accumulators, or an engine without the accumulating reduce)
+    rc = launch_colsum_finalize(w.colsum, col_apply_blocks(s.Vo, s.Co, b.dtype), s.Co, db, stream, b.acc_bias);
+    if (rc != SG_OK) return rc;
+  }
   if (sink_w && !sunk) {      // (an engine without the accumulating epilogue ran -- a single BLAS product: one add launch)
     const float* srcs[3];
     float* dsts[3];
@@ -654,17 +663,28 @@ int part_run(const sg_block& b, hipStream_t stream) {
     rc = launch_col_apply(1, b.dY, b.lddy, b.H, b.ldh, scale, shift, mean, invstd, w.co + 4 * Co, w.co + 2 * Co, w.co + 3 * Co, b.slope,
                           dH, lddh, V, Co, b.dtype, stream, w.colsum);
     if (rc != SG_OK) return rc;
-    rc = launch_colsum_finalize(w.colsum, col_apply_blocks(V, Co, b.dtype), Co, b.dvec + 5 * Co, stream, b.acc_bias);
-    if (rc != SG_OK) return rc;
+    if (b.order != 0) {        // (the weight gradient of an order-1 block is finished in a later phase: the sums get their own launch)
+      rc = launch_colsum_finalize(w.colsum, col_apply_blocks(V, Co, b.dtype), Co, b.dvec + 5 * Co, stream, b.acc_bias);
+      if (rc != SG_OK) return rc;
+    }
     if (b.order == 0) {
       GradSink sink;
       if (sink_w) {
         for (int k = 0; k < b.K; ++k) sink.dst[k] = b.acc_W[k];
         sink.mode = 1; sink.Cin = (int)Ci; sink.Cout = (int)Co;
+        sink.cs_partial = w.colsum;                 // the bias sums ride in the weight gradient's reduce (see backward())
+        sink.cs_nb = col_apply_blocks(V, Co, b.dtype);
+        sink.cs_C = (int)Co;
+        sink.cs_out = b.dvec + 5 * Co;
+        sink.cs_acc = b.acc_bias;
       }
       bool sunk = false;
       rc = dense_tn(dH, lddh, b.T, b.ldt, V, Co, KCi, b.dtype, w.tn, b.dW, KCi, w.blas, kBlasWorkspace, stream, sink_w ? &sink : nullptr, &sunk);
       if (rc != SG_OK) return rc;
+      if (!(sink_w && sunk)) {
+        rc = launch_colsum_finalize(w.colsum, col_apply_blocks(V, Co, b.dtype), Co, b.dvec + 5 * Co, stream, b.acc_bias);
+        if (rc != SG_OK) return rc;
+      }
       if (sink_w && !sunk) {
         const float* srcs[3]; float* dsts[3]; int64_t ld[3], rows[3], cols[3];
         for (int k = 0; k < b.K; ++k) { srcs[k] = b.dW + k * Ci; ld[k] = KCi; dsts[k] = b.acc_W[k]; rows[k] = Co; cols[k] = Ci; }

@@ -518,6 +518,11 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_tn_bf16(const TnArgs g) {
 __global__ __launch_bounds__(1024) void tn_reduce(const float* __restrict__ W, int n_slabs, int64_t elems, int Kp,
                                                   float* __restrict__ out, int64_t ldo, const GradSink sink) {
   __shared__ f32x4 s_part[16][64];
+  const int main_blocks = (int)((elems / 4 + 63) / 64);
+  if ((int)blockIdx.x >= main_blocks) {                        // the rider's workgroups (GradSink::cs_*)
+    colsum_ride(sink, (int)blockIdx.x - main_blocks);
+    return;
+  }
   const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
   const int64_t e = ((int64_t)blockIdx.x * 64 + x) * 4;      // Kp % 8 == 0: a float4 stays inside one row
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -600,7 +605,7 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
       SG_HIP_TRY(hipGetLastError());
       ++slabs;
     }
-    tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo, sink);
+    tn_reduce<<<(int)((elems / 4 + 63) / 64) + (sink.cs_partial ? sink.cs_C : 0), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo, sink);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
   }
@@ -621,7 +626,7 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
   gemm_tn_bf16<<<g.n_blocks, kThreads, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   const int64_t elems = N * Kp;
-  tn_reduce<<<(int)((elems / 4 + 63) / 64), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo, sink);
+  tn_reduce<<<(int)((elems / 4 + 63) / 64) + (sink.cs_partial ? sink.cs_C : 0), 1024, 0, stream>>>(workspace, (int)slabs, elems, (int)Kp, out, ldo, sink);
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }

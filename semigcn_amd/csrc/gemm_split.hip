@@ -626,6 +626,11 @@ template <bool TR>
 __global__ __launch_bounds__(1024) void split_tn_reduce(const float* __restrict__ W, int n_slabs, int64_t elems, int cols,
                                                         float* __restrict__ out, int64_t ldo, const GradSink sink) {
   __shared__ f32x4 s_part[16][64];
+  const int main_blocks = (int)((elems / 4 + 63) / 64);
+  if ((int)blockIdx.x >= main_blocks) {                        // the rider's workgroups (GradSink::cs_*)
+    colsum_ride(sink, (int)blockIdx.x - main_blocks);
+    return;
+  }
   const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
   const int64_t e = ((int64_t)blockIdx.x * 64 + x) * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -798,7 +803,7 @@ int launch_gemm_tn_f32s(const float* A, int64_t lda, const float* B, int64_t ldb
   gemm_tn_f32s<<<8 * (items < 32 ? items : 32), kSplitThreads, 0, stream>>>(g);
   SG_HIP_TRY(hipGetLastError());
   const int64_t elems = N * Kp;
-  const int blocks = (int)((elems / 4 + 63) / 64);
+  const int blocks = (int)((elems / 4 + 63) / 64) + (sink.cs_partial ? sink.cs_C : 0);      // (+ the rider's workgroups)
   if (tr) split_tn_reduce<true><<<blocks, 1024, 0, stream>>>(g.W, g.slabs, elems, g.Kp, out, ldo, sink);
   else split_tn_reduce<false><<<blocks, 1024, 0, stream>>>(g.W, g.slabs, elems, g.Kp, out, ldo, sink);
   SG_HIP_TRY(hipGetLastError());
@@ -811,7 +816,7 @@ int launch_split_tn_reduce(const float* ws, int n_slabs, int64_t N, int64_t Kp, 
                            hipStream_t stream) {
   SG_REQUIRE(Kp % 4 == 0 && ldo % 4 == 0, "split_tn_reduce: the column count and the row stride must be multiples of 4");
   const int64_t elems = N * Kp;
-  const int blocks = (int)((elems / 4 + 63) / 64);
+  const int blocks = (int)((elems / 4 + 63) / 64) + ((sink && sink->cs_partial) ? sink->cs_C : 0);
   split_tn_reduce<false><<<blocks, 1024, 0, stream>>>(ws, n_slabs, elems, (int)Kp, out, ldo, sink ? *sink : GradSink{});
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;

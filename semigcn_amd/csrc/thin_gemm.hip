@@ -160,6 +160,10 @@ __global__ __launch_bounds__(kThinBlock) void thin_tn_partial(const T* __restric
 __global__ __launch_bounds__(kThinBlock) void thin_tn_reduce(const float* __restrict__ part, int nblocks, int N, int K,
                                                              float* __restrict__ out, int64_t ldo, const GradSink sink) {
   __shared__ float s_p[kThinBlock];
+  if ((int)blockIdx.x >= kThinElems) {                         // the rider's workgroups (GradSink::cs_*)
+    colsum_ride(sink, (int)blockIdx.x - kThinElems);
+    return;
+  }
   const int P = thin_pitch(K);
   const int slot = blockIdx.x, n = slot / P, k = slot % P;
   if (n >= N || k >= K) return;
@@ -221,7 +225,8 @@ int launch_thin_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
     return SG_ERR_UNSUPPORTED;
   }
   SG_HIP_TRY(hipGetLastError());
-  thin_tn_reduce<<<kThinElems, kThinBlock, 0, stream>>>(workspace, (int)nb, (int)N, (int)K, out, ldo, sink ? *sink : GradSink{});
+  thin_tn_reduce<<<kThinElems + ((sink && sink->cs_partial) ? sink->cs_C : 0), kThinBlock, 0, stream>>>(workspace, (int)nb, (int)N, (int)K, out, ldo,
+                                                                                                    sink ? *sink : GradSink{});
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
 }
