@@ -400,8 +400,8 @@ SG_API int sg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, in
  *   sg_gemm_tn_f32:  out[N, Kp] (row stride ldo) = A[M, N]^T B[M, Kp], a reduction over all M vertices; workspace: float32
  *                    [sg_gemm_tn_f32_slabs(M, N, Kp), N_pad, Kp_pad] slab partials (sg_gemm_tn_f32_workspace bytes), added
  *                    in slab order: deterministic.  N, Kp, lda, ldb multiples of 4, ldo % 4 == 0, M >= 4096.
- * Weight matrices of 4 .. 48 rows and columns -- one of the two up to 96 since round 6 -- (multiples of 4; the 16 -> 32 and
- * 32 -> 16 layers of the SGCN, the 32 -> 32 layers of the MGCN) are HBM-bound and below the matrix-core tile: the same entry points run them as plain float32 FMA chains on the vector ALUs (csrc/gemm_mid.hip; any M,
+ * Weight matrices of 4 .. 48 rows and columns (multiples of 4; the 16 -> 32 and 32 -> 16 layers) are HBM-bound and below the
+ * matrix-core tile: the same entry points run them as plain float32 FMA chains on the vector ALUs (csrc/gemm_mid.hip; any M,
  * no workspace for nt, sg_gemm_tn_f32_workspace bytes of block partials for tn, same deterministic reduce).
  * ------------------------------------------------------------------------- */
 SG_API int sg_gemm_nt_f32_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
@@ -696,8 +696,7 @@ enum sg_tune_knob {
                               wherever they take the shape, the BLAS library for the rest; bit 0 = the BLAS library for all of
                               them (A/B switch); bits 1 / 2 / 3 = only the forward / input-gradient / weight-gradient products go to the
                               library (bisecting aid); bit 5 = no 128-row tiles: forward / input-gradient products below 16 K rows
-                              go to the library as in round 5 (A/B switch) -- unless bit 4 sends them to the 256-row kernel; bit 6 = the
-                              small-weight kernels take at most 48 x 48 weights as in round 5 (A/B switch) */
+                              go to the library as in round 5 (A/B switch) -- unless bit 4 sends them to the 256-row kernel */
   SG_TUNE_BN_ROWS = 9      /* BatchNorm + activation apply passes: 0 (default) = by shape (rows of >= 1 KB, backward passes from 512 B:
                               every workgroup walks ONE contiguous range of rows; else row groups strided over the grid), 1 = contiguous
                               everywhere, 2 = strided everywhere (A/B switch) */

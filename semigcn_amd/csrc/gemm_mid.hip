@@ -1,6 +1,4 @@
-// float32 products with a SMALL weight matrix (4 .. 48 rows and columns, multiples of 4; since round 6 one of the two up to 96:
-// the 32 -> 32-channel layers of the MGCN, [V,96] x [96,32] and its gradients, util/meshnet.py:92-95 -- 0.83 ms of c3's
-// 5.75 ms and 3.5 ms of the 1 M-vertex MGCN's 43 ms were still hipBLASLt calls) that neither the thin kernels
+// float32 products with a SMALL weight matrix (4 .. 48 rows and columns, multiples of 4) that neither the thin kernels
 // (<= 256 weight entries, thin_gemm.hip) nor the split-bf16 matrix-core kernels (N, K >= 64, K a multiple of 32,
 // gemm_split.hip) take: the 16 -> 32 and 32 -> 16 layers of the SGCN (`lins[k]` on [V, 48] x [48, 32] and
 // [V, 32] x [32, 48], util/networks.py:40-53 via [3P] ChebConv.forward) with their input and weight gradients, and the narrow
@@ -25,25 +23,25 @@ constexpr int kMidBlock = 256;
 constexpr int kMidChunk = 128;
 constexpr int kMidRowsPerBlock = 512;
 
-template <int P, int TB>      // K rounded up to a multiple of 16; TB rows (= threads) per block
-__global__ __launch_bounds__(TB) void mid_nt(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t w_rs,
+template <int P>      // K rounded up to 16 / 32 / 48
+__global__ __launch_bounds__(kMidBlock) void mid_nt(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t w_rs,
                                                     int64_t w_cs, const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
                                                     int64_t V, int N, int K) {
   extern __shared__ float s_mid[];                   // weights [N][P] (zero beyond K) | rows: x [256][K + 1], then y [256][N + 1]
   float* const s_w = s_mid;
   float* const s_io = s_mid + N * P;
   const int tid = threadIdx.x;
-  for (int i = tid; i < N * P; i += TB) {
+  for (int i = tid; i < N * P; i += kMidBlock) {
     const int n = i / P, k = i - n * P;
     s_w[i] = k < K ? W[(int64_t)n * w_rs + (int64_t)k * w_cs] : 0.f;
   }
-  const int64_t row0 = (int64_t)blockIdx.x * TB;
-  const int rows = (int)(V - row0 < TB ? V - row0 : TB);
+  const int64_t row0 = (int64_t)blockIdx.x * kMidBlock;
+  const int rows = (int)(V - row0 < kMidBlock ? V - row0 : kMidBlock);
   const int px = K + 1, py = N + 1;                  // odd pitches: a thread per row reads without bank conflicts
   {
     const int per_row = K >> 2;
     const float* const X0 = X + row0 * ldx;
-    for (int i = tid; i < rows * per_row; i += TB) {
+    for (int i = tid; i < rows * per_row; i += kMidBlock) {
       const int r = i / per_row, c = (i - r * per_row) << 2;
       const float4 v = *(const float4*)(X0 + (int64_t)r * ldx + c);
       float* q = s_io + r * px + c;
@@ -72,7 +70,7 @@ __global__ __launch_bounds__(TB) void mid_nt(const float* __restrict__ X, int64_
   {
     const int per_row = N >> 2;
     float* const Y0 = Y + row0 * ldy;
-    for (int i = tid; i < rows * per_row; i += TB) {
+    for (int i = tid; i < rows * per_row; i += kMidBlock) {
       const int r = i / per_row, c = (i - r * per_row) << 2;
       const float* q = s_io + r * py + c;
       *(float4*)(Y0 + (int64_t)r * ldy + c) = make_float4(q[0], q[1], q[2], q[3]);
@@ -158,15 +156,12 @@ __global__ __launch_bounds__(kMidBlock) void mid_tn_partial(const float* __restr
   }
 }
 
-inline int mid_t(int64_t n) { return n <= 16 ? 2 : (n <= 32 ? 4 : (n <= 48 ? 6 : (n <= 64 ? 8 : 12))); }
+inline int mid_t(int64_t n) { return n <= 16 ? 2 : (n <= 32 ? 4 : 6); }
 
 }  // namespace
 
-// (48 x 48: 256 rows of a block and the weights fit into 64 KB of LDS; one side up to 96 with 128 rows per block)
-bool mid_shape(int64_t N, int64_t K) {
-  const int64_t wide = split_variant_bit(6) ? 48 : 96;      // SG_TUNE_F32_ENGINE bit 6: the round-5 limit (A/B switch)
-  return N >= 4 && K >= 4 && N % 4 == 0 && K % 4 == 0 && N <= wide && K <= wide && (N <= 48 || K <= 48);
-}
+// (48: the rows of a block and the weights fit into 64 KB of LDS)
+bool mid_shape(int64_t N, int64_t K) { return N >= 4 && N <= 48 && K >= 4 && K <= 48 && N % 4 == 0 && K % 4 == 0; }
 
 static int64_t mid_tn_blocks(int64_t M) { return (M + kMidRowsPerBlock - 1) / kMidRowsPerBlock; }
 int64_t mid_tn_workspace(int64_t M, int64_t N, int64_t Kp) { return mid_tn_blocks(M) * N * Kp; }      // float32 elements
@@ -176,25 +171,15 @@ int launch_mid_nt(const float* X, int64_t ldx, const float* W, int64_t w_rs, int
   SG_REQUIRE(mid_shape(N, K) && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0,
              "mid_nt: unsupported shape or alignment (N=%lld K=%lld)", (long long)N, (long long)K);
   if (M == 0) return SG_OK;
-  const int64_t wide = (K > N ? K : N) + 1;
-  const int tb = wide > 49 ? 128 : kMidBlock;      // rows per block: the staging area stays near 50 KB (two or three blocks per CU)
-  const int64_t nb = (M + tb - 1) / tb;
+  const int64_t nb = (M + kMidBlock - 1) / kMidBlock;
   SG_REQUIRE(nb < ((int64_t)1 << 31), "mid_nt: too many rows");
   const int P = (int)((K + 15) / 16 * 16);
-  const size_t lds = (size_t)(N * P + tb * wide) * sizeof(float);
-#define SG_MID_NT(PP, TB) mid_nt<PP, TB><<<(int)nb, TB, lds, stream>>>(X, ldx, W, w_rs, w_cs, bias, Y, ldy, M, (int)N, (int)K)
-  if (tb == kMidBlock) {
-    if (P == 16) SG_MID_NT(16, kMidBlock);
-    else if (P == 32) SG_MID_NT(32, kMidBlock);
-    else SG_MID_NT(48, kMidBlock);
-  } else {
-    if (P == 16) SG_MID_NT(16, 128);
-    else if (P == 32) SG_MID_NT(32, 128);
-    else if (P == 48) SG_MID_NT(48, 128);
-    else if (P == 64) SG_MID_NT(64, 128);
-    else if (P == 80) SG_MID_NT(80, 128);
-    else SG_MID_NT(96, 128);
-  }
+  const int64_t wide = (K > N ? K : N) + 1;
+  const size_t lds = (size_t)(N * P + kMidBlock * wide) * sizeof(float);
+#define SG_MID_NT(PP) mid_nt<PP><<<(int)nb, kMidBlock, lds, stream>>>(X, ldx, W, w_rs, w_cs, bias, Y, ldy, M, (int)N, (int)K)
+  if (P == 16) SG_MID_NT(16);
+  else if (P == 32) SG_MID_NT(32);
+  else SG_MID_NT(48);
 #undef SG_MID_NT
   SG_HIP_TRY(hipGetLastError());
   return SG_OK;
@@ -213,22 +198,11 @@ int launch_mid_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int6
   do {                                                      \
     if (tk == 2) SG_MID_TN(TN, 2);                          \
     else if (tk == 4) SG_MID_TN(TN, 4);                     \
-    else if (tk == 6) SG_MID_TN(TN, 6);                     \
-    else if (tk == 8) SG_MID_TN(TN, 8);                     \
-    else SG_MID_TN(TN, 12);                                 \
-  } while (0)
-#define SG_MID_TN_WIDE(TN)                                  \
-  do {                                                      \
-    if (tk == 2) SG_MID_TN(TN, 2);                          \
-    else if (tk == 4) SG_MID_TN(TN, 4);                     \
     else SG_MID_TN(TN, 6);                                  \
   } while (0)
   if (tn == 2) SG_MID_TN_ROW(2);
   else if (tn == 4) SG_MID_TN_ROW(4);
-  else if (tn == 6) SG_MID_TN_ROW(6);
-  else if (tn == 8) SG_MID_TN_WIDE(8);           // (mid_shape: when one side is wider than 48 the other is at most 48)
-  else SG_MID_TN_WIDE(12);
-#undef SG_MID_TN_WIDE
+  else SG_MID_TN_ROW(6);
 #undef SG_MID_TN_ROW
 #undef SG_MID_TN
   SG_HIP_TRY(hipGetLastError());

@@ -681,7 +681,6 @@ bool split_nt_pays(int64_t M, int64_t N, int64_t K) {
   const int64_t items = ((M + 127) / 128) * ((N + 127) / 128);
   return !(items < 128 && K >= 384);
 }
-bool split_variant_bit(int bit) { return (g_split_variant >> bit) & 1; }
 bool split_engine_enabled(int kind) { return !(g_split_variant & 1) && !(g_split_variant & (2 << kind)); }      // kind 0 nt, 1 nn, 2 tn
 
 static inline int split_nf(int64_t N) { return N % 256 == 0 || N > 640 ? 16 : (N % 128 == 0 || N <= 128 ? 8 : 16); }

@@ -308,7 +308,6 @@ int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_r
 int set_split_tuning(int value);
 int set_bn_rows_tuning(int value);
 bool split_engine_enabled(int kind = 0);
-bool split_variant_bit(int bit);      // SG_TUNE_F32_ENGINE bit
 bool gemm_tn_f32s_supported(int64_t M, int64_t N, int64_t Kp, int64_t lda, int64_t ldb);
 int64_t gemm_tn_f32s_workspace(int64_t M, int64_t N, int64_t Kp);
 int launch_split_tn_reduce(const float* ws, int n_slabs, int64_t N, int64_t Kp, float* out, int64_t ldo, const GradSink* sink,

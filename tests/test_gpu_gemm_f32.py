@@ -104,9 +104,7 @@ def test_split_tn_random_data_strides_and_error_vs_float64(M, N, Kp):
     assert e_own <= 1.25 * e_lib + 3e-8 and e_own < 6e-7, (e_own, e_lib)
 
 
-MID_SHAPES = [(50000, 32, 48), (50000, 48, 32), (1000, 16, 48), (777, 48, 48), (4099, 8, 20), (256, 4, 4), (33333, 24, 36),
-              # one side up to 96 (round 6): the 32 -> 32-channel layers of the MGCN (util/meshnet.py:92-95), ragged row counts
-              (30000, 32, 96), (30001, 96, 32), (777, 64, 32), (5000, 48, 96), (1000, 96, 4), (129, 8, 80)]
+MID_SHAPES = [(50000, 32, 48), (50000, 48, 32), (1000, 16, 48), (777, 48, 48), (4099, 8, 20), (256, 4, 4), (33333, 24, 36)]
 
 
 @pytest.mark.parametrize("M,N,K", MID_SHAPES)
