@@ -138,7 +138,9 @@ SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, 
  * fma chain over its neighbours in ascending id -- the SAME BITS as the chain kernel
  * (tests/test_gpu_parity.py::test_f32_ring_kernel_equals_the_rows_kernel_bit_for_bit;
  * SG_TUNE_FLAGS bit 13 switches the tiled float32 pipeline off, for A/B timing only).
- * The tile records are built by the first aggregation that can use them.
+ * The tile records are built by the first aggregation that can use them: THAT call allocates device memory and synchronises
+ * the stream twice (it is not asynchronous; never the case while the stream is being captured -- such a call runs on the chain
+ * kernel and leaves the build to the next eager one); a failed build is retried by the next call.
  * Non-finite inputs: the gathers run in fixed-size batches whose unused slots
  * are switched off by a ZERO WEIGHT on a row that is read anyway (a neighbour of
  * one of the rows the same wavefront works on, or row 0; in the tiled kernel: any

@@ -63,9 +63,13 @@ int build_pending_records(const Csr& c_, hipStream_t stream) {
   if (st != hipStreamCaptureStatusNone) return SG_OK;
   std::lock_guard<std::mutex> lock(g_rec_mu);          // (forward and backward passes run on different host threads)
   Csr& c = const_cast<Csr&>(c_);
-  if (!c.rec_pending) return SG_OK;
-  c.rec_pending = false;
-  return build_ring_records(&c, c.pend_scale_src, c.pend_scale_dst, c.pend_row_id, stream);
+  if (!__atomic_load_n(&c.rec_pending, __ATOMIC_ACQUIRE)) return SG_OK;
+  // the flag is cleared only AFTER a successful build (release: a thread that reads it false, outside the mutex, also
+  // sees the finished record pointers); a failed build -- out of memory, say -- leaves it set, so the next aggregation tries
+  // again instead of the graph staying on the rows kernel for good
+  const int rc = build_ring_records(&c, c.pend_scale_src, c.pend_scale_dst, c.pend_row_id, stream);
+  if (rc == SG_OK) __atomic_store_n(&c.rec_pending, false, __ATOMIC_RELEASE);
+  return rc;
 }
 
 int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64_t ldx,
@@ -80,7 +84,7 @@ int run_csr(const Csr& c, const float* sd, const float* ss, const void* X, int64
   if (X0 && (rc = check_dense("X0", X0, ldx0, C)) != SG_OK) return rc;
   if (X1 && (rc = check_dense("X1", X1, ldx1, C)) != SG_OK) return rc;
   SG_REQUIRE(X != Y, "Y must not alias X");
-  if (c.rec_pending && (dtype == SG_BF16 || (dtype == SG_F32 && ring_f32_enabled())) && (C == 128 || C == 256) &&
+  if (__atomic_load_n(&c.rec_pending, __ATOMIC_ACQUIRE) && (dtype == SG_BF16 || (dtype == SG_F32 && ring_f32_enabled())) && (C == 128 || C == 256) &&
       (rc = build_pending_records(c, stream)) != SG_OK)
     return rc;
   SpmmArgs a;

@@ -39,6 +39,7 @@ struct LtApi {
   decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
   decltype(&hipblasLtMatmul) Matmul = nullptr;
   decltype(&hipblasLtGetVersion) GetVersion = nullptr;      // (optional: absent from very old builds)
+  decltype(&hipblasLtDestroy) Destroy = nullptr;            // (optional: only used to drop a handle of a refused library)
   bool ok = false;
   std::string why;
 };
@@ -76,6 +77,7 @@ const LtApi& lt_api() {     // call with g_lt_mu held
             bind(so, "hipblasLtMatmulAlgoGetHeuristic", &g_lt.Heuristic) && bind(so, "hipblasLtMatmul", &g_lt.Matmul);
   if (!ok) g_lt.why = "libhipblaslt.so.1 lacks an expected entry point";
   bind(so, "hipblasLtGetVersion", &g_lt.GetVersion);
+  bind(so, "hipblasLtDestroy", &g_lt.Destroy);
   g_lt.ok = ok;
   return g_lt;
 }
@@ -125,16 +127,30 @@ int lt_gemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const void* A, in
   int dev = 0;
   SG_HIP_TRY(hipGetDevice(&dev));
   SG_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d out of range", dev);
+  static int g_lt_refused = 0;        // (under g_lt_mu) the version the loaded library reported when it was refused: sticky
+  if (g_lt_refused) {
+    set_error("the loaded libhipblaslt reports version %d; this library was built against major version %d", g_lt_refused, HIPBLASLT_VERSION_MAJOR);
+    return SG_ERR_UNSUPPORTED;
+  }
   if (!g_lt_handle[dev]) {
-    SG_LT_TRY(lt.Create(&g_lt_handle[dev]));
     // the structs and enums this file was compiled against (hipblasLtMatmulAlgo_t is passed by value into the plan cache) are
-    // those of ONE major version of the library: a process that loaded another one is refused, not miscomputed
+    // those of ONE major version of the library: a process that loaded another one is refused, not miscomputed.  The handle
+    // is published only AFTER the check (a handle stored first made every later call skip it), and the refusal sticks.
+    hipblasLtHandle_t h = nullptr;
+    SG_LT_TRY(lt.Create(&h));
     int ver = 0;
-    if (lt.GetVersion && lt.GetVersion(g_lt_handle[dev], &ver) == HIPBLAS_STATUS_SUCCESS && ver / 100000 != HIPBLASLT_VERSION_MAJOR &&
-        ver / 10000 != HIPBLASLT_VERSION_MAJOR) {      // (major * 100000 + minor * 100 + patch; older builds: major * 10000)
-      set_error("the loaded libhipblaslt reports version %d; this library was built against major version %d", ver, HIPBLASLT_VERSION_MAJOR);
-      return SG_ERR_UNSUPPORTED;
+    if (lt.GetVersion && lt.GetVersion(h, &ver) == HIPBLAS_STATUS_SUCCESS) {
+      // major * 100000 + minor * 100 + patch in the builds this was checked against, major * 10000 + .. in older ones: a version is
+      // refused only when NEITHER decoding gives the major version of the headers (a build with major 0 passes the first test with
+      // any version below 100000 -- such a library predates the plan structs used here by years and does not export Heuristic)
+      if (ver / 100000 != HIPBLASLT_VERSION_MAJOR && ver / 10000 != HIPBLASLT_VERSION_MAJOR) {
+        g_lt_refused = ver ? ver : -1;
+        if (lt.Destroy) (void)lt.Destroy(h);
+        set_error("the loaded libhipblaslt reports version %d; this library was built against major version %d", ver, HIPBLASLT_VERSION_MAJOR);
+        return SG_ERR_UNSUPPORTED;
+      }
     }
+    g_lt_handle[dev] = h;
   }
   PlanKey key{dev, opA, opB, dt_in, dt_out, bias ? 1 : 0, batch, M, N, K, lda, ldb, ldc, sa, sb, sc};
   auto it = g_plans.find(key);
