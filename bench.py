@@ -785,9 +785,10 @@ def supervise_rank(args) -> int:
         env = dict(os.environ)
         env["SEMIGCN_BENCH_ATTEMPT"], env["SEMIGCN_BENCH_MARK"] = str(attempt), mark
         # the library's own communicator meets real peers for the first time in attempt 1: if its known-answer collectives hang
-        # (rather than disagree) the worker ends itself after 30 s (dist._HangGuard, exit code 86) instead of sitting out the
-        # attempt's limit, and attempt 2 runs with the collectives on torch.distributed
-        env.setdefault("SEMIGCN_DIST_KNOWN_ANSWER_TIMEOUT", "30")
+        # (rather than disagree) the worker ends itself after 45 s (dist._HangGuard, exit code 86) instead of sitting out the
+        # attempt's limit, and attempt 2 runs with the collectives on torch.distributed.  The guard covers the three native
+        # collectives and a device synchronise only: torch.distributed's reference collectives run before it.
+        env.setdefault("SEMIGCN_DIST_KNOWN_ANSWER_TIMEOUT", "45")
         if attempt > 1:
             env["SEMIGCN_BENCH_FIRST_FAILURE"] = " | ".join(reasons)[:600]
             # a store prefix / port of its own: the earlier attempts' keys (and, without an agent store, their listening socket)

@@ -611,29 +611,33 @@ def _base_comm(lay):
         if comm is not None:
             comm.close()
         return give_up("ncclCommInitRank failed on a rank" + (f" (here: {err})" if err else ""))
-    # -- 3. known answers (the two-communicator rule below holds: every torch collective is awaited before a native one starts)
+    # -- 3. known answers (the two-communicator rule below holds: every torch collective is awaited before a native one starts).
+    #       torch.distributed's side runs FIRST and outside the hang guard: its first all-to-all sets up the process group's own
+    #       point-to-point channels (seconds on eight ranks) and must not be mistaken for a hang of the library's communicator
     ok = True
     try:
-        with _HangGuard("the known-answer exchange of the library's own communicator"):
-            send = torch.empty((lay.n_send, 4), dtype=torch.float32, device=dev)
-            send[:, 0] = float(lay.rank)
-            send[:, 1] = torch.arange(lay.n_send, device=dev, dtype=torch.float32)
-            send[:, 2:] = 0.5
-            got = torch.full((lay.n_ext - lay.n_own, 4), -1.0, device=dev)
-            want = torch.full_like(got, -2.0)
+        send = torch.empty((lay.n_send, 4), dtype=torch.float32, device=dev)
+        send[:, 0] = float(lay.rank)
+        send[:, 1] = torch.arange(lay.n_send, device=dev, dtype=torch.float32)
+        send[:, 2:] = 0.5
+        got = torch.full((lay.n_ext - lay.n_own, 4), -1.0, device=dev)
+        want = torch.full_like(got, -2.0)
+        red = torch.arange(7, device=dev, dtype=torch.float32) * float(lay.rank + 1)
+        red_want = red.clone()
+        gin = torch.arange(5, device=dev, dtype=torch.float32) + 10.0 * lay.rank
+        gout = torch.full((lay.world * 5,), -1.0, device=dev)
+        gwant = torch.full_like(gout, -2.0)
+        _all_to_all_rows(want, send, lay.recv_splits, lay.send_splits, lay.group)
+        collective_counts["all_to_all"] -= 1
+        _pg_all_reduce(red_want, dist.ReduceOp.SUM, lay.group)
+        _pg_all_gather(gwant, gin, lay.group)
+        torch.cuda.synchronize(dev)
+        with _HangGuard("the known-answer collectives of the library's own communicator"):
             comm.halo_exchange(got, send)
-            _all_to_all_rows(want, send, lay.recv_splits, lay.send_splits, lay.group)
-            collective_counts["all_to_all"] -= 1
-            red = torch.arange(7, device=dev, dtype=torch.float32) * float(lay.rank + 1)
-            red_want = red.clone()
             comm.all_reduce_(red)
-            _pg_all_reduce(red_want, dist.ReduceOp.SUM, lay.group)
-            gin = torch.arange(5, device=dev, dtype=torch.float32) + 10.0 * lay.rank
-            gout = torch.full((lay.world * 5,), -1.0, device=dev)
-            gwant = torch.full_like(gout, -2.0)
             comm.all_gather(gout, gin)
-            _pg_all_gather(gwant, gin, lay.group)
-            ok = bool(torch.equal(got, want)) and bool(torch.equal(red, red_want)) and bool(torch.equal(gout, gwant))
+            torch.cuda.synchronize(dev)
+        ok = bool(torch.equal(got, want)) and bool(torch.equal(red, red_want)) and bool(torch.equal(gout, gwant))
     except Exception as e:                                  # noqa: BLE001
         ok, err = False, f"{type(e).__name__}: {e}"
     if not _agree(ok, lay.group, dev):

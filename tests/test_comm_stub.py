@@ -226,7 +226,7 @@ def test_a_failed_send_closes_its_group_and_names_the_step(stub):
 
 def test_hang_guard_ends_the_worker_with_its_own_exit_code(tmp_path):
     """a known-answer exchange that HANGS must fail the attempt fast: with
-    SEMIGCN_DIST_KNOWN_ANSWER_TIMEOUT set (bench.py's supervisor sets 30 s for its workers) a timer thread ends the process
+    SEMIGCN_DIST_KNOWN_ANSWER_TIMEOUT set (bench.py's supervisor sets 45 s for its workers) a timer thread ends the process
     with exit code 86 and leaves a mark for the supervisor; without the variable nothing is ever ended."""
     import subprocess
     code = ("import os, sys, time; sys.path.insert(0, %r); from semigcn_amd import dist as d\n"
