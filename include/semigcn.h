@@ -504,12 +504,20 @@ typedef struct sg_block {
    *   wpack    order 0: Wcat [Cout, K*Cin]; order 1: Wstack [K*Cout, Cin]     in the feature dtype
    *   wpack_t  (nullable) its transpose: bf16 features read it in the input-gradient product on the MFMA kernel
    *   wpack32 / wpack32_t  (nullable) the same two in float32 -- for products with a tiny weight matrix (Cout, K*Cin <= 16: sg_thin_*)
-   *   bias_k   (order 1 with a bias) the bias padded with zeros to K*Cout floats: it rides in on Z_0 */
+   *   bias_k   (order 1 with a bias) the bias padded with zeros to K*Cout floats: it rides in on Z_0
+   *   wsplit / wsplit_t  (nullable; float32 features) the split-bf16 images of the weight matrix for the forward and for the
+   *            input-gradient product -- sg_gemm_nt_f32_workspace(N, K) bytes each, 16-byte aligned, N x K = Cout x K*Cin and
+   *            K*Cin x Cout (order 0) / K*Cout x Cin and Cin x K*Cout (order 1).  Given, the images are rebuilt ONLY when
+   *            refresh_weights != 0 (every fifth iteration of the reference's loop) instead of inside each product; NULL: as
+   *            before, every float32 product splits its weights into scratch.  The images are specific to V (the tile shape
+   *            follows the row count) and to the tuning knobs at the time of the refresh: change a knob, refresh. */
   void* wpack;
   void* wpack_t;
   float* wpack32;
   float* wpack32_t;
   float* bias_k;
+  void* wsplit;
+  void* wsplit_t;
   /* activations (feature dtype, unit column stride, row strides in elements).
    * order 0: T is the [V, K*Cin] buffer whose first Cin columns hold the input on entry -- X == T when the producer wrote it
    * there, else the library copies X in; order 1: T is not used (NULL) and X [V, Cin] is read in place.

@@ -41,6 +41,7 @@ class sg_block(ctypes.Structure):
                 ("W", c_void_p * 3), ("bias", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
                 ("running_mean", c_void_p), ("running_var", c_void_p), ("batches_tracked", c_void_p),
                 ("wpack", c_void_p), ("wpack_t", c_void_p), ("wpack32", c_void_p), ("wpack32_t", c_void_p), ("bias_k", c_void_p),
+                ("wsplit", c_void_p), ("wsplit_t", c_void_p),
                 ("X", c_void_p), ("ldx", c_int64), ("T", c_void_p), ("ldt", c_int64), ("H", c_void_p), ("stats", c_void_p),
                 ("Y", c_void_p), ("ldy", c_int64),
                 ("dY", c_void_p), ("lddy", c_int64), ("dX", c_void_p), ("lddx", c_int64), ("dW", c_void_p), ("dvec", c_void_p),
@@ -533,10 +534,16 @@ TUNE_F32_ENGINE = 8
 TUNE_BN_ROWS = 9
 
 
+#: bumped by every tuning_set: a BlockPlan's packed weight copies (the split-bf16 images in particular: their tile shape follows
+#: SG_TUNE_F32_ENGINE) are rebuilt at the first call after a knob changed
+tuning_generation = [0]
+
+
 def tuning_set(knob: int, value: int) -> None:
     """Launch tuning of the aggregation kernel (benchmarking aid; results do not depend on it)."""
     _check(load().sg_tuning_set(int(knob), int(value)), "sg_tuning_set")
     _sizes.cache_clear()          # the GEMM tile knob changes sg_gemm_tile_rows / sg_gemm_row_tiles
+    tuning_generation[0] += 1     # packed weight images follow the knobs (functional.BlockPlan.stale re-packs after a change)
 
 
 @functools.lru_cache(maxsize=512)
@@ -824,6 +831,11 @@ def gemm_nt_f32_supported(A: torch.Tensor, N: int, ldc: Optional[int] = None) ->
         return False
     M, K = A.shape
     return bool(_sizes("sg_gemm_nt_f32_supported", int(M), int(N), int(K), int(A.stride(0)), int(ldc if ldc is not None else N)))
+
+
+def gemm_nt_f32_workspace(N: int, K: int) -> int:
+    """Bytes of the split-bf16 image of an [N, K] weight matrix (``sg_gemm_nt_f32_workspace``; 0 for small-weight shapes)."""
+    return _sizes("sg_gemm_nt_f32_workspace", int(N), int(K))
 
 
 def gemm_nt_f32_pays(M: int, N: int, K: int) -> bool:

@@ -223,6 +223,12 @@ int spmm(const sg_block& b, bool transpose, const void* X, int64_t ldx, const vo
 
 inline char* col(void* base, int64_t cols, int64_t e) { return (char*)base + cols * e; }
 
+// shapes launch_pack_split builds an image for (what gemm_nt_f32s_supported asks of N and K)
+inline bool split_image_shape(int64_t N, int64_t K) { return N >= 64 && N % 4 == 0 && K >= 64 && K % 32 == 0; }
+inline const void* split_image(const sg_block& b, bool transposed, int64_t N, int64_t K) {
+  return (b.dtype == SG_F32 && split_image_shape(N, K)) ? (transposed ? b.wsplit_t : b.wsplit) : nullptr;
+}
+
 int pack(const sg_block& b, hipStream_t stream) {
   SG_REQUIRE(b.wpack != nullptr, "sg_block: wpack is null");
   PackArgs a;
@@ -235,6 +241,20 @@ int pack(const sg_block& b, hipStream_t stream) {
   const int64_t n = (int64_t)b.K * b.Cin * b.Cout;
   pack_weights<<<(int)((n + 255) / 256), 256, 0, stream>>>(a);
   SG_HIP_TRY(hipGetLastError());
+  // float32 features: the split-bf16 images of the weight matrix, once per weight update instead of once per product
+  // (sg_block::wsplit / wsplit_t; a shape the split kernels do not take gets no image and its products pack nothing either)
+  if (b.dtype == SG_F32 && (b.wsplit || b.wsplit_t)) {
+    const int64_t na = b.order == 0 ? b.Cout : (int64_t)b.K * b.Cout, ka = b.order == 0 ? (int64_t)b.K * b.Cin : b.Cin;
+    const float* const w32 = (const float*)b.wpack;                   // [na, ka] row-major in the feature dtype = float32
+    if (b.wsplit && split_image_shape(na, ka)) {
+      int rc = launch_pack_split(w32, ka, 1, b.V, na, ka, b.wsplit, stream);
+      if (rc != SG_OK) return rc;
+    }
+    if (b.wsplit_t && split_image_shape(ka, na)) {                      // the input-gradient product reads the same storage as [ka, na]^T
+      int rc = launch_pack_split(w32, 1, ka, b.V, ka, na, b.wsplit_t, stream);
+      if (rc != SG_OK) return rc;
+    }
+  }
   return SG_OK;
 }
 
@@ -283,14 +303,14 @@ int forward(const sg_block& b, hipStream_t stream) {
     }
     const bool want = b.training && b.pool_mode == 0;      // (pooled rows have other statistics than the tiles of Hc)
     rc = dense_nt(b.T, b.ldt, b.wpack, b.wpack32, s.KCi, b.bias, Hc, s.Co, s.V, s.Co, s.KCi, b.dtype, want ? w.moments : nullptr,
-                  &tile_moments, w.blas, kBlasWorkspace, stream, pt);
+                  &tile_moments, w.blas, kBlasWorkspace, stream, pt, Planes{}, split_image(b, false, s.Co, s.KCi), b.V);
     if (rc != SG_OK) return rc;
   } else {
     // Z = X Wstack^T (+ bias on Z_0); Clenshaw in place: b_k = Z_k + 2 L^ b_(k+1) - b_(k+2); out = Z_0 + L^ b_1 - b_2
     const Planes pz = s.planes_ok ? s.pl : Planes{};
     const int64_t ldz = pz.on() ? s.Co : s.KCo;
     rc = dense_nt(b.X, b.ldx, b.wpack, nullptr, s.Ci, b.bias ? b.bias_k : nullptr, w.Z, ldz, s.V, s.KCo, s.Ci, b.dtype, nullptr,
-                  nullptr, w.blas, kBlasWorkspace, stream, Planes{}, pz);
+                  nullptr, w.blas, kBlasWorkspace, stream, Planes{}, pz, split_image(b, false, s.KCo, s.Ci), b.V);
     if (rc != SG_OK) return rc;
     auto z = [&](int k) { return pz.on() ? col(w.Z, k * pz.stride, s.e) : col(w.Z, k * s.Co, s.e); };
     for (int k = b.K - 2; k >= 1; --k) {
@@ -405,7 +425,7 @@ int backward(const sg_block& b, hipStream_t stream) {
       void* const dT = b.K == 1 ? b.dX : w.G;
       const int64_t ldt = b.K == 1 ? b.lddx : (pt.on() ? s.Ci : s.KCi);
       rc = dense_nn(dHc, lddc, b.wpack, s.KCi, b.wpack_t, s.Co, b.wpack32_t, dT, ldt, s.V, s.KCi, s.Co, b.dtype, w.blas,
-                    kBlasWorkspace, stream, Planes{}, pt);
+                    kBlasWorkspace, stream, Planes{}, pt, split_image(b, true, s.KCi, s.Co), b.V);
       if (rc != SG_OK) return rc;
       if (b.K > 1) {
         auto g = [&](int k) { return pt.on() ? col(dT, k * pt.stride, s.e) : col(dT, k * s.Ci, s.e); };
@@ -429,7 +449,7 @@ int backward(const sg_block& b, hipStream_t stream) {
     }
     if (b.need_dx) {
       rc = dense_nn(w.G, ldg, b.wpack, s.Ci, b.wpack_t, s.KCo, nullptr, b.dX, b.lddx, s.V, s.Ci, s.KCo, b.dtype, w.blas,
-                    kBlasWorkspace, stream, pg);
+                    kBlasWorkspace, stream, pg, Planes{}, split_image(b, true, s.Ci, s.KCo), b.V);
       if (rc != SG_OK) return rc;
     }
     rc = dense_tn(w.G, ldg, b.X, b.ldx, s.V, s.KCo, s.Ci, b.dtype, w.tn, b.dW, s.Ci, w.blas, kBlasWorkspace, stream,
@@ -588,14 +608,14 @@ int part_run(const sg_block& b, hipStream_t stream) {
       if ((rc = agg(b.graph_wide, b.T, b.ldt, nullptr, 0, nullptr, 0, col(b.T, Ci, e), b.ldt, Ci, 1.f, 0.f, 0.f)) != SG_OK) return rc;
       if ((rc = agg(b.graph, col(b.T, Ci, e), b.ldt, b.T, b.ldt, nullptr, 0, col(b.T, 2 * Ci, e), b.ldt, Ci, 2.f, -1.f, 0.f)) != SG_OK) return rc;
       rc = dense_nt(b.T, b.ldt, b.wpack, b.wpack32, KCi, b.bias, b.H, b.ldh, V, Co, KCi, b.dtype, b.training ? w.moments : nullptr,
-                    &tile_moments, w.blas, kBlasWorkspace, stream);
+                    &tile_moments, w.blas, kBlasWorkspace, stream, Planes{}, Planes{}, split_image(b, false, Co, KCi), b.V);
       if (rc != SG_OK) return rc;
     } else {
       SG_REQUIRE(b.X && b.ldx >= Ci, "sg_block_run (conv): order 1 needs the [V_ext, Cin] input X");
       if (b.bias) SG_REQUIRE(b.bias_k != nullptr, "sg_block_run (conv): order 1 with a bias needs bias_k");
       // the product on ALL V_ext rows (the halo rows' share is a few per cent): no exchange between product and aggregation
       rc = dense_nt(b.X, b.ldx, b.wpack, nullptr, Ci, b.bias ? b.bias_k : nullptr, w.Z, KCo, Ve, KCo, Ci, b.dtype, nullptr, nullptr,
-                    w.blas, kBlasWorkspace, stream);
+                    w.blas, kBlasWorkspace, stream, Planes{}, Planes{}, split_image(b, false, KCo, Ci), b.V);
       if (rc != SG_OK) return rc;
       char* z0 = (char*)w.Z;
       char* z1 = col(w.Z, Co, e);
@@ -691,7 +711,8 @@ int part_run(const sg_block& b, hipStream_t stream) {
         if ((rc = launch_multi_add(b.K, srcs, ld, rows, cols, dsts, stream)) != SG_OK) return rc;
       }
       // the K gradient blocks of the owned rows; blocks 1, 2 of the boundary rows go to the peers
-      rc = dense_nn(dH, lddh, b.wpack, KCi, b.wpack_t, Co, b.wpack32_t, b.G, KCi, V, KCi, Co, b.dtype, w.blas, kBlasWorkspace, stream);
+      rc = dense_nn(dH, lddh, b.wpack, KCi, b.wpack_t, Co, b.wpack32_t, b.G, KCi, V, KCi, Co, b.dtype, w.blas, kBlasWorkspace, stream,
+                    Planes{}, Planes{}, split_image(b, true, KCi, Co), b.V);
       if (rc != SG_OK) return rc;
       if ((rc = pack_to(b, col(b.G, Ci, e), KCi, 2 * Ci, nullptr, 0, stream)) != SG_OK) return rc;
     } else {
@@ -718,7 +739,8 @@ int part_run(const sg_block& b, hipStream_t stream) {
       if ((rc = agg(b.graph_wide, g0, KCo, nullptr, 0, nullptr, 0, g1, KCo, Co, 1.f, 0.f, 0.f)) != SG_OK) return rc;
       if ((rc = agg(b.graph, g1, KCo, g0, KCo, nullptr, 0, g2, KCo, Co, 2.f, -1.f, 0.f)) != SG_OK) return rc;
       if (b.need_dx) {
-        rc = dense_nn(b.G, KCo, b.wpack, Ci, b.wpack_t, KCo, nullptr, b.dX, b.lddx, V, Ci, KCo, b.dtype, w.blas, kBlasWorkspace, stream);
+        rc = dense_nn(b.G, KCo, b.wpack, Ci, b.wpack_t, KCo, nullptr, b.dX, b.lddx, V, Ci, KCo, b.dtype, w.blas, kBlasWorkspace, stream,
+                      Planes{}, Planes{}, split_image(b, true, Ci, KCo), b.V);
         if (rc != SG_OK) return rc;
       }
       GradSink sink;

@@ -277,7 +277,7 @@ bool dense_planes_ok_tn(int dtype, int64_t M, int64_t N, int64_t Kp) {
 
 int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64_t ldb, const float* bias, void* C, int64_t ldc,
              int64_t M, int64_t N, int64_t K, int dtype, float* moments, bool* moments_done, void* blas_ws, size_t blas_ws_bytes,
-             hipStream_t stream, Planes pa, Planes pc) {
+             hipStream_t stream, Planes pa, Planes pc, const void* presplit, int64_t presplit_rows) {
   if (moments_done) *moments_done = false;
   if (M == 0 || N == 0) return SG_OK;
   if (pa.on() || pc.on()) {
@@ -300,11 +300,11 @@ int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64
     TraceScope ts(1, dtype, 1, M, N, K, stream);
     return launch_gemm_nt(A, lda, Bp, ldb, bias, C, ldc, M, N, K, dtype, mom, stream);
   }
-  if (dtype == SG_F32 && split_engine_enabled(0) && split_nt_pays(M, N, K) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) && blas_ws &&
-      (int64_t)blas_ws_bytes >= gemm_nt_f32s_workspace(N, K)) {
+  if (dtype == SG_F32 && split_engine_enabled(0) && split_nt_pays(M, N, K) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) &&
+      (presplit || (blas_ws && (int64_t)blas_ws_bytes >= gemm_nt_f32s_workspace(N, K)))) {
     TraceScope ts(1, dtype, 4, M, N, K, stream);
     return launch_gemm_nt_f32s((const float*)A, lda, (const float*)Bp, ldb, 1, bias, (float*)C, ldc, M, N, K, blas_ws,
-                               (int64_t)blas_ws_bytes, stream);
+                               (int64_t)blas_ws_bytes, stream, presplit, presplit_rows);
   }
   if (dtype == SG_F32 && split_engine_enabled(0) && mid_shape(N, K) && lda % 4 == 0 && ldc % 4 == 0 && a16(A) && a16(C)) {
     TraceScope ts(1, dtype, 2, M, N, K, stream);
@@ -316,7 +316,7 @@ int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64
 
 int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void* Bt, int64_t ldbt, const float* Bt32, void* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream,
-             Planes pa, Planes pc) {
+             Planes pa, Planes pc, const void* presplit, int64_t presplit_rows) {
   // C[M, N] = A[M, K] B[K, N]; Bt = B^T [N, K] where a transposed copy exists (the MFMA / thin kernels read that one)
   if (M == 0 || N == 0) return SG_OK;
   if (pa.on() || pc.on()) {
@@ -334,11 +334,11 @@ int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void
     TraceScope ts(1, dtype, 1, M, N, K, stream);
     return launch_gemm_nt(A, lda, Bt, ldbt, nullptr, C, ldc, M, N, K, dtype, nullptr, stream);
   }
-  if (dtype == SG_F32 && split_engine_enabled(1) && split_nt_pays(M, N, K) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) && blas_ws &&
-      (int64_t)blas_ws_bytes >= gemm_nt_f32s_workspace(N, K)) {
+  if (dtype == SG_F32 && split_engine_enabled(1) && split_nt_pays(M, N, K) && gemm_nt_f32s_supported(M, N, K, lda, ldc) && a16(A) && a16(C) &&
+      (presplit || (blas_ws && (int64_t)blas_ws_bytes >= gemm_nt_f32s_workspace(N, K)))) {
     TraceScope ts(1, dtype, 4, M, N, K, stream);      // B is [K, N]: element (n, k) at Bp[k * ldb + n]
     return launch_gemm_nt_f32s((const float*)A, lda, (const float*)Bp, 1, ldb, nullptr, (float*)C, ldc, M, N, K, blas_ws,
-                               (int64_t)blas_ws_bytes, stream);
+                               (int64_t)blas_ws_bytes, stream, presplit, presplit_rows);
   }
   if (dtype == SG_F32 && split_engine_enabled(1) && mid_shape(N, K) && lda % 4 == 0 && ldc % 4 == 0 && a16(A) && a16(C)) {
     TraceScope ts(1, dtype, 2, M, N, K, stream);      // B is [K, N]: element (n, k) at Bp[k * ldb + n]

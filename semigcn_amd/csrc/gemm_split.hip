@@ -699,34 +699,63 @@ int64_t gemm_nt_f32s_workspace(int64_t N, int64_t K) {      // bytes of the spli
   return ((N + nt - 1) / nt) * (K / 32) * (3 * nf * 1024);
 }
 
-// C[M, N] = A[M, K] op(W) (+ bias): W element (n, k) at W[n * w_rs + k * w_cs]
-int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
-                        int64_t ldc, int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes, hipStream_t stream) {
-  SG_REQUIRE(gemm_nt_f32s_supported(M, N, K, lda, ldc), "sg_gemm_nt_f32: unsupported shape (M=%lld N=%lld K=%lld)", (long long)M,
-             (long long)N, (long long)K);
-  SG_REQUIRE((((uintptr_t)A | (uintptr_t)C | (uintptr_t)ws) & 15) == 0, "sg_gemm_nt_f32: misaligned operand");
-  SG_REQUIRE(ws && ws_bytes >= gemm_nt_f32s_workspace(N, K), "sg_gemm_nt_f32: workspace too small (%lld bytes given, %lld needed)",
-             (long long)ws_bytes, (long long)gemm_nt_f32s_workspace(N, K));
-  const bool small = split_small_rows(M);
+// The split image of W for a product whose tile shape is picked by `variant_rows` (the row count the image is packed for: a
+// block packs once per weight update for ITS row count and runs products of V or V_ext rows on it), into `out`
+// (gemm_nt_f32s_workspace(N, K) bytes).  W element (n, k) at W[n * w_rs + k * w_cs].
+static int pack_split_into(const float* W, int64_t w_rs, int64_t w_cs, int64_t variant_rows, int64_t N, int64_t K, void* out,
+                           hipStream_t stream, int* nf_out, bool* small_out) {
+  const bool small = split_small_rows(variant_rows);
   const int nf = small ? 8 : split_nf(N);
   const int nt = nf * 16;
-  const int rt = small ? 128 : 256;
   PackSplit p;
   p.W = W; p.rs = w_rs; p.cs = w_cs;
   p.N = (int)N; p.K = (int)K; p.NF = nf;
   p.n_col_tiles = (int)((N + nt - 1) / nt);
-  p.out = (uint8_t*)ws;
+  p.out = (uint8_t*)out;
   const int64_t n_frag = (int64_t)p.n_col_tiles * (K / 32) * nf;
   pack_split<<<(int)((n_frag + 3) / 4), 256, 0, stream>>>(p);
   SG_HIP_TRY(hipGetLastError());
+  if (nf_out) *nf_out = nf;
+  if (small_out) *small_out = small;
+  return SG_OK;
+}
+
+int launch_pack_split(const float* W, int64_t w_rs, int64_t w_cs, int64_t variant_rows, int64_t N, int64_t K, void* out,
+                      hipStream_t stream) {
+  SG_REQUIRE(W && out && ((uintptr_t)out & 15) == 0 && N >= 64 && K >= 64 && K % 32 == 0, "pack_split: bad argument");
+  return pack_split_into(W, w_rs, w_cs, variant_rows, N, K, out, stream, nullptr, nullptr);
+}
+
+// C[M, N] = A[M, K] op(W) (+ bias): W element (n, k) at W[n * w_rs + k * w_cs].  `prepacked` (nullable): the image of W that
+// launch_pack_split built for `variant_rows` rows -- no packing launch, ws is not touched (round 6: a block packs when its
+// weights change, i.e. every fifth iteration of the reference's loop, not in each of its two products per iteration).
+int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
+                        int64_t ldc, int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes, hipStream_t stream,
+                        const void* prepacked, int64_t variant_rows) {
+  SG_REQUIRE(gemm_nt_f32s_supported(M, N, K, lda, ldc), "sg_gemm_nt_f32: unsupported shape (M=%lld N=%lld K=%lld)", (long long)M,
+             (long long)N, (long long)K);
+  SG_REQUIRE((((uintptr_t)A | (uintptr_t)C | (uintptr_t)ws | (uintptr_t)prepacked) & 15) == 0, "sg_gemm_nt_f32: misaligned operand");
+  bool small = false;
+  int nf = 0;
+  if (prepacked) {
+    small = split_small_rows(variant_rows);
+    nf = small ? 8 : split_nf(N);
+  } else {
+    SG_REQUIRE(ws && ws_bytes >= gemm_nt_f32s_workspace(N, K), "sg_gemm_nt_f32: workspace too small (%lld bytes given, %lld needed)",
+               (long long)ws_bytes, (long long)gemm_nt_f32s_workspace(N, K));
+    int rc = pack_split_into(W, w_rs, w_cs, M, N, K, ws, stream, &nf, &small);
+    if (rc != SG_OK) return rc;
+  }
+  const int nt = nf * 16;
+  const int rt = small ? 128 : 256;
 
   SplitNt g;
   g.A = A; g.lda = lda;
-  g.Bp = (const uint8_t*)ws;
+  g.Bp = (const uint8_t*)(prepacked ? prepacked : ws);
   g.bias = bias;
   g.C = C; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
-  g.n_col_tiles = p.n_col_tiles;
+  g.n_col_tiles = (int)((N + nt - 1) / nt);
   g.n_row_tiles = (int)((M + rt - 1) / rt);
   int dev = 0, cus = 256;
   SG_HIP_TRY(hipGetDevice(&dev));

@@ -304,7 +304,10 @@ int launch_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64
 bool gemm_nt_f32s_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
 int64_t gemm_nt_f32s_workspace(int64_t N, int64_t K);
 int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
-                        int64_t ldc, int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes, hipStream_t stream);
+                        int64_t ldc, int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes, hipStream_t stream,
+                        const void* prepacked = nullptr, int64_t variant_rows = 0);
+int launch_pack_split(const float* W, int64_t w_rs, int64_t w_cs, int64_t variant_rows, int64_t N, int64_t K, void* out,
+                      hipStream_t stream);
 int set_split_tuning(int value);
 int set_bn_rows_tuning(int value);
 bool split_engine_enabled(int kind = 0);
@@ -374,14 +377,14 @@ int64_t dense_tn_workspace(int dtype, int64_t M, int64_t N, int64_t Kp);
 // pa / pc: A / C kept as planes (served by the 128-row MFMA kernel only: dense_planes_ok says whether a shape gets there)
 int dense_nt(const void* A, int64_t lda, const void* Bp, const float* B32, int64_t ldb, const float* bias, void* C, int64_t ldc,
              int64_t M, int64_t N, int64_t K, int dtype, float* moments, bool* moments_done, void* blas_ws, size_t blas_ws_bytes,
-             hipStream_t stream, Planes pa = {}, Planes pc = {});
+             hipStream_t stream, Planes pa = {}, Planes pc = {}, const void* presplit = nullptr, int64_t presplit_rows = 0);
 // do the nt product [M, K] x [N, K]^T and the tn product [M, N]^T [M, Kp] of these sizes run on the kernels that take planes?
 bool dense_planes_ok_nt(int dtype, int64_t M, int64_t N, int64_t K);
 bool dense_planes_ok_tn(int dtype, int64_t M, int64_t N, int64_t Kp);
 // C[M, N] = A[M, K] Bp[K, N]; Bt (nullable) = Bp^T [N, K] in the feature dtype, Bt32 (nullable) in float32
 int dense_nn(const void* A, int64_t lda, const void* Bp, int64_t ldb, const void* Bt, int64_t ldbt, const float* Bt32, void* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype, void* blas_ws, size_t blas_ws_bytes, hipStream_t stream,
-             Planes pa = {}, Planes pc = {});
+             Planes pa = {}, Planes pc = {}, const void* presplit = nullptr, int64_t presplit_rows = 0);
 // out[N, Kp] (float32) = A[M, N]^T B[M, Kp]; ws: dense_tn_workspace() floats
 // sink (nullable): also += the result into the K weight accumulators; *sunk tells whether the engine that ran could do it
 int dense_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t Kp, int dtype, float* ws,

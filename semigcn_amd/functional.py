@@ -96,6 +96,11 @@ def _tn_thin(dout: torch.Tensor, T: torch.Tensor) -> bool:
 USE_SPLIT_F32 = os.environ.get("SEMIGCN_F32_BLAS") != "1"
 
 
+#: float32 blocks keep the split-bf16 images of their weights between weight updates (sg_block::wsplit / wsplit_t); False: every
+#: product splits its weights into scratch, as before round 6 (A/B and test switch)
+USE_SPLIT_IMAGES = os.environ.get("SEMIGCN_NO_SPLIT_IMAGES") != "1"
+
+
 def _tn_split(dout: torch.Tensor, T: torch.Tensor) -> bool:
     return (USE_SPLIT_F32 and dout.is_cuda and dout.dtype == torch.float32 and T.dtype == torch.float32
             and not _tn_thin(dout, T) and capi.gemm_tn_f32_supported(dout, T))
@@ -1130,12 +1135,23 @@ class BlockPlan:
                    torch.empty(n, dtype=torch.float32, device=dev) if thin else None,
                    torch.empty(n, dtype=torch.float32, device=dev) if thin else None,
                    torch.empty(self.K * self.Cout, dtype=torch.float32, device=dev) if (self.order == 1 and self.cbias is not None) else None]
+            # float32 features: the split-bf16 images of the weights for the forward / input-gradient products, rebuilt by the library
+            # only when the weights changed (sg_block::wsplit, wsplit_t) instead of inside each product
+            ent += [None, None]
+            if dtype == torch.float32 and USE_SPLIT_IMAGES:
+                na, ka = (self.Cout, self.K * self.Cin) if self.order == 0 else (self.K * self.Cout, self.Cin)
+                for slot, (nn_, kk_) in ((6, (na, ka)), (7, (ka, na))):
+                    nb = capi.gemm_nt_f32_workspace(nn_, kk_) if (nn_ >= 64 and kk_ >= 64 and kk_ % 32 == 0 and nn_ % 4 == 0) else 0
+                    if nb > 0:
+                        ent[slot] = torch.empty(nb, dtype=torch.uint8, device=dev)
             self._packs[dtype] = ent
         blk.wpack = ent[1].data_ptr()
         blk.wpack_t = None if ent[2] is None else ent[2].data_ptr()
         blk.wpack32 = None if ent[3] is None else ent[3].data_ptr()
         blk.wpack32_t = None if ent[4] is None else ent[4].data_ptr()
         blk.bias_k = None if ent[5] is None else ent[5].data_ptr()
+        blk.wsplit = None if ent[6] is None else ent[6].data_ptr()
+        blk.wsplit_t = None if ent[7] is None else ent[7].data_ptr()
 
     def stale(self, dtype: torch.dtype, capturing: bool) -> int:
         """1 when the packed copies for ``dtype`` are older than the parameters (version counters: optimiser steps and
@@ -1144,7 +1160,7 @@ class BlockPlan:
         v = 0 if self.cbias is None else self.cbias._version
         for w in self.weights:
             v += w._version
-        key = (self._mark, v)
+        key = (self._mark, v, capi.tuning_generation[0])
         ent = self._packs[dtype]
         if ent[0] != key or capturing:
             ent[0] = key

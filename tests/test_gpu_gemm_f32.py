@@ -198,3 +198,42 @@ def test_float32_block_runs_on_the_split_kernels_and_matches_the_blas_engine(cin
         if n.endswith("0.bias"):          # the conv bias in front of a BatchNorm: zero in exact arithmetic, rounding noise on both sides
             continue
         assert float((a - b).norm() / b.norm()) < 5e-6, n
+
+
+@pytest.mark.parametrize("nu,nv", [(160, 128), (100, 50)])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (256, 128), (128, 128)])
+def test_cached_split_images_give_the_bits_of_per_product_packing_and_follow_the_weights(cin, cout, nu, nv):
+    """Round 6: a float32 block keeps the split-bf16 images of its weight matrix (sg_block::wsplit / wsplit_t) and rebuilds them
+    only when the weights changed.  Same bits as a block that splits its weights inside every product (forward, input gradient,
+    parameter gradients, running statistics) -- before AND after an in-place weight update, at both tile shapes."""
+    import copy
+    from semigcn_amd import synth
+    from semigcn_amd.graph import MeshGraph
+    from test_gpu_blocks import _block_module, _run
+    m = synth.torus_mesh(nu, nv)
+    g = MeshGraph.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), m.num_vertices)
+    seq_a = _block_module(cin, cout)
+    seq_b = copy.deepcopy(seq_a)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((m.num_vertices, cin), device=DEV, generator=gen)
+    r = torch.randn((m.num_vertices, cout), device=DEV, generator=gen)
+
+    def run(seq, images):
+        old = F_sg.USE_SPLIT_IMAGES
+        F_sg.USE_SPLIT_IMAGES = images
+        try:
+            return _run(seq, g, x, r)
+        finally:
+            F_sg.USE_SPLIT_IMAGES = old
+
+    for step in range(3):
+        res_a, res_b = run(seq_a, True), run(seq_b, False)
+        for a, b in zip(res_a[:-1], res_b[:-1]):
+            assert torch.equal(a, b), step
+        with torch.no_grad():                      # an optimiser step's worth of change: the version counters move, the images follow
+            for p_a, p_b in zip(seq_a.parameters(), seq_b.parameters()):
+                d = 0.01 * torch.randn(p_a.shape, device=DEV, generator=gen)
+                p_a.add_(d)
+                p_b.add_(d)
+    # and the outputs did change with the weights (the images were not left stale)
+    assert not torch.equal(run(seq_a, True)[0], res_a[0])
