@@ -418,7 +418,10 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     # SGCN: the aggregation kernel's event pairs are recorded INSIDE the timed region (the contract; ~0.7 % of the 1 M iteration).
     # MGCN has 66 aggregations + 12 pool passes per iteration on meshes down to 10 K vertices, where two event records per launch
     # double the iteration: its launches are timed in a pass of their own right after the timed region (`measured_over` says so)
-    in_region = args.model == "sgcn"
+    # The same goes for the reference's own mesh sizes (5 K - 50 K vertices: an event pair per launch costs a 50 K iteration 10 %):
+    # in the region from 200 K vertices on, where the pairs cost under 1 %
+    nu_, nv_ = map(int, args.mesh.split("x"))
+    in_region = args.model == "sgcn" and nu_ * nv_ >= 200_000
     if traced and in_region:
         timer = TraceTimer(("agg", "pool"))
     if DIST_ON:
