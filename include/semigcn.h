@@ -413,6 +413,10 @@ SG_API int sg_gemm_nt_f32_supported(int64_t M, int64_t N, int64_t K, int64_t lda
  * than 128 such tiles over K >= 384 (at 5 K rows: [V,768]x[768,256] and [V,384]x[384,256]).  SG_TUNE_F32_ENGINE bit 5 switches
  * the variant off (then: 1 from 16 384 rows on, or always with bit 4). */
 SG_API int sg_gemm_nt_f32_pays(int64_t M, int64_t N, int64_t K);
+/* Which tile shape -- and therefore which layout of the split weight image -- serves a product of M rows: 1 = 128-row tiles,
+ * 0 = 256-row tiles.  An image built for one variant (sg_block::wsplit with that block's V) must not be handed to a block whose
+ * V falls into the other: a host that applies one set of weights to meshes of both size classes keeps an image per variant. */
+SG_API int sg_gemm_nt_f32_variant(int64_t M);
 SG_API int64_t sg_gemm_nt_f32_workspace(int64_t N, int64_t K);
 SG_API int sg_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
                           int64_t ldc, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream);
@@ -509,8 +513,8 @@ typedef struct sg_block {
    *            input-gradient product -- sg_gemm_nt_f32_workspace(N, K) bytes each, 16-byte aligned, N x K = Cout x K*Cin and
    *            K*Cin x Cout (order 0) / K*Cout x Cin and Cin x K*Cout (order 1).  Given, the images are rebuilt ONLY when
    *            refresh_weights != 0 (every fifth iteration of the reference's loop) instead of inside each product; NULL: as
-   *            before, every float32 product splits its weights into scratch.  The images are specific to V (the tile shape
-   *            follows the row count) and to the tuning knobs at the time of the refresh: change a knob, refresh. */
+   *            before, every float32 product splits its weights into scratch.  The images are specific to the tile variant of V
+   *            (sg_gemm_nt_f32_variant) and to the tuning knobs at the time of the refresh: change a knob, refresh. */
   void* wpack;
   void* wpack_t;
   float* wpack32;

@@ -111,6 +111,7 @@ _SIGNATURES = {
                            c_int, c_void_p, c_void_p]),
     "sg_gemm_nt_f32_supported": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
     "sg_gemm_nt_f32_pays": (c_int, [c_int64, c_int64, c_int64]),
+    "sg_gemm_nt_f32_variant": (c_int, [c_int64]),
     "sg_gemm_nt_f32_workspace": (c_int64, [c_int64, c_int64]),
     "sg_gemm_nt_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                c_int64, c_void_p, c_int64, c_void_p]),
@@ -836,6 +837,11 @@ def gemm_nt_f32_supported(A: torch.Tensor, N: int, ldc: Optional[int] = None) ->
 def gemm_nt_f32_workspace(N: int, K: int) -> int:
     """Bytes of the split-bf16 image of an [N, K] weight matrix (``sg_gemm_nt_f32_workspace``; 0 for small-weight shapes)."""
     return _sizes("sg_gemm_nt_f32_workspace", int(N), int(K))
+
+
+def gemm_nt_f32_variant(M: int) -> int:
+    """Tile variant (= layout of the split weight image) that serves a float32 product of M rows (``sg_gemm_nt_f32_variant``)."""
+    return _sizes("sg_gemm_nt_f32_variant", int(M))
 
 
 def gemm_nt_f32_pays(M: int, N: int, K: int) -> bool:

@@ -593,6 +593,8 @@ SG_API int sg_gemm_nt_f32_supported(int64_t M, int64_t N, int64_t K, int64_t lda
   return (gemm_nt_f32s_supported(M, N, K, lda, ldc) || (M >= 0 && mid_shape(N, K) && lda % 4 == 0 && ldc % 4 == 0)) ? 1 : 0;
 }
 
+SG_API int sg_gemm_nt_f32_variant(int64_t M) { return gemm_nt_f32s_variant(M); }
+
 SG_API int sg_gemm_nt_f32_pays(int64_t M, int64_t N, int64_t K) {
   return (mid_shape(N, K) || split_nt_pays(M, N, K)) ? 1 : 0;
 }

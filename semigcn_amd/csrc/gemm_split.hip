@@ -687,6 +687,7 @@ static inline int split_nf(int64_t N) { return N % 256 == 0 || N > 640 ? 16 : (N
 // few rows: 128 x 128 tiles on four wavefronts (the 128-column weight image is never larger than the 256-column one, so the
 // workspace size -- a function of N and K alone -- covers both)
 static inline bool split_small_rows(int64_t M) { return M < kSplitNtPaysRows && !(g_split_variant & 32); }
+int gemm_nt_f32s_variant(int64_t M) { return split_small_rows(M) ? 1 : 0; }
 
 bool gemm_nt_f32s_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
   return M >= 128 && M < ((int64_t)1 << 31) - 512 && N >= 64 && N % 4 == 0 && K >= 64 && K % 32 == 0 && lda % 4 == 0 &&

@@ -306,6 +306,7 @@ int64_t gemm_nt_f32s_workspace(int64_t N, int64_t K);
 int launch_gemm_nt_f32s(const float* A, int64_t lda, const float* W, int64_t w_rs, int64_t w_cs, const float* bias, float* C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes, hipStream_t stream,
                         const void* prepacked = nullptr, int64_t variant_rows = 0);
+int gemm_nt_f32s_variant(int64_t M);       // 1: the 128-row tiles (and their image layout) serve a product of M rows, 0: the 256-row ones
 int launch_pack_split(const float* W, int64_t w_rs, int64_t w_cs, int64_t variant_rows, int64_t N, int64_t K, void* out,
                       hipStream_t stream);
 int set_split_tuning(int value);

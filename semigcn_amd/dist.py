@@ -1025,7 +1025,8 @@ class _PartChainFn(torch.autograd.Function):
         if Ve > V:
             b.in_halo.copy_(x_halo)
         for i, p in enumerate(plans):
-            b.f_seg[i][0 if i == 0 else 1].refresh_weights = p.stale(dtype, False)
+            d0 = b.f_seg[i][0 if i == 0 else 1]
+            d0.refresh_weights = p.stale(dtype, False, int(d0.V))
         y = torch.empty((V, plans[-1].Cout), dtype=dtype, device=dev)
         b.f_tail[0].Y = y.data_ptr()
         comm = lay.native_comm() if all(training) else None

@@ -1136,24 +1136,30 @@ class BlockPlan:
                    torch.empty(n, dtype=torch.float32, device=dev) if thin else None,
                    torch.empty(self.K * self.Cout, dtype=torch.float32, device=dev) if (self.order == 1 and self.cbias is not None) else None]
             # float32 features: the split-bf16 images of the weights for the forward / input-gradient products, rebuilt by the library
-            # only when the weights changed (sg_block::wsplit, wsplit_t) instead of inside each product
-            ent += [None, None]
-            if dtype == torch.float32 and USE_SPLIT_IMAGES:
-                na, ka = (self.Cout, self.K * self.Cin) if self.order == 0 else (self.K * self.Cout, self.Cin)
-                for slot, (nn_, kk_) in ((6, (na, ka)), (7, (ka, na))):
-                    nb = capi.gemm_nt_f32_workspace(nn_, kk_) if (nn_ >= 64 and kk_ >= 64 and kk_ % 32 == 0 and nn_ % 4 == 0) else 0
-                    if nb > 0:
-                        ent[slot] = torch.empty(nb, dtype=torch.uint8, device=dev)
+            # only when the weights changed (sg_block::wsplit, wsplit_t) instead of inside each product.  One pair of images per TILE
+            # VARIANT (the layout follows the row count's size class, sg_gemm_nt_f32_variant): a module applied to a 5 K and a 50 K
+            # mesh in one autograd graph must not have one mesh's forward overwrite what the other's backward still reads
+            ent += [{}, {}, {}]          # [6], [7]: variant -> image; [8]: variant -> staleness key of that pair
             self._packs[dtype] = ent
         blk.wpack = ent[1].data_ptr()
         blk.wpack_t = None if ent[2] is None else ent[2].data_ptr()
         blk.wpack32 = None if ent[3] is None else ent[3].data_ptr()
         blk.wpack32_t = None if ent[4] is None else ent[4].data_ptr()
         blk.bias_k = None if ent[5] is None else ent[5].data_ptr()
-        blk.wsplit = None if ent[6] is None else ent[6].data_ptr()
-        blk.wsplit_t = None if ent[7] is None else ent[7].data_ptr()
+        blk.wsplit = blk.wsplit_t = None
+        if dtype == torch.float32 and USE_SPLIT_IMAGES:
+            var = capi.gemm_nt_f32_variant(int(blk.V))
+            if var not in ent[8]:
+                na, ka = (self.Cout, self.K * self.Cin) if self.order == 0 else (self.K * self.Cout, self.Cin)
+                for slot, (nn_, kk_) in ((6, (na, ka)), (7, (ka, na))):
+                    nb = capi.gemm_nt_f32_workspace(nn_, kk_) if (nn_ >= 64 and kk_ >= 64 and kk_ % 32 == 0 and nn_ % 4 == 0) else 0
+                    ent[slot][var] = torch.empty(nb, dtype=torch.uint8, device=dev) if nb > 0 else None
+                ent[8][var] = None
+            a, b = ent[6][var], ent[7][var]
+            blk.wsplit = None if a is None else a.data_ptr()
+            blk.wsplit_t = None if b is None else b.data_ptr()
 
-    def stale(self, dtype: torch.dtype, capturing: bool) -> int:
+    def stale(self, dtype: torch.dtype, capturing: bool, rows: int = 0) -> int:
         """1 when the packed copies for ``dtype`` are older than the parameters (version counters: optimiser steps and
         every autograd-visible in-place update bump them) -- the library then rebuilds them in the same call; inside a
         hipGraph capture always (the packing is part of the graph: replays see new weights)."""
@@ -1162,8 +1168,11 @@ class BlockPlan:
             v += w._version
         key = (self._mark, v, capi.tuning_generation[0])
         ent = self._packs[dtype]
-        if ent[0] != key or capturing:
+        var = capi.gemm_nt_f32_variant(rows) if (rows and dtype == torch.float32 and ent[8]) else None
+        if ent[0] != key or capturing or (var is not None and ent[8].get(var, key) != key):
             ent[0] = key
+            if var is not None:
+                ent[8][var] = key         # (the refresh rebuilds the images of THIS descriptor's variant only)
             return 1
         return 0
 
@@ -1171,6 +1180,8 @@ class BlockPlan:
         """Forget the packed copies' state (after a write through ``.data`` that the version counters do not see)."""
         for ent in self._packs.values():
             ent[0] = None
+            for var in ent[8]:
+                ent[8][var] = None
 
 
 def _up256(n: int) -> int:
@@ -1356,7 +1367,7 @@ class _ChainFn(torch.autograd.Function):
             chain._train[0] = training
         capturing = torch.cuda.is_current_stream_capturing()
         for i, p in enumerate(plans):
-            blks[i].refresh_weights = p.stale(dtype, capturing)
+            blks[i].refresh_weights = p.stale(dtype, capturing, int(blks[i].V))
         a0, w0 = arena.data_ptr(), ws.data_ptr()
         dyn = (a0, w0, y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0), None if base is None else base.data_ptr())
         if dyn != chain._dyn[0]:

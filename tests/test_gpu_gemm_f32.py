@@ -237,3 +237,43 @@ def test_cached_split_images_give_the_bits_of_per_product_packing_and_follow_the
                 p_b.add_(d)
     # and the outputs did change with the weights (the images were not left stale)
     assert not torch.equal(run(seq_a, True)[0], res_a[0])
+
+
+def test_one_module_on_meshes_of_both_size_classes_keeps_an_image_per_tile_variant():
+    """The split image's layout follows the tile variant (128-row tiles below 16 K rows, 256-row tiles from there on).  ONE block
+    applied to a 5 K-vertex and a 20 K-vertex mesh inside one autograd graph (shared weights): the second forward must not
+    overwrite the image the first mesh's backward still reads -- an image pair per variant (functional.BlockPlan.bind).  Bits
+    against the per-product packing."""
+    import copy
+    from semigcn_amd import synth
+    from semigcn_amd.graph import MeshGraph
+    from test_gpu_blocks import _block_module
+    meshes = [synth.torus_mesh(100, 50), synth.torus_mesh(160, 128)]
+    graphs = [MeshGraph.from_edge_index(torch.from_numpy(m.edge_index).to(DEV), m.num_vertices) for m in meshes]
+    assert capi.gemm_nt_f32_variant(meshes[0].num_vertices) == 1 and capi.gemm_nt_f32_variant(meshes[1].num_vertices) == 0
+    seq_a = _block_module(128, 128)
+    seq_b = copy.deepcopy(seq_a)
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    xs = [torch.randn((m.num_vertices, 128), device=DEV, generator=gen) for m in meshes]
+
+    def run(seq, images):
+        old = F_sg.USE_SPLIT_IMAGES
+        F_sg.USE_SPLIT_IMAGES = images
+        try:
+            seq.train()
+            seq.zero_grad()
+            ins = [x.clone().requires_grad_(True) for x in xs]
+            ys = [seq(x, g) for x, g in zip(ins, graphs)]          # small mesh first, then the large one: its refresh comes second
+            (ys[0].square().mean() + ys[1].square().mean()).backward()
+            return [y.detach().clone() for y in ys] + [x.grad.clone() for x in ins] + [p.grad.clone() for p in seq.parameters()]
+        finally:
+            F_sg.USE_SPLIT_IMAGES = old
+
+    for step in range(2):
+        for a, b in zip(run(seq_a, True), run(seq_b, False)):
+            assert torch.equal(a, b), step
+        with torch.no_grad():
+            for p_a, p_b in zip(seq_a.parameters(), seq_b.parameters()):
+                d = 0.01 * torch.randn(p_a.shape, device=DEV, generator=gen)
+                p_a.add_(d)
+                p_b.add_(d)
