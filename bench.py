@@ -439,6 +439,8 @@ def timed_run(trainer, args, device, world, with_timer: bool):
     # passes (forward, backward) per iteration that ran as ONE sg_part_run call with the collectives enqueued by the library
     timed_run.native_runs = [round((sgdist.native_runs[i] - nr0[i]) / args.steps, 2) for i in range(2)] if DIST_ON else None
     capi.set_launch_timer(None)
+    if DIST_ON:      # (counted over the timed region only: the launch-timing pass below runs more iterations)
+        timed_run.collectives = {k: (v - c0[k]) / args.steps for k, v in sgdist.collective_counts.items()}
     timed_run.timer_dt, timed_run.timer_steps = dt, args.steps
     timed_run.timer_where = "the timed region"
     if traced and in_region:
@@ -453,8 +455,6 @@ def timed_run(trainer, args, device, world, with_timer: bool):
         timed_run.timer_dt, timed_run.timer_steps = time.perf_counter() - t1, extra
         timed_run.timer_where = f"{extra} iterations after the timed region (HIP events on the launching stream)"
         timer.stop()
-    if DIST_ON:
-        timed_run.collectives = {k: (v - c0[k]) / args.steps for k, v in sgdist.collective_counts.items()}
     timed_run.gemm_timer, timed_run.gemm_steps = None, 0
     if with_timer:
         from semigcn_amd import functional as F_sg
