@@ -140,7 +140,8 @@ SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, 
  * SG_TUNE_FLAGS bit 13 switches the tiled float32 pipeline off, for A/B timing only).
  * The tile records are built by the first aggregation that can use them: THAT call allocates device memory and synchronises
  * the stream twice (it is not asynchronous; never the case while the stream is being captured -- such a call runs on the chain
- * kernel and leaves the build to the next eager one); a failed build is retried by the next call.
+ * kernel and leaves the build to the next eager one); a failed build is retried by the next call.  sg_graph_prepare builds
+ * them ahead of time (a no-op for other widths / dtypes, or when they exist), after which every sg_spmm is asynchronous.
  * Non-finite inputs: the gathers run in fixed-size batches whose unused slots
  * are switched off by a ZERO WEIGHT on a row that is read anyway (a neighbour of
  * one of the rows the same wavefront works on, or row 0; in the tiled kernel: any
@@ -148,6 +149,7 @@ SG_API int sg_graph_export(const sg_graph* g, int32_t* rowptr, int32_t* colidx, 
  * few output rows that are not its neighbours but lie within 32 rows of one; for
  * finite X the result is exactly the CSR sum.
  * ------------------------------------------------------------------------- */
+SG_API int sg_graph_prepare(const sg_graph* g, int64_t C, int dtype, void* stream);
 SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx, const void* X0,
             int64_t ldx0, const void* X1, int64_t ldx1, void* Y, int64_t ldy, int64_t C, int dtype,
             float alpha, float beta, float gamma, void* stream);

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "sg_graph_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sg_spmm": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                         c_void_p, c_int64, c_int64, c_int, c_float, c_float, c_float, c_void_p]),
+    "sg_graph_prepare": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
     "sg_pool_create": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, POINTER(c_void_p)]),
     "sg_pool_destroy": (c_int, [c_void_p]),
     "sg_pool_mean": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
@@ -389,6 +390,13 @@ class GraphHandle:
         with _on_device(self.device):
             _check(load().sg_graph_export(self._h, _ptr(rp), _ptr(ci), _ptr(ds), _stream(rp)), "sg_graph_export")
         return rp, ci, ds
+
+    def prepare(self, C: int, dtype: torch.dtype) -> None:
+        """Build the tile records an aggregation of C channels of ``dtype`` would otherwise build at its first call
+        (``sg_graph_prepare``: that call allocates and synchronises); afterwards every ``spmm`` is asynchronous."""
+        with _on_device(self.device):
+            _check(load().sg_graph_prepare(self._h, int(C), _DTYPES[dtype], torch.cuda.current_stream(self.device).cuda_stream),
+                   "sg_graph_prepare")
 
     def spmm(self, X: torch.Tensor, Y: torch.Tensor, *, alpha: float = 1.0, X0: Optional[torch.Tensor] = None,
              beta: float = 0.0, X1: Optional[torch.Tensor] = None, gamma: float = 0.0,

@@ -368,6 +368,20 @@ SG_API int sg_spmm(const sg_graph* g, int transpose, const void* X, int64_t ldx,
                  beta, gamma, (hipStream_t)stream);
 }
 
+// the lazy build makes the FIRST sg_spmm of 128 / 256 channels on a graph allocate and synchronise.  A host that wants
+// every sg_spmm asynchronous (or that captures its first iteration into a hipGraph on another stream) builds the records here.
+SG_API int sg_graph_prepare(const sg_graph* g, int64_t C, int dtype, void* stream) {
+  SG_REQUIRE(g != nullptr, "sg_graph_prepare: null graph");
+  if (!(C == 128 || C == 256) || !(dtype == SG_BF16 || (dtype == SG_F32 && ring_f32_enabled()))) return SG_OK;   // nothing to build
+  const Csr* all[3] = {&g->fwd, &g->bwd, &g->loc};
+  for (const Csr* c : all) {
+    if (!__atomic_load_n(&const_cast<Csr*>(c)->rec_pending, __ATOMIC_ACQUIRE)) continue;
+    const int rc = build_pending_records(*c, (hipStream_t)stream);
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
+}
+
 SG_API int sg_pool_create(const int64_t* fine, const int64_t* coarse, int64_t n, int64_t n_fine,
                    int64_t n_coarse, void* stream_, sg_pool** out) {
   SG_REQUIRE(out != nullptr, "sg_pool_create: out is null");

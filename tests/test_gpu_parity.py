@@ -1860,3 +1860,23 @@ def test_batchnorm_apply_passes_do_not_depend_on_which_rows_a_workgroup_takes(dt
         ref = res[1][1].double().sum(0)
         for rows in (1, 2):
             assert float((res[rows][2].double() - ref).abs().max()) <= 2e-5 * float(res[1][1].double().abs().sum(0).max())
+
+
+def test_graph_prepare_builds_the_tile_records_ahead_of_the_first_aggregation():
+    """sg_graph_prepare: the tile records that the first 128- / 256-channel aggregation would build -- an allocation and
+    two stream synchronisations inside sg_spmm -- built ahead of time; idempotent, a no-op for widths that use no records, and the
+    aggregation that follows gives the bits of one on a graph that built them lazily."""
+    m = synth.torus_mesh(96, 64)
+    V = m.num_vertices
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    lazy, ahead = _ring_graph(ei, V), _ring_graph(ei, V)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for dtype in (torch.bfloat16, torch.float32):
+        x = torch.randn(V, 256, device=DEV, generator=gen).to(dtype)
+        ahead.prepare(64, dtype)              # no records for this width: nothing happens
+        ahead.prepare(256, dtype)
+        ahead.prepare(256, dtype)             # idempotent
+        a = ahead.spmm(x, torch.empty_like(x))
+        b = lazy.spmm(x, torch.empty_like(x))
+        assert torch.equal(a, b)
+        assert rel(a.float(), oracle_lhat(ei.cpu(), x.float().cpu())) < (1e-6 if dtype == torch.float32 else 1e-2)
